@@ -1,0 +1,95 @@
+"""The oracle (oracle/netquery_numpy.py) against every golden vector produced by
+the reference itself (oracle/make_golden.py).  CPU only."""
+import copy
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from golden_utils import GOLDEN, case_names, load_case, load_params, model_files
+from oracle import netquery_numpy as O
+
+# fp32 reference vs fp64 oracle
+SCORE_ATOL = 2e-6
+LOSS_RTOL = 2e-6
+GRAD_RTOL, GRAD_ATOL = 2e-4, 2e-7
+
+
+@pytest.mark.parametrize("path,dec,inter,d", model_files(), ids=lambda v: os.path.basename(v) if isinstance(v, str) and v.endswith(".npz") else None)
+def test_scores_loss_grads(path, dec, inter, d):
+    z = np.load(path)
+    params = load_params(z, d)
+    names = case_names(z)
+    assert names
+    for case in names:
+        c = load_case(z, case)
+        plan = O.make_plan(c["type"], c["rels"])
+        pos = O.forward_scores(params, plan, dec, inter, c["target"], c["anchors"])
+        neg = O.forward_scores(params, plan, dec, inter, c["neg"], c["anchors"])
+        np.testing.assert_allclose(pos, c["pos"], atol=SCORE_ATOL, rtol=1e-5, err_msg=case)
+        np.testing.assert_allclose(neg, c["negscore"], atol=SCORE_ATOL, rtol=1e-5, err_msg=case)
+        loss, sp, sn, grads = O.margin_fwd_bwd(params, plan, dec, inter, c["target"], c["neg"], c["anchors"],
+                                               margin=c["margin"])
+        np.testing.assert_allclose(sp, c["pos"], atol=SCORE_ATOL, rtol=1e-5)
+        np.testing.assert_allclose(loss, c["loss"], rtol=LOSS_RTOL, atol=1e-7, err_msg=case)
+        touched = O.touched_keys(plan, dec, inter)
+        assert touched == set(c["grads"].keys()), case
+        for k, g in c["grads"].items():
+            scale = max(np.abs(g).max(), 1e-12)
+            np.testing.assert_allclose(grads[k], g, rtol=GRAD_RTOL, atol=GRAD_ATOL + 1e-5 * scale,
+                                       err_msg="%s %s" % (case, k))
+        for k in set(grads) - touched:
+            assert not grads[k].any(), (case, k)
+
+
+@pytest.mark.parametrize("path,dec,inter,d", model_files(32), ids=lambda v: os.path.basename(v) if isinstance(v, str) and v.endswith(".npz") else None)
+def test_adam_three_steps(path, dec, inter, d):
+    z = np.load(path)
+    p0 = load_params(z, d)
+    for case in case_names(z):
+        c = load_case(z, case)
+        if "adam_neg" not in c:
+            continue
+        plan = O.make_plan(c["type"], c["rels"])
+        params = {k: v.astype(np.float64) for k, v in p0.items()}
+        state = {}
+        touched = O.touched_keys(plan, dec, inter)
+        for step in range(3):
+            loss, _, _, grads = O.margin_fwd_bwd(params, plan, dec, inter, c["target"], c["adam_neg"][step],
+                                                 c["anchors"], margin=c["margin"])
+            # step 0 is exact; later steps inherit Adam's noise amplification (see below)
+            np.testing.assert_allclose(loss, c["adam_loss"][step], rtol=2e-6 if step == 0 else 2e-2, err_msg=case)
+            O.adam_step(params, grads, state, touched)
+        assert touched == set(c["adam_delta"].keys())
+        for k, delta in c["adam_delta"].items():
+            got = params[k] - p0[k].astype(np.float64)
+            # Adam's first steps are sign-like: dp = lr * g / (|g| + 1e-8).  An element whose exact
+            # gradient is 0 but whose fp32 gradient is rounding noise (~1e-9, e.g. the cancelling
+            # projection g - xhat (xhat.g)) moves by a visible fraction of lr in the reference, and
+            # min/relu then flip discretely.  So: nearly every element must agree tightly, a few
+            # noise-driven outliers may differ by a few lr.
+            diff = np.abs(got - delta)
+            assert diff.max() < 4e-2, (case, k, diff.max())
+            assert np.median(diff) < 5e-4, (case, k, np.median(diff))
+        for k in set(params) - touched:
+            assert np.array_equal(params[k], p0[k].astype(np.float64))
+
+
+def test_adam_single_step_formula():
+    """One torch.optim.Adam step on random (p, g, m, v, step) against the restatement."""
+    import torch
+    rng = np.random.RandomState(0)
+    p = rng.randn(50, 8).astype(np.float32)
+    params = {"x": p.astype(np.float64)}
+    tp = torch.nn.Parameter(torch.from_numpy(p.copy()))
+    opt = torch.optim.Adam([tp], lr=0.01)
+    state = {}
+    for step in range(4):
+        g = (rng.randn(50, 8) * 10 ** rng.uniform(-6, 0, size=(50, 8))).astype(np.float32)
+        g[rng.rand(50, 8) < 0.3] = 0
+        tp.grad = torch.from_numpy(g.copy())
+        opt.step()
+        O.adam_step(params, {"x": g.astype(np.float64)}, state, ["x"])
+        np.testing.assert_allclose(params["x"], tp.detach().numpy(), rtol=0, atol=3e-6)
