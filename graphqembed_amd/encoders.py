@@ -1,0 +1,67 @@
+"""Node encoders.  Only the depth-0 ``DirectEncoder`` is on the accelerated path
+(netquery/encoders.py:11-45): an embedding-table lookup followed by
+a per-vector L2 normalisation.  Here the class is the *owner of the tables* and of the
+node-id -> table-row mapping; the gather + normalise themselves happen inside the fused
+HIP kernel (graphqembed_amd/csrc/gqe_kernels.hip: ``gather_norm``).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch.nn as nn
+
+
+class DirectEncoder(nn.Module):
+    """``DirectEncoder(features, feature_modules)`` as in the reference; tables are
+    registered as ``feat-<mode>`` so state_dict keys stay ``enc.feat-<mode>.weight``.
+
+    ``node_maps`` ({mode: {node_id: index}}, table row = index + 1 as in
+    netquery/bio/data_utils.py:20-21) replaces what the reference hides inside the
+    ``features`` closure; without it rows are ``node_id + 1`` (utils.py:19-20).
+    """
+
+    def __init__(self, features, feature_modules, node_maps=None):
+        super(DirectEncoder, self).__init__()
+        for name, module in feature_modules.items():
+            self.add_module("feat-" + name, module)
+        self.features = features
+        self.modes = list(feature_modules.keys())
+        self.node_maps = node_maps
+        self._lut = {}
+
+    def table(self, mode):
+        return getattr(self, "feat-" + mode)
+
+    def _lookup(self, mode):
+        lut = self._lut.get(mode)
+        if lut is None:
+            nm = self.node_maps[mode]
+            ids = np.fromiter((k for k in nm.keys() if k >= 0), dtype=np.int64)
+            lo, hi = (int(ids.min()), int(ids.max())) if len(ids) else (0, 0)
+            arr = np.full(hi - lo + 1, -1, dtype=np.int32)
+            for k, v in nm.items():
+                if k >= 0:
+                    arr[k - lo] = v + 1
+            lut = self._lut[mode] = (lo, arr)
+        return lut
+
+    def rows(self, nodes, mode):
+        """Vectorised node ids -> int32 table rows (node -1 -> the dummy row 0)."""
+        nodes = np.asarray(nodes, dtype=np.int64)
+        if self.node_maps is None:
+            return (nodes + 1).astype(np.int32)
+        lo, arr = self._lookup(mode)
+        out = np.zeros(len(nodes), dtype=np.int32)
+        real = nodes >= 0
+        if real.any():
+            rel = nodes[real] - lo
+            if (rel < 0).any() or (rel >= len(arr)).any():
+                raise KeyError("node id outside mode %r" % mode)
+            got = arr[rel]
+            if (got < 0).any():
+                raise KeyError("node id not in mode %r" % mode)
+            out[real] = got
+        return out
+
+    def forward(self, nodes, mode, offset=None, **kwargs):
+        raise NotImplementedError("DirectEncoder is evaluated inside the fused HIP kernel; call "
+                                  "QueryEncoderDecoder.forward / margin_loss")

@@ -1,0 +1,299 @@
+"""ctypes binding of libgqe.so (include/gqe.h) + the flat parameter arena.
+
+PyTorch is used only as the owner of device memory and streams: every pointer handed
+to the library is ``tensor.data_ptr()`` of a tensor this module keeps alive, and every
+call is enqueued on ``torch.cuda.current_stream()``.
+
+There is NO CPU fallback: importing the package works without the library (so host-side
+code and CPU tests can run), but anything that computes raises ``GqeLibraryError`` if
+``libgqe.so`` is missing or no HIP device is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+ABI_VERSION = 1
+MAX_BRANCH, MAX_HOPS, MAX_BATCHES, MAX_DIM, MAX_SEGS = 3, 3, 64, 256, 96
+TQ = 16
+
+DECODERS = {"bilinear-diag": 0, "transe": 1, "bilinear": 2}           # utils.py:128-137
+INTER_DECODERS = {"min": 0, "mean": 1, "min-simple": 2, "mean-simple": 3}  # utils.py:139-150
+QTYPES = {"1-chain": 0, "2-chain": 1, "3-chain": 2, "2-inter": 3, "3-inter": 4,
+          "3-inter_chain": 5, "3-chain_inter": 6}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgqe.so")
+
+
+class GqeLibraryError(RuntimeError):
+    pass
+
+
+class GqeError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libgqe error %d: %s" % (code, msg))
+        self.code = code
+
+
+class gqe_config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("dim", C.c_int32),
+                ("decoder", C.c_int32), ("inter", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class gqe_batch(C.Structure):
+    _fields_ = [("qtype", C.c_int32), ("n_queries", C.c_int32), ("n_anchors", C.c_int32),
+                ("idx_offset", C.c_int32),
+                ("target_table", C.c_int64), ("anchor_table", C.c_int64 * MAX_BRANCH),
+                ("n_hops", C.c_int32 * MAX_BRANCH), ("n_final", C.c_int32),
+                ("hop_param", (C.c_int64 * MAX_HOPS) * MAX_BRANCH),
+                ("final_param", C.c_int64), ("pre_param", C.c_int64), ("post_param", C.c_int64),
+                ("margin", C.c_float), ("loss_weight", C.c_float),
+                ("out_offset", C.c_int32), ("reserved", C.c_int32)]
+
+
+class gqe_segment(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("numel", C.c_int64), ("step", C.c_int32), ("reserved", C.c_int32)]
+
+
+# every symbol include/gqe.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = OrderedDict([
+    ("gqe_abi_version", (C.c_int, [])),
+    ("gqe_last_error", (C.c_char_p, [_P])),
+    ("gqe_create", (C.c_int, [C.POINTER(gqe_config), C.POINTER(_P)])),
+    ("gqe_destroy", (C.c_int, [_P])),
+    ("gqe_bind_arena", (C.c_int, [_P, _P, _P, _P, _P, C.c_int64])),
+    ("gqe_workspace_bytes", (C.c_int64, [_P, C.c_int64, C.c_int32])),
+    ("gqe_bind_workspace", (C.c_int, [_P, _P, C.c_int64])),
+    ("gqe_forward", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P])),
+    ("gqe_margin_fwd_bwd", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P, _P, _P])),
+    ("gqe_adam_step", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P])),
+    ("gqe_sgd_step", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, C.c_float, _P])),
+    ("gqe_zero_grads", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, _P])),
+    ("gqe_timing_enable", (C.c_int, [_P, C.c_int32])),
+    ("gqe_timing_read", (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)])),
+])
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libgqe.so and type every entry point; raises GqeLibraryError if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise GqeLibraryError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). There is no CPU fallback." % p)
+    try:
+        lib = C.CDLL(p)
+    except OSError as e:
+        raise GqeLibraryError("cannot load %s: %s" % (p, e))
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gqe_abi_version() != ABI_VERSION:
+        raise GqeLibraryError("libgqe ABI %d != binding ABI %d" % (lib.gqe_abi_version(), ABI_VERSION))
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _align(x, a):
+    return (x + a - 1) // a * a
+
+
+class ArenaLayout(object):
+    """Where each parameter tensor (state_dict key of the reference) lives in the flat arena."""
+
+    ALIGN = 64  # floats
+
+    def __init__(self):
+        self.entries = OrderedDict()   # key -> (offset, shape)
+        self.total = 0
+
+    def add(self, key, shape):
+        if key in self.entries:
+            raise ValueError("duplicate parameter %r" % key)
+        numel = int(np.prod(shape))
+        self.entries[key] = (self.total, tuple(int(s) for s in shape))
+        self.total = _align(self.total + numel, self.ALIGN)
+        return self.entries[key][0]
+
+    def offset(self, key):
+        return self.entries[key][0]
+
+    def numel(self, key):
+        return int(np.prod(self.entries[key][1]))
+
+    def view(self, flat, key):
+        off, shape = self.entries[key]
+        return flat[off:off + int(np.prod(shape))].view(*shape)
+
+
+class Engine(object):
+    """One gqe_ctx + the tensors it borrows."""
+
+    def __init__(self, dim, decoder, inter_decoder, layout, device=None, max_queries=8192, max_batches=16):
+        import torch
+        if not torch.cuda.is_available():
+            raise GqeLibraryError("no HIP device visible to torch; the query path only runs on an MI355X "
+                                  "(there is no CPU fallback)")
+        self.lib = load_library()
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.dim = int(dim)
+        self.decoder = decoder
+        self.inter_decoder = inter_decoder
+        self.layout = layout
+        cfg = gqe_config(ABI_VERSION, self.device.index or 0, self.dim, DECODERS[decoder], INTER_DECODERS[inter_decoder])
+        handle = _P()
+        rc = self.lib.gqe_create(C.byref(cfg), C.byref(handle))
+        if rc != 0:
+            raise GqeError(rc, (self.lib.gqe_last_error(None) or b"").decode())
+        self.ctx = handle
+        n = max(layout.total, 64)
+        z = lambda: torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.params, self.grads, self.exp_avg, self.exp_avg_sq = z(), z(), z(), z()
+        self._check(self.lib.gqe_bind_arena(self.ctx, self.params.data_ptr(), self.grads.data_ptr(),
+                                            self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), n))
+        self.workspace = None
+        self.max_queries = self.max_batches = 0
+        self.reserve(max_queries, max_batches)
+        self.steps = {k: 0 for k in layout.entries}   # per-tensor Adam step counters
+
+    # -- plumbing ---------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise GqeError(rc, (self.lib.gqe_last_error(self.ctx) or b"").decode())
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reserve(self, max_queries, max_batches):
+        if max_queries <= self.max_queries and max_batches <= self.max_batches:
+            return
+        self.max_queries = max(max_queries, self.max_queries)
+        self.max_batches = max(max_batches, self.max_batches)
+        nbytes = self.lib.gqe_workspace_bytes(self.ctx, self.max_queries, self.max_batches)
+        if nbytes < 0:
+            raise GqeError(int(nbytes), "gqe_workspace_bytes")
+        self.torch.cuda.synchronize(self.device)
+        self.workspace = self.torch.empty(int(nbytes) + 256, dtype=self.torch.uint8, device=self.device)
+        ptr = _align(self.workspace.data_ptr(), 256)
+        self._check(self.lib.gqe_bind_workspace(self.ctx, ptr, int(nbytes)))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.torch.cuda.synchronize(self.device)
+            self.lib.gqe_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- batches ----------------------------------------------------------------
+    @staticmethod
+    def make_batches(descs):
+        arr = (gqe_batch * len(descs))()
+        for i, dsc in enumerate(descs):
+            b = arr[i]
+            b.qtype, b.n_queries, b.n_anchors, b.idx_offset = dsc["qtype"], dsc["n"], dsc["n_anchors"], dsc["idx_offset"]
+            b.target_table = dsc["target_table"]
+            for k in range(MAX_BRANCH):
+                b.anchor_table[k] = dsc["anchor_table"][k] if k < len(dsc["anchor_table"]) else -1
+                hops = dsc["hops"][k] if k < len(dsc["hops"]) else ()
+                b.n_hops[k] = len(hops)
+                for h in range(MAX_HOPS):
+                    b.hop_param[k][h] = hops[h] if h < len(hops) else -1
+            b.n_final = 1 if dsc.get("final", -1) >= 0 else 0
+            b.final_param = dsc.get("final", -1)
+            b.pre_param = dsc.get("pre", -1)
+            b.post_param = dsc.get("post", -1)
+            b.margin = dsc.get("margin", 1.0)
+            b.loss_weight = dsc.get("weight", 1.0)
+            b.out_offset = dsc["out_offset"]
+        return arr
+
+    def _idx_arg(self, idx):
+        """idx: torch int32 CUDA tensor (already resident) or a numpy int32 array (host feed)."""
+        if isinstance(idx, np.ndarray):
+            if idx.dtype != np.int32 or not idx.flags["C_CONTIGUOUS"]:
+                idx = np.ascontiguousarray(idx, dtype=np.int32)
+            return idx, C.c_void_p(idx.ctypes.data), int(idx.size), 0
+        assert idx.dtype == self.torch.int32 and idx.is_cuda and idx.is_contiguous()
+        return idx, C.c_void_p(idx.data_ptr()), int(idx.numel()), 1
+
+    def forward(self, descs, idx, n_scores, out=None):
+        """gqe_forward: scores[n_scores] for the listed batches."""
+        total = sum(dsc["n"] for dsc in descs)
+        self.reserve(total, len(descs))
+        arr = self.make_batches(descs)
+        keep, ptr, n_idx, on_dev = self._idx_arg(idx)
+        scores = out if out is not None else self.torch.empty(n_scores, dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.gqe_forward(self.ctx, arr, len(descs), ptr, n_idx, on_dev, scores.data_ptr(), self._stream()))
+        return scores
+
+    def margin_fwd_bwd(self, descs, idx, n_scores=0, want_scores=False, losses=None):
+        """gqe_margin_fwd_bwd: grads += d(sum_i w_i loss_i); returns (losses[n+1], pos, neg)."""
+        total = sum(dsc["n"] for dsc in descs)
+        self.reserve(total, len(descs))
+        arr = self.make_batches(descs)
+        keep, ptr, n_idx, on_dev = self._idx_arg(idx)
+        t = self.torch
+        if losses is None:
+            losses = t.empty(len(descs) + 1, dtype=t.float32, device=self.device)
+        pos = neg = None
+        pp = pn = None
+        if want_scores:
+            pos = t.empty(n_scores, dtype=t.float32, device=self.device)
+            neg = t.empty(n_scores, dtype=t.float32, device=self.device)
+            pp, pn = pos.data_ptr(), neg.data_ptr()
+        self._check(self.lib.gqe_margin_fwd_bwd(self.ctx, arr, len(descs), ptr, n_idx, on_dev, losses.data_ptr(),
+                                                pp, pn, self._stream()))
+        return losses, pos, neg
+
+    # -- optimiser --------------------------------------------------------------
+    def _segments(self, keys, bump):
+        arr = (gqe_segment * len(keys))()
+        for i, k in enumerate(keys):
+            if bump:
+                self.steps[k] += 1
+            arr[i].offset = self.layout.offset(k)
+            arr[i].numel = self.layout.numel(k)
+            arr[i].step = max(self.steps[k], 1)
+        return arr
+
+    def adam_step(self, keys, lr=0.01, betas=(0.9, 0.999), eps=1e-8):
+        keys = [k for k in self.layout.entries if k in set(keys)]   # arena order
+        arr = self._segments(keys, True)
+        self._check(self.lib.gqe_adam_step(self.ctx, arr, len(keys), lr, betas[0], betas[1], eps, self._stream()))
+
+    def sgd_step(self, keys, lr=0.01):
+        keys = [k for k in self.layout.entries if k in set(keys)]
+        arr = self._segments(keys, False)
+        self._check(self.lib.gqe_sgd_step(self.ctx, arr, len(keys), lr, self._stream()))
+
+    def zero_grads(self, keys):
+        keys = [k for k in self.layout.entries if k in set(keys)]
+        if not keys:
+            return
+        arr = self._segments(keys, False)
+        self._check(self.lib.gqe_zero_grads(self.ctx, arr, len(keys), self._stream()))
+
+    # -- timing (bench.py roofline) ------------------------------------------------
+    def timing_enable(self, on):
+        self._check(self.lib.gqe_timing_enable(self.ctx, 1 if on else 0))
+
+    def timing_read(self, kernel):
+        ms, n = C.c_float(0), C.c_int32(0)
+        self._check(self.lib.gqe_timing_read(self.ctx, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,217 @@
+"""``QueryEncoderDecoder`` — the drop-in boundary (netquery/model.py:57-127).
+
+Same constructor and the same two public methods as the reference:
+    QueryEncoderDecoder(graph, enc, path_dec, inter_dec)
+    .forward(formula, queries, source_nodes)              -> scores[B]
+    .margin_loss(formula, queries, hard_negatives=False, margin=1) -> 0-dim loss
+(``loss.backward()`` / ``optimizer.step()`` keep working), plus the fused fast path the
+trainer uses:
+    .margin_step(items)   all (formula, slice) batches of an iteration in ONE grouped launch.
+
+What differs is where the arithmetic happens: parameters are re-homed into one flat fp32
+arena in HBM and every score / gradient is produced by libgqe.so's HIP kernels
+(gqe_forward / gqe_margin_fwd_bwd, include/gqe.h).  There is no torch fallback.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .engine import ArenaLayout, Engine
+from .tensorize import (FormulaPlan, pack_forward_batches, pack_margin_batches,
+                        reference_negative_nodes)
+
+
+class _MarginLossFn(torch.autograd.Function):
+    """loss value now; gradients when (and scaled by what) autograd asks for them."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, plan, target, neg, anchors, margin):
+        ctx.model, ctx.plan, ctx.margin = model, plan, margin
+        ctx.rows = (target, neg, anchors)
+        n = len(target)
+        descs, idx, n_scores = pack_forward_batches([(plan, np.concatenate([target, neg]),
+                                                      np.concatenate([anchors, anchors], axis=1))])
+        scores = model.engine.forward(descs, idx, n_scores)
+        hinge = torch.clamp(margin - (scores[:n] - scores[n:]), min=0)
+        return hinge.mean()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model, plan = ctx.model, ctx.plan
+        target, neg, anchors = ctx.rows
+        weight = float(grad_out.item())
+        model._prepare_grads(plan.touched)
+        descs, idx, n_scores = pack_margin_batches([(plan, target, neg, anchors, weight, ctx.margin)])
+        model.engine.margin_fwd_bwd(descs, idx)
+        model._mark_touched(plan.touched)
+        return (None,) * 7
+
+
+class QueryEncoderDecoder(nn.Module):
+    """Encoder-decoder that scores conjunctive queries (edges, metapaths, intersections)."""
+
+    def __init__(self, graph, enc, path_dec, inter_dec, device=None, max_queries=8192, max_batches=16):
+        super(QueryEncoderDecoder, self).__init__()
+        self.enc = enc
+        self.path_dec = path_dec
+        self.inter_dec = inter_dec
+        self.graph = graph
+        layout = ArenaLayout()
+        dims = set()
+        for name, p in self.named_parameters():
+            layout.add(name, p.shape)
+            dims.add(int(p.shape[-1]))
+        if len(dims) != 1:
+            raise Exception("the fused path needs one embedding dimension for every mode, got %s" % sorted(dims))
+        self.dim = dims.pop()
+        self.layout = layout
+        self.engine = Engine(self.dim, path_dec.kind, inter_dec.kind, layout, device=device,
+                             max_queries=max_queries, max_batches=max_batches)
+        # re-home every parameter into the arena (state_dict keys and values unchanged)
+        for name, p in self.named_parameters():
+            view = layout.view(self.engine.params, name)
+            view.copy_(p.data)
+            p.data = view
+        self._plans = {}
+        self._touched = set()      # tensors with a gradient since the last optimiser step
+        self._dirty = set()        # tensors whose grad-arena segment may be non-zero
+        self._autograd_anchor = torch.zeros((), device=self.engine.device, requires_grad=True)
+
+    # -- helpers ----------------------------------------------------------------
+    def plan(self, formula):
+        p = self._plans.get(formula)
+        if p is None:
+            p = self._plans[formula] = FormulaPlan(formula, self.layout, self.inter_dec.kind)
+        return p
+
+    def _rows(self, formula, queries, source_nodes):
+        target = self.enc.rows(source_nodes, formula.target_mode)
+        anchors = np.stack([self.enc.rows([q.anchor_nodes[i] for q in queries], m)
+                            for i, m in enumerate(formula.anchor_modes)])
+        return target, anchors
+
+    def _param(self, key):
+        mod, _, name = key.partition(".")
+        obj = getattr(self, mod)
+        if name.endswith(".weight") and mod == "enc":
+            return getattr(obj, name[:-7]).weight
+        return getattr(obj, name)
+
+    def _prepare_grads(self, keys):
+        """torch.optim compatibility: expose arena gradients as ``param.grad`` views; a
+        tensor whose grad was reset to None (optimizer.zero_grad) starts from zero."""
+        stale = []
+        for k in keys:
+            p = self._param(k)
+            if p.grad is None:
+                if k in self._dirty:
+                    stale.append(k)
+                p.grad = self.layout.view(self.engine.grads, k)
+        if stale:
+            self.engine.zero_grads(stale)
+
+    def _mark_touched(self, keys):
+        self._touched.update(keys)
+        self._dirty.update(keys)
+
+    # -- reference API ------------------------------------------------------------
+    def forward(self, formula, queries, source_nodes):
+        """scores[B] of ``source_nodes`` as the target of each query (model.py:70-109)."""
+        if len(queries) != len(source_nodes):
+            raise Exception("queries and source_nodes differ in length")
+        target, anchors = self._rows(formula, queries, source_nodes)
+        descs, idx, n = pack_forward_batches([(self.plan(formula), target, anchors)])
+        return self.engine.forward(descs, idx, n)
+
+    def margin_loss(self, formula, queries, hard_negatives=False, margin=1):
+        """mean_b max(0, margin - (s+_b - s-_b)) with one negative per query chosen as the
+        reference chooses it (model.py:112-127)."""
+        neg_nodes = reference_negative_nodes(self.graph, formula, queries, hard_negatives)
+        target, anchors = self._rows(formula, queries, [q.target_node for q in queries])
+        neg = self.enc.rows(neg_nodes, formula.target_mode)
+        return _MarginLossFn.apply(self._autograd_anchor, self, self.plan(formula), target, neg, anchors, float(margin))
+
+    # -- fused fast path -----------------------------------------------------------
+    def margin_step(self, items, want_scores=False, idx_device=None):
+        """All batches of one training iteration in one grouped launch.
+
+        items: [(formula, target_rows[n], neg_rows[n], anchor_rows[k,n], loss_weight, margin)]
+        Accumulates d(sum_i w_i loss_i) into the gradient arena and returns
+        (losses[len(items)+1] device tensor, pos, neg)."""
+        packed = [(self.plan(f), t, ng, a, w, m) for (f, t, ng, a, w, m) in items]
+        descs, idx, n_scores = pack_margin_batches(packed)
+        out = self.engine.margin_fwd_bwd(descs, idx if idx_device is None else idx_device,
+                                         n_scores=n_scores, want_scores=want_scores)
+        for p in packed:
+            self._mark_touched(p[0].touched)
+        return out
+
+    def score_batches(self, items):
+        """items: [(formula, target_rows, anchor_rows)] -> one scores tensor (concatenated)."""
+        packed = [(self.plan(f), t, a) for (f, t, a) in items]
+        descs, idx, n = pack_forward_batches(packed)
+        return self.engine.forward(descs, idx, n)
+
+
+class _FusedOptimizer(object):
+    """optimizer.step() + optimizer.zero_grad() as one HIP pass over the tensors that
+    received a gradient this iteration (torch semantics: others are skipped and keep their
+    own step count — SURVEY.md Appendix B)."""
+
+    def __init__(self, model, lr):
+        self.model = model
+        self.lr = lr
+
+    def zero_grad(self, set_to_none=True):
+        m = self.model
+        if m._dirty:
+            m.engine.zero_grads(sorted(m._dirty))
+            m._dirty.clear()
+        m._touched.clear()
+        for p in m.parameters():
+            p.grad = None
+
+    def _done(self):
+        m = self.model
+        m._dirty -= m._touched
+        m._touched.clear()
+        for p in m.parameters():
+            p.grad = None
+
+
+class FusedAdam(_FusedOptimizer):
+    """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) (netquery/bio/train.py:62)."""
+
+    def __init__(self, model, lr=0.01, betas=(0.9, 0.999), eps=1e-8):
+        _FusedOptimizer.__init__(self, model, lr)
+        self.betas, self.eps = betas, eps
+
+    def step(self):
+        m = self.model
+        if m._touched:
+            m.engine.adam_step(m._touched, self.lr, self.betas, self.eps)
+        self._done()
+
+    def state_dict(self):
+        e = self.model.engine
+        return {"steps": dict(e.steps), "exp_avg": e.exp_avg.clone(), "exp_avg_sq": e.exp_avg_sq.clone(),
+                "lr": self.lr, "betas": self.betas, "eps": self.eps}
+
+    def load_state_dict(self, sd):
+        e = self.model.engine
+        e.steps.update(sd["steps"])
+        e.exp_avg.copy_(sd["exp_avg"])
+        e.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.lr, self.betas, self.eps = sd["lr"], tuple(sd["betas"]), sd["eps"]
+
+
+class FusedSGD(_FusedOptimizer):
+    """torch.optim.SGD(lr, momentum=0) (netquery/bio/train.py:60)."""
+
+    def step(self):
+        m = self.model
+        if m._touched:
+            m.engine.sgd_step(m._touched, self.lr)
+        self._done()

@@ -1,0 +1,141 @@
+"""Factories and evaluation (netquery/utils.py).
+
+  get_encoder / get_metapath_decoder / get_intersection_decoder   utils.py:93-150
+  eval_auc_queries                                                utils.py:35-67
+  eval_perc_queries                                               utils.py:70-91
+  setup_logging                                                   utils.py:152-167
+
+The two eval functions keep the reference's protocol (which negatives are drawn, with
+which seed, in which order, how scores are grouped) but push each formula's chunk
+through ``QueryEncoderDecoder.forward`` on the GPU.
+"""
+from __future__ import annotations
+
+import logging
+import random
+
+import numpy as np
+import torch
+
+from .decoders import (BilinearDiagMetapathDecoder, BilinearMetapathDecoder, SetIntersection,
+                       SimpleSetIntersection, TransEMetapathDecoder)
+from .encoders import DirectEncoder
+
+
+def get_encoder(depth, graph, out_dims, feature_modules, cuda=True, node_maps=None):
+    if depth < 0 or depth > 3:
+        raise Exception("Depth must be between 0 and 3 (inclusive)")
+    if depth != 0:
+        raise Exception("only the depth-0 DirectEncoder is on the MI355X fast path "
+                        "(GraphSAGE-style encoders of netquery/encoders.py:47-129 are out of scope)")
+    return DirectEncoder(graph.features, feature_modules, node_maps=node_maps)
+
+
+def get_metapath_decoder(graph, out_dims, decoder):
+    if decoder == "bilinear":
+        return BilinearMetapathDecoder(graph.relations, out_dims)
+    if decoder == "transe":
+        return TransEMetapathDecoder(graph.relations, out_dims)
+    if decoder == "bilinear-diag":
+        return BilinearDiagMetapathDecoder(graph.relations, out_dims)
+    raise Exception("Metapath decoder not recognized.")
+
+
+def get_intersection_decoder(graph, out_dims, decoder):
+    if decoder == "mean":
+        return SetIntersection(out_dims, out_dims, agg_func=torch.mean)
+    if decoder == "mean-simple":
+        return SimpleSetIntersection(agg_func=torch.mean)
+    if decoder == "min":
+        return SetIntersection(out_dims, out_dims, agg_func=torch.min)
+    if decoder == "min-simple":
+        return SimpleSetIntersection(agg_func=torch.min)
+    raise Exception("Intersection decoder not recognized.")
+
+
+def _auc(labels, scores):
+    """Area under the ROC curve = P(score_pos > score_neg) + 0.5 P(tie) (rank statistic);
+    what sklearn.metrics.roc_auc_score returns for binary labels."""
+    labels = np.asarray(labels)
+    scores = np.asarray(scores, dtype=np.float64)
+    order = np.argsort(scores, kind="mergesort")
+    ranks = np.empty(len(scores), dtype=np.float64)
+    s = scores[order]
+    i = 0
+    while i < len(s):                      # average ranks over ties
+        j = i
+        while j + 1 < len(s) and s[j + 1] == s[i]:
+            j += 1
+        ranks[order[i:j + 1]] = 0.5 * (i + j) + 1.0
+        i = j + 1
+    n_pos = float(labels.sum())
+    n_neg = float(len(labels) - n_pos)
+    if n_pos == 0 or n_neg == 0:
+        raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
+    return (ranks[labels == 1].sum() - n_pos * (n_pos + 1) / 2.0) / (n_pos * n_neg)
+
+
+def _percentile_of_score(a, score):
+    """scipy.stats.percentileofscore(a, score) with the default kind='rank'."""
+    a = np.asarray(a)
+    n = len(a)
+    if n == 0:
+        return np.nan
+    left = np.count_nonzero(a < score)
+    right = np.count_nonzero(a <= score)
+    return (left + right + (1 if right > left else 0)) * 50.0 / n
+
+
+def _chunks(formula_queries, batch_size):
+    for offset in range(0, len(formula_queries), batch_size):
+        yield formula_queries[offset:offset + batch_size]
+
+
+def eval_auc_queries(test_queries, enc_dec, batch_size=1000, hard_negatives=False, seed=0):
+    """Overall and per-formula ROC AUC with ONE random negative per query; the negative
+    draw replays the reference's ``random.seed(seed)`` / ``random.choice`` sequence."""
+    predictions, labels, formula_aucs = [], [], {}
+    random.seed(seed)
+    for formula in test_queries:
+        f_labels, f_preds = [], []
+        for batch in _chunks(test_queries[formula], batch_size):
+            if hard_negatives:
+                negatives = [random.choice(q.hard_neg_samples) for q in batch]
+            else:
+                negatives = [random.choice(q.neg_samples) for q in batch]
+            f_labels.extend([1] * len(batch) + [0] * len(negatives))
+            scores = enc_dec.forward(formula, batch + batch, [q.target_node for q in batch] + negatives)
+            f_preds.extend(scores.detach().cpu().tolist())
+        formula_aucs[formula] = _auc(f_labels, np.nan_to_num(f_preds))
+        labels.extend(f_labels)
+        predictions.extend(f_preds)
+    return _auc(labels, np.nan_to_num(predictions)), formula_aucs
+
+
+def eval_perc_queries(test_queries, enc_dec, batch_size=1000, hard_negatives=False):
+    """Mean percentile rank of the true target among ALL stored negatives of its query."""
+    perc_scores = []
+    for formula in test_queries:
+        for batch in _chunks(test_queries[formula], batch_size):
+            lists = [q.hard_neg_samples if hard_negatives else q.neg_samples for q in batch]
+            lengths = [len(l) for l in lists]
+            negatives = [n for l in lists for n in l]
+            rep = [q for q, k in zip(batch, lengths) for _ in range(k)]
+            scores = enc_dec.forward(formula, batch + rep, [q.target_node for q in batch] + negatives)
+            scores = scores.detach().cpu().numpy()
+            neg_scores, cum = scores[len(batch):], 0
+            for i, k in enumerate(lengths):
+                perc_scores.append(_percentile_of_score(neg_scores[cum:cum + k], scores[i]))
+                cum += k
+    return np.mean(perc_scores)
+
+
+def setup_logging(log_file, console=True):
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s",
+                        filename=log_file, filemode="w")
+    if console:
+        handler = logging.StreamHandler()
+        handler.setLevel(logging.INFO)
+        handler.setFormatter(logging.Formatter("%(asctime)s - %(levelname)s - %(message)s"))
+        logging.getLogger("").addHandler(handler)
+    return logging

@@ -1,0 +1,163 @@
+/* gqe.h — C ABI of libgqe.so: the MI355X (gfx950) conjunctive-query embedding hot path.
+ *
+ * The reference (williamleif/graphqembed, 100 % Python) exposes NO FFI / plugin /
+ * operator registry for this path: its boundary is the Python nn.Module
+ * netquery.model.QueryEncoderDecoder (model.py:57-127).  This header is the boundary a
+ * native replacement sits behind; graphqembed_amd/model.py re-provides the Python class with
+ * the reference's signatures on top of it (ctypes), and INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.  Each entry point cites what it replaces.
+ *
+ * Conventions
+ *   - plain C types only; every device pointer is BORROWED (never freed by the library);
+ *   - all work is enqueued on the caller's hipStream_t (passed as void*); no hidden syncs;
+ *   - every function returns 0 on success or a negative gqe_status; gqe_last_error() gives text;
+ *   - one gqe_ctx per (process, device); a ctx is not thread-safe, different ctxs are independent.
+ *
+ * Memory model
+ *   All trainable parameters live in ONE flat fp32 arena ("params", P floats):
+ *   [tables of every mode | relation vectors or matrices | Pre/Post matrices], each tensor
+ *   starting at a 64-float-aligned offset.  grads / exp_avg / exp_avg_sq are arenas of the
+ *   same layout.  A "segment" is one parameter tensor (= one state_dict key of the reference).
+ *   Node indices are int32 TABLE ROWS (reference: node_maps[mode][node] + 1,
+ *   bio/data_utils.py:20-21), vectors are rows of d floats.
+ */
+#ifndef GQE_H
+#define GQE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GQE_ABI_VERSION 1
+#define GQE_MAX_BRANCH 3
+#define GQE_MAX_HOPS 3
+#define GQE_MAX_BATCHES 64
+#define GQE_MAX_DIM 256
+
+typedef enum {
+  GQE_OK = 0,
+  GQE_ERR_ARG = -1,        /* bad argument / unsupported configuration            */
+  GQE_ERR_HIP = -2,        /* a HIP runtime call failed                           */
+  GQE_ERR_STATE = -3,      /* arena / workspace not bound                         */
+  GQE_ERR_WORKSPACE = -5   /* bound workspace too small for this call             */
+} gqe_status;
+
+/* --decoder of the reference (utils.py:128-137) */
+typedef enum { GQE_DEC_BILINEAR_DIAG = 0, GQE_DEC_TRANSE = 1, GQE_DEC_BILINEAR = 2 } gqe_decoder;
+/* --inter_decoder of the reference (utils.py:139-150) */
+typedef enum { GQE_INTER_MIN = 0, GQE_INTER_MEAN = 1, GQE_INTER_MIN_SIMPLE = 2, GQE_INTER_MEAN_SIMPLE = 3 } gqe_inter;
+/* Formula.query_type (graph.py:13-24) */
+typedef enum {
+  GQE_Q_1CHAIN = 0, GQE_Q_2CHAIN = 1, GQE_Q_3CHAIN = 2,
+  GQE_Q_2INTER = 3, GQE_Q_3INTER = 4, GQE_Q_3INTER_CHAIN = 5, GQE_Q_3CHAIN_INTER = 6
+} gqe_qtype;
+
+typedef struct gqe_ctx gqe_ctx;
+
+typedef struct {
+  int32_t abi_version;   /* GQE_ABI_VERSION                                        */
+  int32_t device;        /* HIP device ordinal                                     */
+  int32_t dim;           /* embedding dim d: multiple of 16, <= GQE_MAX_DIM        */
+  int32_t decoder;       /* gqe_decoder                                            */
+  int32_t inter;         /* gqe_inter                                              */
+  int32_t reserved[3];
+} gqe_config;
+
+/* One batch = one margin_loss / forward call of the reference: every query shares one
+ * Formula (train_helpers.py:100-106), so relation parameters are batch-uniform.
+ * All *_param / *_table fields are arena offsets in floats.
+ *
+ * chain types (1/2/3-chain): n_anchors = 1; hops[0][0..n_hops[0]) are the relations r1..rk
+ *   in target->anchor order, applied on the TARGET side (decoders.py:142-147,200-205,228-233).
+ * intersection types: branch i is anchor i; hops[i][*] are the already-reversed relations in
+ *   the order they are applied to the anchor (model.py:80-91, 102-105); pre/post are the
+ *   SetIntersection matrices of the intersection mode (-1 for the *-simple decoders);
+ *   final_param is the projection applied after the intersection (3-chain_inter, model.py:107),
+ *   -1 otherwise.
+ * Index layout (int32, at idx_offset in the idx buffer):
+ *   target[B] | negative[B] (margin calls only; absent for gqe_forward) | anchor_0[B] | ... */
+typedef struct {
+  int32_t qtype;                                  /* gqe_qtype                               */
+  int32_t n_queries;                              /* B >= 1                                  */
+  int32_t n_anchors;                              /* 1..3                                    */
+  int32_t idx_offset;                             /* in int32 elements                       */
+  int64_t target_table;
+  int64_t anchor_table[GQE_MAX_BRANCH];
+  int32_t n_hops[GQE_MAX_BRANCH];
+  int32_t n_final;                                /* 0 or 1                                  */
+  int64_t hop_param[GQE_MAX_BRANCH][GQE_MAX_HOPS];
+  int64_t final_param;
+  int64_t pre_param;
+  int64_t post_param;
+  float margin;                                   /* model.py:112 (default 1)                */
+  float loss_weight;                              /* weight of this batch's mean loss in the
+                                                     iteration loss (train_helpers.py:51,69-72);
+                                                     gradients are scaled by it              */
+  int32_t out_offset;                             /* where this batch's B scores go          */
+  int32_t reserved;
+} gqe_batch;
+
+/* One parameter tensor for the optimiser (torch.optim semantics: a tensor with no gradient
+ * this iteration is skipped and keeps its own step counter). */
+typedef struct {
+  int64_t offset;        /* arena offset (floats), multiple of 4                            */
+  int64_t numel;
+  int32_t step;          /* this tensor's Adam step count AFTER this update (>= 1)          */
+  int32_t reserved;
+} gqe_segment;
+
+int gqe_abi_version(void);
+const char* gqe_last_error(const gqe_ctx* ctx);   /* ctx may be NULL: last create error */
+
+/* replaces: QueryEncoderDecoder.__init__ + enc_dec.cuda() (model.py:62-68, bio/train.py:56-57) */
+int gqe_create(const gqe_config* cfg, gqe_ctx** out);
+int gqe_destroy(gqe_ctx* ctx);
+
+/* Bind the parameter / gradient / Adam-moment arenas (device pointers, n floats each).
+ * grads, exp_avg, exp_avg_sq may be NULL for inference-only use. */
+int gqe_bind_arena(gqe_ctx* ctx, float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n);
+
+/* Scratch the fused kernels need for `max_queries` queries in one call (bytes). */
+int64_t gqe_workspace_bytes(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches);
+int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes);
+
+/* replaces: QueryEncoderDecoder.forward (model.py:70-109) for n_batches formulas at once.
+ * idx: int32 index buffer (device pointer if idx_on_device, else host pointer: copied through
+ * the ctx's pinned staging ring with hipMemcpyAsync).  scores: device, sum of B floats. */
+int gqe_forward(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches,
+                const int32_t* idx, int64_t n_idx, int32_t idx_on_device,
+                float* scores, void* stream);
+
+/* replaces: margin_loss forward (model.py:112-127) + loss.backward() (train_helpers.py:78)
+ * for n_batches (formula, query-slice) pairs in ONE grouped launch.  Gradients of
+ * sum_i loss_weight_i * loss_i are ACCUMULATED into the bound grads arena.
+ * losses: device, n_batches + 1 floats (mean hinge loss per batch, then the weighted sum).
+ * pos_scores / neg_scores: device, optional (NULL to skip). */
+int gqe_margin_fwd_bwd(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches,
+                       const int32_t* idx, int64_t n_idx, int32_t idx_on_device,
+                       float* losses, float* pos_scores, float* neg_scores, void* stream);
+
+/* replaces: optimizer.step() + optimizer.zero_grad() for torch.optim.Adam
+ * (bio/train.py:62, train_helpers.py:50,79): one fused pass p,g,m,v -> p,m,v and g := 0
+ * over the listed segments only. */
+int gqe_adam_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs,
+                  float lr, float beta1, float beta2, float eps, void* stream);
+/* replaces: torch.optim.SGD(momentum=0).step() + zero_grad (bio/train.py:60) */
+int gqe_sgd_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, float lr, void* stream);
+/* replaces: optimizer.zero_grad() alone */
+int gqe_zero_grads(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, void* stream);
+
+/* Timing of the most recent launches of each kernel on the stream they ran on, measured with
+ * hipEvents recorded by the library when enabled (bench.py's roofline block uses this:
+ * torch.cuda.Event cannot see a raw hipStream).  kernel: 0 = fused fwd/bwd, 1 = param-grad
+ * GEMM, 2 = optimiser.  Returns the average milliseconds over the recorded launches and
+ * their count, then clears the record. */
+int gqe_timing_enable(gqe_ctx* ctx, int32_t on);
+int gqe_timing_read(gqe_ctx* ctx, int32_t kernel, float* avg_ms, int32_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GQE_H */

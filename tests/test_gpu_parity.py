@@ -1,0 +1,226 @@
+"""-m gpu: the HIP path (through libgqe.so's C ABI) against the golden vectors of the
+reference and against the fp64 oracle.  Tolerances (fp32 device arithmetic, atomics in
+arbitrary order): scores atol 2e-5, loss rtol 1e-4, gradients rtol 2e-3 + atol 1e-6*scale."""
+import numpy as np
+import pytest
+
+from golden_utils import case_names, load_case, load_params, model_files
+from oracle import netquery_numpy as O
+
+pytestmark = pytest.mark.gpu
+
+SCORE_ATOL = 2e-5
+LOSS_RTOL = 1e-4
+
+
+def assert_grads_close(got, want, what):
+    for k in want:
+        scale = max(float(np.abs(want[k]).max()), 1e-12)
+        np.testing.assert_allclose(got[k], want[k], rtol=2e-3, atol=2e-6 * scale + 1e-9,
+                                   err_msg="%s %s" % (what, k))
+
+
+def _ids(v):
+    import os
+    return os.path.basename(v) if isinstance(v, str) and v.endswith(".npz") else None
+
+
+@pytest.mark.parametrize("path,dec,inter,d", model_files(), ids=_ids)
+def test_golden_scores_loss_grads(path, dec, inter, d):
+    import torch
+    from gpu_utils import engine_from_params, plan_for, read_arena
+    from graphqembed_amd.tensorize import pack_forward_batches, pack_margin_batches
+    z = np.load(path)
+    params = load_params(z, d)
+    eng = engine_from_params(params, d, dec, inter)
+    for case in case_names(z):
+        c = load_case(z, case)
+        plan = plan_for(eng, c["type"], c["rels"])
+        # forward only (gqe_forward): positives and negatives as two target lists
+        descs, idx, n = pack_forward_batches([(plan, c["target"], c["anchors"]), (plan, c["neg"], c["anchors"])])
+        s = eng.forward(descs, idx, n).cpu().numpy()
+        B = len(c["target"])
+        np.testing.assert_allclose(s[:B], c["pos"], atol=SCORE_ATOL, rtol=1e-4, err_msg=case)
+        np.testing.assert_allclose(s[B:], c["negscore"], atol=SCORE_ATOL, rtol=1e-4, err_msg=case)
+        # fused forward + backward (gqe_margin_fwd_bwd)
+        eng.grads.zero_()
+        descs, idx, n = pack_margin_batches([(plan, c["target"], c["neg"], c["anchors"], 1.0, c["margin"])])
+        losses, pos, neg = eng.margin_fwd_bwd(descs, idx, n, want_scores=True)
+        np.testing.assert_allclose(pos.cpu().numpy(), c["pos"], atol=SCORE_ATOL, rtol=1e-4, err_msg=case)
+        np.testing.assert_allclose(neg.cpu().numpy(), c["negscore"], atol=SCORE_ATOL, rtol=1e-4, err_msg=case)
+        l = losses.cpu().numpy()
+        np.testing.assert_allclose(l[0], c["loss"], rtol=LOSS_RTOL, err_msg=case)
+        np.testing.assert_allclose(l[1], c["loss"], rtol=LOSS_RTOL, err_msg=case)
+        got = read_arena(eng, eng.grads)
+        assert_grads_close(got, c["grads"], case)
+        for k in set(got) - set(c["grads"]):
+            assert not got[k].any(), (case, k)
+        assert plan.touched == set(c["grads"].keys()), case
+    eng.close()
+
+
+@pytest.mark.parametrize("path,dec,inter,d", model_files(32), ids=_ids)
+def test_golden_adam_three_steps(path, dec, inter, d):
+    from gpu_utils import engine_from_params, load_params as put, plan_for, read_arena
+    from graphqembed_amd.tensorize import pack_margin_batches
+    z = np.load(path)
+    p0 = load_params(z, d)
+    eng = engine_from_params(p0, d, dec, inter)
+    for case in case_names(z):
+        c = load_case(z, case)
+        if "adam_neg" not in c:
+            continue
+        put(eng, p0)
+        eng.grads.zero_(); eng.exp_avg.zero_(); eng.exp_avg_sq.zero_()
+        eng.steps = {k: 0 for k in eng.steps}
+        plan = plan_for(eng, c["type"], c["rels"])
+        for step in range(3):
+            descs, idx, n = pack_margin_batches([(plan, c["target"], c["adam_neg"][step], c["anchors"], 1.0, c["margin"])])
+            losses, _, _ = eng.margin_fwd_bwd(descs, idx, n)
+            np.testing.assert_allclose(losses.cpu().numpy()[0], c["adam_loss"][step],
+                                       rtol=LOSS_RTOL if step == 0 else 2e-2, err_msg=case)
+            eng.adam_step(plan.touched)
+        got = read_arena(eng, eng.params)
+        assert float(eng.grads.abs().max()) == 0.0
+        for k, delta in c["adam_delta"].items():
+            diff = np.abs(got[k].astype(np.float64) - p0[k] - delta)
+            # see tests/test_oracle_golden.py: Adam amplifies rounding noise on ~zero gradients
+            assert diff.max() < 4e-2 and np.median(diff) < 5e-4, (case, k, diff.max(), np.median(diff))
+        for k in set(got) - set(c["adam_delta"]):
+            assert np.array_equal(got[k], p0[k]), (case, k)
+    eng.close()
+
+
+def test_adam_kernel_matches_formula():
+    """gqe_adam_step on random state, 4 steps, two tensors with different step counters and a
+    ragged tail, against the fp64 restatement of torch.optim.Adam."""
+    import torch
+    from gpu_utils import engine_from_params, read_arena
+    rng = np.random.RandomState(1)
+    params = {"enc.feat-a.weight": rng.randn(37, 16).astype(np.float32),
+              "path_dec.a_r_a": rng.randn(16).astype(np.float32),
+              "enc.feat-b.weight": rng.randn(1031, 16).astype(np.float32)}
+    eng = engine_from_params(params, 16, "bilinear-diag", "min-simple")
+    ref = {k: v.astype(np.float64) for k, v in params.items()}
+    state = {}
+    for step in range(4):
+        keys = list(params) if step % 2 == 0 else ["enc.feat-b.weight", "path_dec.a_r_a"]
+        grads = {}
+        for k in keys:
+            g = (rng.randn(*params[k].shape) * 10 ** rng.uniform(-6, 0, size=params[k].shape)).astype(np.float32)
+            g[rng.rand(*g.shape) < 0.3] = 0
+            grads[k] = g
+            eng.layout.view(eng.grads, k).copy_(torch.from_numpy(g))
+        eng.adam_step(keys)
+        O.adam_step(ref, {k: v.astype(np.float64) for k, v in grads.items()}, state, keys)
+        got = read_arena(eng, eng.params)
+        for k in params:
+            np.testing.assert_allclose(got[k], ref[k], rtol=0, atol=3e-6, err_msg="%s step %d" % (k, step))
+        assert float(eng.grads.abs().max()) == 0.0
+    # SGD + zero
+    k = "enc.feat-b.weight"
+    g = rng.randn(*params[k].shape).astype(np.float32)
+    eng.layout.view(eng.grads, k).copy_(torch.from_numpy(g))
+    before = read_arena(eng, eng.params)[k]
+    eng.sgd_step([k], lr=0.05)
+    np.testing.assert_allclose(read_arena(eng, eng.params)[k], before - 0.05 * g, atol=1e-6)
+    eng.layout.view(eng.grads, k).fill_(3.0)
+    eng.zero_grads([k])
+    assert float(eng.grads.abs().max()) == 0.0
+    eng.close()
+
+
+CONFIGS = [("bilinear-diag", "min"), ("bilinear-diag", "mean-simple"), ("transe", "mean"),
+           ("transe", "min-simple"), ("bilinear", "min"), ("bilinear", "mean-simple")]
+
+
+@pytest.mark.parametrize("d", [16, 64, 128, 256])
+@pytest.mark.parametrize("dec,inter", CONFIGS)
+def test_random_schema_vs_oracle(dec, inter, d):
+    """Every query type, ragged / tiny / hub-heavy batches, all in ONE grouped launch, against
+    the fp64 oracle; then the same batches launched one by one must give the same gradients."""
+    from gpu_utils import (TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for,
+                           random_params, read_arena, toy_batch)
+    from graphqembed_amd.tensorize import pack_margin_batches
+    rng = np.random.RandomState(d * 7 + len(dec) + len(inter))
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
+    eng = engine_from_params(params, d, dec, inter)
+    sizes = {"1-chain": 1, "2-chain": 17, "3-chain": 64, "2-inter": 33, "3-inter": 16, "3-inter_chain": 5,
+             "3-chain_inter": 48}
+    items, want_l, grads = [], [], O.zero_grads_like(params)
+    want_p, want_n = [], []
+    for j, (qtype, B) in enumerate(sizes.items()):
+        t, g, a = toy_batch(rng, qtype, B, hub=(j % 2 == 0))
+        w = [1.0, 0.01, 0.01, 0.005, 0.005, 0.5, 2.0][j]
+        m = 1.0 if j != 3 else 0.3
+        items.append((plan_for(eng, qtype, TOY_FORMULAS[qtype]), t, g, a, w, m))
+        l, sp, sn, _ = O.margin_fwd_bwd(params, O.make_plan(qtype, TOY_FORMULAS[qtype]), dec, inter, t, g, a,
+                                        margin=m, weight=w, grads=grads)
+        want_l.append(l); want_p.append(sp); want_n.append(sn)
+    descs, idx, n = pack_margin_batches(items)
+    losses, pos, neg = eng.margin_fwd_bwd(descs, idx, n, want_scores=True)
+    np.testing.assert_allclose(pos.cpu().numpy(), np.concatenate(want_p), atol=SCORE_ATOL, rtol=1e-4)
+    np.testing.assert_allclose(neg.cpu().numpy(), np.concatenate(want_n), atol=SCORE_ATOL, rtol=1e-4)
+    l = losses.cpu().numpy()
+    np.testing.assert_allclose(l[:-1], want_l, rtol=LOSS_RTOL, atol=1e-6)
+    np.testing.assert_allclose(l[-1], sum(w * x for (_, _, _, _, w, _), x in zip(items, want_l)), rtol=LOSS_RTOL)
+    grouped = read_arena(eng, eng.grads)
+    assert_grads_close(grouped, grads, "%s/%s d=%d" % (dec, inter, d))
+    # one launch per batch
+    eng.grads.zero_()
+    for it in items:
+        descs, idx, n = pack_margin_batches([it])
+        eng.margin_fwd_bwd(descs, idx, n)
+    single = read_arena(eng, eng.grads)
+    assert_grads_close(single, grouped, "single vs grouped")
+    eng.close()
+
+
+def test_full_batch_512_d128_device_resident_indices():
+    """BASELINE-size batches (B=512, d=128, bilinear-diag + SetIntersection-min, the 9-batch full
+    mix) with the index feed already in HBM; checked against the fp64 oracle."""
+    import torch
+    from gpu_utils import (TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for,
+                           random_params, read_arena, toy_batch)
+    from graphqembed_amd.tensorize import pack_margin_batches
+    rng = np.random.RandomState(5)
+    d, dec, inter = 128, "bilinear-diag", "min"
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
+    eng = engine_from_params(params, d, dec, inter, max_queries=4608, max_batches=9)
+    mix = [("1-chain", 1.0), ("2-chain", 0.01), ("3-chain", 0.01), ("2-inter", 0.005), ("2-inter", 0.005),
+           ("3-inter", 0.005), ("3-inter", 0.005), ("3-inter_chain", 0.005), ("3-inter_chain", 0.005)]
+    items, grads, want_l = [], O.zero_grads_like(params), []
+    for qtype, w in mix:
+        t, g, a = toy_batch(rng, qtype, 512)
+        items.append((plan_for(eng, qtype, TOY_FORMULAS[qtype]), t, g, a, w, 1.0))
+        l, _, _, _ = O.margin_fwd_bwd(params, O.make_plan(qtype, TOY_FORMULAS[qtype]), dec, inter, t, g, a, weight=w, grads=grads)
+        want_l.append(l)
+    descs, idx, n = pack_margin_batches(items)
+    didx = torch.from_numpy(idx).cuda()
+    losses, _, _ = eng.margin_fwd_bwd(descs, didx, n)
+    np.testing.assert_allclose(losses.cpu().numpy()[:-1], want_l, rtol=LOSS_RTOL)
+    assert_grads_close(read_arena(eng, eng.grads), grads, "full mix")
+    eng.close()
+
+
+def test_error_paths():
+    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, toy_batch
+    from graphqembed_amd.engine import GqeError
+    from graphqembed_amd.tensorize import pack_margin_batches
+    rng = np.random.RandomState(0)
+    params = random_params(rng, 16, "bilinear-diag", "min", TOY_SIZES, TOY_KINDS)
+    eng = engine_from_params(params, 16, "bilinear-diag", "min")
+    plan = plan_for(eng, "2-inter", TOY_FORMULAS["2-inter"])
+    t, g, a = toy_batch(rng, "2-inter", 8)
+    descs, idx, n = pack_margin_batches([(plan, t, g, a, 1.0, 1.0)])
+    with pytest.raises(GqeError):                 # index buffer too short
+        eng.margin_fwd_bwd(descs, idx[:-3], n)
+    bad = dict(descs[0]); bad["n_anchors"] = 3
+    with pytest.raises(GqeError):
+        eng.margin_fwd_bwd([bad], idx, n)
+    bad = dict(descs[0]); bad["target_table"] = 10 ** 9
+    with pytest.raises(GqeError):
+        eng.margin_fwd_bwd([bad], idx, n)
+    with pytest.raises(GqeError):
+        eng.adam_step([])  if False else eng._check(eng.lib.gqe_adam_step(eng.ctx, None, 0, 0.01, 0.9, 0.999, 1e-8, None))
+    eng.close()
