@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py — queries/sec of the fused MI355X training step on the BASELINE workload.
+
+    python bench.py [--gpus N --steps K --warmup W]            # N=1 directly
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+step      = one training iteration of the reference's post-burn-in schedule over the
+            "Bio full conjunctive mix" (train_helpers.py:50-79): 9 batches x B=512 =
+            4 608 (query, negative) pairs -> fused forward/backward (one grouped launch),
+            deferred matrix gradients, [N>1: RCCL all-reduce of the dense gradient arena],
+            one fused dense Adam step (+ grad re-zero).
+workload  = "bio-synth" (SURVEY.md §8d C3): 5 modes / 97 000 nodes / 14 directed relations,
+            d=128, bilinear-diag decoder + SetIntersection(min), P = 12 582 912 parameters;
+            index feeds of 32 distinct pre-sampled iterations are resident in HBM.
+value     = whole-job queries/s = K * 4608 * N / max-over-ranks wall time (weak scaling:
+            every rank trains its own 4 608 queries per step; gradients are averaged).
+roofline  = the dominant kernel (fused Adam pass): algorithmic bytes 32 B/param/step
+            (SURVEY.md §8d A_step) / its mean launch duration measured with hipEvents on the
+            launch stream inside the timed region; peak 8 TB/s (MI355X_MICROARCH.md).
+cpu_baseline = oracle/netquery_torch.py (torch-CPU port of the reference's iteration: two
+            eager forwards per batch, one autograd backward, dense torch.optim.Adam) on the
+            same parameters and the same batches, timed on this host (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0
+
+
+def build_layout(g, d, decoder, inter):
+    from graphqembed_amd.engine import ArenaLayout
+    from graphqembed_amd.tensorize import post_key, pre_key, rel_key, table_key
+    layout = ArenaLayout()
+    for m in g.modes:
+        layout.add(table_key(m), (g.mode_sizes[m] + 2, d))        # len(node_maps)+1 rows (bio/data_utils.py:14-17)
+    for m in g.relations:                                         # decoders.py:136-140 order
+        for (to, name) in g.relations[m]:
+            layout.add(rel_key((m, name, to)), (d, d) if decoder == "bilinear" else (d,))
+    if not inter.endswith("simple"):
+        for m in g.modes:
+            layout.add(pre_key(m), (d, d))
+            layout.add(post_key(m), (d, d))
+    return layout
+
+
+def init_params(eng, d, seed):
+    """The reference's initial distributions (bio/data_utils.py:19, decoders.py:139,225,282-285)."""
+    import torch
+    gen = torch.Generator(device=eng.device)
+    gen.manual_seed(seed)
+    for k, (off, shape) in eng.layout.entries.items():
+        v = eng.layout.view(eng.params, k)
+        if k.startswith("enc."):
+            v.normal_(0, 1.0 / d, generator=gen)
+        elif len(shape) == 1:
+            v.uniform_(-6.0 / np.sqrt(d), 6.0 / np.sqrt(d), generator=gen)
+        else:
+            lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+            v.uniform_(-lim, lim, generator=gen)
+
+
+def algorithmic_bytes_per_query(qtype, d):
+    rows = {"1-chain": 3, "2-chain": 3, "3-chain": 3, "2-inter": 4, "3-inter_chain": 4, "3-chain_inter": 4, "3-inter": 5}[qtype]
+    return rows * (8 * d + 4)                                      # SURVEY.md §8d A_q
+
+
+def cpu_baseline(eng, decoder, inter, item_sets, budget_s, queries_per_iter):
+    """Time the torch-CPU port on the same parameters / batches (bounded sample)."""
+    import torch
+    from oracle.netquery_numpy import make_plan
+    from oracle.netquery_torch import TorchPort
+    torch.cuda.synchronize()
+    host = eng.params.cpu().numpy()
+    params = {k: host[off:off + int(np.prod(shape))].reshape(shape).copy() for k, (off, shape) in eng.layout.entries.items()}
+    port = TorchPort(params, decoder, inter)
+    sets = [[(make_plan(f.query_type, f.rels), t, g, a, w, m) for (f, t, g, a, w, m) in items] for items in item_sets]
+    port.train_iteration(sets[0])                                  # warm-up (allocator, Adam state)
+    n, t0 = 0, time.time()
+    while True:
+        port.train_iteration(sets[(n + 1) % len(sets)])
+        n += 1
+        el = time.time() - t0
+        if el >= budget_s or n >= 200:
+            break
+    return {"value": round(n * queries_per_iter / el, 1), "unit": "queries/s", "cores": int(torch.get_num_threads()),
+            "kind": "port", "sample": "%d full-mix iterations (9x512 queries, P=%d, dense torch Adam) in %.1f s; "
+            "oracle/netquery_torch.py, torch %s" % (n, eng.layout.total, el, torch.__version__)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--batch-size", type=int, default=512)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--decoder", default="bilinear-diag")
+    ap.add_argument("--inter-decoder", default="min")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from graphqembed_amd import synth
+    from graphqembed_amd.engine import Engine
+    from graphqembed_amd.tensorize import FormulaPlan, pack_margin_batches
+
+    d, B = args.dim, args.batch_size
+    g = synth.bio_synth(seed=0)
+    layout = build_layout(g, d, args.decoder, args.inter_decoder)
+    mix = synth.FULL_MIX
+    qpi = B * len(mix)                                             # queries per iteration per GPU
+    eng = Engine(d, args.decoder, args.inter_decoder, layout, max_queries=qpi, max_batches=len(mix))
+    init_params(eng, d, seed=0)                                    # same seed on every rank: replicas start equal
+    pools = synth.make_pools(g, sorted(set(m[0] for m in mix)), formulas_per_type=6, pool_size=max(16 * B, 8192), seed=0)
+
+    n_distinct = 32
+    item_sets, prepared = [], []
+    plans = {}
+    for s in range(n_distinct):
+        items = synth.mix_iteration(pools, mix, s, B, rank=rank, world=world)
+        item_sets.append(items)
+        packed = []
+        for (f, t, ng, a, w, m) in items:
+            if f not in plans:
+                plans[f] = FormulaPlan(f, layout, args.inter_decoder)
+            packed.append((plans[f], t, ng, a, w, m))
+        descs, idx, _ = pack_margin_batches(packed)
+        ps = eng.prepare_margin(descs, torch.from_numpy(idx).to(eng.device))
+        ps["adam"] = eng.prepare_adam(set().union(*[p[0].touched for p in packed]))
+        ps["aq_bytes"] = sum(algorithmic_bytes_per_query(f.query_type, d) * len(t) for (f, t, _, _, _, _) in items)
+        ps["p_touched"] = sum(layout.numel(k) for k in ps["adam"]["keys"])
+        prepared.append(ps)
+
+    def step(i):
+        ps = prepared[i % n_distinct]
+        eng.run_margin(ps)
+        if dist is not None:
+            dist.all_reduce(eng.grads)                             # RCCL sum of the dense gradient arena (xGMI)
+        eng.run_adam(ps["adam"])
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    eng.timing_enable(True)                                        # hipEvent pairs are recycled after warm-up
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    for k in range(3):
+        eng.timing_read(k)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_fused, n_fused = eng.timing_read(0)
+    ms_gemm, n_gemm = eng.timing_read(1)
+    ms_opt, n_opt = eng.timing_read(2)
+    eng.timing_enable(False)
+    loss = float(prepared[(args.warmup + args.steps - 1) % n_distinct]["losses"][-1].item())
+    if not np.isfinite(loss):
+        raise SystemExit("non-finite loss")
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = args.steps * qpi * world / elapsed
+    used = [prepared[(args.warmup + i) % n_distinct] for i in range(min(args.steps, n_distinct))]
+    a_step = 32.0 * np.mean([p["p_touched"] for p in used])        # bytes per optimiser launch
+    a_q = float(np.mean([p["aq_bytes"] for p in used]))            # bytes per fused fwd/bwd launch
+    achieved = a_step / (ms_opt * 1e-3) / 1e9 if ms_opt > 0 else 0.0
+    out = {
+        "metric": "queries/sec, Bio full conjunctive mix d=%d, at 1/2/4/8 MI355X" % d,
+        "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "bio-synth full mix (1/2/3-chain, 2/3-inter x{neg,hard}, 3-inter_chain x{neg,hard}): "
+                               "%d batches x B=%d per GPU per step, d=%d, %s + SetIntersection(%s), P=%d, Adam lr 0.01"
+                               % (len(mix), B, d, args.decoder, args.inter_decoder, layout.total),
+                   "graph": "5 modes, 97000 nodes, 14 directed relations, 60000 edges/kind, seed 0",
+                   "queries_per_step_per_gpu": qpi, "parallelism": "dp%d" % world,
+                   "gradient_exchange": "none" if world == 1 else "RCCL all-reduce of the %d-float gradient arena" % layout.total},
+        "roofline": {"bound": "hbm", "kernel": "gqe_opt_kernel<ADAM> (fused Adam + grad re-zero)",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": a_step, "avg_launch_ms": round(ms_opt, 5), "launches": n_opt},
+        "kernels": {"fused_fwd_bwd": {"avg_launch_ms": round(ms_fused, 5), "launches": n_fused,
+                                      "algorithmic_bytes_per_launch": a_q,
+                                      "achieved_GBs": round(a_q / (ms_fused * 1e-3) / 1e9, 1) if ms_fused > 0 else None},
+                    "pair_gemm": {"avg_launch_ms": round(ms_gemm, 5), "launches": n_gemm}},
+        "step_roofline": {"algorithmic_bytes_per_step": a_step + a_q,
+                          "achieved_GBs": round((a_step + a_q) / (ms_per_step * 1e-3) / 1e9, 1),
+                          "frac": round((a_step + a_q) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "final_loss": round(loss, 6),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(eng, args.decoder, args.inter_decoder, item_sets[:8], args.cpu_seconds, qpi)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,7 @@ struct gqe_ctx {
   std::string err;
   bool timing = false;
   std::vector<TimedLaunch> timed[3];
+  std::vector<TimedLaunch> event_pool;  // recycled hipEvent pairs (creation is not free)
 };
 
 namespace {
@@ -103,8 +104,13 @@ int ring_acquire(gqe_ctx* ctx, size_t bytes, RingSlot** out) {
 int timing_begin(gqe_ctx* ctx, int kind, hipStream_t st) {
   if (!ctx->timing) return GQE_OK;
   TimedLaunch t;
-  HIP_TRY(ctx, hipEventCreate(&t.start));
-  HIP_TRY(ctx, hipEventCreate(&t.stop));
+  if (!ctx->event_pool.empty()) {
+    t = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+  } else {
+    HIP_TRY(ctx, hipEventCreate(&t.start));
+    HIP_TRY(ctx, hipEventCreate(&t.stop));
+  }
   HIP_TRY(ctx, hipEventRecord(t.start, st));
   ctx->timed[kind].push_back(t);
   return GQE_OK;
@@ -399,10 +405,11 @@ int gqe_destroy(gqe_ctx* ctx) {
     if (s.host) (void)hipHostFree(s.host);
   }
   for (auto& tv : ctx->timed)
-    for (auto& t : tv) {
-      (void)hipEventDestroy(t.start);
-      (void)hipEventDestroy(t.stop);
-    }
+    for (auto& t : tv) ctx->event_pool.push_back(t);
+  for (auto& t : ctx->event_pool) {
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+  }
   delete ctx;
   return GQE_OK;
 }
@@ -480,8 +487,7 @@ int gqe_timing_read(gqe_ctx* ctx, int32_t kernel, float* avg_ms, int32_t* count)
     HIP_TRY(ctx, hipEventElapsedTime(&ms, t.start, t.stop));
     total += ms;
     ++n;
-    (void)hipEventDestroy(t.start);
-    (void)hipEventDestroy(t.stop);
+    ctx->event_pool.push_back(t);
   }
   ctx->timed[kernel].clear();
   *avg_ms = n ? (float)(total / n) : 0.f;

@@ -261,6 +261,34 @@ class Engine(object):
                                                 pp, pn, self._stream()))
         return losses, pos, neg
 
+    # -- pre-packed steps (lowest host overhead: bench / steady-state trainer) ------
+    def prepare_margin(self, descs, idx_dev):
+        """Freeze one iteration's batches: ctypes descriptors + HBM-resident index feed."""
+        total = sum(dsc["n"] for dsc in descs)
+        self.reserve(total, len(descs))
+        t = self.torch
+        assert idx_dev.dtype == t.int32 and idx_dev.is_cuda and idx_dev.is_contiguous()
+        return {"arr": self.make_batches(descs), "n": len(descs), "idx": idx_dev,
+                "idx_ptr": C.c_void_p(idx_dev.data_ptr()), "n_idx": int(idx_dev.numel()),
+                "losses": t.zeros(len(descs) + 1, dtype=t.float32, device=self.device), "queries": total}
+
+    def run_margin(self, ps, stream=None):
+        self._check(self.lib.gqe_margin_fwd_bwd(self.ctx, ps["arr"], ps["n"], ps["idx_ptr"], ps["n_idx"], 1,
+                                                ps["losses"].data_ptr(), None, None,
+                                                stream if stream is not None else self._stream()))
+
+    def prepare_adam(self, keys):
+        keys = [k for k in self.layout.entries if k in set(keys)]
+        return {"keys": keys, "arr": self._segments(keys, False), "n": len(keys)}
+
+    def run_adam(self, pa, lr=0.01, betas=(0.9, 0.999), eps=1e-8, stream=None):
+        arr, steps = pa["arr"], self.steps
+        for i, k in enumerate(pa["keys"]):
+            steps[k] += 1
+            arr[i].step = steps[k]
+        self._check(self.lib.gqe_adam_step(self.ctx, arr, pa["n"], lr, betas[0], betas[1], eps,
+                                           stream if stream is not None else self._stream()))
+
     # -- optimiser --------------------------------------------------------------
     def _segments(self, keys, bump):
         arr = (gqe_segment * len(keys))()

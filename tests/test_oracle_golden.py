@@ -93,3 +93,23 @@ def test_adam_single_step_formula():
         opt.step()
         O.adam_step(params, {"x": g.astype(np.float64)}, state, ["x"])
         np.testing.assert_allclose(params["x"], tp.detach().numpy(), rtol=0, atol=3e-6)
+
+
+@pytest.mark.parametrize("path,dec,inter,d", model_files(), ids=lambda v: os.path.basename(v) if isinstance(v, str) and v.endswith(".npz") else None)
+def test_torch_port_matches_golden(path, dec, inter, d):
+    """oracle/netquery_torch.py (bench.py's cpu_baseline) reproduces the reference's scores,
+    loss and gradients."""
+    from oracle.netquery_torch import TorchPort
+    z = np.load(path)
+    params = load_params(z, d)
+    for case in case_names(z):
+        c = load_case(z, case)
+        port = TorchPort(params, dec, inter)
+        plan = O.make_plan(c["type"], c["rels"])
+        loss = port.margin_loss(plan, c["target"], c["neg"], c["anchors"], c["margin"])
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), c["loss"], rtol=1e-6, err_msg=case)
+        got = port.grads()
+        for k, g in c["grads"].items():
+            np.testing.assert_allclose(got[k], g, rtol=1e-4, atol=1e-7 + 1e-5 * np.abs(g).max(), err_msg="%s %s" % (case, k))
+        assert set(k for k, g in got.items() if g is not None) == set(c["grads"].keys())
