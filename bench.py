@@ -36,6 +36,17 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the newest committed PMC summary (profiles/r*_pmc_traffic.json); the
+    counters cannot be collected from inside this process, so this is the last profiled value."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+
+
 def build_layout(g, d, decoder, inter):
     from graphqembed_amd.engine import ArenaLayout
     from graphqembed_amd.tensorize import post_key, pre_key, rel_key, table_key
@@ -209,7 +220,8 @@ def main():
                    "gradient_exchange": "none" if world == 1 else "RCCL all-reduce of the %d-float gradient arena" % layout.total},
         "roofline": {"bound": "hbm", "kernel": "gqe_opt_kernel<ADAM> (fused Adam + grad re-zero)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": pmc_traffic("gqe_opt_kernel") if (d, B, args.decoder, args.inter_decoder) == (128, 512, "bilinear-diag", "min") else None,
                      "algorithmic_bytes_per_launch": a_step, "avg_launch_ms": round(ms_opt, 5), "launches": n_opt},
         "kernels": {"fused_fwd_bwd": {"avg_launch_ms": round(ms_fused, 5), "launches": n_fused,
                                       "algorithmic_bytes_per_launch": a_q,
