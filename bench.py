@@ -168,6 +168,7 @@ def main():
         ps = prepared[i % n_distinct]
         eng.run_margin(ps)
         if dist is not None:
+            eng.materialize()                                      # per-row gradient lists -> dense arena
             dist.all_reduce(eng.grads)                             # RCCL sum of the dense gradient arena (xGMI)
         eng.run_adam(ps["adam"])
 

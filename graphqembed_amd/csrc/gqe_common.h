@@ -1,0 +1,93 @@
+// gqe_common.h — device helpers shared by the gfx950 kernels.
+#ifndef GQE_COMMON_H
+#define GQE_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gqe_dev.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DEC_DIAG 0
+#define DEC_TRANSE 1
+#define DEC_BILINEAR 2
+#define COS_EPS 1e-8f
+
+// ------------------------------------------------------------------------------------------
+// vector-of-a-row helpers: a wave owns a row of d floats, lane l holds elements j = l + 64*c.
+// When d == 64*NC is a compile-time fact (FULL kernels) the j < d guards fold away.
+// ------------------------------------------------------------------------------------------
+template <int NC>
+struct Vec {
+  float v[NC];
+};
+
+template <int NC>
+__device__ __forceinline__ Vec<NC> vzero() {
+  Vec<NC> r;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) r.v[c] = 0.f;
+  return r;
+}
+
+template <int NC>
+__device__ __forceinline__ Vec<NC> vload(const float* p, int d, int lane) {
+  Vec<NC> r;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int j = lane + 64 * c;
+    r.v[c] = (j < d) ? p[j] : 0.f;
+  }
+  return r;
+}
+
+template <int NC>
+__device__ __forceinline__ void vstore(float* p, const Vec<NC>& x, int d, int lane) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int j = lane + 64 * c;
+    if (j < d) p[j] = x.v[c];
+  }
+}
+
+template <int NC>
+__device__ __forceinline__ void vatomic_add(float* p, const Vec<NC>& x, int d, int lane) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int j = lane + 64 * c;
+    if (j < d) unsafeAtomicAdd(p + j, x.v[c]);
+  }
+}
+
+// wave64 all-reduce on the DPP path (no LDS crossbar): quad swaps, row mirrors, row broadcasts, then the
+// total (lane 63) is broadcast through an SGPR with v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, false));
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+  x += dpp_get<0xB1, 0xF>(x);   // quad_perm [1,0,3,2]
+  x += dpp_get<0x4E, 0xF>(x);   // quad_perm [2,3,0,1]
+  x += dpp_get<0x141, 0xF>(x);  // row_half_mirror
+  x += dpp_get<0x140, 0xF>(x);  // row_mirror          -> every lane holds its row's sum
+  x += dpp_get<0x142, 0xA>(x);  // row_bcast15 -> rows 1,3
+  x += dpp_get<0x143, 0xC>(x);  // row_bcast31 -> rows 2,3 -> lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+template <int NC>
+__device__ __forceinline__ float vdot(const Vec<NC>& a, const Vec<NC>& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) s += a.v[c] * b.v[c];
+  return wave_sum(s);
+}
+
+#define VEC_OP(out, expr)                          \
+  _Pragma("unroll") for (int c = 0; c < NC; ++c) { \
+    (out).v[c] = (expr);                           \
+  }
+
+#endif

@@ -7,12 +7,15 @@
 
 #include "../../include/gqe.h"
 
-#define GQE_TQ 16            // queries per tile (= per workgroup)
-#define GQE_WAVES 4          // wave64s per workgroup
+#define GQE_TQ 16            // queries per tile (= per workgroup of the fused kernel)
+#define GQE_FWAVES 8         // wave64s per workgroup of the fused kernel
+#define GQE_FTHREADS 512
+#define GQE_WAVES 4          // wave64s per workgroup of the pair-GEMM / optimiser kernels
 #define GQE_THREADS 256
 #define GQE_OPT_CHUNK 1024   // floats per optimiser chunk (256 threads x float4)
 #define GQE_MAX_SEGS 96
 #define GQE_GEMM_KCHUNK 128  // queries per pair-GEMM unit
+#define GQE_PROF_SLOTS 16     // wall_clock64 stamps per workgroup (debug profile)
 
 // Device-side view of one batch (gqe_batch + launch geometry + scratch slots).
 struct GqeDevBatch {
@@ -25,6 +28,9 @@ struct GqeDevBatch {
   int64_t hop_param[GQE_MAX_BRANCH][GQE_MAX_HOPS];
   int64_t final_param, pre_param, post_param;
   int64_t scratch_base;  // float offset of this batch's scratch rows in the workspace
+  int64_t target_head;                    // index of the target table's row 0 in the gradient-list heads
+  int64_t anchor_head[GQE_MAX_BRANCH];
+  int64_t entry_base;                     // first contribution entry of this batch: [role][query]
   float margin, grad_scale, inv_B, loss_weight;
   // scratch slots (row blocks of Bpad x d floats); -1 = unused
   int32_t slot_x[GQE_MAX_BRANCH][GQE_MAX_HOPS];   // bilinear: input of hop h of branch i
@@ -45,15 +51,55 @@ struct GqeGemmJob {
 
 struct GqeDevSeg {
   int64_t offset, numel, chunk_begin;
+  int64_t rows, head_base;  // tables only
   float step_size, bc2_sqrt;
+  int32_t is_table, pad;
 };
 
-size_t gqe_fused_lds_bytes(int d);
-hipError_t gqe_launch_fused(int dec, int mlp, int inter_min, bool bwd, int tiles, hipStream_t st, const GqeDevBatch* db,
-                            int nb, const float* params, float* grads, float* ws, const int32_t* idx, int d,
-                            float* losses, float* pos, float* neg);
+#define GQE_OPT_ADAM 0
+#define GQE_OPT_SGD 1
+#define GQE_OPT_ZERO 2
+#define GQE_OPT_MATERIALIZE 3
+
+struct GqeOptArgs {
+  int mode;
+  bool lists;         // some table has pending gradient lists
+  bool dense_tables;  // the dense gradient of the tables has to be read (and re-zeroed) too
+  const GqeDevSeg* segs;
+  int n_segs;
+  long long total_chunks;
+  float *p, *g, *m, *v;
+  int32_t* head;
+  const int32_t* next;
+  const float* contrib;
+  int d;
+  float lr, b1, b2, eps;
+  hipStream_t stream;
+};
+
+// everything one fused launch needs (built by gqe_host.cpp, consumed by the per-variant launchers)
+struct GqeFusedArgs {
+  const GqeDevBatch* batches;
+  int n_batches;
+  const int16_t* tile_batch;  // tile -> batch index
+  int tiles;
+  const float* params;
+  float* grads;
+  float* ws;
+  const int32_t* idx;
+  int d;
+  float *losses, *pos, *neg;
+  int inter_min;
+  bool bwd;
+  long long* prof;
+  hipStream_t stream;
+  int32_t* head;   // gradient lists: head[table row] -> newest contribution entry (-1 = none)
+  int32_t* next;   // next[entry]
+  float* contrib;  // contrib[entry][d]
+};
+
+hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a);
 hipError_t gqe_launch_pair_gemm(int n_units, hipStream_t st, const GqeGemmJob* jobs, const float* ws, float* grads, int d);
-hipError_t gqe_launch_opt(int mode, hipStream_t st, const GqeDevSeg* segs, int n_segs, long long total_chunks, float* p,
-                          float* g, float* m, float* v, float lr, float b1, float b2, float eps);
+hipError_t gqe_launch_opt(const GqeOptArgs& a);
 
 #endif

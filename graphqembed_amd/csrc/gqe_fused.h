@@ -1,0 +1,904 @@
+// gqe_fused.h — the fused forward(+backward) kernel of the conjunctive-query path (gfx950).
+//
+// What is computed follows netquery/model.py:70-127, encoders.py:40-43, decoders.py:142-150,
+// 200-208, 228-236, 288-319 (maths: SURVEY.md Appendix B / oracle/netquery_numpy.py).  How:
+//   * one workgroup = 8 wave64 owns a TILE of 16 queries of ONE batch (= one Formula), so every
+//     relation parameter is workgroup-uniform; one grouped launch covers all batches of an iteration;
+//   * the tile's table rows are fetched with one coalesced index read, then EVERY embedding row the
+//     tile needs (target, negative, up to 3 anchors per query) is requested at once — one wave per row,
+//     lanes strided over the row — and stays in registers for the whole kernel (the backward re-uses it);
+//   * reductions over a row are DPP wave reductions whose result lands in an SGPR;
+//   * element-wise decoders (bilinear-diag, TransE) are wave ops on those registers;
+//   * d x d contractions (Bilinear hops, SetIntersection Pre/Post, and their transposes in the backward)
+//     run on the matrix cores with the exact-fp32 v_mfma_f32_16x16x4_f32: 16-query LDS tiles are the B
+//     operand, the matrix streams from L2 as the A operand with all of a wave's loads in flight at once;
+//     the Pre matrix is loaded ONCE for all 2-3 branches, and relu + first-arg-min / mean run on the MFMA
+//     accumulators before anything is written back;
+//   * the positive and the negative score share the query side (the reference recomputes it);
+//   * a row gradient is written once, coalesced, as a contribution entry and linked onto its table row
+//     with ONE 4-byte atomic exchange (the optimiser pass sums the lists); relation-vector gradients and
+//     the loss are reduced per workgroup before they touch an atomic; d x d matrix gradients are deferred
+//     to the pair-GEMM kernel through (left,right) scratch rows.
+#ifndef GQE_FUSED_H
+#define GQE_FUSED_H
+
+#include "gqe_common.h"
+
+#define RPW (GQE_TQ / GQE_FWAVES)  // query rows owned by one wave
+
+struct TileEnv {
+  const GqeDevBatch* b;
+  const float* params;
+  float* grads;
+  float* ws;  // scratch (floats)
+  int32_t* head;
+  int32_t* next;
+  float* contrib;
+  int d, DP, wave, lane, q0;  // q0 = first query of this tile
+};
+
+__device__ __forceinline__ float* scratch_row(const TileEnv& e, int slot, int r) {
+  return e.ws + e.b->scratch_base + ((size_t)slot * e.b->Bpad + e.q0 + r) * e.d;
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA tile contractions.  v_mfma_f32_16x16x4_f32: lane l feeds A[i=l&15][k=l>>4] and
+// B[k=l>>4][j=l&15], receives D[i=4*(l>>4)+r][j=l&15] (r = 0..3).  A lane fetches 4 consecutive k
+// per k-block, so MFMA step s of k-block kb contracts k = 16*kb + 4*(l>>4) + s for A and B alike.
+// Wave w owns the 16-row output slabs i0 = 16*(w, w+8, ...).
+//   TRANS = false: A[i][k] = M[i][k]  (M . x : "project", decoders.py:150; Pre/Post forward)
+//   TRANS = true : A[i][k] = M[k][i]  (M^T . x : x^T M of decoders.py:145; every backward)
+// ------------------------------------------------------------------------------------------
+template <bool TRANS, int KB>
+__device__ __forceinline__ void load_a_slab(float4 (&a)[KB], const float* __restrict__ M, int d, int nkb, int i0, int lq,
+                                            int lk) {
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    if (kb < nkb) {
+      if (!TRANS) {
+        a[kb] = *reinterpret_cast<const float4*>(M + (size_t)(i0 + lq) * d + kb * 16 + 4 * lk);
+      } else {
+        const float* mp = M + (size_t)(kb * 16 + 4 * lk) * d + i0 + lq;
+        a[kb] = make_float4(mp[0], mp[d], mp[2 * d], mp[3 * d]);
+      }
+    } else {
+      a[kb] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+__device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+  return acc;
+}
+
+// dst[q][i] = sum_k A[i][k] src[q][k]   (one source tile)
+template <bool TRANS, int NC>
+__device__ __forceinline__ void tile_matmul(float* __restrict__ dst, const float* __restrict__ M,
+                                            const float* __restrict__ src, int d, int DP, int wave, int lane) {
+  constexpr int KB = 4 * NC;
+  const int lq = lane & 15, lk = lane >> 4, nkb = d >> 4;
+  for (int i0 = wave * 16; i0 < d; i0 += GQE_FWAVES * 16) {
+    float4 a[KB];
+    load_a_slab<TRANS, KB>(a, M, d, nkb, i0, lq, lk);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      if (kb < nkb) {
+        const float4 b = *reinterpret_cast<const float4*>(src + lq * DP + kb * 16 + 4 * lk);
+        acc = mfma4(a[kb], b, acc);
+      }
+    }
+    *reinterpret_cast<float4*>(dst + lq * DP + i0 + 4 * lk) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
+// SetIntersection forward for NB branches at once (decoders.py:288-299):
+//   z_b = Pre . e_b ; h = agg_b relu(z_b) ; meta = (relu signs << 4) | first arg-min
+// The Pre slab is loaded once and shared by the branches; relu / min / mean run on the accumulators.
+template <int NC, int NB>
+__device__ __forceinline__ void pre_intersect(float* __restrict__ th, int* __restrict__ tmeta,
+                                              const float* __restrict__ P, float* const (&te)[GQE_MAX_BRANCH], int d,
+                                              int DP, int wave, int lane, int inter_min) {
+  constexpr int KB = 4 * NC;
+  const int lq = lane & 15, lk = lane >> 4, nkb = d >> 4;
+  for (int i0 = wave * 16; i0 < d; i0 += GQE_FWAVES * 16) {
+    float4 a[KB];
+    load_a_slab<false, KB>(a, P, d, nkb, i0, lq, lk);
+    f32x4 acc[NB];
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) acc[bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      if (kb < nkb) {
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi) {
+          const float4 b = *reinterpret_cast<const float4*>(te[bi] + lq * DP + kb * 16 + 4 * lk);
+          acc[bi] = mfma4(a[kb], b, acc[bi]);
+        }
+      }
+    }
+    float hv[4];
+    int mv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float best = fmaxf(acc[0][r], 0.f);
+      int meta = (acc[0][r] > 0.f) << 4;
+#pragma unroll
+      for (int bi = 1; bi < NB; ++bi) {
+        const float z = acc[bi][r];
+        const float v = fmaxf(z, 0.f);
+        meta |= (z > 0.f) << (4 + bi);
+        if (inter_min) {
+          if (v < best) {  // strict: torch.min keeps the FIRST minimum
+            best = v;
+            meta = (meta & ~3) | bi;
+          }
+        } else {
+          best += v;
+        }
+      }
+      hv[r] = inter_min ? best : best / (float)NB;
+      mv[r] = meta;
+    }
+    *reinterpret_cast<float4*>(th + lq * DP + i0 + 4 * lk) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+    *reinterpret_cast<int4*>(tmeta + lq * DP + i0 + 4 * lk) = make_int4(mv[0], mv[1], mv[2], mv[3]);
+  }
+}
+
+__device__ __forceinline__ float mask_gz(float gh, int meta, int bi, int inter_min, float inv_n, bool mlp) {
+  float g = inter_min ? (((meta & 3) == bi) ? gh : 0.f) : gh * inv_n;
+  if (mlp && !((meta >> (4 + bi)) & 1)) g = 0.f;  // relu'(z) = [z > 0]
+  return g;
+}
+
+// SetIntersection backward for NB branches at once: g_e_b = Pre^T . g_z_b with
+// g_z_b = mask_b(meta) (.) g_h built on the fly as the B operand (never materialised in LDS).
+template <int NC, int NB>
+__device__ __forceinline__ void pre_intersect_bwd(float* const (&te)[GQE_MAX_BRANCH], const float* __restrict__ P,
+                                                  const float* __restrict__ tgh, const int* __restrict__ tmeta, int d,
+                                                  int DP, int wave, int lane, int inter_min) {
+  constexpr int KB = 4 * NC;
+  const int lq = lane & 15, lk = lane >> 4, nkb = d >> 4;
+  const float inv_n = 1.f / (float)NB;
+  for (int i0 = wave * 16; i0 < d; i0 += GQE_FWAVES * 16) {
+    float4 a[KB];
+    load_a_slab<true, KB>(a, P, d, nkb, i0, lq, lk);
+    f32x4 acc[NB];
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) acc[bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      if (kb < nkb) {
+        const float4 gh = *reinterpret_cast<const float4*>(tgh + lq * DP + kb * 16 + 4 * lk);
+        const int4 mt = *reinterpret_cast<const int4*>(tmeta + lq * DP + kb * 16 + 4 * lk);
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi) {
+          const float4 b = make_float4(mask_gz(gh.x, mt.x, bi, inter_min, inv_n, true), mask_gz(gh.y, mt.y, bi, inter_min, inv_n, true),
+                                       mask_gz(gh.z, mt.z, bi, inter_min, inv_n, true), mask_gz(gh.w, mt.w, bi, inter_min, inv_n, true));
+          acc[bi] = mfma4(a[kb], b, acc[bi]);
+        }
+      }
+    }
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi)
+      *reinterpret_cast<float4*>(te[bi] + lq * DP + i0 + 4 * lk) = make_float4(acc[bi][0], acc[bi][1], acc[bi][2], acc[bi][3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The RPW embedding rows one wave owns for one role (target / negative / anchor i), in registers for
+// the whole kernel: gathered once, L2-normalised (encoders.py:41-43: x / ||x||, no eps), reused by the
+// backward.  row < 0 marks a padding query (vector 0).
+// ------------------------------------------------------------------------------------------
+template <int NC>
+struct RowSet {
+  Vec<NC> x[RPW];
+  float nrm[RPW];
+  int row[RPW];
+};
+
+template <int NC>
+__device__ __forceinline__ void rows_issue(RowSet<NC>& rs, const TileEnv& e, int64_t table, const int* s_rows) {
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = s_rows[e.wave * RPW + rr];
+    rs.row[rr] = row;
+    rs.x[rr] = vload<NC>(e.params + table + (size_t)(row < 0 ? 0 : row) * e.d, e.d, e.lane);
+  }
+}
+
+template <int NC>
+__device__ __forceinline__ void rows_finish(RowSet<NC>& rs) {
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    if (rs.row[rr] < 0) {
+      rs.x[rr] = vzero<NC>();
+      rs.nrm[rr] = 1.f;
+    } else {
+      const float n = sqrtf(vdot<NC>(rs.x[rr], rs.x[rr]));
+      rs.nrm[rr] = n;
+      const float inv = 1.f / n;
+      VEC_OP(rs.x[rr], rs.x[rr].v[c] * inv);
+    }
+  }
+}
+
+// backward of x/||x||:  (g - xhat (xhat.g)) / ||x||.  The row gradient is written ONCE, coalesced, as
+// contribution entry (role, query) and pushed onto the table row's list with one 4-byte atomic exchange;
+// the optimiser pass (or gqe_materialize_grads) sums the lists.  role: 0 target, 1 negative, 2+i anchor i.
+template <int NC>
+__device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_base, int role, int r, int row,
+                                                 const Vec<NC>& xhat, float nrm, const Vec<NC>& g) {
+  const float pg = vdot<NC>(xhat, g);
+  const float inv = 1.f / nrm;
+  Vec<NC> gx;
+  VEC_OP(gx, (g.v[c] - xhat.v[c] * pg) * inv);
+  const int64_t entry = e.b->entry_base + (int64_t)role * e.b->B + (e.q0 + r);
+  vstore<NC>(e.contrib + entry * e.d, gx, e.d, e.lane);
+  if (e.lane == 0) {
+    const int old = __hip_atomic_exchange(e.head + head_base + row, (int)entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    e.next[entry] = old;
+  }
+}
+
+// cross-wave reduction of per-wave partial relation-vector gradients, then one atomic row per block
+template <int NC>
+__device__ __forceinline__ void flush_vec_grad(const TileEnv& e, float* red /*[GQE_FWAVES][d]*/, int64_t param,
+                                               const Vec<NC>& part) {
+  __syncthreads();
+  vstore<NC>(red + e.wave * e.d, part, e.d, e.lane);
+  __syncthreads();
+  if (e.wave == 0) {
+    Vec<NC> s = vload<NC>(red, e.d, e.lane);
+#pragma unroll
+    for (int w = 1; w < GQE_FWAVES; ++w) {
+      Vec<NC> t = vload<NC>(red + w * e.d, e.d, e.lane);
+      VEC_OP(s, s.v[c] + t.v[c]);
+    }
+    vatomic_add<NC>(e.grads + param, s, e.d, e.lane);
+  }
+}
+
+template <int NC>
+__device__ __forceinline__ void tile_to_scratch(const TileEnv& e, int slot, const float* tile) {
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int r = e.wave * RPW + rr;
+    vstore<NC>(scratch_row(e, slot, r), vload<NC>(tile + r * e.DP, e.d, e.lane), e.d, e.lane);
+  }
+}
+
+template <int DEC, bool MLP, int NC, bool FULL, bool BWD>
+__global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBatch* __restrict__ batches, int n_batches,
+                                                                const int16_t* __restrict__ tile_batch,
+                                                                const float* __restrict__ params,
+                                                                float* __restrict__ grads, float* __restrict__ ws,
+                                                                const int32_t* __restrict__ idx, int d_arg,
+                                                                float* __restrict__ losses, float* __restrict__ pos_out,
+                                                                float* __restrict__ neg_out, int inter_min,
+                                                                int32_t* __restrict__ head, int32_t* __restrict__ next,
+                                                                float* __restrict__ contrib,
+                                                                long long* __restrict__ prof) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+#define GQE_STAMP(k)                                                                                              \
+  do {                                                                                                            \
+    if (prof && threadIdx.x == 0) prof[(size_t)blockIdx.x * GQE_PROF_SLOTS + (k)] = (long long)wall_clock64(); \
+  } while (0)
+  GQE_STAMP(0);
+  const int d = FULL ? 64 * NC : d_arg;
+  const int bi = tile_batch[blockIdx.x];
+  const GqeDevBatch* __restrict__ b = batches + bi;
+  TileEnv e;
+  e.b = b;
+  e.params = params;
+  e.grads = grads;
+  e.ws = ws;
+  e.head = head;
+  e.next = next;
+  e.contrib = contrib;
+  e.d = d;
+  e.DP = d + 4;
+  e.wave = threadIdx.x >> 6;
+  e.lane = threadIdx.x & 63;
+  e.q0 = ((int)blockIdx.x - b->tile_begin) * GQE_TQ;
+  const int DP = e.DP, lane = e.lane, wave = e.wave;
+  const int B = b->B;
+  const bool has_neg = b->has_neg != 0;
+  const int n = b->n_anchors;
+
+  // ---- LDS carve: 7 float tiles [16][DP] + meta tile + red[8][d] + index block ----
+  float* te[GQE_MAX_BRANCH];
+  te[0] = smem;
+  te[1] = te[0] + GQE_TQ * DP;
+  te[2] = te[1] + GQE_TQ * DP;
+  float* tt = te[2] + GQE_TQ * DP;    // temp / ping-pong
+  float* tacc = tt + GQE_TQ * DP;     // h (MLP) or q (simple); later g_h
+  float* tq = tacc + GQE_TQ * DP;     // q
+  float* tg = tq + GQE_TQ * DP;       // g_q
+  int* tmeta = reinterpret_cast<int*>(tg + GQE_TQ * DP);
+  float* red = reinterpret_cast<float*>(tmeta + GQE_TQ * DP);
+  int* s_idx = reinterpret_cast<int*>(red + GQE_FWAVES * d);  // [5][16]: target, negative, anchor 0..2
+
+  // ---- the tile's table rows: one coalesced read, then every gather is issued at once ----
+  if (threadIdx.x < 5 * GQE_TQ) {
+    const int role = threadIdx.x / GQE_TQ, r = threadIdx.x % GQE_TQ;
+    const int q = e.q0 + r;
+    int v = -1;
+    const bool used = (role == 0) || (role == 1 && has_neg) || (role >= 2 && role - 2 < n);
+    if (used && q < B) {
+      const int src = (role == 0) ? 0 : (role == 1) ? 1 : (has_neg ? role : role - 1);
+      v = idx[b->idx_offset + (size_t)src * B + q];
+    }
+    s_idx[threadIdx.x] = v;
+  }
+  __syncthreads();
+  GQE_STAMP(1);
+  RowSet<NC> RA[GQE_MAX_BRANCH], RT, RN;
+  rows_issue<NC>(RT, e, b->target_table, s_idx);
+  if (has_neg) rows_issue<NC>(RN, e, b->target_table, s_idx + GQE_TQ);
+#pragma unroll
+  for (int i = 0; i < GQE_MAX_BRANCH; ++i)
+    if (i < n) rows_issue<NC>(RA[i], e, b->anchor_table[i], s_idx + (2 + i) * GQE_TQ);
+  rows_finish<NC>(RT);
+  if (has_neg) {
+    rows_finish<NC>(RN);
+  } else {
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      RN.x[rr] = vzero<NC>();
+      RN.nrm[rr] = 1.f;
+      RN.row[rr] = -1;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < GQE_MAX_BRANCH; ++i)
+    if (i < n) rows_finish<NC>(RA[i]);
+
+  const bool is_chain = b->qtype <= 2;
+  const float gscale = b->grad_scale;  // loss_weight / B
+  float loss_part = 0.f;
+  GQE_STAMP(2);
+
+  if (is_chain) {
+    // =====================================================================================
+    // chains: score(target, anchor) with the relations applied on the TARGET side
+    // =====================================================================================
+    const int K = b->n_hops[0];
+    if (DEC != DEC_BILINEAR) {
+      // ---- bilinear-diag / TransE: everything stays in registers, one wave per query ----
+      Vec<NC> w[GQE_MAX_HOPS];
+      Vec<NC> wcomb;  // diag: prod_h w_h ; transe: sum_h w_h
+      VEC_OP(wcomb, (DEC == DEC_DIAG) ? 1.f : 0.f);
+#pragma unroll
+      for (int h = 0; h < GQE_MAX_HOPS; ++h) {
+        if (h < K) {
+          w[h] = vload<NC>(params + b->hop_param[0][h], d, lane);
+          VEC_OP(wcomb, (DEC == DEC_DIAG) ? wcomb.v[c] * w[h].v[c] : wcomb.v[c] + w[h].v[c]);
+        } else {
+          VEC_OP(w[h], (DEC == DEC_DIAG) ? 1.f : 0.f);
+        }
+      }
+      Vec<NC> gw_acc = vzero<NC>();  // diag: sum_rows (cp t+ + cn t-) (.) a ; transe: sum_rows (gu+ + gu-)
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int q = e.q0 + wave * RPW + rr;
+        if (q >= B) continue;  // wave-uniform
+        const Vec<NC>& a = RA[0].x[rr];
+        const Vec<NC>& tp = RT.x[rr];
+        const Vec<NC>& tn = RN.x[rr];
+        float sp, sn = 0.f;
+        float nap = 1.f, nup = 1.f, nun = 1.f;  // transe cosine norms
+        Vec<NC> up, un;
+        if (DEC == DEC_DIAG) {
+          // decoders.py:228-233: acts = t * w1 * .. * wk ; score = sum(acts * a)   (raw dot)
+          up = tp;
+          un = tn;
+#pragma unroll
+          for (int h = 0; h < GQE_MAX_HOPS; ++h) {
+            if (h < K) {
+              VEC_OP(up, up.v[c] * w[h].v[c]);
+              VEC_OP(un, un.v[c] * w[h].v[c]);
+            }
+          }
+          sp = vdot<NC>(up, a);
+          if (has_neg) sn = vdot<NC>(un, a);
+        } else {
+          // decoders.py:200-205: u = t + sum w ; score = cos(a, u)
+          VEC_OP(up, tp.v[c] + wcomb.v[c]);
+          VEC_OP(un, tn.v[c] + wcomb.v[c]);
+          nap = fmaxf(sqrtf(vdot<NC>(a, a)), COS_EPS);
+          nup = fmaxf(sqrtf(vdot<NC>(up, up)), COS_EPS);
+          sp = vdot<NC>(a, up) / (nap * nup);
+          if (has_neg) {
+            nun = fmaxf(sqrtf(vdot<NC>(un, un)), COS_EPS);
+            sn = vdot<NC>(a, un) / (nap * nun);
+          }
+        }
+        if (lane == 0) {
+          if (pos_out) pos_out[b->out_offset + q] = sp;
+          if (neg_out && has_neg) neg_out[b->out_offset + q] = sn;
+        }
+        if (!BWD) continue;
+        const float hinge = b->margin - (sp - sn);
+        if (hinge > 0.f) {
+          loss_part += hinge;
+          const float cp = -gscale, cn = gscale;
+          Vec<NC> ga, gtp, gtn;
+          if (DEC == DEC_DIAG) {
+            Vec<NC> tmix;
+            VEC_OP(tmix, cp * tp.v[c] + cn * tn.v[c]);
+            VEC_OP(ga, tmix.v[c] * wcomb.v[c]);
+            VEC_OP(gtp, cp * wcomb.v[c] * a.v[c]);
+            VEC_OP(gtn, cn * wcomb.v[c] * a.v[c]);
+            VEC_OP(gw_acc, gw_acc.v[c] + tmix.v[c] * a.v[c]);
+          } else {
+            // d cos(a,u)/da = u/(na nu) - s a/na^2 ; d/du = a/(na nu) - s u/nu^2
+            const float ipp = 1.f / (nap * nup), ipn = 1.f / (nap * nun);
+            const float iup = sp / (nup * nup), iun = sn / (nun * nun), iaa = 1.f / (nap * nap);
+            VEC_OP(gtp, cp * (a.v[c] * ipp - up.v[c] * iup));
+            VEC_OP(gtn, cn * (a.v[c] * ipn - un.v[c] * iun));
+            VEC_OP(ga, cp * (up.v[c] * ipp - sp * a.v[c] * iaa) + cn * (un.v[c] * ipn - sn * a.v[c] * iaa));
+            VEC_OP(gw_acc, gw_acc.v[c] + gtp.v[c] + gtn.v[c]);
+          }
+          scatter_norm_bwd<NC>(e, b->target_head, 0, wave * RPW + rr, RT.row[rr], tp, RT.nrm[rr], gtp);
+          scatter_norm_bwd<NC>(e, b->target_head, 1, wave * RPW + rr, RN.row[rr], tn, RN.nrm[rr], gtn);
+          scatter_norm_bwd<NC>(e, b->anchor_head[0], 2, wave * RPW + rr, RA[0].row[rr], a, RA[0].nrm[rr], ga);
+        }
+      }
+      if (BWD) {
+#pragma unroll
+        for (int h = 0; h < GQE_MAX_HOPS; ++h) {
+          if (h < K) {
+            Vec<NC> part = gw_acc;
+            if (DEC == DEC_DIAG) {
+              // d/dw_h = sum_rows (..) (.) prod_{j != h} w_j   (w[j >= K] = 1)
+#pragma unroll
+              for (int j = 0; j < GQE_MAX_HOPS; ++j)
+                if (j != h) VEC_OP(part, part.v[c] * w[j].v[c]);
+            }
+            flush_vec_grad<NC>(e, red, b->hop_param[0][h], part);
+          }
+        }
+      }
+    } else {
+      // ---- full Bilinear chain (decoders.py:142-147): act = t^T M1..Mk ; s = cos(act, a) ----
+      // te[0]/te[1]: u+ ping-pong, te[2]/tt: u- ping-pong; the anchor stays in registers
+      float* cur[2] = {te[0], te[2]};
+      float* alt[2] = {te[1], tt};
+      const int nside = has_neg ? 2 : 1;
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr;
+        vstore<NC>(cur[0] + r * DP, RT.x[rr], d, lane);
+        if (has_neg) vstore<NC>(cur[1] + r * DP, RN.x[rr], d, lane);
+        if (BWD) {
+          vstore<NC>(scratch_row(e, b->slot_act[0][0], r), RT.x[rr], d, lane);
+          vstore<NC>(scratch_row(e, b->slot_act[1][0], r), RN.x[rr], d, lane);
+        }
+      }
+      for (int h = 0; h < K; ++h) {
+        __syncthreads();
+        for (int s = 0; s < nside; ++s)
+          tile_matmul<true, NC>(alt[s], params + b->hop_param[0][h], cur[s], d, DP, wave, lane);
+        __syncthreads();
+        for (int s = 0; s < nside; ++s) {
+          float* tmp = cur[s];
+          cur[s] = alt[s];
+          alt[s] = tmp;
+        }
+        if (BWD && h + 1 < K)
+          for (int s = 0; s < nside; ++s) tile_to_scratch<NC>(e, b->slot_act[s][h + 1], cur[s]);
+      }
+      // scores + gradient seeds; g_u overwrites u in place
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr;
+        const int q = e.q0 + r;
+        const Vec<NC>& a = RA[0].x[rr];
+        const float nac = fmaxf(sqrtf(vdot<NC>(a, a)), COS_EPS);
+        Vec<NC> u[2];
+        float su[2] = {0.f, 0.f}, nu[2] = {1.f, 1.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s < nside) {
+            u[s] = vload<NC>(cur[s] + r * DP, d, lane);
+            nu[s] = fmaxf(sqrtf(vdot<NC>(u[s], u[s])), COS_EPS);
+            su[s] = vdot<NC>(u[s], a) / (nu[s] * nac);
+          } else {
+            u[s] = vzero<NC>();
+          }
+        }
+        if (q < B && lane == 0) {
+          if (pos_out) pos_out[b->out_offset + q] = su[0];
+          if (neg_out && has_neg) neg_out[b->out_offset + q] = su[1];
+        }
+        if (!BWD) continue;
+        const float hinge = b->margin - (su[0] - su[1]);
+        const bool act = (q < B) && hinge > 0.f;
+        if (act) loss_part += hinge;
+        const float cf[2] = {act ? -gscale : 0.f, act ? gscale : 0.f};
+        Vec<NC> ga = vzero<NC>();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const float iun = 1.f / (nu[s] * nac), iuu = su[s] / (nu[s] * nu[s]), iaa = su[s] / (nac * nac);
+          Vec<NC> gu;
+          VEC_OP(gu, cf[s] * (a.v[c] * iun - u[s].v[c] * iuu));
+          VEC_OP(ga, ga.v[c] + cf[s] * (u[s].v[c] * iun - a.v[c] * iaa));
+          vstore<NC>(cur[s] + r * DP, gu, d, lane);
+        }
+        if (act) scatter_norm_bwd<NC>(e, b->anchor_head[0], 2, wave * RPW + rr, RA[0].row[rr], a, RA[0].nrm[rr], ga);
+      }
+      if (BWD) {
+        // back through the hops: act_{h+1} = act_h M_h  =>  g_act_h = g_act_{h+1} M_h^T (= M . g per row),
+        // dM_h += act_h^T g_act_{h+1}  (deferred: pair (slot_act[s][h], slot_gact[s][h]))
+        for (int h = K - 1; h >= 0; --h) {
+          for (int s = 0; s < 2; ++s) tile_to_scratch<NC>(e, b->slot_gact[s][h], cur[s]);
+          __syncthreads();
+          for (int s = 0; s < 2; ++s)
+            tile_matmul<false, NC>(alt[s], params + b->hop_param[0][h], cur[s], d, DP, wave, lane);
+          __syncthreads();
+          for (int s = 0; s < 2; ++s) {
+            float* tmp = cur[s];
+            cur[s] = alt[s];
+            alt[s] = tmp;
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+          const int r = wave * RPW + rr;
+          if (e.q0 + r >= B) continue;
+          scatter_norm_bwd<NC>(e, b->target_head, 0, r, RT.row[rr], RT.x[rr], RT.nrm[rr], vload<NC>(cur[0] + r * DP, d, lane));
+          scatter_norm_bwd<NC>(e, b->target_head, 1, r, RN.row[rr], RN.x[rr], RN.nrm[rr], vload<NC>(cur[1] + r * DP, d, lane));
+        }
+      }
+    }
+  } else {
+    // =====================================================================================
+    // intersections: q = I( Proj(a_1), Proj(a_2)[, Proj(a_3)] ) [-> Proj]; s = cos(t, q)
+    // =====================================================================================
+    const float inv_n = 1.f / (float)n;
+    // ---- branch vectors e_i -> te[i] ----
+#pragma unroll
+    for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
+      if (i >= n) continue;
+      const int nh = b->n_hops[i];
+      if (DEC == DEC_BILINEAR) {
+        // stage so that the ping-pong te[i] <-> tt ends in te[i]
+        float* src = (nh & 1) ? tt : te[i];
+        float* dst = (nh & 1) ? te[i] : tt;
+        if (i > 0) __syncthreads();  // tt is shared by the branches
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+          const int r = wave * RPW + rr;
+          vstore<NC>(src + r * DP, RA[i].x[rr], d, lane);
+          if (BWD) vstore<NC>(scratch_row(e, b->slot_x[i][0], r), RA[i].x[rr], d, lane);
+        }
+        for (int h = 0; h < nh; ++h) {
+          __syncthreads();
+          tile_matmul<false, NC>(dst, params + b->hop_param[i][h], src, d, DP, wave, lane);
+          __syncthreads();
+          float* tmp = src;
+          src = dst;
+          dst = tmp;
+          if (BWD && h + 1 < nh) tile_to_scratch<NC>(e, b->slot_x[i][h + 1], src);
+        }
+        if (MLP && BWD) tile_to_scratch<NC>(e, b->slot_e[i], te[i]);
+      } else {
+        Vec<NC> w0 = vload<NC>(params + b->hop_param[i][0], d, lane);
+        Vec<NC> w1 = w0;
+        if (nh > 1) w1 = vload<NC>(params + b->hop_param[i][1], d, lane);
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+          const int r = wave * RPW + rr;
+          Vec<NC> x = RA[i].x[rr];
+          VEC_OP(x, (DEC == DEC_DIAG) ? x.v[c] * w0.v[c] : x.v[c] + w0.v[c]);
+          if (nh > 1) VEC_OP(x, (DEC == DEC_DIAG) ? x.v[c] * w1.v[c] : x.v[c] + w1.v[c]);
+          vstore<NC>(te[i] + r * DP, x, d, lane);
+          if (MLP && BWD) vstore<NC>(scratch_row(e, b->slot_e[i], r), x, d, lane);
+        }
+      }
+    }
+    // ---- intersection -> tacc (+ tmeta) ----
+    if (MLP) {
+      __syncthreads();
+      if (n == 3)
+        pre_intersect<NC, 3>(tacc, tmeta, params + b->pre_param, te, d, DP, wave, lane, inter_min);
+      else
+        pre_intersect<NC, 2>(tacc, tmeta, params + b->pre_param, te, d, DP, wave, lane, inter_min);
+      __syncthreads();
+    } else {
+      // element-wise first-arg-min / mean over the branches, own rows
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int j = lane + 64 * c;
+          if (j >= d) continue;
+          float best = te[0][r * DP + j];
+          int meta = 0x70;
+#pragma unroll
+          for (int i = 1; i < GQE_MAX_BRANCH; ++i) {
+            if (i < n) {
+              const float v = te[i][r * DP + j];
+              if (inter_min) {
+                if (v < best) {
+                  best = v;
+                  meta = 0x70 | i;
+                }
+              } else {
+                best += v;
+              }
+            }
+          }
+          tacc[r * DP + j] = inter_min ? best : best / (float)n;
+          tmeta[r * DP + j] = meta;
+        }
+      }
+    }
+    GQE_STAMP(3);
+    float* tqq = tacc;  // where q lives
+    if (MLP) {
+      if (BWD) tile_to_scratch<NC>(e, b->slot_hh, tacc);
+      tile_matmul<false, NC>(tq, params + b->post_param, tacc, d, DP, wave, lane);  // q = Post . h
+      __syncthreads();
+      tqq = tq;
+    }
+    // optional projection after the intersection (3-chain_inter, model.py:107); te[] are free now
+    float* tqpre = tqq;  // q before the final projection (needed by its backward)
+    if (b->n_final) {
+      if (DEC == DEC_BILINEAR) {
+        if (BWD) tile_to_scratch<NC>(e, b->slot_fx, tqq);
+        if (!MLP) __syncthreads();
+        tile_matmul<false, NC>(te[0], params + b->final_param, tqq, d, DP, wave, lane);
+        __syncthreads();
+      } else {
+        Vec<NC> w = vload<NC>(params + b->final_param, d, lane);
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+          const int r = wave * RPW + rr;
+          Vec<NC> x = vload<NC>(tqq + r * DP, d, lane);
+          VEC_OP(x, (DEC == DEC_DIAG) ? x.v[c] * w.v[c] : x.v[c] + w.v[c]);
+          vstore<NC>(te[0] + r * DP, x, d, lane);
+        }
+      }
+      tqq = te[0];
+    }
+    // ---- scores, hinge, gradient seeds (own rows; no cross-wave traffic) ----
+    GQE_STAMP(4);
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int r = wave * RPW + rr;
+      const int q = e.q0 + r;
+      Vec<NC> qv = vload<NC>(tqq + r * DP, d, lane);
+      const float nq = fmaxf(sqrtf(vdot<NC>(qv, qv)), COS_EPS);
+      const Vec<NC>& tp = RT.x[rr];
+      const Vec<NC>& tn = RN.x[rr];
+      const float ncp = fmaxf(sqrtf(vdot<NC>(tp, tp)), COS_EPS);
+      const float ncn = fmaxf(sqrtf(vdot<NC>(tn, tn)), COS_EPS);
+      const float sp = vdot<NC>(tp, qv) / (ncp * nq);
+      const float sn = has_neg ? vdot<NC>(tn, qv) / (ncn * nq) : 0.f;
+      if (q < B && lane == 0) {
+        if (pos_out) pos_out[b->out_offset + q] = sp;
+        if (neg_out && has_neg) neg_out[b->out_offset + q] = sn;
+      }
+      if (!BWD) continue;
+      const float hinge = b->margin - (sp - sn);
+      const bool act = (q < B) && hinge > 0.f;
+      if (act) loss_part += hinge;
+      const float cp = act ? -gscale : 0.f, cn = act ? gscale : 0.f;
+      const float ipq = 1.f / (ncp * nq), inq = 1.f / (ncn * nq), iqq = 1.f / (nq * nq);
+      Vec<NC> gq, gtp, gtn;
+      VEC_OP(gq, cp * (tp.v[c] * ipq - sp * qv.v[c] * iqq) + cn * (tn.v[c] * inq - sn * qv.v[c] * iqq));
+      vstore<NC>(tg + r * DP, gq, d, lane);
+      if (act) {
+        const float ipp = sp / (ncp * ncp), inn = sn / (ncn * ncn);
+        VEC_OP(gtp, cp * (qv.v[c] * ipq - tp.v[c] * ipp));
+        VEC_OP(gtn, cn * (qv.v[c] * inq - tn.v[c] * inn));
+        scatter_norm_bwd<NC>(e, b->target_head, 0, wave * RPW + rr, RT.row[rr], tp, RT.nrm[rr], gtp);
+        scatter_norm_bwd<NC>(e, b->target_head, 1, wave * RPW + rr, RN.row[rr], tn, RN.nrm[rr], gtn);
+      }
+    }
+    GQE_STAMP(5);
+    if (BWD) {
+      // ---- backward of the final projection: g (tile tgc) -> grad wrt q_pre ----
+      float* tgc = tg;
+      if (b->n_final) {
+        if (DEC == DEC_BILINEAR) {
+          tile_to_scratch<NC>(e, b->slot_fg, tg);
+          __syncthreads();
+          tile_matmul<true, NC>(te[1], params + b->final_param, tg, d, DP, wave, lane);
+          __syncthreads();
+          tgc = te[1];
+        } else {
+          Vec<NC> w = vload<NC>(params + b->final_param, d, lane);
+          Vec<NC> gw = vzero<NC>();
+#pragma unroll
+          for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr;
+            Vec<NC> g = vload<NC>(tg + r * DP, d, lane);
+            if (DEC == DEC_DIAG) {
+              Vec<NC> qp = vload<NC>(tqpre + r * DP, d, lane);
+              VEC_OP(gw, gw.v[c] + g.v[c] * qp.v[c]);
+              VEC_OP(g, g.v[c] * w.v[c]);
+              vstore<NC>(tg + r * DP, g, d, lane);
+            } else {
+              VEC_OP(gw, gw.v[c] + g.v[c]);
+            }
+          }
+          flush_vec_grad<NC>(e, red, b->final_param, gw);
+        }
+      }
+      // ---- backward of Post: g_h -> tacc (h itself is already parked in scratch) ----
+      float* tgh = tgc;  // grad wrt h (MLP) or wrt the intersection output (simple)
+      if (MLP) {
+        tile_to_scratch<NC>(e, b->slot_gq, tgc);
+        __syncthreads();
+        tile_matmul<true, NC>(tacc, params + b->post_param, tgc, d, DP, wave, lane);  // g_h = Post^T g_q
+        __syncthreads();
+        tgh = tacc;
+      }
+      GQE_STAMP(6);
+      // ---- backward of Pre for all branches: g_e_i -> te[i] ----
+      if (MLP) {
+#pragma unroll
+        for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
+          if (i >= n) continue;
+#pragma unroll
+          for (int rr = 0; rr < RPW; ++rr) {  // g_z_i rows for the deferred dPre (own rows)
+            const int r = wave * RPW + rr;
+            Vec<NC> gz;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              const int j = lane + 64 * c;
+              gz.v[c] = (j < d) ? mask_gz(tgh[r * DP + j], tmeta[r * DP + j], i, inter_min, inv_n, true) : 0.f;
+            }
+            vstore<NC>(scratch_row(e, b->slot_gz[i], r), gz, d, lane);
+          }
+        }
+        if (n == 3)
+          pre_intersect_bwd<NC, 3>(te, params + b->pre_param, tgh, tmeta, d, DP, wave, lane, inter_min);
+        else
+          pre_intersect_bwd<NC, 2>(te, params + b->pre_param, tgh, tmeta, d, DP, wave, lane, inter_min);
+        __syncthreads();
+      } else if (DEC == DEC_BILINEAR) {
+        // simple intersection + Bilinear hops: the masked gradient has to be a tile for the MFMA
+        if (tgc == te[1]) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
+          if (i >= n) continue;
+          float* dstt = (tgh == te[i]) ? tt : te[i];
+#pragma unroll
+          for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              const int j = lane + 64 * c;
+              if (j < d) dstt[r * DP + j] = mask_gz(tgh[r * DP + j], tmeta[r * DP + j], i, inter_min, inv_n, false);
+            }
+          }
+        }
+      }
+      // ---- back through the hops of every branch, scatter the anchors ----
+#pragma unroll
+      for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
+        if (i >= n) continue;
+        const int nh = b->n_hops[i];
+        if (DEC == DEC_BILINEAR) {
+          float* tcur = (!MLP && tgh == te[i]) ? tt : te[i];
+          float* tnext = tq;  // tq is dead in the backward; tt may hold another branch's masked gradient
+          for (int h = nh - 1; h >= 0; --h) {
+            tile_to_scratch<NC>(e, b->slot_gy[i][h], tcur);
+            __syncthreads();
+            tile_matmul<true, NC>(tnext, params + b->hop_param[i][h], tcur, d, DP, wave, lane);
+            __syncthreads();
+            float* tmp = tcur;
+            tcur = tnext;
+            tnext = tmp;
+          }
+#pragma unroll
+          for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr;
+            if (e.q0 + r >= B) continue;
+            scatter_norm_bwd<NC>(e, b->anchor_head[i], 2 + i, r, RA[i].row[rr], RA[i].x[rr], RA[i].nrm[rr],
+                                 vload<NC>(tcur + r * DP, d, lane));
+          }
+          __syncthreads();  // tt / tq are rewritten by the next branch
+        } else {
+          Vec<NC> w0 = vload<NC>(params + b->hop_param[i][0], d, lane);
+          Vec<NC> w1 = w0;
+          if (nh > 1) w1 = vload<NC>(params + b->hop_param[i][1], d, lane);
+          Vec<NC> gw0 = vzero<NC>(), gw1 = vzero<NC>();
+#pragma unroll
+          for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr;
+            if (e.q0 + r >= B) continue;
+            const Vec<NC>& x = RA[i].x[rr];
+            Vec<NC> g;
+            if (MLP) {
+              g = vload<NC>(te[i] + r * DP, d, lane);
+            } else {
+#pragma unroll
+              for (int c = 0; c < NC; ++c) {
+                const int j = lane + 64 * c;
+                g.v[c] = (j < d) ? mask_gz(tgh[r * DP + j], tmeta[r * DP + j], i, inter_min, inv_n, false) : 0.f;
+              }
+            }
+            if (DEC == DEC_DIAG) {
+              // x_1 = x_0 (.) w0, e = x_1 (.) w1 : walk back from the last hop
+              if (nh > 1) {
+                VEC_OP(gw1, gw1.v[c] + g.v[c] * x.v[c] * w0.v[c]);
+                VEC_OP(g, g.v[c] * w1.v[c]);
+              }
+              VEC_OP(gw0, gw0.v[c] + g.v[c] * x.v[c]);
+              VEC_OP(g, g.v[c] * w0.v[c]);
+            } else {
+              VEC_OP(gw0, gw0.v[c] + g.v[c]);
+            }
+            scatter_norm_bwd<NC>(e, b->anchor_head[i], 2 + i, r, RA[i].row[rr], x, RA[i].nrm[rr], g);
+          }
+          flush_vec_grad<NC>(e, red, b->hop_param[i][0], gw0);
+          if (nh > 1) flush_vec_grad<NC>(e, red, b->hop_param[i][1], (DEC == DEC_DIAG) ? gw1 : gw0);
+        }
+      }
+    }
+  }
+  GQE_STAMP(7);
+  if (BWD) {
+    // mean hinge loss of the batch (model.py:124-126) and the weighted iteration loss: reduce the 8 waves in
+    // LDS first — thousands of same-address device atomics serialise at ~12 ns each.
+    __syncthreads();
+    if (lane == 0) red[wave] = loss_part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float l = 0.f;
+#pragma unroll
+      for (int w = 0; w < GQE_FWAVES; ++w) l += red[w];
+      if (l != 0.f) {
+        l *= b->inv_B;
+        unsafeAtomicAdd(losses + bi, l);
+        unsafeAtomicAdd(losses + n_batches, l * b->loss_weight);
+      }
+    }
+  }
+  GQE_STAMP(8);
+#undef GQE_STAMP
+}
+
+// ------------------------------------------------------------------------------------------
+// per-(DEC, MLP) launcher, instantiated once per translation unit (gqe_fused_inst.hip)
+// ------------------------------------------------------------------------------------------
+inline size_t gqe_fused_lds_bytes_impl(int d) {
+  const int DP = d + 4;
+  return (size_t)(8 * GQE_TQ * DP + GQE_FWAVES * d + 5 * GQE_TQ) * sizeof(float);
+}
+
+template <int DEC, bool MLP, int NC, bool FULL>
+static hipError_t launch_fused_v(const GqeFusedArgs& a) {
+  const size_t lds = gqe_fused_lds_bytes_impl(a.d);
+  if (a.bwd)
+    hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true>), dim3(a.tiles), dim3(GQE_FTHREADS), lds, a.stream, a.batches,
+                       a.n_batches, a.tile_batch, a.params, a.grads, a.ws, a.idx, a.d, a.losses, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.prof);
+  else
+    hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, false>), dim3(a.tiles), dim3(GQE_FTHREADS), lds, a.stream, a.batches,
+                       a.n_batches, a.tile_batch, a.params, a.grads, a.ws, a.idx, a.d, a.losses, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.prof);
+  return hipGetLastError();
+}
+
+template <int DEC, bool MLP>
+static hipError_t launch_fused_dm(const GqeFusedArgs& a) {
+  const int nc = (a.d + 63) / 64;
+  const bool full = (a.d % 64) == 0;
+  switch (nc) {
+    case 1: return full ? launch_fused_v<DEC, MLP, 1, true>(a) : launch_fused_v<DEC, MLP, 1, false>(a);
+    case 2: return full ? launch_fused_v<DEC, MLP, 2, true>(a) : launch_fused_v<DEC, MLP, 2, false>(a);
+    case 3: return launch_fused_v<DEC, MLP, 3, false>(a);
+    default: return full ? launch_fused_v<DEC, MLP, 4, true>(a) : launch_fused_v<DEC, MLP, 4, false>(a);
+  }
+}
+
+#endif

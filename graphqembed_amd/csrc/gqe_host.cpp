@@ -1,10 +1,19 @@
 // gqe_host.cpp — host side of libgqe.so: context, launch planning, pinned staging, C ABI (include/gqe.h).
 //
-// Per call the host builds a compact "plan" (device batch descriptors, pair-GEMM jobs, optionally the
-// int32 index feed), writes it into a pinned ring slot and ships it with ONE hipMemcpyAsync on the
-// caller's stream; the kernels are then enqueued on the same stream.  Nothing here synchronises.
+// Per call the host builds a compact "plan" (device batch descriptors, pair-GEMM jobs, tile->batch map,
+// optionally the int32 index feed), writes it into a pinned ring slot and ships it with ONE
+// hipMemcpyAsync on the caller's stream; the kernels are then enqueued on the same stream.  Nothing
+// here synchronises (except re-use of a ring slot whose copy has not finished yet).
+//
+// Gradient bookkeeping.  Embedding-row gradients are NOT scattered with 128 atomics per row: every
+// (query, role) contribution is written once, coalesced, into a contribution buffer and pushed onto
+// a per-table-row linked list with ONE 4-byte atomic exchange (head[row], next[entry]).  The optimiser
+// pass walks the (mostly empty, length <= a few) lists while it streams p/m/v, so the dense gradient of
+// the tables is never written, re-read or re-zeroed.  gqe_materialize_grads() folds the lists into the
+// dense gradient arena for callers that need it (torch.optim compatibility, the DP all-reduce, tests).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -17,7 +26,8 @@
 namespace {
 
 constexpr int kRing = 4;
-constexpr int kMaxSlots = 20;  // upper bound of scratch slots any batch can use
+constexpr int kMaxSlots = 20;      // upper bound of pair-scratch slots any batch can use
+constexpr int kRolesPerQuery = 5;  // target, negative, <= 3 anchors
 
 thread_local std::string g_create_error;
 
@@ -32,6 +42,17 @@ struct TimedLaunch {
   hipEvent_t start, stop;
 };
 
+struct Table {
+  int64_t offset, rows, head_base;
+  bool pending;  // has un-consumed gradient lists
+};
+
+struct Layout {  // byte offsets inside the bound workspace
+  size_t jobs_off, map_off, plan_cap, idx_off, idx_cap, scratch_off, scratch_cap;
+  size_t seg_off, head_off, next_off, contrib_off, total;
+  int64_t max_entries;
+};
+
 }  // namespace
 
 struct gqe_ctx {
@@ -40,9 +61,17 @@ struct gqe_ctx {
   int64_t n_arena = 0;
   char* ws = nullptr;
   int64_t ws_bytes = 0;
+  int64_t cap_queries = 0;
+  int32_t cap_batches = 0;
+  Layout lay{};
+  std::vector<Table> tables;
+  int64_t total_rows = 0;
+  int64_t entries_used = 0;
+  bool dense_dirty = false;  // the dense gradient of some table may be non-zero (after materialize)
   RingSlot ring[kRing];
   int ring_next = 0;
   std::string err;
+  long long* prof = nullptr;  // optional per-workgroup phase stamps (gqe_debug_profile)
   bool timing = false;
   std::vector<TimedLaunch> timed[3];
   std::vector<TimedLaunch> event_pool;  // recycled hipEvent pairs (creation is not free)
@@ -63,9 +92,9 @@ int fail(gqe_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
-#define HIP_TRY(ctx, call)                                                                         \
-  do {                                                                                             \
-    hipError_t e_ = (call);                                                                        \
+#define HIP_TRY(ctx, call)                                                                             \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
     if (e_ != hipSuccess) return fail(ctx, GQE_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
   } while (0)
 
@@ -81,6 +110,25 @@ int anchors_of(int qtype) {
     case GQE_Q_3INTER: return 3;
     default: return -1;
   }
+}
+
+Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches) {
+  Layout L;
+  const int64_t rows = max_queries + (int64_t)GQE_TQ * max_batches;  // queries incl. tile padding
+  L.jobs_off = align_up(sizeof(GqeDevBatch) * GQE_MAX_BATCHES, 256);
+  L.map_off = L.jobs_off + align_up(sizeof(GqeGemmJob) * GQE_MAX_BATCHES * 16, 256);
+  L.plan_cap = L.map_off + align_up(sizeof(int16_t) * (size_t)(rows / GQE_TQ + GQE_MAX_BATCHES + 1), 256);
+  L.idx_off = L.plan_cap;
+  L.idx_cap = align_up((size_t)rows * kRolesPerQuery * sizeof(int32_t), 256);
+  L.scratch_off = L.idx_off + L.idx_cap;
+  L.scratch_cap = align_up((size_t)rows * kMaxSlots * ctx->cfg.dim * sizeof(float), 256);
+  L.seg_off = L.scratch_off + L.scratch_cap;
+  L.head_off = L.seg_off + align_up(sizeof(GqeDevSeg) * GQE_MAX_SEGS, 256);
+  L.max_entries = rows * kRolesPerQuery;
+  L.next_off = L.head_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
+  L.contrib_off = L.next_off + align_up(sizeof(int32_t) * (size_t)L.max_entries, 256);
+  L.total = L.contrib_off + align_up(sizeof(float) * (size_t)L.max_entries * ctx->cfg.dim, 256);
+  return L;
 }
 
 // get a pinned ring slot of at least `bytes`; waits only if the slot's previous copy is still running
@@ -125,13 +173,22 @@ int timing_end(gqe_ctx* ctx, int kind, hipStream_t st) {
 struct Plan {
   std::vector<GqeDevBatch> batches;
   std::vector<GqeGemmJob> jobs;
+  std::vector<int16_t> tile_batch;
+  std::vector<int> touched_tables;
   int tiles = 0;
   int units = 0;
   int64_t scratch_floats = 0;
+  int64_t entries = 0;
 };
 
 bool off_ok(const gqe_ctx* ctx, int64_t off, int64_t numel) {
   return off >= 0 && (off % 4) == 0 && off + numel <= ctx->n_arena;
+}
+
+int table_of(const gqe_ctx* ctx, int64_t offset) {
+  for (size_t t = 0; t < ctx->tables.size(); ++t)
+    if (ctx->tables[t].offset == offset) return (int)t;
+  return -1;
 }
 
 // Translate the caller's batches into device descriptors, scratch slots and deferred matrix-gradient jobs.
@@ -141,6 +198,7 @@ int build_plan(gqe_ctx* ctx, const gqe_batch* in, int n, int64_t n_idx, bool bwd
   const bool mlp = is_mlp(ctx);
   const int64_t vec = bil ? (int64_t)d * d : d;
   int64_t scratch = scratch_origin;
+  int64_t entry = ctx->entries_used;
   for (int bi = 0; bi < n; ++bi) {
     const gqe_batch& s = in[bi];
     const int na = anchors_of(s.qtype);
@@ -173,6 +231,21 @@ int build_plan(gqe_ctx* ctx, const gqe_batch* in, int n, int64_t n_idx, bool bwd
       if (!off_ok(ctx, s.anchor_table[i], d)) return fail(ctx, GQE_ERR_ARG, "batch %d: anchor_table[%d] outside the arena", bi, i);
       b.anchor_table[i] = s.anchor_table[i];
     }
+    if (bwd) {
+      // gradient lists: entries [role][query], role 0 target, 1 negative, 2+i anchor i
+      const int tt = table_of(ctx, s.target_table);
+      if (tt < 0) return fail(ctx, GQE_ERR_STATE, "batch %d: target_table %lld is not a registered table (gqe_set_tables)", bi, (long long)s.target_table);
+      b.target_head = ctx->tables[tt].head_base;
+      plan->touched_tables.push_back(tt);
+      for (int i = 0; i < na; ++i) {
+        const int ta = table_of(ctx, s.anchor_table[i]);
+        if (ta < 0) return fail(ctx, GQE_ERR_STATE, "batch %d: anchor_table[%d] is not a registered table (gqe_set_tables)", bi, i);
+        b.anchor_head[i] = ctx->tables[ta].head_base;
+        plan->touched_tables.push_back(ta);
+      }
+      b.entry_base = entry;
+      entry += (int64_t)(2 + na) * s.n_queries;
+    }
     for (int i = 0; i < nbr; ++i) {
       const int nh = s.n_hops[i];
       const int max_h = chain ? (s.qtype + 1) : ((s.qtype == GQE_Q_3INTER_CHAIN && i == 1) ? 2 : 1);
@@ -198,7 +271,7 @@ int build_plan(gqe_ctx* ctx, const gqe_batch* in, int n, int64_t n_idx, bool bwd
         b.post_param = s.post_param;
       }
     }
-    // ---- scratch slots + deferred dM jobs (training only) ----
+    // ---- pair-scratch slots + deferred dM jobs (training only) ----
     int nslot = 0;
     b.scratch_base = scratch;
     const int64_t slot_floats = (int64_t)b.Bpad * d;
@@ -256,9 +329,11 @@ int build_plan(gqe_ctx* ctx, const gqe_batch* in, int n, int64_t n_idx, bool bwd
     if (nslot > kMaxSlots) return fail(ctx, GQE_ERR_ARG, "internal: %d scratch slots", nslot);
     scratch += (int64_t)nslot * slot_floats;
     plan->tiles += b.Bpad / GQE_TQ;
+    plan->tile_batch.insert(plan->tile_batch.end(), b.Bpad / GQE_TQ, (int16_t)bi);
     plan->batches.push_back(b);
   }
   plan->scratch_floats = scratch - scratch_origin;
+  plan->entries = entry - ctx->entries_used;
   return GQE_OK;
 }
 
@@ -273,102 +348,188 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int d = ctx->cfg.dim;
+  const Layout& L = ctx->lay;
 
-  // workspace: [plan bytes | idx (if staged) | pad to 256 B | scratch floats]
   Plan plan;
-  const size_t plan_cap = align_up(sizeof(GqeDevBatch) * GQE_MAX_BATCHES, 256) + align_up(sizeof(GqeGemmJob) * GQE_MAX_BATCHES * 16, 256);
-  const size_t idx_bytes = idx_on_device ? 0 : (size_t)n_idx * sizeof(int32_t);
-  const size_t scratch_origin_bytes = align_up(plan_cap + idx_bytes, 256);
-  int rc = build_plan(ctx, batches, n_batches, n_idx, bwd, (int64_t)(scratch_origin_bytes / sizeof(float)), &plan);
+  int rc = build_plan(ctx, batches, n_batches, n_idx, bwd, (int64_t)(L.scratch_off / sizeof(float)), &plan);
   if (rc != GQE_OK) return rc;
-  const size_t need = scratch_origin_bytes + (size_t)plan.scratch_floats * sizeof(float);
-  const int64_t usable = ctx->ws_bytes - (int64_t)align_up(sizeof(GqeDevSeg) * GQE_MAX_SEGS, 256);
-  if ((int64_t)need > usable)
-    return fail(ctx, GQE_ERR_WORKSPACE, "workspace too small: need %zu bytes, usable %lld", need, (long long)usable);
-
   const size_t batch_bytes = sizeof(GqeDevBatch) * plan.batches.size();
-  const size_t jobs_off = align_up(sizeof(GqeDevBatch) * GQE_MAX_BATCHES, 256);
   const size_t jobs_bytes = sizeof(GqeGemmJob) * plan.jobs.size();
-  if (jobs_off + jobs_bytes > plan_cap) return fail(ctx, GQE_ERR_ARG, "too many deferred matrix-gradient jobs (%zu)", plan.jobs.size());
-  const size_t idx_off = plan_cap;
-  const size_t copy_bytes = idx_on_device ? (jobs_bytes ? jobs_off + jobs_bytes : batch_bytes) : idx_off + idx_bytes;
+  const size_t map_bytes = sizeof(int16_t) * plan.tile_batch.size();
+  const size_t idx_bytes = idx_on_device ? 0 : (size_t)n_idx * sizeof(int32_t);
+  if (jobs_bytes > L.map_off - L.jobs_off || L.map_off + map_bytes > L.plan_cap || idx_bytes > L.idx_cap ||
+      (size_t)plan.scratch_floats * sizeof(float) > L.scratch_cap)
+    return fail(ctx, GQE_ERR_WORKSPACE, "workspace too small for %d batches / %d tiles (bound for %lld queries, %d batches)",
+                n_batches, plan.tiles, (long long)ctx->cap_queries, ctx->cap_batches);
+  if (ctx->entries_used + plan.entries > L.max_entries)
+    return fail(ctx, GQE_ERR_WORKSPACE, "gradient contribution buffer full (%lld + %lld > %lld entries): step or "
+                "gqe_materialize_grads first", (long long)ctx->entries_used, (long long)plan.entries, (long long)L.max_entries);
+
+  const size_t copy_bytes = idx_on_device ? L.map_off + map_bytes : L.idx_off + idx_bytes;
   RingSlot* slot;
   rc = ring_acquire(ctx, copy_bytes, &slot);
   if (rc != GQE_OK) return rc;
   memcpy(slot->host, plan.batches.data(), batch_bytes);
-  if (jobs_bytes) memcpy(slot->host + jobs_off, plan.jobs.data(), jobs_bytes);
-  if (!idx_on_device) memcpy(slot->host + idx_off, idx, idx_bytes);
+  if (jobs_bytes) memcpy(slot->host + L.jobs_off, plan.jobs.data(), jobs_bytes);
+  memcpy(slot->host + L.map_off, plan.tile_batch.data(), map_bytes);
+  if (!idx_on_device) memcpy(slot->host + L.idx_off, idx, idx_bytes);
   HIP_TRY(ctx, hipMemcpyAsync(ctx->ws, slot->host, copy_bytes, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipEventRecord(slot->done, st));
   slot->in_flight = true;
 
-  const GqeDevBatch* d_batches = reinterpret_cast<const GqeDevBatch*>(ctx->ws);
-  const GqeGemmJob* d_jobs = reinterpret_cast<const GqeGemmJob*>(ctx->ws + jobs_off);
-  const int32_t* d_idx = idx_on_device ? idx : reinterpret_cast<const int32_t*>(ctx->ws + idx_off);
-  float* d_ws = reinterpret_cast<float*>(ctx->ws);
+  GqeFusedArgs fa;
+  fa.batches = reinterpret_cast<const GqeDevBatch*>(ctx->ws);
+  fa.n_batches = n_batches;
+  fa.tile_batch = reinterpret_cast<const int16_t*>(ctx->ws + L.map_off);
+  fa.tiles = plan.tiles;
+  fa.params = ctx->params;
+  fa.grads = ctx->grads;
+  fa.ws = reinterpret_cast<float*>(ctx->ws);
+  fa.idx = idx_on_device ? idx : reinterpret_cast<const int32_t*>(ctx->ws + L.idx_off);
+  fa.d = d;
+  fa.losses = losses;
+  fa.pos = pos;
+  fa.neg = neg;
+  fa.inter_min = is_min(ctx) ? 1 : 0;
+  fa.bwd = bwd;
+  fa.prof = ctx->prof;
+  fa.stream = st;
+  fa.head = reinterpret_cast<int32_t*>(ctx->ws + L.head_off);
+  fa.next = reinterpret_cast<int32_t*>(ctx->ws + L.next_off);
+  fa.contrib = reinterpret_cast<float*>(ctx->ws + L.contrib_off);
   if (bwd) HIP_TRY(ctx, hipMemsetAsync(losses, 0, sizeof(float) * (n_batches + 1), st));
 
   rc = timing_begin(ctx, 0, st);
   if (rc != GQE_OK) return rc;
-  HIP_TRY(ctx, gqe_launch_fused(ctx->cfg.decoder, is_mlp(ctx) ? 1 : 0, is_min(ctx) ? 1 : 0, bwd, plan.tiles, st, d_batches,
-                                n_batches, ctx->params, ctx->grads, d_ws, d_idx, d, losses, pos, neg));
+  HIP_TRY(ctx, gqe_launch_fused(ctx->cfg.decoder, is_mlp(ctx) ? 1 : 0, fa));
   rc = timing_end(ctx, 0, st);
   if (rc != GQE_OK) return rc;
-  if (bwd && plan.units > 0) {
-    rc = timing_begin(ctx, 1, st);
-    if (rc != GQE_OK) return rc;
-    HIP_TRY(ctx, gqe_launch_pair_gemm(plan.units, st, d_jobs, d_ws, ctx->grads, d));
-    rc = timing_end(ctx, 1, st);
-    if (rc != GQE_OK) return rc;
+  if (bwd) {
+    ctx->entries_used += plan.entries;
+    for (int t : plan.touched_tables) ctx->tables[t].pending = true;
+    if (plan.units > 0) {
+      rc = timing_begin(ctx, 1, st);
+      if (rc != GQE_OK) return rc;
+      HIP_TRY(ctx, gqe_launch_pair_gemm(plan.units, st, reinterpret_cast<const GqeGemmJob*>(ctx->ws + L.jobs_off), fa.ws, ctx->grads, d));
+      rc = timing_end(ctx, 1, st);
+      if (rc != GQE_OK) return rc;
+    }
   }
   return GQE_OK;
 }
 
+// mode: GQE_OPT_ADAM / SGD / ZERO / MATERIALIZE (gqe_dev.h)
 int run_opt(gqe_ctx* ctx, int mode, const gqe_segment* segs, int32_t n_segs, float lr, float b1, float b2, float eps,
             void* stream) {
   if (!ctx) return GQE_ERR_ARG;
-  if (!segs || n_segs < 1 || n_segs > GQE_MAX_SEGS) return fail(ctx, GQE_ERR_ARG, "n_segs must be in [1,%d]", GQE_MAX_SEGS);
   if (!ctx->params || !ctx->grads) return fail(ctx, GQE_ERR_STATE, "parameter / gradient arenas not bound");
-  if (mode == 0 && (!ctx->m || !ctx->v)) return fail(ctx, GQE_ERR_STATE, "Adam moment arenas not bound");
+  if (mode == GQE_OPT_ADAM && (!ctx->m || !ctx->v)) return fail(ctx, GQE_ERR_STATE, "Adam moment arenas not bound");
   if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  std::vector<GqeDevSeg> ds(n_segs);
+  const int d = ctx->cfg.dim;
+  std::vector<GqeDevSeg> ds;
   long long chunks = 0;
-  for (int i = 0; i < n_segs; ++i) {
-    const gqe_segment& s = segs[i];
-    if (s.offset < 0 || (s.offset % 4) != 0 || s.numel < 1 || s.offset + s.numel > ctx->n_arena)
-      return fail(ctx, GQE_ERR_ARG, "segment %d [%lld,+%lld) outside the arena or misaligned", i, (long long)s.offset, (long long)s.numel);
-    if (mode == 0 && s.step < 1) return fail(ctx, GQE_ERR_ARG, "segment %d: Adam step must be >= 1", i);
-    ds[i].offset = s.offset;
-    ds[i].numel = s.numel;
-    ds[i].chunk_begin = chunks;
-    chunks += (s.numel + GQE_OPT_CHUNK - 1) / GQE_OPT_CHUNK;
-    if (mode == 0) {
-      // torch.optim.Adam: step_size = lr / (1 - b1^t); denom = sqrt(v) / sqrt(1 - b2^t) + eps  (python doubles)
-      const double bc1 = 1.0 - std::pow((double)b1, (double)s.step);
-      const double bc2 = 1.0 - std::pow((double)b2, (double)s.step);
-      ds[i].step_size = (float)((double)lr / bc1);
-      ds[i].bc2_sqrt = (float)std::sqrt(bc2);
+  std::vector<char> seen(ctx->tables.size(), 0);
+  bool lists = false;
+  auto push = [&](int64_t offset, int64_t numel, int step, int table) {
+    GqeDevSeg g;
+    memset(&g, 0, sizeof g);
+    g.offset = offset;
+    g.numel = numel;
+    g.chunk_begin = chunks;
+    g.is_table = table >= 0 ? 1 : 0;
+    if (table >= 0) {
+      const int tpr = d / 4, rpc = GQE_THREADS / tpr;
+      g.rows = ctx->tables[table].rows;
+      g.head_base = ctx->tables[table].head_base;
+      chunks += (g.rows + rpc - 1) / rpc;
+      seen[table] = 1;
+      lists = lists || ctx->tables[table].pending;
     } else {
-      ds[i].step_size = lr;
-      ds[i].bc2_sqrt = 1.f;
+      chunks += (numel + GQE_OPT_CHUNK - 1) / GQE_OPT_CHUNK;
     }
+    if (mode == GQE_OPT_ADAM) {
+      // torch.optim.Adam: step_size = lr / (1 - b1^t); denom = sqrt(v) / sqrt(1 - b2^t) + eps  (python doubles)
+      const double bc1 = 1.0 - std::pow((double)b1, (double)step);
+      const double bc2 = 1.0 - std::pow((double)b2, (double)step);
+      g.step_size = (float)((double)lr / bc1);
+      g.bc2_sqrt = (float)std::sqrt(bc2);
+    } else {
+      g.step_size = lr;
+      g.bc2_sqrt = 1.f;
+    }
+    ds.push_back(g);
+  };
+  if (mode == GQE_OPT_MATERIALIZE) {
+    for (size_t t = 0; t < ctx->tables.size(); ++t)
+      if (ctx->tables[t].pending) push(ctx->tables[t].offset, ctx->tables[t].rows * d, 1, (int)t);
+    if (ds.empty()) {  // nothing pending: the dense gradient simply becomes authoritative
+      ctx->entries_used = 0;
+      ctx->dense_dirty = true;
+      return GQE_OK;
+    }
+  } else {
+    if (!segs || n_segs < 1 || n_segs > GQE_MAX_SEGS) return fail(ctx, GQE_ERR_ARG, "n_segs must be in [1,%d]", GQE_MAX_SEGS);
+    for (int i = 0; i < n_segs; ++i) {
+      const gqe_segment& s = segs[i];
+      if (s.offset < 0 || (s.offset % 4) != 0 || s.numel < 1 || s.offset + s.numel > ctx->n_arena)
+        return fail(ctx, GQE_ERR_ARG, "segment %d [%lld,+%lld) outside the arena or misaligned", i, (long long)s.offset, (long long)s.numel);
+      if (mode == GQE_OPT_ADAM && s.step < 1) return fail(ctx, GQE_ERR_ARG, "segment %d: Adam step must be >= 1", i);
+      const int t = table_of(ctx, s.offset);
+      if (t >= 0 && s.numel != ctx->tables[t].rows * d) return fail(ctx, GQE_ERR_ARG, "segment %d covers a table only partly", i);
+      push(s.offset, s.numel, s.step, t);
+    }
+    if (mode != GQE_OPT_ZERO)
+      for (size_t t = 0; t < ctx->tables.size(); ++t)
+        if (ctx->tables[t].pending && !seen[t])
+          return fail(ctx, GQE_ERR_STATE, "table at offset %lld has pending gradients but is not among the stepped segments",
+                      (long long)ctx->tables[t].offset);
   }
-  // the segment table has its own region at the tail of the workspace
-  const size_t seg_bytes = sizeof(GqeDevSeg) * n_segs;
-  const size_t seg_off = (size_t)ctx->ws_bytes - align_up(sizeof(GqeDevSeg) * GQE_MAX_SEGS, 256);
+  const size_t seg_bytes = sizeof(GqeDevSeg) * ds.size();
   RingSlot* slot;
   int rc = ring_acquire(ctx, seg_bytes, &slot);
   if (rc != GQE_OK) return rc;
   memcpy(slot->host, ds.data(), seg_bytes);
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->ws + seg_off, slot->host, seg_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->ws + ctx->lay.seg_off, slot->host, seg_bytes, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipEventRecord(slot->done, st));
   slot->in_flight = true;
+  GqeOptArgs oa;
+  oa.mode = mode;
+  oa.lists = lists;
+  oa.dense_tables = ctx->dense_dirty || mode == GQE_OPT_ZERO;
+  oa.segs = reinterpret_cast<const GqeDevSeg*>(ctx->ws + ctx->lay.seg_off);
+  oa.n_segs = (int)ds.size();
+  oa.total_chunks = chunks;
+  oa.p = ctx->params;
+  oa.g = ctx->grads;
+  oa.m = ctx->m;
+  oa.v = ctx->v;
+  oa.head = reinterpret_cast<int32_t*>(ctx->ws + ctx->lay.head_off);
+  oa.next = reinterpret_cast<const int32_t*>(ctx->ws + ctx->lay.next_off);
+  oa.contrib = reinterpret_cast<const float*>(ctx->ws + ctx->lay.contrib_off);
+  oa.d = d;
+  oa.lr = lr;
+  oa.b1 = b1;
+  oa.b2 = b2;
+  oa.eps = eps;
+  oa.stream = st;
   rc = timing_begin(ctx, 2, st);
   if (rc != GQE_OK) return rc;
-  HIP_TRY(ctx, gqe_launch_opt(mode, st, reinterpret_cast<const GqeDevSeg*>(ctx->ws + seg_off), n_segs, chunks, ctx->params,
-                              ctx->grads, ctx->m, ctx->v, lr, b1, b2, eps));
-  return timing_end(ctx, 2, st);
+  HIP_TRY(ctx, gqe_launch_opt(oa));
+  rc = timing_end(ctx, 2, st);
+  if (rc != GQE_OK) return rc;
+  // bookkeeping: which lists are consumed now
+  bool any_pending = false;
+  for (size_t t = 0; t < ctx->tables.size(); ++t) {
+    if (seen[t]) ctx->tables[t].pending = false;
+    any_pending = any_pending || ctx->tables[t].pending;
+  }
+  if (!any_pending) ctx->entries_used = 0;
+  if (mode == GQE_OPT_MATERIALIZE)
+    ctx->dense_dirty = true;
+  else if (!any_pending)
+    ctx->dense_dirty = false;
+  return GQE_OK;
 }
 
 }  // namespace
@@ -428,23 +589,42 @@ int gqe_bind_arena(gqe_ctx* ctx, float* params, float* grads, float* exp_avg, fl
   return GQE_OK;
 }
 
-int64_t gqe_workspace_bytes(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches) {
-  if (!ctx || max_queries < 1 || max_batches < 1) return GQE_ERR_ARG;
-  const size_t plan_cap = align_up(sizeof(GqeDevBatch) * GQE_MAX_BATCHES, 256) + align_up(sizeof(GqeGemmJob) * GQE_MAX_BATCHES * 16, 256);
-  const int64_t rows = max_queries + (int64_t)GQE_TQ * max_batches;
-  const size_t idx_bytes = (size_t)rows * (2 + GQE_MAX_BRANCH) * sizeof(int32_t);
-  const size_t scratch = (size_t)rows * kMaxSlots * ctx->cfg.dim * sizeof(float);
-  const size_t seg_tail = align_up(sizeof(GqeDevSeg) * GQE_MAX_SEGS, 256);
-  return (int64_t)(align_up(plan_cap + idx_bytes, 256) + scratch + seg_tail + 256);
+int gqe_set_tables(gqe_ctx* ctx, const int64_t* offsets, const int64_t* rows, int32_t n_tables) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (!offsets || !rows || n_tables < 1 || n_tables > GQE_MAX_SEGS) return fail(ctx, GQE_ERR_ARG, "bad table list");
+  if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "gradients pending; step or materialize before changing the tables");
+  ctx->tables.clear();
+  ctx->total_rows = 0;
+  for (int t = 0; t < n_tables; ++t) {
+    if (offsets[t] < 0 || (offsets[t] % 4) || rows[t] < 1) return fail(ctx, GQE_ERR_ARG, "table %d: bad offset / rows", t);
+    ctx->tables.push_back(Table{offsets[t], rows[t], ctx->total_rows, false});
+    ctx->total_rows += rows[t];
+  }
+  ctx->ws = nullptr;  // the workspace layout depends on the tables: it must be bound again
+  return GQE_OK;
 }
 
-int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes) {
+int64_t gqe_workspace_bytes(gqe_ctx* ctx, int64_t max_queries, int32_t max_batches) {
+  if (!ctx || max_queries < 1 || max_batches < 1 || max_batches > GQE_MAX_BATCHES) return GQE_ERR_ARG;
+  ctx->cap_queries = max_queries;
+  ctx->cap_batches = max_batches;
+  return (int64_t)make_layout(ctx, max_queries, max_batches).total;
+}
+
+int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* stream) {
   if (!ctx) return GQE_ERR_ARG;
-  if (!workspace || bytes < (int64_t)(1 << 16)) return fail(ctx, GQE_ERR_ARG, "workspace is NULL or smaller than 64 KiB");
+  if (!workspace) return fail(ctx, GQE_ERR_ARG, "workspace is NULL");
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(ctx, GQE_ERR_ARG, "workspace must be 256-byte aligned");
+  if (ctx->cap_queries < 1) return fail(ctx, GQE_ERR_STATE, "call gqe_workspace_bytes first");
+  if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "gradients pending; step or materialize before re-binding the workspace");
+  const Layout L = make_layout(ctx, ctx->cap_queries, ctx->cap_batches);
+  if ((int64_t)L.total > bytes) return fail(ctx, GQE_ERR_WORKSPACE, "workspace has %lld bytes, %zu needed", (long long)bytes, L.total);
   ctx->ws = static_cast<char*>(workspace);
-  // the last 256-aligned block is reserved for the optimiser's segment table
-  ctx->ws_bytes = bytes / 256 * 256;
+  ctx->ws_bytes = bytes;
+  ctx->lay = L;
+  // empty gradient lists: head[row] = -1
+  HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.head_off, 0xff, L.next_off - L.head_off, reinterpret_cast<hipStream_t>(stream)));
+  for (auto& t : ctx->tables) t.pending = false;
   return GQE_OK;
 }
 
@@ -459,16 +639,26 @@ int gqe_margin_fwd_bwd(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches
   return run_queries(ctx, batches, n_batches, idx, n_idx, idx_on_device, true, losses, pos_scores, neg_scores, stream);
 }
 
+int gqe_materialize_grads(gqe_ctx* ctx, void* stream) {
+  return run_opt(ctx, GQE_OPT_MATERIALIZE, nullptr, 0, 0.f, 0.f, 0.f, 0.f, stream);
+}
+
 int gqe_adam_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, float lr, float beta1, float beta2, float eps, void* stream) {
-  return run_opt(ctx, 0, segs, n_segs, lr, beta1, beta2, eps, stream);
+  return run_opt(ctx, GQE_OPT_ADAM, segs, n_segs, lr, beta1, beta2, eps, stream);
 }
 
 int gqe_sgd_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, float lr, void* stream) {
-  return run_opt(ctx, 1, segs, n_segs, lr, 0.f, 0.f, 0.f, stream);
+  return run_opt(ctx, GQE_OPT_SGD, segs, n_segs, lr, 0.f, 0.f, 0.f, stream);
 }
 
 int gqe_zero_grads(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, void* stream) {
-  return run_opt(ctx, 2, segs, n_segs, 0.f, 0.f, 0.f, 0.f, stream);
+  return run_opt(ctx, GQE_OPT_ZERO, segs, n_segs, 0.f, 0.f, 0.f, 0.f, stream);
+}
+
+int gqe_debug_profile(gqe_ctx* ctx, long long* stamps) {
+  if (!ctx) return GQE_ERR_ARG;
+  ctx->prof = stamps;
+  return GQE_OK;
 }
 
 int gqe_timing_enable(gqe_ctx* ctx, int32_t on) {

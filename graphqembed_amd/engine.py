@@ -66,14 +66,17 @@ SYMBOLS = OrderedDict([
     ("gqe_create", (C.c_int, [C.POINTER(gqe_config), C.POINTER(_P)])),
     ("gqe_destroy", (C.c_int, [_P])),
     ("gqe_bind_arena", (C.c_int, [_P, _P, _P, _P, _P, C.c_int64])),
+    ("gqe_set_tables", (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32])),
     ("gqe_workspace_bytes", (C.c_int64, [_P, C.c_int64, C.c_int32])),
-    ("gqe_bind_workspace", (C.c_int, [_P, _P, C.c_int64])),
+    ("gqe_bind_workspace", (C.c_int, [_P, _P, C.c_int64, _P])),
+    ("gqe_materialize_grads", (C.c_int, [_P, _P])),
     ("gqe_forward", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P])),
     ("gqe_margin_fwd_bwd", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P, _P, _P])),
     ("gqe_adam_step", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P])),
     ("gqe_sgd_step", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, C.c_float, _P])),
     ("gqe_zero_grads", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, _P])),
     ("gqe_timing_enable", (C.c_int, [_P, C.c_int32])),
+    ("gqe_debug_profile", (C.c_int, [_P, _P])),
     ("gqe_timing_read", (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)])),
 ])
 
@@ -162,6 +165,12 @@ class Engine(object):
         self.params, self.grads, self.exp_avg, self.exp_avg_sq = z(), z(), z(), z()
         self._check(self.lib.gqe_bind_arena(self.ctx, self.params.data_ptr(), self.grads.data_ptr(),
                                             self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), n))
+        tables = [(off, shape[0]) for k, (off, shape) in layout.entries.items()
+                  if k.startswith("enc.") and len(shape) == 2 and shape[1] == self.dim]
+        if tables:
+            offs = (C.c_int64 * len(tables))(*[t[0] for t in tables])
+            rows = (C.c_int64 * len(tables))(*[t[1] for t in tables])
+            self._check(self.lib.gqe_set_tables(self.ctx, offs, rows, len(tables)))
         self.workspace = None
         self.max_queries = self.max_batches = 0
         self.reserve(max_queries, max_batches)
@@ -180,13 +189,15 @@ class Engine(object):
             return
         self.max_queries = max(max_queries, self.max_queries)
         self.max_batches = max(max_batches, self.max_batches)
-        nbytes = self.lib.gqe_workspace_bytes(self.ctx, self.max_queries, self.max_batches)
+        if self.workspace is not None:
+            self.materialize()            # pending gradient lists live in the old workspace
+        nbytes = self.lib.gqe_workspace_bytes(self.ctx, self.max_queries, min(self.max_batches, MAX_BATCHES))
         if nbytes < 0:
             raise GqeError(int(nbytes), "gqe_workspace_bytes")
         self.torch.cuda.synchronize(self.device)
         self.workspace = self.torch.empty(int(nbytes) + 256, dtype=self.torch.uint8, device=self.device)
         ptr = _align(self.workspace.data_ptr(), 256)
-        self._check(self.lib.gqe_bind_workspace(self.ctx, ptr, int(nbytes)))
+        self._check(self.lib.gqe_bind_workspace(self.ctx, ptr, int(nbytes), self._stream()))
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -288,6 +299,10 @@ class Engine(object):
             arr[i].step = steps[k]
         self._check(self.lib.gqe_adam_step(self.ctx, arr, pa["n"], lr, betas[0], betas[1], eps,
                                            stream if stream is not None else self._stream()))
+
+    def materialize(self):
+        """Fold pending per-row gradient lists into the dense gradient arena (gqe_materialize_grads)."""
+        self._check(self.lib.gqe_materialize_grads(self.ctx, self._stream()))
 
     # -- optimiser --------------------------------------------------------------
     def _segments(self, keys, bump):

@@ -45,6 +45,7 @@ class _MarginLossFn(torch.autograd.Function):
         model._prepare_grads(plan.touched)
         descs, idx, n_scores = pack_margin_batches([(plan, target, neg, anchors, weight, ctx.margin)])
         model.engine.margin_fwd_bwd(descs, idx)
+        model.engine.materialize()      # param.grad views must see the embedding-row gradients
         model._mark_touched(plan.touched)
         return (None,) * 7
 

@@ -119,9 +119,16 @@ int gqe_destroy(gqe_ctx* ctx);
  * grads, exp_avg, exp_avg_sq may be NULL for inference-only use. */
 int gqe_bind_arena(gqe_ctx* ctx, float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n);
 
-/* Scratch the fused kernels need for `max_queries` queries in one call (bytes). */
-int64_t gqe_workspace_bytes(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches);
-int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes);
+/* Declare which arena tensors are embedding tables (offset in floats, number of rows of d floats).
+ * Row gradients of tables are kept as per-row contribution lists (one 4-byte atomic per row instead
+ * of d float atomics) that the optimiser pass consumes directly; must precede gqe_workspace_bytes. */
+int gqe_set_tables(gqe_ctx* ctx, const int64_t* offsets, const int64_t* rows, int32_t n_tables);
+
+/* Workspace the kernels need for up to `max_queries` queries / `max_batches` batches between two
+ * optimiser steps (bytes); gqe_bind_workspace binds a buffer of at least that size (256-byte aligned)
+ * and resets the gradient lists on `stream`.  The capacities given here are remembered by the ctx. */
+int64_t gqe_workspace_bytes(gqe_ctx* ctx, int64_t max_queries, int32_t max_batches);
+int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* stream);
 
 /* replaces: QueryEncoderDecoder.forward (model.py:70-109) for n_batches formulas at once.
  * idx: int32 index buffer (device pointer if idx_on_device, else host pointer: copied through
@@ -132,12 +139,18 @@ int gqe_forward(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches,
 
 /* replaces: margin_loss forward (model.py:112-127) + loss.backward() (train_helpers.py:78)
  * for n_batches (formula, query-slice) pairs in ONE grouped launch.  Gradients of
- * sum_i loss_weight_i * loss_i are ACCUMULATED into the bound grads arena.
+ * sum_i loss_weight_i * loss_i are ACCUMULATED: relation / Pre / Post gradients into the bound grads arena,
+ * embedding-row gradients into the tables' contribution lists (see gqe_set_tables).
  * losses: device, n_batches + 1 floats (mean hinge loss per batch, then the weighted sum).
  * pos_scores / neg_scores: device, optional (NULL to skip). */
 int gqe_margin_fwd_bwd(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches,
                        const int32_t* idx, int64_t n_idx, int32_t idx_on_device,
                        float* losses, float* pos_scores, float* neg_scores, void* stream);
+
+/* Fold the pending per-row gradient lists of the tables into the dense gradient arena (+=), for callers
+ * that need a dense gradient: torch.optim compatibility (param.grad), the data-parallel all-reduce, tests.
+ * The next optimiser pass then also reads (and re-zeroes) the dense table gradient. */
+int gqe_materialize_grads(gqe_ctx* ctx, void* stream);
 
 /* replaces: optimizer.step() + optimizer.zero_grad() for torch.optim.Adam
  * (bio/train.py:62, train_helpers.py:50,79): one fused pass p,g,m,v -> p,m,v and g := 0
@@ -155,6 +168,9 @@ int gqe_zero_grads(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, void* 
  * GEMM, 2 = optimiser.  Returns the average milliseconds over the recorded launches and
  * their count, then clears the record. */
 int gqe_timing_enable(gqe_ctx* ctx, int32_t on);
+/* Debug: when `stamps` (device, 16 int64 per workgroup of the next fused launches) is non-NULL the fused
+ * kernel records wall_clock64() (100 MHz) at its phase boundaries; NULL switches it off. */
+int gqe_debug_profile(gqe_ctx* ctx, long long* stamps);
 int gqe_timing_read(gqe_ctx* ctx, int32_t kernel, float* avg_ms, int32_t* count);
 
 #ifdef __cplusplus

@@ -23,6 +23,8 @@ def load_params(eng, params):
 
 def read_arena(eng, flat):
     import torch
+    if flat is eng.grads:
+        eng.materialize()          # embedding-row gradients live in per-row lists until asked for
     torch.cuda.synchronize()
     host = flat.cpu().numpy()
     out = {}

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark: per-launch time of the fused kernel for different batch compositions
+(bio-synth, d=128 by default).  python tools/kbench.py [--dim 128] [--decoder bilinear-diag] [--inter min]"""
+import argparse, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from bench import build_layout, init_params
+from graphqembed_amd import synth
+from graphqembed_amd.engine import Engine
+from graphqembed_amd.tensorize import FormulaPlan, pack_margin_batches, pack_forward_batches
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--dim", type=int, default=128)
+ap.add_argument("--decoder", default="bilinear-diag")
+ap.add_argument("--inter", default="min")
+ap.add_argument("--reps", type=int, default=50)
+args = ap.parse_args()
+d = args.dim
+g = synth.bio_synth(seed=0)
+layout = build_layout(g, d, args.decoder, args.inter)
+eng = Engine(d, args.decoder, args.inter, layout, max_queries=9 * 4096, max_batches=16)
+init_params(eng, d, 0)
+types = ["1-chain", "2-chain", "3-chain", "2-inter", "3-inter", "3-inter_chain", "3-chain_inter"]
+pools = synth.make_pools(g, types, formulas_per_type=4, pool_size=16384, seed=0)
+plans = {}
+def items_for(mix, B, step=0):
+    out = []
+    for (f, t, ng, a, w, m) in synth.mix_iteration(pools, mix, step, B):
+        if f not in plans: plans[f] = FormulaPlan(f, layout, args.inter)
+        out.append((plans[f], t, ng, a, w, m))
+    return out
+def time_margin(mix, B, label):
+    sets = []
+    for s in range(4):
+        descs, idx, _ = pack_margin_batches(items_for(mix, B, s))
+        sets.append(eng.prepare_margin(descs, torch.from_numpy(idx).cuda()))
+    for ps in sets: eng.run_margin(ps); eng.materialize()
+    torch.cuda.synchronize(); eng.timing_enable(True)
+    for r in range(args.reps): eng.run_margin(sets[r % 4]); eng.materialize()
+    torch.cuda.synchronize()
+    f, nf = eng.timing_read(0); gm, ng_ = eng.timing_read(1); eng.timing_enable(False)
+    tiles = sum((B + 15) // 16 for _ in mix)
+    print("%-38s B=%5d tiles=%5d fused %8.2f us  pair_gemm %7.2f us" % (label, B, tiles, f * 1e3, gm * 1e3), flush=True)
+    eng.grads.zero_()
+def time_forward(mix, B, label):
+    its = items_for(mix, B)
+    descs, idx, n = pack_forward_batches([(p, t, a) for (p, t, ng, a, w, m) in its])
+    didx = torch.from_numpy(idx).cuda(); out = torch.empty(n, device="cuda")
+    for _ in range(3): eng.forward(descs, didx, n, out=out)
+    torch.cuda.synchronize(); eng.timing_enable(True)
+    for r in range(args.reps): eng.forward(descs, didx, n, out=out)
+    torch.cuda.synchronize(); f, nf = eng.timing_read(0); eng.timing_enable(False)
+    print("%-38s B=%5d forward-only %8.2f us" % (label, B, f * 1e3), flush=True)
+for qt in types:
+    hard = "inter" in qt
+    time_margin([(qt, 0.01, hard)] * 9, 512, "9x " + qt)
+for qt in ["1-chain", "2-inter", "3-inter"]:
+    time_margin([(qt, 0.01, False)] * 1, 16, "1 tile " + qt)
+    time_margin([(qt, 0.01, False)] * 9, 64, "36 tiles " + qt)
+    time_margin([(qt, 0.01, False)] * 8, 512, "256 tiles " + qt)
+time_margin(list(synth.FULL_MIX), 512, "full mix")
+time_margin(list(synth.FULL_MIX), 4096, "full mix")
+time_forward(list(synth.FULL_MIX), 512, "full mix")
+
+# ---- phase profile of the full mix (wall_clock64 stamps, 100 MHz) ----
+import ctypes as C
+def phase_profile(mix, B, label):
+    its = items_for(mix, B)
+    descs, idx, _ = pack_margin_batches(its)
+    ps = eng.prepare_margin(descs, torch.from_numpy(idx).cuda())
+    tiles = sum((B + 15) // 16 for _ in mix)
+    stamps = torch.zeros(tiles * 16, dtype=torch.int64, device="cuda")
+    eng.run_margin(ps); eng.materialize(); torch.cuda.synchronize()
+    eng._check(eng.lib.gqe_debug_profile(eng.ctx, stamps.data_ptr()))
+    eng.run_margin(ps); eng.materialize(); torch.cuda.synchronize()
+    eng._check(eng.lib.gqe_debug_profile(eng.ctx, None))
+    st = stamps.cpu().numpy().reshape(tiles, 16).astype(np.float64)
+    t0 = st[:, 0].min()
+    names = ["start", "idx", "rows", "branches", "post/final", "score", "postT", "branches_bwd", "loss"]
+    print("== phase profile %s B=%d (us since first block start; per batch type: median over its tiles)" % (label, B))
+    off = 0
+    for (qt, w, hard) in mix:
+        nt = (B + 15) // 16
+        blk = st[off:off + nt]; off += nt
+        rel = (blk - t0) / 100.0
+        cells = []
+        for k in range(9):
+            col = rel[:, k][blk[:, k] > 0]
+            cells.append("%s=%6.1f" % (names[k], np.median(col)) if len(col) else "%s=   n/a" % names[k])
+        print("%-14s %s  end(max)=%6.1f" % (qt + ("*" if hard else ""), " ".join(cells), rel[:, 8].max()))
+phase_profile(list(synth.FULL_MIX), 512, "full mix")
