@@ -49,11 +49,23 @@ struct GqeGemmJob {
   int32_t K, unit_begin, unit_end, pad;
 };
 
+// One parameter tensor the optimiser has ever been asked to step ("universe" table, device resident,
+// re-uploaded only when a new tensor shows up).  Which tensors a given pass touches, and with which Adam
+// bias corrections, travels in the kernel arguments (GqeOptActive / GqeStepCoef): no per-step upload.
 struct GqeDevSeg {
-  int64_t offset, numel, chunk_begin;
+  int64_t offset, numel, n_chunks;
   int64_t rows, head_base;  // tables only
-  float step_size, bc2_sqrt;
   int32_t is_table, pad;
+};
+
+struct GqeOptActive {
+  uint8_t group[GQE_MAX_SEGS];  // per universe entry: 0xFF = not stepped, else index into GqeStepCoef
+};
+
+#define GQE_MAX_STEP_GROUPS 32
+struct GqeStepCoef {
+  float step_size[GQE_MAX_STEP_GROUPS];  // lr / (1 - b1^t)
+  float bc2_sqrt[GQE_MAX_STEP_GROUPS];   // sqrt(1 - b2^t)
 };
 
 #define GQE_OPT_ADAM 0
@@ -74,6 +86,8 @@ struct GqeOptArgs {
   const float* contrib;
   int d;
   float lr, b1, b2, eps;
+  GqeStepCoef coef;
+  GqeOptActive active;
   hipStream_t stream;
 };
 
@@ -88,7 +102,7 @@ struct GqeFusedArgs {
   float* ws;
   const int32_t* idx;
   int d;
-  float *losses, *pos, *neg;
+  float *tile_loss, *pos, *neg;  // tile_loss: one partial hinge sum per tile (workspace)
   int inter_min;
   bool bwd;
   long long* prof;
@@ -99,7 +113,8 @@ struct GqeFusedArgs {
 };
 
 hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a);
-hipError_t gqe_launch_pair_gemm(int n_units, hipStream_t st, const GqeGemmJob* jobs, const float* ws, float* grads, int d);
+hipError_t gqe_launch_pair_gemm(int n_units, hipStream_t st, const GqeGemmJob* jobs, const float* ws, float* grads, int d,
+                                const GqeDevBatch* batches, int n_batches, const float* tile_loss, float* losses);
 hipError_t gqe_launch_opt(const GqeOptArgs& a);
 
 #endif

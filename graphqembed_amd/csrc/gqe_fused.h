@@ -278,7 +278,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
                                                                 const float* __restrict__ params,
                                                                 float* __restrict__ grads, float* __restrict__ ws,
                                                                 const int32_t* __restrict__ idx, int d_arg,
-                                                                float* __restrict__ losses, float* __restrict__ pos_out,
+                                                                float* __restrict__ tile_loss, float* __restrict__ pos_out,
                                                                 float* __restrict__ neg_out, int inter_min,
                                                                 int32_t* __restrict__ head, int32_t* __restrict__ next,
                                                                 float* __restrict__ contrib,
@@ -850,7 +850,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
   GQE_STAMP(7);
   if (BWD) {
     // mean hinge loss of the batch (model.py:124-126) and the weighted iteration loss: reduce the 8 waves in
-    // LDS first — thousands of same-address device atomics serialise at ~12 ns each.
+    // LDS (thousands of same-address device atomics serialise at ~12 ns each) and park one partial per tile.
     __syncthreads();
     if (lane == 0) red[wave] = loss_part;
     __syncthreads();
@@ -858,11 +858,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
       float l = 0.f;
 #pragma unroll
       for (int w = 0; w < GQE_FWAVES; ++w) l += red[w];
-      if (l != 0.f) {
-        l *= b->inv_B;
-        unsafeAtomicAdd(losses + bi, l);
-        unsafeAtomicAdd(losses + n_batches, l * b->loss_weight);
-      }
+      tile_loss[blockIdx.x] = l;  // summed per batch by the finalize block of the pair-GEMM launch
     }
   }
   GQE_STAMP(8);
@@ -882,10 +878,10 @@ static hipError_t launch_fused_v(const GqeFusedArgs& a) {
   const size_t lds = gqe_fused_lds_bytes_impl(a.d);
   if (a.bwd)
     hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true>), dim3(a.tiles), dim3(GQE_FTHREADS), lds, a.stream, a.batches,
-                       a.n_batches, a.tile_batch, a.params, a.grads, a.ws, a.idx, a.d, a.losses, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.prof);
+                       a.n_batches, a.tile_batch, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.prof);
   else
     hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, false>), dim3(a.tiles), dim3(GQE_FTHREADS), lds, a.stream, a.batches,
-                       a.n_batches, a.tile_batch, a.params, a.grads, a.ws, a.idx, a.d, a.losses, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.prof);
+                       a.n_batches, a.tile_batch, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.prof);
   return hipGetLastError();
 }
 

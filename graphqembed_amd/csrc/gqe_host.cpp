@@ -18,6 +18,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -48,7 +49,7 @@ struct Table {
 };
 
 struct Layout {  // byte offsets inside the bound workspace
-  size_t jobs_off, map_off, plan_cap, idx_off, idx_cap, scratch_off, scratch_cap;
+  size_t jobs_off, map_off, plan_cap, idx_off, idx_cap, buf_stride, tloss_off, scratch_off, scratch_cap;
   size_t seg_off, head_off, next_off, contrib_off, total;
   int64_t max_entries;
 };
@@ -70,9 +71,20 @@ struct gqe_ctx {
   bool dense_dirty = false;  // the dense gradient of some table may be non-zero (after materialize)
   RingSlot ring[kRing];
   int ring_next = 0;
+  // launch plans (and host index feeds) are uploaded on a side stream into one of two device buffers, so the
+  // copy for iteration i+1 overlaps the kernels of iteration i instead of sitting between them
+  hipStream_t up = nullptr;
+  hipEvent_t plan_ready[2] = {nullptr, nullptr}, plan_free[2] = {nullptr, nullptr};
+  bool plan_free_set[2] = {false, false};
+  int plan_buf = 0;
   std::string err;
   long long* prof = nullptr;  // optional per-workgroup phase stamps (gqe_debug_profile)
-  bool timing = false;
+  std::map<int64_t, int> adam_steps;          // per-tensor step counters for callers that pass step <= 0
+  std::vector<GqeDevSeg> universe;             // every tensor ever stepped (device copy at lay.seg_off)
+  size_t universe_uploaded = 0;                // entries of `universe` the device table already holds
+  int timing = 0;                              // record every `timing`-th launch of each kernel (0 = off)
+  long long timing_calls[3] = {0, 0, 0};
+  bool timing_open[3] = {false, false, false};
   std::vector<TimedLaunch> timed[3];
   std::vector<TimedLaunch> event_pool;  // recycled hipEvent pairs (creation is not free)
 };
@@ -120,7 +132,9 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
   L.plan_cap = L.map_off + align_up(sizeof(int16_t) * (size_t)(rows / GQE_TQ + GQE_MAX_BATCHES + 1), 256);
   L.idx_off = L.plan_cap;
   L.idx_cap = align_up((size_t)rows * kRolesPerQuery * sizeof(int32_t), 256);
-  L.scratch_off = L.idx_off + L.idx_cap;
+  L.buf_stride = L.idx_off + L.idx_cap;   // [plan | staged indices] exists twice (double-buffered uploads)
+  L.tloss_off = 2 * L.buf_stride;
+  L.scratch_off = L.tloss_off + align_up(sizeof(float) * (size_t)(rows / GQE_TQ + GQE_MAX_BATCHES + 1), 256);
   L.scratch_cap = align_up((size_t)rows * kMaxSlots * ctx->cfg.dim * sizeof(float), 256);
   L.seg_off = L.scratch_off + L.scratch_cap;
   L.head_off = L.seg_off + align_up(sizeof(GqeDevSeg) * GQE_MAX_SEGS, 256);
@@ -150,7 +164,10 @@ int ring_acquire(gqe_ctx* ctx, size_t bytes, RingSlot** out) {
 }
 
 int timing_begin(gqe_ctx* ctx, int kind, hipStream_t st) {
+  ctx->timing_open[kind] = false;
   if (!ctx->timing) return GQE_OK;
+  if ((ctx->timing_calls[kind]++ % ctx->timing) != 0) return GQE_OK;
+  ctx->timing_open[kind] = true;
   TimedLaunch t;
   if (!ctx->event_pool.empty()) {
     t = ctx->event_pool.back();
@@ -165,7 +182,7 @@ int timing_begin(gqe_ctx* ctx, int kind, hipStream_t st) {
 }
 
 int timing_end(gqe_ctx* ctx, int kind, hipStream_t st) {
-  if (!ctx->timing) return GQE_OK;
+  if (!ctx->timing_open[kind]) return GQE_OK;
   HIP_TRY(ctx, hipEventRecord(ctx->timed[kind].back().stop, st));
   return GQE_OK;
 }
@@ -373,21 +390,34 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   if (jobs_bytes) memcpy(slot->host + L.jobs_off, plan.jobs.data(), jobs_bytes);
   memcpy(slot->host + L.map_off, plan.tile_batch.data(), map_bytes);
   if (!idx_on_device) memcpy(slot->host + L.idx_off, idx, idx_bytes);
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->ws, slot->host, copy_bytes, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipEventRecord(slot->done, st));
+  if (!ctx->up) {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->up, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->plan_ready[k], hipEventDisableTiming));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->plan_free[k], hipEventDisableTiming));
+    }
+  }
+  const int buf = ctx->plan_buf;
+  ctx->plan_buf ^= 1;
+  char* dev_plan = ctx->ws + (size_t)buf * L.buf_stride;
+  if (ctx->plan_free_set[buf]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->up, ctx->plan_free[buf], 0));
+  HIP_TRY(ctx, hipMemcpyAsync(dev_plan, slot->host, copy_bytes, hipMemcpyHostToDevice, ctx->up));
+  HIP_TRY(ctx, hipEventRecord(slot->done, ctx->up));
   slot->in_flight = true;
+  HIP_TRY(ctx, hipEventRecord(ctx->plan_ready[buf], ctx->up));
+  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->plan_ready[buf], 0));
 
   GqeFusedArgs fa;
-  fa.batches = reinterpret_cast<const GqeDevBatch*>(ctx->ws);
+  fa.batches = reinterpret_cast<const GqeDevBatch*>(dev_plan);
   fa.n_batches = n_batches;
-  fa.tile_batch = reinterpret_cast<const int16_t*>(ctx->ws + L.map_off);
+  fa.tile_batch = reinterpret_cast<const int16_t*>(dev_plan + L.map_off);
   fa.tiles = plan.tiles;
   fa.params = ctx->params;
   fa.grads = ctx->grads;
   fa.ws = reinterpret_cast<float*>(ctx->ws);
-  fa.idx = idx_on_device ? idx : reinterpret_cast<const int32_t*>(ctx->ws + L.idx_off);
+  fa.idx = idx_on_device ? idx : reinterpret_cast<const int32_t*>(dev_plan + L.idx_off);
   fa.d = d;
-  fa.losses = losses;
+  fa.tile_loss = reinterpret_cast<float*>(ctx->ws + L.tloss_off);
   fa.pos = pos;
   fa.neg = neg;
   fa.inter_min = is_min(ctx) ? 1 : 0;
@@ -397,7 +427,6 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   fa.head = reinterpret_cast<int32_t*>(ctx->ws + L.head_off);
   fa.next = reinterpret_cast<int32_t*>(ctx->ws + L.next_off);
   fa.contrib = reinterpret_cast<float*>(ctx->ws + L.contrib_off);
-  if (bwd) HIP_TRY(ctx, hipMemsetAsync(losses, 0, sizeof(float) * (n_batches + 1), st));
 
   rc = timing_begin(ctx, 0, st);
   if (rc != GQE_OK) return rc;
@@ -407,15 +436,39 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   if (bwd) {
     ctx->entries_used += plan.entries;
     for (int t : plan.touched_tables) ctx->tables[t].pending = true;
-    if (plan.units > 0) {
-      rc = timing_begin(ctx, 1, st);
-      if (rc != GQE_OK) return rc;
-      HIP_TRY(ctx, gqe_launch_pair_gemm(plan.units, st, reinterpret_cast<const GqeGemmJob*>(ctx->ws + L.jobs_off), fa.ws, ctx->grads, d));
-      rc = timing_end(ctx, 1, st);
-      if (rc != GQE_OK) return rc;
-    }
+    // deferred matrix gradients + the finalize block that turns per-tile hinge sums into losses[]
+    rc = timing_begin(ctx, 1, st);
+    if (rc != GQE_OK) return rc;
+    HIP_TRY(ctx, gqe_launch_pair_gemm(plan.units, st, reinterpret_cast<const GqeGemmJob*>(dev_plan + L.jobs_off), fa.ws, ctx->grads, d,
+                                      fa.batches, n_batches, fa.tile_loss, losses));
+    rc = timing_end(ctx, 1, st);
+    if (rc != GQE_OK) return rc;
   }
+  HIP_TRY(ctx, hipEventRecord(ctx->plan_free[buf], st));
+  ctx->plan_free_set[buf] = true;
   return GQE_OK;
+}
+
+int universe_index(gqe_ctx* ctx, int64_t offset, int64_t numel, int table) {
+  for (size_t i = 0; i < ctx->universe.size(); ++i)
+    if (ctx->universe[i].offset == offset && ctx->universe[i].numel == numel) return (int)i;
+  if (ctx->universe.size() >= GQE_MAX_SEGS) return -1;
+  const int d = ctx->cfg.dim;
+  GqeDevSeg g;
+  memset(&g, 0, sizeof g);
+  g.offset = offset;
+  g.numel = numel;
+  g.is_table = table >= 0 ? 1 : 0;
+  if (table >= 0) {
+    const int tpr = d / 4, rpc = GQE_THREADS / tpr;
+    g.rows = ctx->tables[table].rows;
+    g.head_base = ctx->tables[table].head_base;
+    g.n_chunks = (g.rows + rpc - 1) / rpc;
+  } else {
+    g.n_chunks = (numel + GQE_OPT_CHUNK - 1) / GQE_OPT_CHUNK;
+  }
+  ctx->universe.push_back(g);
+  return (int)ctx->universe.size() - 1;
 }
 
 // mode: GQE_OPT_ADAM / SGD / ZERO / MATERIALIZE (gqe_dev.h)
@@ -427,43 +480,51 @@ int run_opt(gqe_ctx* ctx, int mode, const gqe_segment* segs, int32_t n_segs, flo
   if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int d = ctx->cfg.dim;
-  std::vector<GqeDevSeg> ds;
+  GqeOptArgs oa;
+  memset(oa.active.group, 0xFF, sizeof oa.active.group);
   long long chunks = 0;
   std::vector<char> seen(ctx->tables.size(), 0);
   bool lists = false;
-  auto push = [&](int64_t offset, int64_t numel, int step, int table) {
-    GqeDevSeg g;
-    memset(&g, 0, sizeof g);
-    g.offset = offset;
-    g.numel = numel;
-    g.chunk_begin = chunks;
-    g.is_table = table >= 0 ? 1 : 0;
+  int group_step[GQE_MAX_STEP_GROUPS];
+  int n_groups = 0;
+  auto activate = [&](int64_t offset, int64_t numel, int step, int table) -> int {
+    const int ui = universe_index(ctx, offset, numel, table);
+    if (ui < 0) return fail(ctx, GQE_ERR_ARG, "more than %d distinct parameter tensors", GQE_MAX_SEGS);
+    if (oa.active.group[ui] != 0xFF) return fail(ctx, GQE_ERR_ARG, "tensor at offset %lld listed twice", (long long)offset);
     if (table >= 0) {
-      const int tpr = d / 4, rpc = GQE_THREADS / tpr;
-      g.rows = ctx->tables[table].rows;
-      g.head_base = ctx->tables[table].head_base;
-      chunks += (g.rows + rpc - 1) / rpc;
       seen[table] = 1;
       lists = lists || ctx->tables[table].pending;
-    } else {
-      chunks += (numel + GQE_OPT_CHUNK - 1) / GQE_OPT_CHUNK;
     }
-    if (mode == GQE_OPT_ADAM) {
-      // torch.optim.Adam: step_size = lr / (1 - b1^t); denom = sqrt(v) / sqrt(1 - b2^t) + eps  (python doubles)
-      const double bc1 = 1.0 - std::pow((double)b1, (double)step);
-      const double bc2 = 1.0 - std::pow((double)b2, (double)step);
-      g.step_size = (float)((double)lr / bc1);
-      g.bc2_sqrt = (float)std::sqrt(bc2);
-    } else {
-      g.step_size = lr;
-      g.bc2_sqrt = 1.f;
+    // tensors with the same Adam step count share one (step_size, bc2_sqrt) pair, passed as kernel arguments
+    if (mode != GQE_OPT_ADAM) step = 1;
+    int gi = 0;
+    while (gi < n_groups && group_step[gi] != step) ++gi;
+    if (gi == n_groups) {
+      if (n_groups == GQE_MAX_STEP_GROUPS) return fail(ctx, GQE_ERR_ARG, "more than %d distinct Adam step counts in one call", GQE_MAX_STEP_GROUPS);
+      group_step[n_groups++] = step;
+      if (mode == GQE_OPT_ADAM) {
+        // torch.optim.Adam: step_size = lr / (1 - b1^t); denom = sqrt(v) / sqrt(1 - b2^t) + eps  (python doubles)
+        oa.coef.step_size[gi] = (float)((double)lr / (1.0 - std::pow((double)b1, (double)step)));
+        oa.coef.bc2_sqrt[gi] = (float)std::sqrt(1.0 - std::pow((double)b2, (double)step));
+      } else {
+        oa.coef.step_size[gi] = lr;
+        oa.coef.bc2_sqrt[gi] = 1.f;
+      }
     }
-    ds.push_back(g);
+    oa.active.group[ui] = (uint8_t)gi;
+    chunks += ctx->universe[ui].n_chunks;
+    return GQE_OK;
   };
+  int rc;
   if (mode == GQE_OPT_MATERIALIZE) {
+    bool any = false;
     for (size_t t = 0; t < ctx->tables.size(); ++t)
-      if (ctx->tables[t].pending) push(ctx->tables[t].offset, ctx->tables[t].rows * d, 1, (int)t);
-    if (ds.empty()) {  // nothing pending: the dense gradient simply becomes authoritative
+      if (ctx->tables[t].pending) {
+        rc = activate(ctx->tables[t].offset, ctx->tables[t].rows * d, 1, (int)t);
+        if (rc != GQE_OK) return rc;
+        any = true;
+      }
+    if (!any) {  // nothing pending: the dense gradient simply becomes authoritative
       ctx->entries_used = 0;
       ctx->dense_dirty = true;
       return GQE_OK;
@@ -474,10 +535,13 @@ int run_opt(gqe_ctx* ctx, int mode, const gqe_segment* segs, int32_t n_segs, flo
       const gqe_segment& s = segs[i];
       if (s.offset < 0 || (s.offset % 4) != 0 || s.numel < 1 || s.offset + s.numel > ctx->n_arena)
         return fail(ctx, GQE_ERR_ARG, "segment %d [%lld,+%lld) outside the arena or misaligned", i, (long long)s.offset, (long long)s.numel);
-      if (mode == GQE_OPT_ADAM && s.step < 1) return fail(ctx, GQE_ERR_ARG, "segment %d: Adam step must be >= 1", i);
+      int step = s.step;
+      if (mode == GQE_OPT_ADAM && step < 1) step = ++ctx->adam_steps[s.offset];   // library-kept counter
+      else if (mode == GQE_OPT_ADAM) ctx->adam_steps[s.offset] = step;
       const int t = table_of(ctx, s.offset);
       if (t >= 0 && s.numel != ctx->tables[t].rows * d) return fail(ctx, GQE_ERR_ARG, "segment %d covers a table only partly", i);
-      push(s.offset, s.numel, s.step, t);
+      rc = activate(s.offset, s.numel, step, t);
+      if (rc != GQE_OK) return rc;
     }
     if (mode != GQE_OPT_ZERO)
       for (size_t t = 0; t < ctx->tables.size(); ++t)
@@ -485,20 +549,22 @@ int run_opt(gqe_ctx* ctx, int mode, const gqe_segment* segs, int32_t n_segs, flo
           return fail(ctx, GQE_ERR_STATE, "table at offset %lld has pending gradients but is not among the stepped segments",
                       (long long)ctx->tables[t].offset);
   }
-  const size_t seg_bytes = sizeof(GqeDevSeg) * ds.size();
-  RingSlot* slot;
-  int rc = ring_acquire(ctx, seg_bytes, &slot);
-  if (rc != GQE_OK) return rc;
-  memcpy(slot->host, ds.data(), seg_bytes);
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->ws + ctx->lay.seg_off, slot->host, seg_bytes, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipEventRecord(slot->done, st));
-  slot->in_flight = true;
-  GqeOptArgs oa;
+  if (ctx->universe_uploaded != ctx->universe.size()) {
+    const size_t seg_bytes = sizeof(GqeDevSeg) * ctx->universe.size();
+    RingSlot* slot;  // happens only when a tensor is stepped for the first time
+    rc = ring_acquire(ctx, seg_bytes, &slot);
+    if (rc != GQE_OK) return rc;
+    memcpy(slot->host, ctx->universe.data(), seg_bytes);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws + ctx->lay.seg_off, slot->host, seg_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipEventRecord(slot->done, st));
+    slot->in_flight = true;
+    ctx->universe_uploaded = ctx->universe.size();
+  }
   oa.mode = mode;
   oa.lists = lists;
   oa.dense_tables = ctx->dense_dirty || mode == GQE_OPT_ZERO;
   oa.segs = reinterpret_cast<const GqeDevSeg*>(ctx->ws + ctx->lay.seg_off);
-  oa.n_segs = (int)ds.size();
+  oa.n_segs = (int)ctx->universe.size();
   oa.total_chunks = chunks;
   oa.p = ctx->params;
   oa.g = ctx->grads;
@@ -565,6 +631,14 @@ int gqe_destroy(gqe_ctx* ctx) {
     if (s.done) (void)hipEventDestroy(s.done);
     if (s.host) (void)hipHostFree(s.host);
   }
+  if (ctx->up) {
+    (void)hipStreamSynchronize(ctx->up);
+    for (int k = 0; k < 2; ++k) {
+      (void)hipEventDestroy(ctx->plan_ready[k]);
+      (void)hipEventDestroy(ctx->plan_free[k]);
+    }
+    (void)hipStreamDestroy(ctx->up);
+  }
   for (auto& tv : ctx->timed)
     for (auto& t : tv) ctx->event_pool.push_back(t);
   for (auto& t : ctx->event_pool) {
@@ -600,6 +674,8 @@ int gqe_set_tables(gqe_ctx* ctx, const int64_t* offsets, const int64_t* rows, in
     ctx->tables.push_back(Table{offsets[t], rows[t], ctx->total_rows, false});
     ctx->total_rows += rows[t];
   }
+  ctx->universe.clear();
+  ctx->universe_uploaded = 0;
   ctx->ws = nullptr;  // the workspace layout depends on the tables: it must be bound again
   return GQE_OK;
 }
@@ -622,6 +698,7 @@ int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* strea
   ctx->ws = static_cast<char*>(workspace);
   ctx->ws_bytes = bytes;
   ctx->lay = L;
+  ctx->universe_uploaded = 0;
   // empty gradient lists: head[row] = -1
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.head_off, 0xff, L.next_off - L.head_off, reinterpret_cast<hipStream_t>(stream)));
   for (auto& t : ctx->tables) t.pending = false;
@@ -661,9 +738,10 @@ int gqe_debug_profile(gqe_ctx* ctx, long long* stamps) {
   return GQE_OK;
 }
 
-int gqe_timing_enable(gqe_ctx* ctx, int32_t on) {
+int gqe_timing_enable(gqe_ctx* ctx, int32_t stride) {
   if (!ctx) return GQE_ERR_ARG;
-  ctx->timing = on != 0;
+  ctx->timing = stride > 0 ? stride : 0;
+  for (int k = 0; k < 3; ++k) ctx->timing_calls[k] = 0;
   return GQE_OK;
 }
 

@@ -9,7 +9,31 @@
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeGemmJob* __restrict__ jobs, int n_units,
                                                                    const float* __restrict__ ws,
-                                                                   float* __restrict__ grads, int d) {
+                                                                   float* __restrict__ grads, int d,
+                                                                   const GqeDevBatch* __restrict__ batches, int n_batches,
+                                                                   const float* __restrict__ tile_loss,
+                                                                   float* __restrict__ losses) {
+  if (blockIdx.x == gridDim.x - 1) {
+    // finalize block: per-batch mean hinge loss (model.py:124-126) and the weighted iteration loss from the
+    // per-tile partials of the fused kernel — plain stores, nothing to zero, no atomics.
+    __shared__ float s_w[GQE_MAX_BATCHES];
+    const int t = threadIdx.x;
+    if (t < n_batches) {
+      const GqeDevBatch* b = batches + t;
+      float l = 0.f;
+      for (int k = 0; k < b->Bpad / GQE_TQ; ++k) l += tile_loss[b->tile_begin + k];
+      l *= b->inv_B;
+      losses[t] = l;
+      s_w[t] = l * b->loss_weight;
+    }
+    __syncthreads();
+    if (t == 0) {
+      float tot = 0.f;
+      for (int k = 0; k < n_batches; ++k) tot += s_w[k];
+      losses[n_batches] = tot;
+    }
+    return;
+  }
   const int wave_global = (int)blockIdx.x * GQE_WAVES + (threadIdx.x >> 6);
   if (wave_global >= n_units) return;
   const int lane = threadIdx.x & 63;
@@ -51,13 +75,13 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeGem
 //   MODE = ADAM | SGD | ZERO (drop gradients) | MATERIALIZE (fold the lists into the dense gradient).
 // ------------------------------------------------------------------------------------------
 template <int MODE>
-__device__ __forceinline__ void opt_update(float4& pp, float4& mm, float4& vv, const float4& gg, const GqeDevSeg& sg,
-                                           float lr, float b1, float b2, float eps) {
+__device__ __forceinline__ void opt_update(float4& pp, float4& mm, float4& vv, const float4& gg, float step_size,
+                                           float bc2_sqrt, float lr, float b1, float b2, float eps) {
   if (MODE == GQE_OPT_ADAM) {
 #define ADAM1(x)                                 \
   mm.x = mm.x + (1.f - b1) * (gg.x - mm.x);      \
   vv.x = vv.x * b2 + (1.f - b2) * gg.x * gg.x;   \
-  pp.x = pp.x - sg.step_size * (mm.x / (sqrtf(vv.x) / sg.bc2_sqrt + eps));
+  pp.x = pp.x - step_size * (mm.x / (sqrtf(vv.x) / bc2_sqrt + eps));
     ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
 #undef ADAM1
   } else {
@@ -75,9 +99,16 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
                                                              float* __restrict__ v, int32_t* __restrict__ head,
                                                              const int32_t* __restrict__ next,
                                                              const float* __restrict__ contrib, int d, float lr, float b1,
-                                                             float b2, float eps) {
-  __shared__ long long s_begin[GQE_MAX_SEGS + 1];
-  for (int i = threadIdx.x; i <= n_segs; i += blockDim.x) s_begin[i] = (i < n_segs) ? segs[i].chunk_begin : total_chunks;
+                                                             float b2, float eps, GqeStepCoef coef, GqeOptActive active) {
+  __shared__ long long s_begin[GQE_MAX_SEGS + 1];  // chunk prefix over the universe; inactive tensors get 0 chunks
+  if (threadIdx.x == 0) {
+    long long run = 0;
+    for (int i = 0; i < n_segs; ++i) {
+      s_begin[i] = run;
+      if (active.group[i] != 0xFF) run += segs[i].n_chunks;
+    }
+    s_begin[n_segs] = run;
+  }
   __syncthreads();
   const int tpr = d >> 2;               // threads per table row
   const int rpc = GQE_THREADS / tpr;    // table rows per chunk
@@ -88,8 +119,11 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
   for (long long ch = blockIdx.x; ch < total_chunks; ch += gridDim.x) {
     while (s_begin[si + 1] <= ch) ++si;  // chunks are visited in increasing order
     const GqeDevSeg sg = segs[si];
+    const long long chunk_begin = s_begin[si];
+    const int grp = active.group[si];
+    const float step_size = coef.step_size[grp], bc2_sqrt = coef.bc2_sqrt[grp];
     if (sg.is_table) {
-      const long long row = (ch - sg.chunk_begin) * rpc + lr_row;
+      const long long row = (ch - chunk_begin) * rpc + lr_row;
       if (lr_row >= rpc || row >= sg.rows) continue;
       const long long off = sg.offset + row * d + c4;
       float4 gg = zero4;
@@ -137,7 +171,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
         mm = *reinterpret_cast<const float4*>(m + off);
         vv = *reinterpret_cast<const float4*>(v + off);
       }
-      opt_update<MODE>(pp, mm, vv, gg, sg, lr, b1, b2, eps);
+      opt_update<MODE>(pp, mm, vv, gg, step_size, bc2_sqrt, lr, b1, b2, eps);
       if (MODE == GQE_OPT_ADAM) {
         *reinterpret_cast<float4*>(m + off) = mm;
         *reinterpret_cast<float4*>(v + off) = vv;
@@ -147,7 +181,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
     }
     if (MODE == GQE_OPT_MATERIALIZE) continue;
     // ---- dense segment ----
-    const long long e0 = (ch - sg.chunk_begin) * GQE_OPT_CHUNK + (long long)threadIdx.x * 4;
+    const long long e0 = (ch - chunk_begin) * GQE_OPT_CHUNK + (long long)threadIdx.x * 4;
     if (e0 >= sg.numel) continue;
     const long long off = sg.offset + e0;
     if (e0 + 4 <= sg.numel) {
@@ -160,7 +194,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
         mm = *reinterpret_cast<const float4*>(m + off);
         vv = *reinterpret_cast<const float4*>(v + off);
       }
-      opt_update<MODE>(pp, mm, vv, gg, sg, lr, b1, b2, eps);
+      opt_update<MODE>(pp, mm, vv, gg, step_size, bc2_sqrt, lr, b1, b2, eps);
       if (MODE == GQE_OPT_ADAM) {
         *reinterpret_cast<float4*>(m + off) = mm;
         *reinterpret_cast<float4*>(v + off) = vv;
@@ -177,7 +211,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
           const float vv = v[o] * b2 + (1.f - b2) * gg * gg;
           m[o] = mm;
           v[o] = vv;
-          p[o] = p[o] - sg.step_size * (mm / (sqrtf(vv) / sg.bc2_sqrt + eps));
+          p[o] = p[o] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
         } else {
           p[o] -= lr * gg;
         }
@@ -204,9 +238,11 @@ hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a) {
   }
 }
 
-hipError_t gqe_launch_pair_gemm(int n_units, hipStream_t st, const GqeGemmJob* jobs, const float* ws, float* grads, int d) {
-  const int blocks = (n_units + GQE_WAVES - 1) / GQE_WAVES;
-  hipLaunchKernelGGL(gqe_pair_gemm_kernel, dim3(blocks), dim3(GQE_THREADS), 0, st, jobs, n_units, ws, grads, d);
+hipError_t gqe_launch_pair_gemm(int n_units, hipStream_t st, const GqeGemmJob* jobs, const float* ws, float* grads, int d,
+                                const GqeDevBatch* batches, int n_batches, const float* tile_loss, float* losses) {
+  const int blocks = (n_units + GQE_WAVES - 1) / GQE_WAVES + 1;  // + the finalize block
+  hipLaunchKernelGGL(gqe_pair_gemm_kernel, dim3(blocks), dim3(GQE_THREADS), 0, st, jobs, n_units, ws, grads, d, batches,
+                     n_batches, tile_loss, losses);
   return hipGetLastError();
 }
 
@@ -214,7 +250,7 @@ template <int MODE>
 static void launch_opt_mode(const GqeOptArgs& a, unsigned blocks) {
 #define GO(L, D)                                                                                                          \
   hipLaunchKernelGGL((gqe_opt_kernel<MODE, L, D>), dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.n_segs,          \
-                     a.total_chunks, a.p, a.g, a.m, a.v, a.head, a.next, a.contrib, a.d, a.lr, a.b1, a.b2, a.eps)
+                     a.total_chunks, a.p, a.g, a.m, a.v, a.head, a.next, a.contrib, a.d, a.lr, a.b1, a.b2, a.eps, a.coef, a.active)
   if (a.lists) {
     if (a.dense_tables) GO(true, true); else GO(true, false);
   } else {

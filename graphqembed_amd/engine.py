@@ -290,14 +290,14 @@ class Engine(object):
 
     def prepare_adam(self, keys):
         keys = [k for k in self.layout.entries if k in set(keys)]
-        return {"keys": keys, "arr": self._segments(keys, False), "n": len(keys)}
+        arr = self._segments(keys, False)
+        for i in range(len(keys)):
+            arr[i].step = 0
+        return {"keys": keys, "arr": arr, "n": len(keys)}
 
     def run_adam(self, pa, lr=0.01, betas=(0.9, 0.999), eps=1e-8, stream=None):
-        arr, steps = pa["arr"], self.steps
-        for i, k in enumerate(pa["keys"]):
-            steps[k] += 1
-            arr[i].step = steps[k]
-        self._check(self.lib.gqe_adam_step(self.ctx, arr, pa["n"], lr, betas[0], betas[1], eps,
+        """step <= 0 in the prepared segments: libgqe keeps the per-tensor Adam step counters."""
+        self._check(self.lib.gqe_adam_step(self.ctx, pa["arr"], pa["n"], lr, betas[0], betas[1], eps,
                                            stream if stream is not None else self._stream()))
 
     def materialize(self):
@@ -333,8 +333,9 @@ class Engine(object):
         self._check(self.lib.gqe_zero_grads(self.ctx, arr, len(keys), self._stream()))
 
     # -- timing (bench.py roofline) ------------------------------------------------
-    def timing_enable(self, on):
-        self._check(self.lib.gqe_timing_enable(self.ctx, 1 if on else 0))
+    def timing_enable(self, stride):
+        """Record hipEvents around every ``stride``-th launch of each kernel (0 / False = off)."""
+        self._check(self.lib.gqe_timing_enable(self.ctx, int(stride)))
 
     def timing_read(self, kernel):
         ms, n = C.c_float(0), C.c_int32(0)

@@ -104,7 +104,8 @@ typedef struct {
 typedef struct {
   int64_t offset;        /* arena offset (floats), multiple of 4                            */
   int64_t numel;
-  int32_t step;          /* this tensor's Adam step count AFTER this update (>= 1)          */
+  int32_t step;          /* this tensor's Adam step count AFTER this update (>= 1); <= 0: the
+                            library keeps (and increments) the counter for this offset          */
   int32_t reserved;
 } gqe_segment;
 
@@ -167,7 +168,7 @@ int gqe_zero_grads(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, void* 
  * torch.cuda.Event cannot see a raw hipStream).  kernel: 0 = fused fwd/bwd, 1 = param-grad
  * GEMM, 2 = optimiser.  Returns the average milliseconds over the recorded launches and
  * their count, then clears the record. */
-int gqe_timing_enable(gqe_ctx* ctx, int32_t on);
+int gqe_timing_enable(gqe_ctx* ctx, int32_t stride);   /* record every stride-th launch; 0 = off */
 /* Debug: when `stamps` (device, 16 int64 per workgroup of the next fused launches) is non-NULL the fused
  * kernel records wall_clock64() (100 MHz) at its phase boundaries; NULL switches it off. */
 int gqe_debug_profile(gqe_ctx* ctx, long long* stamps);

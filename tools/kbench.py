@@ -37,10 +37,10 @@ def time_margin(mix, B, label):
         descs, idx, _ = pack_margin_batches(items_for(mix, B, s))
         sets.append(eng.prepare_margin(descs, torch.from_numpy(idx).cuda()))
     for ps in sets: eng.run_margin(ps); eng.materialize()
-    torch.cuda.synchronize(); eng.timing_enable(True)
+    torch.cuda.synchronize(); eng.timing_enable(1)
     for r in range(args.reps): eng.run_margin(sets[r % 4]); eng.materialize()
     torch.cuda.synchronize()
-    f, nf = eng.timing_read(0); gm, ng_ = eng.timing_read(1); eng.timing_enable(False)
+    f, nf = eng.timing_read(0); gm, ng_ = eng.timing_read(1); eng.timing_enable(0)
     tiles = sum((B + 15) // 16 for _ in mix)
     print("%-38s B=%5d tiles=%5d fused %8.2f us  pair_gemm %7.2f us" % (label, B, tiles, f * 1e3, gm * 1e3), flush=True)
     eng.grads.zero_()
@@ -49,9 +49,9 @@ def time_forward(mix, B, label):
     descs, idx, n = pack_forward_batches([(p, t, a) for (p, t, ng, a, w, m) in its])
     didx = torch.from_numpy(idx).cuda(); out = torch.empty(n, device="cuda")
     for _ in range(3): eng.forward(descs, didx, n, out=out)
-    torch.cuda.synchronize(); eng.timing_enable(True)
+    torch.cuda.synchronize(); eng.timing_enable(1)
     for r in range(args.reps): eng.forward(descs, didx, n, out=out)
-    torch.cuda.synchronize(); f, nf = eng.timing_read(0); eng.timing_enable(False)
+    torch.cuda.synchronize(); f, nf = eng.timing_read(0); eng.timing_enable(0)
     print("%-38s B=%5d forward-only %8.2f us" % (label, B, f * 1e3), flush=True)
 for qt in types:
     hard = "inter" in qt
