@@ -17,36 +17,51 @@
 #define GQE_GEMM_KCHUNK 128  // queries per pair-GEMM unit
 #define GQE_PROF_SLOTS 16     // wall_clock64 stamps per workgroup (debug profile)
 
-// Device-side view of one batch (gqe_batch + launch geometry + scratch slots).
-struct GqeDevBatch {
-  int32_t qtype, B, n_anchors, idx_offset;
-  int32_t tile_begin, out_offset, has_neg, n_final;
+#define GQE_LAUNCH_BATCHES 16  // batches per fused launch: their dynamic descriptors travel as kernel arguments
+#define GQE_MAX_FORMULAS 2048  // distinct (formula, decoder layout) descriptors cached on the device
+#define GQE_MAX_JOBS 8         // deferred matrix-gradient jobs one batch can generate
+
+// Static part of a batch: everything that depends only on the Formula (and the parameter layout).
+// Lives in a device-resident table that grows when a new formula is seen; never re-uploaded otherwise.
+struct GqeDevFormula {
+  int32_t qtype, n_anchors, n_final, n_slots;
   int32_t n_hops[GQE_MAX_BRANCH];
-  int32_t Bpad;
+  int32_t n_jobs;
   int64_t target_table;
   int64_t anchor_table[GQE_MAX_BRANCH];
   int64_t hop_param[GQE_MAX_BRANCH][GQE_MAX_HOPS];
   int64_t final_param, pre_param, post_param;
-  int64_t scratch_base;  // float offset of this batch's scratch rows in the workspace
   int64_t target_head;                    // index of the target table's row 0 in the gradient-list heads
   int64_t anchor_head[GQE_MAX_BRANCH];
-  int64_t entry_base;                     // first contribution entry of this batch: [role][query]
-  float margin, grad_scale, inv_B, loss_weight;
+  // deferred dM += L^T R jobs: parameter + the two scratch slots
+  int64_t job_param[GQE_MAX_JOBS];
+  int8_t job_L[GQE_MAX_JOBS], job_R[GQE_MAX_JOBS];
   // scratch slots (row blocks of Bpad x d floats); -1 = unused
-  int32_t slot_x[GQE_MAX_BRANCH][GQE_MAX_HOPS];   // bilinear: input of hop h of branch i
-  int32_t slot_gy[GQE_MAX_BRANCH][GQE_MAX_HOPS];  // bilinear: grad wrt output of hop h of branch i
-  int32_t slot_e[GQE_MAX_BRANCH];                 // MLP: e_i (input of Pre)
-  int32_t slot_gz[GQE_MAX_BRANCH];                // MLP: grad wrt Pre.e_i
-  int32_t slot_hh, slot_gq;                       // MLP: h (input of Post), grad wrt q
-  int32_t slot_fx, slot_fg;                       // bilinear final projection: input, grad wrt output
-  int32_t slot_act[2][GQE_MAX_HOPS];              // bilinear chain: act_h of the +/- side
-  int32_t slot_gact[2][GQE_MAX_HOPS];             // bilinear chain: grad wrt act_{h+1}
+  int8_t slot_x[GQE_MAX_BRANCH][GQE_MAX_HOPS];   // bilinear: input of hop h of branch i
+  int8_t slot_gy[GQE_MAX_BRANCH][GQE_MAX_HOPS];  // bilinear: grad wrt output of hop h of branch i
+  int8_t slot_e[GQE_MAX_BRANCH];                 // MLP: e_i (input of Pre)
+  int8_t slot_gz[GQE_MAX_BRANCH];                // MLP: grad wrt Pre.e_i
+  int8_t slot_hh, slot_gq;                       // MLP: h (input of Post), grad wrt q
+  int8_t slot_fx, slot_fg;                       // bilinear final projection: input, grad wrt output
+  int8_t slot_act[2][GQE_MAX_HOPS];              // bilinear chain: act_h of the +/- side
+  int8_t slot_gact[2][GQE_MAX_HOPS];             // bilinear chain: grad wrt act_{h+1}
 };
 
-// dM += L^T R over K rows (L, R: float offsets into the workspace, rows of d floats)
-struct GqeGemmJob {
-  int64_t param_off, L_off, R_off;
-  int32_t K, unit_begin, unit_end, pad;
+// Dynamic part of a batch (sizes, offsets of this call), passed BY VALUE in the kernel arguments:
+// no plan upload, no event between the host and the launch.
+struct GqeDynBatch {
+  int32_t formula, B, Bpad, idx_offset;
+  int32_t out_offset, tile_begin, has_neg, unit_begin;  // unit_begin: first pair-GEMM unit of this batch
+  int64_t entry_base;    // first contribution entry of this batch: [role][query]
+  int64_t scratch_base;  // float offset of this batch's scratch rows in the workspace
+  float margin, grad_scale, inv_B, loss_weight;
+  int32_t loss_index, pad;  // where this batch's loss goes in the caller's losses[]
+};
+
+struct GqeDynPlan {
+  int32_t n_batches, tiles, units, first;  // first != 0: this launch starts the weighted total (=), else +=
+  int32_t total_index, pad[3];
+  GqeDynBatch b[GQE_LAUNCH_BATCHES];
 };
 
 // One parameter tensor the optimiser has ever been asked to step ("universe" table, device resident,
@@ -93,10 +108,8 @@ struct GqeOptArgs {
 
 // everything one fused launch needs (built by gqe_host.cpp, consumed by the per-variant launchers)
 struct GqeFusedArgs {
-  const GqeDevBatch* batches;
-  int n_batches;
-  const int16_t* tile_batch;  // tile -> batch index
-  int tiles;
+  GqeDynPlan plan;
+  const GqeDevFormula* formulas;
   const float* params;
   float* grads;
   float* ws;
@@ -113,8 +126,7 @@ struct GqeFusedArgs {
 };
 
 hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a);
-hipError_t gqe_launch_pair_gemm(int n_units, hipStream_t st, const GqeGemmJob* jobs, const float* ws, float* grads, int d,
-                                const GqeDevBatch* batches, int n_batches, const float* tile_loss, float* losses);
+hipError_t gqe_launch_pair_gemm(const GqeFusedArgs& a, float* losses);
 hipError_t gqe_launch_opt(const GqeOptArgs& a);
 
 #endif

@@ -27,7 +27,8 @@
 #define RPW (GQE_TQ / GQE_FWAVES)  // query rows owned by one wave
 
 struct TileEnv {
-  const GqeDevBatch* b;
+  GqeDynBatch b;  // by value: the plan is a kernel argument, never take its address
+  const GqeDevFormula* f;
   const float* params;
   float* grads;
   float* ws;  // scratch (floats)
@@ -38,7 +39,7 @@ struct TileEnv {
 };
 
 __device__ __forceinline__ float* scratch_row(const TileEnv& e, int slot, int r) {
-  return e.ws + e.b->scratch_base + ((size_t)slot * e.b->Bpad + e.q0 + r) * e.d;
+  return e.ws + e.b.scratch_base + ((size_t)slot * e.b.Bpad + e.q0 + r) * e.d;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -237,7 +238,7 @@ __device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_
   const float inv = 1.f / nrm;
   Vec<NC> gx;
   VEC_OP(gx, (g.v[c] - xhat.v[c] * pg) * inv);
-  const int64_t entry = e.b->entry_base + (int64_t)role * e.b->B + (e.q0 + r);
+  const int64_t entry = e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
   vstore<NC>(e.contrib + entry * e.d, gx, e.d, e.lane);
   if (e.lane == 0) {
     const int old = __hip_atomic_exchange(e.head + head_base + row, (int)entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -273,8 +274,8 @@ __device__ __forceinline__ void tile_to_scratch(const TileEnv& e, int slot, cons
 }
 
 template <int DEC, bool MLP, int NC, bool FULL, bool BWD>
-__global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBatch* __restrict__ batches, int n_batches,
-                                                                const int16_t* __restrict__ tile_batch,
+__global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPlan plan,
+                                                                const GqeDevFormula* __restrict__ formulas,
                                                                 const float* __restrict__ params,
                                                                 float* __restrict__ grads, float* __restrict__ ws,
                                                                 const int32_t* __restrict__ idx, int d_arg,
@@ -290,10 +291,14 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
   } while (0)
   GQE_STAMP(0);
   const int d = FULL ? 64 * NC : d_arg;
-  const int bi = tile_batch[blockIdx.x];
-  const GqeDevBatch* __restrict__ b = batches + bi;
+  int bi = 0;  // which batch owns this tile: the plan is a kernel argument (SGPRs), a few scalar compares
+#pragma unroll 1
+  while (bi + 1 < plan.n_batches && (int)blockIdx.x >= plan.b[bi + 1].tile_begin) ++bi;
+  const GqeDynBatch b = plan.b[bi];
+  const GqeDevFormula* __restrict__ f = formulas + b.formula;
   TileEnv e;
   e.b = b;
+  e.f = f;
   e.params = params;
   e.grads = grads;
   e.ws = ws;
@@ -304,11 +309,11 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
   e.DP = d + 4;
   e.wave = threadIdx.x >> 6;
   e.lane = threadIdx.x & 63;
-  e.q0 = ((int)blockIdx.x - b->tile_begin) * GQE_TQ;
+  e.q0 = ((int)blockIdx.x - b.tile_begin) * GQE_TQ;
   const int DP = e.DP, lane = e.lane, wave = e.wave;
-  const int B = b->B;
-  const bool has_neg = b->has_neg != 0;
-  const int n = b->n_anchors;
+  const int B = b.B;
+  const bool has_neg = b.has_neg != 0;
+  const int n = f->n_anchors;
 
   // ---- LDS carve: 7 float tiles [16][DP] + meta tile + red[8][d] + index block ----
   float* te[GQE_MAX_BRANCH];
@@ -331,18 +336,18 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
     const bool used = (role == 0) || (role == 1 && has_neg) || (role >= 2 && role - 2 < n);
     if (used && q < B) {
       const int src = (role == 0) ? 0 : (role == 1) ? 1 : (has_neg ? role : role - 1);
-      v = idx[b->idx_offset + (size_t)src * B + q];
+      v = idx[b.idx_offset + (size_t)src * B + q];
     }
     s_idx[threadIdx.x] = v;
   }
   __syncthreads();
   GQE_STAMP(1);
   RowSet<NC> RA[GQE_MAX_BRANCH], RT, RN;
-  rows_issue<NC>(RT, e, b->target_table, s_idx);
-  if (has_neg) rows_issue<NC>(RN, e, b->target_table, s_idx + GQE_TQ);
+  rows_issue<NC>(RT, e, f->target_table, s_idx);
+  if (has_neg) rows_issue<NC>(RN, e, f->target_table, s_idx + GQE_TQ);
 #pragma unroll
   for (int i = 0; i < GQE_MAX_BRANCH; ++i)
-    if (i < n) rows_issue<NC>(RA[i], e, b->anchor_table[i], s_idx + (2 + i) * GQE_TQ);
+    if (i < n) rows_issue<NC>(RA[i], e, f->anchor_table[i], s_idx + (2 + i) * GQE_TQ);
   rows_finish<NC>(RT);
   if (has_neg) {
     rows_finish<NC>(RN);
@@ -358,8 +363,8 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
   for (int i = 0; i < GQE_MAX_BRANCH; ++i)
     if (i < n) rows_finish<NC>(RA[i]);
 
-  const bool is_chain = b->qtype <= 2;
-  const float gscale = b->grad_scale;  // loss_weight / B
+  const bool is_chain = f->qtype <= 2;
+  const float gscale = b.grad_scale;  // loss_weight / B
   float loss_part = 0.f;
   GQE_STAMP(2);
 
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
     // =====================================================================================
     // chains: score(target, anchor) with the relations applied on the TARGET side
     // =====================================================================================
-    const int K = b->n_hops[0];
+    const int K = f->n_hops[0];
     if (DEC != DEC_BILINEAR) {
       // ---- bilinear-diag / TransE: everything stays in registers, one wave per query ----
       Vec<NC> w[GQE_MAX_HOPS];
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
 #pragma unroll
       for (int h = 0; h < GQE_MAX_HOPS; ++h) {
         if (h < K) {
-          w[h] = vload<NC>(params + b->hop_param[0][h], d, lane);
+          w[h] = vload<NC>(params + f->hop_param[0][h], d, lane);
           VEC_OP(wcomb, (DEC == DEC_DIAG) ? wcomb.v[c] * w[h].v[c] : wcomb.v[c] + w[h].v[c]);
         } else {
           VEC_OP(w[h], (DEC == DEC_DIAG) ? 1.f : 0.f);
@@ -419,11 +424,11 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
           }
         }
         if (lane == 0) {
-          if (pos_out) pos_out[b->out_offset + q] = sp;
-          if (neg_out && has_neg) neg_out[b->out_offset + q] = sn;
+          if (pos_out) pos_out[b.out_offset + q] = sp;
+          if (neg_out && has_neg) neg_out[b.out_offset + q] = sn;
         }
         if (!BWD) continue;
-        const float hinge = b->margin - (sp - sn);
+        const float hinge = b.margin - (sp - sn);
         if (hinge > 0.f) {
           loss_part += hinge;
           const float cp = -gscale, cn = gscale;
@@ -444,9 +449,9 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
             VEC_OP(ga, cp * (up.v[c] * ipp - sp * a.v[c] * iaa) + cn * (un.v[c] * ipn - sn * a.v[c] * iaa));
             VEC_OP(gw_acc, gw_acc.v[c] + gtp.v[c] + gtn.v[c]);
           }
-          scatter_norm_bwd<NC>(e, b->target_head, 0, wave * RPW + rr, RT.row[rr], tp, RT.nrm[rr], gtp);
-          scatter_norm_bwd<NC>(e, b->target_head, 1, wave * RPW + rr, RN.row[rr], tn, RN.nrm[rr], gtn);
-          scatter_norm_bwd<NC>(e, b->anchor_head[0], 2, wave * RPW + rr, RA[0].row[rr], a, RA[0].nrm[rr], ga);
+          scatter_norm_bwd<NC>(e, f->target_head, 0, wave * RPW + rr, RT.row[rr], tp, RT.nrm[rr], gtp);
+          scatter_norm_bwd<NC>(e, f->target_head, 1, wave * RPW + rr, RN.row[rr], tn, RN.nrm[rr], gtn);
+          scatter_norm_bwd<NC>(e, f->anchor_head[0], 2, wave * RPW + rr, RA[0].row[rr], a, RA[0].nrm[rr], ga);
         }
       }
       if (BWD) {
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
               for (int j = 0; j < GQE_MAX_HOPS; ++j)
                 if (j != h) VEC_OP(part, part.v[c] * w[j].v[c]);
             }
-            flush_vec_grad<NC>(e, red, b->hop_param[0][h], part);
+            flush_vec_grad<NC>(e, red, f->hop_param[0][h], part);
           }
         }
       }
@@ -476,14 +481,14 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
         vstore<NC>(cur[0] + r * DP, RT.x[rr], d, lane);
         if (has_neg) vstore<NC>(cur[1] + r * DP, RN.x[rr], d, lane);
         if (BWD) {
-          vstore<NC>(scratch_row(e, b->slot_act[0][0], r), RT.x[rr], d, lane);
-          vstore<NC>(scratch_row(e, b->slot_act[1][0], r), RN.x[rr], d, lane);
+          vstore<NC>(scratch_row(e, f->slot_act[0][0], r), RT.x[rr], d, lane);
+          vstore<NC>(scratch_row(e, f->slot_act[1][0], r), RN.x[rr], d, lane);
         }
       }
       for (int h = 0; h < K; ++h) {
         __syncthreads();
         for (int s = 0; s < nside; ++s)
-          tile_matmul<true, NC>(alt[s], params + b->hop_param[0][h], cur[s], d, DP, wave, lane);
+          tile_matmul<true, NC>(alt[s], params + f->hop_param[0][h], cur[s], d, DP, wave, lane);
         __syncthreads();
         for (int s = 0; s < nside; ++s) {
           float* tmp = cur[s];
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
           alt[s] = tmp;
         }
         if (BWD && h + 1 < K)
-          for (int s = 0; s < nside; ++s) tile_to_scratch<NC>(e, b->slot_act[s][h + 1], cur[s]);
+          for (int s = 0; s < nside; ++s) tile_to_scratch<NC>(e, f->slot_act[s][h + 1], cur[s]);
       }
       // scores + gradient seeds; g_u overwrites u in place
 #pragma unroll
@@ -513,11 +518,11 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
           }
         }
         if (q < B && lane == 0) {
-          if (pos_out) pos_out[b->out_offset + q] = su[0];
-          if (neg_out && has_neg) neg_out[b->out_offset + q] = su[1];
+          if (pos_out) pos_out[b.out_offset + q] = su[0];
+          if (neg_out && has_neg) neg_out[b.out_offset + q] = su[1];
         }
         if (!BWD) continue;
-        const float hinge = b->margin - (su[0] - su[1]);
+        const float hinge = b.margin - (su[0] - su[1]);
         const bool act = (q < B) && hinge > 0.f;
         if (act) loss_part += hinge;
         const float cf[2] = {act ? -gscale : 0.f, act ? gscale : 0.f};
@@ -530,16 +535,16 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
           VEC_OP(ga, ga.v[c] + cf[s] * (u[s].v[c] * iun - a.v[c] * iaa));
           vstore<NC>(cur[s] + r * DP, gu, d, lane);
         }
-        if (act) scatter_norm_bwd<NC>(e, b->anchor_head[0], 2, wave * RPW + rr, RA[0].row[rr], a, RA[0].nrm[rr], ga);
+        if (act) scatter_norm_bwd<NC>(e, f->anchor_head[0], 2, wave * RPW + rr, RA[0].row[rr], a, RA[0].nrm[rr], ga);
       }
       if (BWD) {
         // back through the hops: act_{h+1} = act_h M_h  =>  g_act_h = g_act_{h+1} M_h^T (= M . g per row),
         // dM_h += act_h^T g_act_{h+1}  (deferred: pair (slot_act[s][h], slot_gact[s][h]))
         for (int h = K - 1; h >= 0; --h) {
-          for (int s = 0; s < 2; ++s) tile_to_scratch<NC>(e, b->slot_gact[s][h], cur[s]);
+          for (int s = 0; s < 2; ++s) tile_to_scratch<NC>(e, f->slot_gact[s][h], cur[s]);
           __syncthreads();
           for (int s = 0; s < 2; ++s)
-            tile_matmul<false, NC>(alt[s], params + b->hop_param[0][h], cur[s], d, DP, wave, lane);
+            tile_matmul<false, NC>(alt[s], params + f->hop_param[0][h], cur[s], d, DP, wave, lane);
           __syncthreads();
           for (int s = 0; s < 2; ++s) {
             float* tmp = cur[s];
@@ -551,8 +556,8 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
         for (int rr = 0; rr < RPW; ++rr) {
           const int r = wave * RPW + rr;
           if (e.q0 + r >= B) continue;
-          scatter_norm_bwd<NC>(e, b->target_head, 0, r, RT.row[rr], RT.x[rr], RT.nrm[rr], vload<NC>(cur[0] + r * DP, d, lane));
-          scatter_norm_bwd<NC>(e, b->target_head, 1, r, RN.row[rr], RN.x[rr], RN.nrm[rr], vload<NC>(cur[1] + r * DP, d, lane));
+          scatter_norm_bwd<NC>(e, f->target_head, 0, r, RT.row[rr], RT.x[rr], RT.nrm[rr], vload<NC>(cur[0] + r * DP, d, lane));
+          scatter_norm_bwd<NC>(e, f->target_head, 1, r, RN.row[rr], RN.x[rr], RN.nrm[rr], vload<NC>(cur[1] + r * DP, d, lane));
         }
       }
     }
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
 #pragma unroll
     for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
       if (i >= n) continue;
-      const int nh = b->n_hops[i];
+      const int nh = f->n_hops[i];
       if (DEC == DEC_BILINEAR) {
         // stage so that the ping-pong te[i] <-> tt ends in te[i]
         float* src = (nh & 1) ? tt : te[i];
@@ -575,22 +580,22 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
         for (int rr = 0; rr < RPW; ++rr) {
           const int r = wave * RPW + rr;
           vstore<NC>(src + r * DP, RA[i].x[rr], d, lane);
-          if (BWD) vstore<NC>(scratch_row(e, b->slot_x[i][0], r), RA[i].x[rr], d, lane);
+          if (BWD) vstore<NC>(scratch_row(e, f->slot_x[i][0], r), RA[i].x[rr], d, lane);
         }
         for (int h = 0; h < nh; ++h) {
           __syncthreads();
-          tile_matmul<false, NC>(dst, params + b->hop_param[i][h], src, d, DP, wave, lane);
+          tile_matmul<false, NC>(dst, params + f->hop_param[i][h], src, d, DP, wave, lane);
           __syncthreads();
           float* tmp = src;
           src = dst;
           dst = tmp;
-          if (BWD && h + 1 < nh) tile_to_scratch<NC>(e, b->slot_x[i][h + 1], src);
+          if (BWD && h + 1 < nh) tile_to_scratch<NC>(e, f->slot_x[i][h + 1], src);
         }
-        if (MLP && BWD) tile_to_scratch<NC>(e, b->slot_e[i], te[i]);
+        if (MLP && BWD) tile_to_scratch<NC>(e, f->slot_e[i], te[i]);
       } else {
-        Vec<NC> w0 = vload<NC>(params + b->hop_param[i][0], d, lane);
+        Vec<NC> w0 = vload<NC>(params + f->hop_param[i][0], d, lane);
         Vec<NC> w1 = w0;
-        if (nh > 1) w1 = vload<NC>(params + b->hop_param[i][1], d, lane);
+        if (nh > 1) w1 = vload<NC>(params + f->hop_param[i][1], d, lane);
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
           const int r = wave * RPW + rr;
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
           VEC_OP(x, (DEC == DEC_DIAG) ? x.v[c] * w0.v[c] : x.v[c] + w0.v[c]);
           if (nh > 1) VEC_OP(x, (DEC == DEC_DIAG) ? x.v[c] * w1.v[c] : x.v[c] + w1.v[c]);
           vstore<NC>(te[i] + r * DP, x, d, lane);
-          if (MLP && BWD) vstore<NC>(scratch_row(e, b->slot_e[i], r), x, d, lane);
+          if (MLP && BWD) vstore<NC>(scratch_row(e, f->slot_e[i], r), x, d, lane);
         }
       }
     }
@@ -606,9 +611,9 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
     if (MLP) {
       __syncthreads();
       if (n == 3)
-        pre_intersect<NC, 3>(tacc, tmeta, params + b->pre_param, te, d, DP, wave, lane, inter_min);
+        pre_intersect<NC, 3>(tacc, tmeta, params + f->pre_param, te, d, DP, wave, lane, inter_min);
       else
-        pre_intersect<NC, 2>(tacc, tmeta, params + b->pre_param, te, d, DP, wave, lane, inter_min);
+        pre_intersect<NC, 2>(tacc, tmeta, params + f->pre_param, te, d, DP, wave, lane, inter_min);
       __syncthreads();
     } else {
       // element-wise first-arg-min / mean over the branches, own rows
@@ -643,21 +648,21 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
     GQE_STAMP(3);
     float* tqq = tacc;  // where q lives
     if (MLP) {
-      if (BWD) tile_to_scratch<NC>(e, b->slot_hh, tacc);
-      tile_matmul<false, NC>(tq, params + b->post_param, tacc, d, DP, wave, lane);  // q = Post . h
+      if (BWD) tile_to_scratch<NC>(e, f->slot_hh, tacc);
+      tile_matmul<false, NC>(tq, params + f->post_param, tacc, d, DP, wave, lane);  // q = Post . h
       __syncthreads();
       tqq = tq;
     }
     // optional projection after the intersection (3-chain_inter, model.py:107); te[] are free now
     float* tqpre = tqq;  // q before the final projection (needed by its backward)
-    if (b->n_final) {
+    if (f->n_final) {
       if (DEC == DEC_BILINEAR) {
-        if (BWD) tile_to_scratch<NC>(e, b->slot_fx, tqq);
+        if (BWD) tile_to_scratch<NC>(e, f->slot_fx, tqq);
         if (!MLP) __syncthreads();
-        tile_matmul<false, NC>(te[0], params + b->final_param, tqq, d, DP, wave, lane);
+        tile_matmul<false, NC>(te[0], params + f->final_param, tqq, d, DP, wave, lane);
         __syncthreads();
       } else {
-        Vec<NC> w = vload<NC>(params + b->final_param, d, lane);
+        Vec<NC> w = vload<NC>(params + f->final_param, d, lane);
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
           const int r = wave * RPW + rr;
@@ -683,11 +688,11 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
       const float sp = vdot<NC>(tp, qv) / (ncp * nq);
       const float sn = has_neg ? vdot<NC>(tn, qv) / (ncn * nq) : 0.f;
       if (q < B && lane == 0) {
-        if (pos_out) pos_out[b->out_offset + q] = sp;
-        if (neg_out && has_neg) neg_out[b->out_offset + q] = sn;
+        if (pos_out) pos_out[b.out_offset + q] = sp;
+        if (neg_out && has_neg) neg_out[b.out_offset + q] = sn;
       }
       if (!BWD) continue;
-      const float hinge = b->margin - (sp - sn);
+      const float hinge = b.margin - (sp - sn);
       const bool act = (q < B) && hinge > 0.f;
       if (act) loss_part += hinge;
       const float cp = act ? -gscale : 0.f, cn = act ? gscale : 0.f;
@@ -699,23 +704,23 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
         const float ipp = sp / (ncp * ncp), inn = sn / (ncn * ncn);
         VEC_OP(gtp, cp * (qv.v[c] * ipq - tp.v[c] * ipp));
         VEC_OP(gtn, cn * (qv.v[c] * inq - tn.v[c] * inn));
-        scatter_norm_bwd<NC>(e, b->target_head, 0, wave * RPW + rr, RT.row[rr], tp, RT.nrm[rr], gtp);
-        scatter_norm_bwd<NC>(e, b->target_head, 1, wave * RPW + rr, RN.row[rr], tn, RN.nrm[rr], gtn);
+        scatter_norm_bwd<NC>(e, f->target_head, 0, wave * RPW + rr, RT.row[rr], tp, RT.nrm[rr], gtp);
+        scatter_norm_bwd<NC>(e, f->target_head, 1, wave * RPW + rr, RN.row[rr], tn, RN.nrm[rr], gtn);
       }
     }
     GQE_STAMP(5);
     if (BWD) {
       // ---- backward of the final projection: g (tile tgc) -> grad wrt q_pre ----
       float* tgc = tg;
-      if (b->n_final) {
+      if (f->n_final) {
         if (DEC == DEC_BILINEAR) {
-          tile_to_scratch<NC>(e, b->slot_fg, tg);
+          tile_to_scratch<NC>(e, f->slot_fg, tg);
           __syncthreads();
-          tile_matmul<true, NC>(te[1], params + b->final_param, tg, d, DP, wave, lane);
+          tile_matmul<true, NC>(te[1], params + f->final_param, tg, d, DP, wave, lane);
           __syncthreads();
           tgc = te[1];
         } else {
-          Vec<NC> w = vload<NC>(params + b->final_param, d, lane);
+          Vec<NC> w = vload<NC>(params + f->final_param, d, lane);
           Vec<NC> gw = vzero<NC>();
 #pragma unroll
           for (int rr = 0; rr < RPW; ++rr) {
@@ -730,15 +735,15 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
               VEC_OP(gw, gw.v[c] + g.v[c]);
             }
           }
-          flush_vec_grad<NC>(e, red, b->final_param, gw);
+          flush_vec_grad<NC>(e, red, f->final_param, gw);
         }
       }
       // ---- backward of Post: g_h -> tacc (h itself is already parked in scratch) ----
       float* tgh = tgc;  // grad wrt h (MLP) or wrt the intersection output (simple)
       if (MLP) {
-        tile_to_scratch<NC>(e, b->slot_gq, tgc);
+        tile_to_scratch<NC>(e, f->slot_gq, tgc);
         __syncthreads();
-        tile_matmul<true, NC>(tacc, params + b->post_param, tgc, d, DP, wave, lane);  // g_h = Post^T g_q
+        tile_matmul<true, NC>(tacc, params + f->post_param, tgc, d, DP, wave, lane);  // g_h = Post^T g_q
         __syncthreads();
         tgh = tacc;
       }
@@ -757,13 +762,13 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
               const int j = lane + 64 * c;
               gz.v[c] = (j < d) ? mask_gz(tgh[r * DP + j], tmeta[r * DP + j], i, inter_min, inv_n, true) : 0.f;
             }
-            vstore<NC>(scratch_row(e, b->slot_gz[i], r), gz, d, lane);
+            vstore<NC>(scratch_row(e, f->slot_gz[i], r), gz, d, lane);
           }
         }
         if (n == 3)
-          pre_intersect_bwd<NC, 3>(te, params + b->pre_param, tgh, tmeta, d, DP, wave, lane, inter_min);
+          pre_intersect_bwd<NC, 3>(te, params + f->pre_param, tgh, tmeta, d, DP, wave, lane, inter_min);
         else
-          pre_intersect_bwd<NC, 2>(te, params + b->pre_param, tgh, tmeta, d, DP, wave, lane, inter_min);
+          pre_intersect_bwd<NC, 2>(te, params + f->pre_param, tgh, tmeta, d, DP, wave, lane, inter_min);
         __syncthreads();
       } else if (DEC == DEC_BILINEAR) {
         // simple intersection + Bilinear hops: the masked gradient has to be a tile for the MFMA
@@ -787,14 +792,14 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
 #pragma unroll
       for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
         if (i >= n) continue;
-        const int nh = b->n_hops[i];
+        const int nh = f->n_hops[i];
         if (DEC == DEC_BILINEAR) {
           float* tcur = (!MLP && tgh == te[i]) ? tt : te[i];
           float* tnext = tq;  // tq is dead in the backward; tt may hold another branch's masked gradient
           for (int h = nh - 1; h >= 0; --h) {
-            tile_to_scratch<NC>(e, b->slot_gy[i][h], tcur);
+            tile_to_scratch<NC>(e, f->slot_gy[i][h], tcur);
             __syncthreads();
-            tile_matmul<true, NC>(tnext, params + b->hop_param[i][h], tcur, d, DP, wave, lane);
+            tile_matmul<true, NC>(tnext, params + f->hop_param[i][h], tcur, d, DP, wave, lane);
             __syncthreads();
             float* tmp = tcur;
             tcur = tnext;
@@ -804,14 +809,14 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
           for (int rr = 0; rr < RPW; ++rr) {
             const int r = wave * RPW + rr;
             if (e.q0 + r >= B) continue;
-            scatter_norm_bwd<NC>(e, b->anchor_head[i], 2 + i, r, RA[i].row[rr], RA[i].x[rr], RA[i].nrm[rr],
+            scatter_norm_bwd<NC>(e, f->anchor_head[i], 2 + i, r, RA[i].row[rr], RA[i].x[rr], RA[i].nrm[rr],
                                  vload<NC>(tcur + r * DP, d, lane));
           }
           __syncthreads();  // tt / tq are rewritten by the next branch
         } else {
-          Vec<NC> w0 = vload<NC>(params + b->hop_param[i][0], d, lane);
+          Vec<NC> w0 = vload<NC>(params + f->hop_param[i][0], d, lane);
           Vec<NC> w1 = w0;
-          if (nh > 1) w1 = vload<NC>(params + b->hop_param[i][1], d, lane);
+          if (nh > 1) w1 = vload<NC>(params + f->hop_param[i][1], d, lane);
           Vec<NC> gw0 = vzero<NC>(), gw1 = vzero<NC>();
 #pragma unroll
           for (int rr = 0; rr < RPW; ++rr) {
@@ -839,10 +844,10 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDevBat
             } else {
               VEC_OP(gw0, gw0.v[c] + g.v[c]);
             }
-            scatter_norm_bwd<NC>(e, b->anchor_head[i], 2 + i, r, RA[i].row[rr], x, RA[i].nrm[rr], g);
+            scatter_norm_bwd<NC>(e, f->anchor_head[i], 2 + i, r, RA[i].row[rr], x, RA[i].nrm[rr], g);
           }
-          flush_vec_grad<NC>(e, red, b->hop_param[i][0], gw0);
-          if (nh > 1) flush_vec_grad<NC>(e, red, b->hop_param[i][1], (DEC == DEC_DIAG) ? gw1 : gw0);
+          flush_vec_grad<NC>(e, red, f->hop_param[i][0], gw0);
+          if (nh > 1) flush_vec_grad<NC>(e, red, f->hop_param[i][1], (DEC == DEC_DIAG) ? gw1 : gw0);
         }
       }
     }
@@ -877,11 +882,11 @@ template <int DEC, bool MLP, int NC, bool FULL>
 static hipError_t launch_fused_v(const GqeFusedArgs& a) {
   const size_t lds = gqe_fused_lds_bytes_impl(a.d);
   if (a.bwd)
-    hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true>), dim3(a.tiles), dim3(GQE_FTHREADS), lds, a.stream, a.batches,
-                       a.n_batches, a.tile_batch, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.prof);
+    hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true>), dim3(a.plan.tiles), dim3(GQE_FTHREADS), lds, a.stream, a.plan,
+                       a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.prof);
   else
-    hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, false>), dim3(a.tiles), dim3(GQE_FTHREADS), lds, a.stream, a.batches,
-                       a.n_batches, a.tile_batch, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.prof);
+    hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, false>), dim3(a.plan.tiles), dim3(GQE_FTHREADS), lds, a.stream, a.plan,
+                       a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.prof);
   return hipGetLastError();
 }
 

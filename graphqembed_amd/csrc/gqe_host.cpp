@@ -49,8 +49,8 @@ struct Table {
 };
 
 struct Layout {  // byte offsets inside the bound workspace
-  size_t jobs_off, map_off, plan_cap, idx_off, idx_cap, buf_stride, tloss_off, scratch_off, scratch_cap;
-  size_t seg_off, head_off, next_off, contrib_off, total;
+  size_t idx_cap, tloss_off, scratch_off, scratch_cap;  // [staged indices x2 | tile losses | pair scratch]
+  size_t seg_off, formula_off, head_off, next_off, contrib_off, total;
   int64_t max_entries;
 };
 
@@ -71,8 +71,13 @@ struct gqe_ctx {
   bool dense_dirty = false;  // the dense gradient of some table may be non-zero (after materialize)
   RingSlot ring[kRing];
   int ring_next = 0;
-  // launch plans (and host index feeds) are uploaded on a side stream into one of two device buffers, so the
-  // copy for iteration i+1 overlaps the kernels of iteration i instead of sitting between them
+  // formula descriptor cache: static per-formula data lives on the device, per-call data travels as kernel
+  // arguments, so a steady-state iteration uploads nothing
+  std::vector<GqeDevFormula> formulas;
+  std::map<std::string, int> formula_ids;
+  size_t formulas_uploaded = 0;
+  // host index feeds are uploaded on a side stream into one of two device buffers, so the copy for
+  // iteration i+1 overlaps the kernels of iteration i instead of sitting between them
   hipStream_t up = nullptr;
   hipEvent_t plan_ready[2] = {nullptr, nullptr}, plan_free[2] = {nullptr, nullptr};
   bool plan_free_set[2] = {false, false};
@@ -127,17 +132,13 @@ int anchors_of(int qtype) {
 Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches) {
   Layout L;
   const int64_t rows = max_queries + (int64_t)GQE_TQ * max_batches;  // queries incl. tile padding
-  L.jobs_off = align_up(sizeof(GqeDevBatch) * GQE_MAX_BATCHES, 256);
-  L.map_off = L.jobs_off + align_up(sizeof(GqeGemmJob) * GQE_MAX_BATCHES * 16, 256);
-  L.plan_cap = L.map_off + align_up(sizeof(int16_t) * (size_t)(rows / GQE_TQ + GQE_MAX_BATCHES + 1), 256);
-  L.idx_off = L.plan_cap;
-  L.idx_cap = align_up((size_t)rows * kRolesPerQuery * sizeof(int32_t), 256);
-  L.buf_stride = L.idx_off + L.idx_cap;   // [plan | staged indices] exists twice (double-buffered uploads)
-  L.tloss_off = 2 * L.buf_stride;
+  L.idx_cap = align_up((size_t)rows * kRolesPerQuery * sizeof(int32_t), 256);  // exists twice (double-buffered uploads)
+  L.tloss_off = 2 * L.idx_cap;
   L.scratch_off = L.tloss_off + align_up(sizeof(float) * (size_t)(rows / GQE_TQ + GQE_MAX_BATCHES + 1), 256);
   L.scratch_cap = align_up((size_t)rows * kMaxSlots * ctx->cfg.dim * sizeof(float), 256);
   L.seg_off = L.scratch_off + L.scratch_cap;
-  L.head_off = L.seg_off + align_up(sizeof(GqeDevSeg) * GQE_MAX_SEGS, 256);
+  L.formula_off = L.seg_off + align_up(sizeof(GqeDevSeg) * GQE_MAX_SEGS, 256);
+  L.head_off = L.formula_off + align_up(sizeof(GqeDevFormula) * GQE_MAX_FORMULAS, 256);
   L.max_entries = rows * kRolesPerQuery;
   L.next_off = L.head_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
   L.contrib_off = L.next_off + align_up(sizeof(int32_t) * (size_t)L.max_entries, 256);
@@ -187,17 +188,6 @@ int timing_end(gqe_ctx* ctx, int kind, hipStream_t st) {
   return GQE_OK;
 }
 
-struct Plan {
-  std::vector<GqeDevBatch> batches;
-  std::vector<GqeGemmJob> jobs;
-  std::vector<int16_t> tile_batch;
-  std::vector<int> touched_tables;
-  int tiles = 0;
-  int units = 0;
-  int64_t scratch_floats = 0;
-  int64_t entries = 0;
-};
-
 bool off_ok(const gqe_ctx* ctx, int64_t off, int64_t numel) {
   return off >= 0 && (off % 4) == 0 && off + numel <= ctx->n_arena;
 }
@@ -208,149 +198,132 @@ int table_of(const gqe_ctx* ctx, int64_t offset) {
   return -1;
 }
 
-// Translate the caller's batches into device descriptors, scratch slots and deferred matrix-gradient jobs.
-int build_plan(gqe_ctx* ctx, const gqe_batch* in, int n, int64_t n_idx, bool bwd, int64_t scratch_origin, Plan* plan) {
+// Validate one caller batch and return the index of its (cached) static descriptor.
+int formula_of(gqe_ctx* ctx, const gqe_batch& s, int bi, int* out_id) {
   const int d = ctx->cfg.dim;
   const bool bil = ctx->cfg.decoder == GQE_DEC_BILINEAR;
   const bool mlp = is_mlp(ctx);
   const int64_t vec = bil ? (int64_t)d * d : d;
-  int64_t scratch = scratch_origin;
-  int64_t entry = ctx->entries_used;
-  for (int bi = 0; bi < n; ++bi) {
-    const gqe_batch& s = in[bi];
-    const int na = anchors_of(s.qtype);
-    if (na < 0) return fail(ctx, GQE_ERR_ARG, "batch %d: unknown query type %d", bi, s.qtype);
-    if (s.n_queries < 1) return fail(ctx, GQE_ERR_ARG, "batch %d: empty batch (n_queries=%d)", bi, s.n_queries);
-    if (s.n_anchors != na) return fail(ctx, GQE_ERR_ARG, "batch %d: query type %d needs %d anchors, got %d", bi, s.qtype, na, s.n_anchors);
-    const bool chain = s.qtype <= GQE_Q_3CHAIN;
-    const int64_t need_idx = (int64_t)s.idx_offset + (int64_t)(na + (bwd ? 2 : 1)) * s.n_queries;
-    if (s.idx_offset < 0 || need_idx > n_idx) return fail(ctx, GQE_ERR_ARG, "batch %d: index range [%d,%lld) exceeds the %lld indices given", bi, s.idx_offset, (long long)need_idx, (long long)n_idx);
-    GqeDevBatch b;
-    memset(&b, 0xff, sizeof b);  // all slots / params = -1
-    b.qtype = s.qtype;
-    b.B = s.n_queries;
-    b.n_anchors = na;
-    b.idx_offset = s.idx_offset;
-    b.tile_begin = plan->tiles;
-    b.out_offset = s.out_offset;
-    b.has_neg = bwd ? 1 : 0;
-    b.n_final = 0;
-    b.Bpad = (int)align_up(s.n_queries, GQE_TQ);
-    b.margin = s.margin;
-    b.loss_weight = s.loss_weight;
-    b.inv_B = 1.0f / (float)s.n_queries;
-    b.grad_scale = s.loss_weight / (float)s.n_queries;
-    if (!off_ok(ctx, s.target_table, d)) return fail(ctx, GQE_ERR_ARG, "batch %d: target_table offset %lld outside the arena", bi, (long long)s.target_table);
-    b.target_table = s.target_table;
-    const int nbr = chain ? 1 : na;
-    for (int i = 0; i < GQE_MAX_BRANCH; ++i) b.n_hops[i] = 0;
-    for (int i = 0; i < na; ++i) {
-      if (!off_ok(ctx, s.anchor_table[i], d)) return fail(ctx, GQE_ERR_ARG, "batch %d: anchor_table[%d] outside the arena", bi, i);
-      b.anchor_table[i] = s.anchor_table[i];
-    }
-    if (bwd) {
-      // gradient lists: entries [role][query], role 0 target, 1 negative, 2+i anchor i
-      const int tt = table_of(ctx, s.target_table);
-      if (tt < 0) return fail(ctx, GQE_ERR_STATE, "batch %d: target_table %lld is not a registered table (gqe_set_tables)", bi, (long long)s.target_table);
-      b.target_head = ctx->tables[tt].head_base;
-      plan->touched_tables.push_back(tt);
-      for (int i = 0; i < na; ++i) {
-        const int ta = table_of(ctx, s.anchor_table[i]);
-        if (ta < 0) return fail(ctx, GQE_ERR_STATE, "batch %d: anchor_table[%d] is not a registered table (gqe_set_tables)", bi, i);
-        b.anchor_head[i] = ctx->tables[ta].head_base;
-        plan->touched_tables.push_back(ta);
-      }
-      b.entry_base = entry;
-      entry += (int64_t)(2 + na) * s.n_queries;
-    }
-    for (int i = 0; i < nbr; ++i) {
-      const int nh = s.n_hops[i];
-      const int max_h = chain ? (s.qtype + 1) : ((s.qtype == GQE_Q_3INTER_CHAIN && i == 1) ? 2 : 1);
-      if (nh != max_h) return fail(ctx, GQE_ERR_ARG, "batch %d: branch %d has %d hops, query type %d needs %d", bi, i, nh, s.qtype, max_h);
-      b.n_hops[i] = nh;
-      for (int h = 0; h < nh; ++h) {
-        if (!off_ok(ctx, s.hop_param[i][h], vec)) return fail(ctx, GQE_ERR_ARG, "batch %d: hop_param[%d][%d] outside the arena", bi, i, h);
-        b.hop_param[i][h] = s.hop_param[i][h];
-      }
-    }
-    if (!chain) {
-      if (s.qtype == GQE_Q_3CHAIN_INTER) {
-        if (s.n_final != 1 || !off_ok(ctx, s.final_param, vec)) return fail(ctx, GQE_ERR_ARG, "batch %d: 3-chain_inter needs one final projection", bi);
-        b.n_final = 1;
-        b.final_param = s.final_param;
-      } else if (s.n_final != 0) {
-        return fail(ctx, GQE_ERR_ARG, "batch %d: only 3-chain_inter has a final projection", bi);
-      }
-      if (mlp) {
-        if (!off_ok(ctx, s.pre_param, (int64_t)d * d) || !off_ok(ctx, s.post_param, (int64_t)d * d))
-          return fail(ctx, GQE_ERR_ARG, "batch %d: pre/post matrices outside the arena", bi);
-        b.pre_param = s.pre_param;
-        b.post_param = s.post_param;
-      }
-    }
-    // ---- pair-scratch slots + deferred dM jobs (training only) ----
-    int nslot = 0;
-    b.scratch_base = scratch;
-    const int64_t slot_floats = (int64_t)b.Bpad * d;
-    auto slot_off = [&](int slot) { return b.scratch_base + (int64_t)slot * slot_floats; };
-    auto add_job = [&](int64_t param, int Lslot, int Rslot) {
-      GqeGemmJob j;
-      j.param_off = param;
-      j.L_off = slot_off(Lslot);
-      j.R_off = slot_off(Rslot);
-      j.K = b.Bpad;
-      const int chunks = (b.Bpad + GQE_GEMM_KCHUNK - 1) / GQE_GEMM_KCHUNK;
-      j.unit_begin = plan->units;
-      plan->units += chunks * (d / 16) * (d / 16);
-      j.unit_end = plan->units;
-      j.pad = 0;
-      plan->jobs.push_back(j);
-    };
-    if (bwd) {
-      if (chain && bil) {
-        for (int sde = 0; sde < 2; ++sde)
-          for (int h = 0; h < b.n_hops[0]; ++h) {
-            b.slot_act[sde][h] = nslot++;
-            b.slot_gact[sde][h] = nslot++;
-            // act_{h+1} = act_h M_h  =>  dM_h += act_h^T g_{h+1}
-            add_job(b.hop_param[0][h], b.slot_act[sde][h], b.slot_gact[sde][h]);
-          }
-      }
-      if (!chain) {
-        if (bil) {
-          for (int i = 0; i < na; ++i)
-            for (int h = 0; h < b.n_hops[i]; ++h) {
-              b.slot_x[i][h] = nslot++;
-              b.slot_gy[i][h] = nslot++;
-              // y = M x  =>  dM += g_y x^T
-              add_job(b.hop_param[i][h], b.slot_gy[i][h], b.slot_x[i][h]);
-            }
-          if (b.n_final) {
-            b.slot_fx = nslot++;
-            b.slot_fg = nslot++;
-            add_job(b.final_param, b.slot_fg, b.slot_fx);
-          }
-        }
-        if (mlp) {
-          for (int i = 0; i < na; ++i) {
-            b.slot_e[i] = nslot++;
-            b.slot_gz[i] = nslot++;
-            add_job(b.pre_param, b.slot_gz[i], b.slot_e[i]);  // z = Pre e  => dPre += g_z e^T
-          }
-          b.slot_hh = nslot++;
-          b.slot_gq = nslot++;
-          add_job(b.post_param, b.slot_gq, b.slot_hh);        // q = Post h => dPost += g_q h^T
-        }
-      }
-    }
-    if (nslot > kMaxSlots) return fail(ctx, GQE_ERR_ARG, "internal: %d scratch slots", nslot);
-    scratch += (int64_t)nslot * slot_floats;
-    plan->tiles += b.Bpad / GQE_TQ;
-    plan->tile_batch.insert(plan->tile_batch.end(), b.Bpad / GQE_TQ, (int16_t)bi);
-    plan->batches.push_back(b);
+  const int na = anchors_of(s.qtype);
+  if (na < 0) return fail(ctx, GQE_ERR_ARG, "batch %d: unknown query type %d", bi, s.qtype);
+  if (s.n_anchors != na) return fail(ctx, GQE_ERR_ARG, "batch %d: query type %d needs %d anchors, got %d", bi, s.qtype, na, s.n_anchors);
+  const bool chain = s.qtype <= GQE_Q_3CHAIN;
+  const int nbr = chain ? 1 : na;
+  // cache key = every static field the caller controls
+  struct Key {
+    int32_t qtype, n_anchors, n_final, n_hops[GQE_MAX_BRANCH];
+    int64_t target_table, anchor_table[GQE_MAX_BRANCH], hop_param[GQE_MAX_BRANCH][GQE_MAX_HOPS], final_param, pre_param, post_param;
+  } key;
+  memset(&key, 0, sizeof key);
+  key.qtype = s.qtype;
+  key.n_anchors = na;
+  key.n_final = s.n_final;
+  key.target_table = s.target_table;
+  for (int i = 0; i < na; ++i) key.anchor_table[i] = s.anchor_table[i];
+  for (int i = 0; i < nbr; ++i) {
+    key.n_hops[i] = s.n_hops[i];
+    for (int h = 0; h < s.n_hops[i] && h < GQE_MAX_HOPS; ++h) key.hop_param[i][h] = s.hop_param[i][h];
   }
-  plan->scratch_floats = scratch - scratch_origin;
-  plan->entries = entry - ctx->entries_used;
+  key.final_param = s.n_final ? s.final_param : -1;
+  key.pre_param = (!chain && mlp) ? s.pre_param : -1;
+  key.post_param = (!chain && mlp) ? s.post_param : -1;
+  const std::string ks(reinterpret_cast<const char*>(&key), sizeof key);
+  auto it = ctx->formula_ids.find(ks);
+  if (it != ctx->formula_ids.end()) {
+    *out_id = it->second;
+    return GQE_OK;
+  }
+  if (ctx->formulas.size() >= GQE_MAX_FORMULAS) return fail(ctx, GQE_ERR_ARG, "more than %d distinct formulas", GQE_MAX_FORMULAS);
+  GqeDevFormula f;
+  memset(&f, 0xff, sizeof f);  // all slots / params = -1
+  f.qtype = s.qtype;
+  f.n_anchors = na;
+  f.n_final = 0;
+  if (!off_ok(ctx, s.target_table, d)) return fail(ctx, GQE_ERR_ARG, "batch %d: target_table offset %lld outside the arena", bi, (long long)s.target_table);
+  f.target_table = s.target_table;
+  const int tt = table_of(ctx, s.target_table);
+  if (tt < 0) return fail(ctx, GQE_ERR_STATE, "batch %d: target_table %lld is not a registered table (gqe_set_tables)", bi, (long long)s.target_table);
+  f.target_head = ctx->tables[tt].head_base;
+  for (int i = 0; i < GQE_MAX_BRANCH; ++i) f.n_hops[i] = 0;
+  for (int i = 0; i < na; ++i) {
+    if (!off_ok(ctx, s.anchor_table[i], d)) return fail(ctx, GQE_ERR_ARG, "batch %d: anchor_table[%d] outside the arena", bi, i);
+    f.anchor_table[i] = s.anchor_table[i];
+    const int ta = table_of(ctx, s.anchor_table[i]);
+    if (ta < 0) return fail(ctx, GQE_ERR_STATE, "batch %d: anchor_table[%d] is not a registered table (gqe_set_tables)", bi, i);
+    f.anchor_head[i] = ctx->tables[ta].head_base;
+  }
+  for (int i = 0; i < nbr; ++i) {
+    const int nh = s.n_hops[i];
+    const int max_h = chain ? (s.qtype + 1) : ((s.qtype == GQE_Q_3INTER_CHAIN && i == 1) ? 2 : 1);
+    if (nh != max_h) return fail(ctx, GQE_ERR_ARG, "batch %d: branch %d has %d hops, query type %d needs %d", bi, i, nh, s.qtype, max_h);
+    f.n_hops[i] = nh;
+    for (int h = 0; h < nh; ++h) {
+      if (!off_ok(ctx, s.hop_param[i][h], vec)) return fail(ctx, GQE_ERR_ARG, "batch %d: hop_param[%d][%d] outside the arena", bi, i, h);
+      f.hop_param[i][h] = s.hop_param[i][h];
+    }
+  }
+  if (!chain) {
+    if (s.qtype == GQE_Q_3CHAIN_INTER) {
+      if (s.n_final != 1 || !off_ok(ctx, s.final_param, vec)) return fail(ctx, GQE_ERR_ARG, "batch %d: 3-chain_inter needs one final projection", bi);
+      f.n_final = 1;
+      f.final_param = s.final_param;
+    } else if (s.n_final != 0) {
+      return fail(ctx, GQE_ERR_ARG, "batch %d: only 3-chain_inter has a final projection", bi);
+    }
+    if (mlp) {
+      if (!off_ok(ctx, s.pre_param, (int64_t)d * d) || !off_ok(ctx, s.post_param, (int64_t)d * d))
+        return fail(ctx, GQE_ERR_ARG, "batch %d: pre/post matrices outside the arena", bi);
+      f.pre_param = s.pre_param;
+      f.post_param = s.post_param;
+    }
+  }
+  // pair-scratch slots + deferred dM jobs (used by training launches only)
+  int nslot = 0, njob = 0;
+  auto add_job = [&](int64_t param, int Lslot, int Rslot) {
+    f.job_param[njob] = param;
+    f.job_L[njob] = (int8_t)Lslot;
+    f.job_R[njob] = (int8_t)Rslot;
+    ++njob;
+  };
+  if (chain && bil) {
+    for (int sde = 0; sde < 2; ++sde)
+      for (int h = 0; h < f.n_hops[0]; ++h) {
+        f.slot_act[sde][h] = (int8_t)nslot++;
+        f.slot_gact[sde][h] = (int8_t)nslot++;
+        add_job(f.hop_param[0][h], f.slot_act[sde][h], f.slot_gact[sde][h]);  // act_{h+1} = act_h M_h => dM_h += act_h^T g_{h+1}
+      }
+  }
+  if (!chain) {
+    if (bil) {
+      for (int i = 0; i < na; ++i)
+        for (int h = 0; h < f.n_hops[i]; ++h) {
+          f.slot_x[i][h] = (int8_t)nslot++;
+          f.slot_gy[i][h] = (int8_t)nslot++;
+          add_job(f.hop_param[i][h], f.slot_gy[i][h], f.slot_x[i][h]);  // y = M x  =>  dM += g_y x^T
+        }
+      if (f.n_final) {
+        f.slot_fx = (int8_t)nslot++;
+        f.slot_fg = (int8_t)nslot++;
+        add_job(f.final_param, f.slot_fg, f.slot_fx);
+      }
+    }
+    if (mlp) {
+      for (int i = 0; i < na; ++i) {
+        f.slot_e[i] = (int8_t)nslot++;
+        f.slot_gz[i] = (int8_t)nslot++;
+        add_job(f.pre_param, f.slot_gz[i], f.slot_e[i]);  // z = Pre e  => dPre += g_z e^T
+      }
+      f.slot_hh = (int8_t)nslot++;
+      f.slot_gq = (int8_t)nslot++;
+      add_job(f.post_param, f.slot_gq, f.slot_hh);        // q = Post h => dPost += g_q h^T
+    }
+  }
+  if (nslot > kMaxSlots || njob > GQE_MAX_JOBS) return fail(ctx, GQE_ERR_ARG, "internal: %d scratch slots / %d jobs", nslot, njob);
+  f.n_slots = nslot;
+  f.n_jobs = njob;
+  ctx->formulas.push_back(f);
+  *out_id = (int)ctx->formulas.size() - 1;
+  ctx->formula_ids[ks] = *out_id;
   return GQE_OK;
 }
 
@@ -366,56 +339,80 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int d = ctx->cfg.dim;
   const Layout& L = ctx->lay;
+  const int tiles_sq = (d / 16) * (d / 16);
 
-  Plan plan;
-  int rc = build_plan(ctx, batches, n_batches, n_idx, bwd, (int64_t)(L.scratch_off / sizeof(float)), &plan);
-  if (rc != GQE_OK) return rc;
-  const size_t batch_bytes = sizeof(GqeDevBatch) * plan.batches.size();
-  const size_t jobs_bytes = sizeof(GqeGemmJob) * plan.jobs.size();
-  const size_t map_bytes = sizeof(int16_t) * plan.tile_batch.size();
-  const size_t idx_bytes = idx_on_device ? 0 : (size_t)n_idx * sizeof(int32_t);
-  if (jobs_bytes > L.map_off - L.jobs_off || L.map_off + map_bytes > L.plan_cap || idx_bytes > L.idx_cap ||
-      (size_t)plan.scratch_floats * sizeof(float) > L.scratch_cap)
-    return fail(ctx, GQE_ERR_WORKSPACE, "workspace too small for %d batches / %d tiles (bound for %lld queries, %d batches)",
-                n_batches, plan.tiles, (long long)ctx->cap_queries, ctx->cap_batches);
-  if (ctx->entries_used + plan.entries > L.max_entries)
-    return fail(ctx, GQE_ERR_WORKSPACE, "gradient contribution buffer full (%lld + %lld > %lld entries): step or "
-                "gqe_materialize_grads first", (long long)ctx->entries_used, (long long)plan.entries, (long long)L.max_entries);
-
-  const size_t copy_bytes = idx_on_device ? L.map_off + map_bytes : L.idx_off + idx_bytes;
-  RingSlot* slot;
-  rc = ring_acquire(ctx, copy_bytes, &slot);
-  if (rc != GQE_OK) return rc;
-  memcpy(slot->host, plan.batches.data(), batch_bytes);
-  if (jobs_bytes) memcpy(slot->host + L.jobs_off, plan.jobs.data(), jobs_bytes);
-  memcpy(slot->host + L.map_off, plan.tile_batch.data(), map_bytes);
-  if (!idx_on_device) memcpy(slot->host + L.idx_off, idx, idx_bytes);
-  if (!ctx->up) {
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->up, hipStreamNonBlocking));
-    for (int k = 0; k < 2; ++k) {
-      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->plan_ready[k], hipEventDisableTiming));
-      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->plan_free[k], hipEventDisableTiming));
+  // ---- validate everything and resolve the formula descriptors before anything is enqueued ----
+  std::vector<int> fid(n_batches);
+  int64_t entries = 0, total_tiles = 0;
+  std::vector<int> touched_tables;
+  for (int bi = 0; bi < n_batches; ++bi) {
+    const gqe_batch& s = batches[bi];
+    if (s.n_queries < 1) return fail(ctx, GQE_ERR_ARG, "batch %d: empty batch (n_queries=%d)", bi, s.n_queries);
+    int rc = formula_of(ctx, s, bi, &fid[bi]);
+    if (rc != GQE_OK) return rc;
+    const int na = ctx->formulas[fid[bi]].n_anchors;
+    const int64_t need_idx = (int64_t)s.idx_offset + (int64_t)(na + (bwd ? 2 : 1)) * s.n_queries;
+    if (s.idx_offset < 0 || need_idx > n_idx) return fail(ctx, GQE_ERR_ARG, "batch %d: index range [%d,%lld) exceeds the %lld indices given", bi, s.idx_offset, (long long)need_idx, (long long)n_idx);
+    entries += (int64_t)(2 + na) * s.n_queries;
+    total_tiles += (s.n_queries + GQE_TQ - 1) / GQE_TQ;
+    if (bwd) {
+      touched_tables.push_back(table_of(ctx, s.target_table));
+      for (int i = 0; i < na; ++i) touched_tables.push_back(table_of(ctx, s.anchor_table[i]));
     }
   }
-  const int buf = ctx->plan_buf;
-  ctx->plan_buf ^= 1;
-  char* dev_plan = ctx->ws + (size_t)buf * L.buf_stride;
-  if (ctx->plan_free_set[buf]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->up, ctx->plan_free[buf], 0));
-  HIP_TRY(ctx, hipMemcpyAsync(dev_plan, slot->host, copy_bytes, hipMemcpyHostToDevice, ctx->up));
-  HIP_TRY(ctx, hipEventRecord(slot->done, ctx->up));
-  slot->in_flight = true;
-  HIP_TRY(ctx, hipEventRecord(ctx->plan_ready[buf], ctx->up));
-  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->plan_ready[buf], 0));
+  const size_t idx_bytes = idx_on_device ? 0 : (size_t)n_idx * sizeof(int32_t);
+  if (idx_bytes > L.idx_cap) return fail(ctx, GQE_ERR_WORKSPACE, "index feed of %lld entries exceeds the bound workspace (%lld queries)", (long long)n_idx, (long long)ctx->cap_queries);
+  if (bwd && ctx->entries_used + entries > L.max_entries)
+    return fail(ctx, GQE_ERR_WORKSPACE, "gradient contribution buffer full (%lld + %lld > %lld entries): step or "
+                "gqe_materialize_grads first", (long long)ctx->entries_used, (long long)entries, (long long)L.max_entries);
+
+  int rc;
+  // ---- new formulas -> device table (rare) ----
+  if (ctx->formulas_uploaded != ctx->formulas.size()) {
+    const size_t off = sizeof(GqeDevFormula) * ctx->formulas_uploaded;
+    const size_t bytes = sizeof(GqeDevFormula) * (ctx->formulas.size() - ctx->formulas_uploaded);
+    RingSlot* slot;
+    rc = ring_acquire(ctx, bytes, &slot);
+    if (rc != GQE_OK) return rc;
+    memcpy(slot->host, ctx->formulas.data() + ctx->formulas_uploaded, bytes);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws + L.formula_off + off, slot->host, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipEventRecord(slot->done, st));
+    slot->in_flight = true;
+    ctx->formulas_uploaded = ctx->formulas.size();
+  }
+  // ---- host index feed -> device, on the side stream ----
+  const int32_t* d_idx = idx;
+  int buf = -1;
+  if (!idx_on_device) {
+    if (!ctx->up) {
+      HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->up, hipStreamNonBlocking));
+      for (int k = 0; k < 2; ++k) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->plan_ready[k], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->plan_free[k], hipEventDisableTiming));
+      }
+    }
+    RingSlot* slot;
+    rc = ring_acquire(ctx, idx_bytes, &slot);
+    if (rc != GQE_OK) return rc;
+    memcpy(slot->host, idx, idx_bytes);
+    buf = ctx->plan_buf;
+    ctx->plan_buf ^= 1;
+    char* dev = ctx->ws + (size_t)buf * L.idx_cap;
+    if (ctx->plan_free_set[buf]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->up, ctx->plan_free[buf], 0));
+    HIP_TRY(ctx, hipMemcpyAsync(dev, slot->host, idx_bytes, hipMemcpyHostToDevice, ctx->up));
+    HIP_TRY(ctx, hipEventRecord(slot->done, ctx->up));
+    slot->in_flight = true;
+    HIP_TRY(ctx, hipEventRecord(ctx->plan_ready[buf], ctx->up));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->plan_ready[buf], 0));
+    d_idx = reinterpret_cast<const int32_t*>(dev);
+  }
 
   GqeFusedArgs fa;
-  fa.batches = reinterpret_cast<const GqeDevBatch*>(dev_plan);
-  fa.n_batches = n_batches;
-  fa.tile_batch = reinterpret_cast<const int16_t*>(dev_plan + L.map_off);
-  fa.tiles = plan.tiles;
+  fa.formulas = reinterpret_cast<const GqeDevFormula*>(ctx->ws + L.formula_off);
   fa.params = ctx->params;
   fa.grads = ctx->grads;
   fa.ws = reinterpret_cast<float*>(ctx->ws);
-  fa.idx = idx_on_device ? idx : reinterpret_cast<const int32_t*>(dev_plan + L.idx_off);
+  fa.idx = d_idx;
   fa.d = d;
   fa.tile_loss = reinterpret_cast<float*>(ctx->ws + L.tloss_off);
   fa.pos = pos;
@@ -428,24 +425,67 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   fa.next = reinterpret_cast<int32_t*>(ctx->ws + L.next_off);
   fa.contrib = reinterpret_cast<float*>(ctx->ws + L.contrib_off);
 
-  rc = timing_begin(ctx, 0, st);
-  if (rc != GQE_OK) return rc;
-  HIP_TRY(ctx, gqe_launch_fused(ctx->cfg.decoder, is_mlp(ctx) ? 1 : 0, fa));
-  rc = timing_end(ctx, 0, st);
-  if (rc != GQE_OK) return rc;
-  if (bwd) {
-    ctx->entries_used += plan.entries;
-    for (int t : plan.touched_tables) ctx->tables[t].pending = true;
-    // deferred matrix gradients + the finalize block that turns per-tile hinge sums into losses[]
-    rc = timing_begin(ctx, 1, st);
+  // ---- launches of <= GQE_LAUNCH_BATCHES batches; per-call data travels as kernel arguments ----
+  int64_t entry = ctx->entries_used;
+  for (int b0 = 0; b0 < n_batches; b0 += GQE_LAUNCH_BATCHES) {
+    const int nb = std::min(GQE_LAUNCH_BATCHES, n_batches - b0);
+    GqeDynPlan& P = fa.plan;
+    memset(&P, 0, sizeof P);
+    P.n_batches = nb;
+    P.first = b0 == 0;
+    P.total_index = n_batches;
+    int64_t scratch = (int64_t)(L.scratch_off / sizeof(float));
+    for (int k = 0; k < nb; ++k) {
+      const gqe_batch& s = batches[b0 + k];
+      const GqeDevFormula& f = ctx->formulas[fid[b0 + k]];
+      GqeDynBatch& b = P.b[k];
+      b.formula = fid[b0 + k];
+      b.B = s.n_queries;
+      b.Bpad = (int)align_up(s.n_queries, GQE_TQ);
+      b.idx_offset = s.idx_offset;
+      b.out_offset = s.out_offset;
+      b.tile_begin = P.tiles;
+      b.has_neg = bwd ? 1 : 0;
+      b.unit_begin = P.units;
+      b.entry_base = entry;
+      b.scratch_base = scratch;
+      b.margin = s.margin;
+      b.loss_weight = s.loss_weight;
+      b.inv_B = 1.0f / (float)s.n_queries;
+      b.grad_scale = s.loss_weight / (float)s.n_queries;
+      b.loss_index = b0 + k;
+      P.tiles += b.Bpad / GQE_TQ;
+      if (bwd) {
+        entry += (int64_t)(2 + f.n_anchors) * s.n_queries;
+        scratch += (int64_t)f.n_slots * b.Bpad * d;
+        P.units += f.n_jobs * ((b.Bpad + GQE_GEMM_KCHUNK - 1) / GQE_GEMM_KCHUNK) * tiles_sq;
+      }
+    }
+    if ((size_t)(scratch * (int64_t)sizeof(float)) > L.scratch_off + L.scratch_cap)
+      return fail(ctx, GQE_ERR_WORKSPACE, "workspace too small for this call (bound for %lld queries, %d batches)",
+                  (long long)ctx->cap_queries, ctx->cap_batches);
+    rc = timing_begin(ctx, 0, st);
     if (rc != GQE_OK) return rc;
-    HIP_TRY(ctx, gqe_launch_pair_gemm(plan.units, st, reinterpret_cast<const GqeGemmJob*>(dev_plan + L.jobs_off), fa.ws, ctx->grads, d,
-                                      fa.batches, n_batches, fa.tile_loss, losses));
-    rc = timing_end(ctx, 1, st);
+    HIP_TRY(ctx, gqe_launch_fused(ctx->cfg.decoder, is_mlp(ctx) ? 1 : 0, fa));
+    rc = timing_end(ctx, 0, st);
     if (rc != GQE_OK) return rc;
+    if (bwd) {
+      // deferred matrix gradients + the finalize block that turns per-tile hinge sums into losses[]
+      rc = timing_begin(ctx, 1, st);
+      if (rc != GQE_OK) return rc;
+      HIP_TRY(ctx, gqe_launch_pair_gemm(fa, losses));
+      rc = timing_end(ctx, 1, st);
+      if (rc != GQE_OK) return rc;
+    }
   }
-  HIP_TRY(ctx, hipEventRecord(ctx->plan_free[buf], st));
-  ctx->plan_free_set[buf] = true;
+  if (bwd) {
+    ctx->entries_used = entry;
+    for (int t : touched_tables) ctx->tables[t].pending = true;
+  }
+  if (buf >= 0) {
+    HIP_TRY(ctx, hipEventRecord(ctx->plan_free[buf], st));
+    ctx->plan_free_set[buf] = true;
+  }
   return GQE_OK;
 }
 
@@ -676,6 +716,9 @@ int gqe_set_tables(gqe_ctx* ctx, const int64_t* offsets, const int64_t* rows, in
   }
   ctx->universe.clear();
   ctx->universe_uploaded = 0;
+  ctx->formulas.clear();
+  ctx->formula_ids.clear();
+  ctx->formulas_uploaded = 0;
   ctx->ws = nullptr;  // the workspace layout depends on the tables: it must be bound again
   return GQE_OK;
 }
@@ -699,6 +742,7 @@ int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* strea
   ctx->ws_bytes = bytes;
   ctx->lay = L;
   ctx->universe_uploaded = 0;
+  ctx->formulas_uploaded = 0;
   // empty gradient lists: head[row] = -1
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.head_off, 0xff, L.next_off - L.head_off, reinterpret_cast<hipStream_t>(stream)));
   for (auto& t : ctx->tables) t.pending = false;

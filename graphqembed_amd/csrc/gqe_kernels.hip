@@ -4,54 +4,61 @@
 
 // ------------------------------------------------------------------------------------------
 // deferred matrix gradients:  dM[i][j] += sum_b L[b][i] * R[b][j]   (rank-B update on the matrix cores)
-// one wave per (job, 16x16 output tile, K chunk); A[i][k=b] = L[b][i0+i], B[k=b][j] = R[b][j0+j]:
-// both operands are read straight from the scratch rows (64 B contiguous per 16 lanes).
+// one wave per unit = (batch, job, 128-query K chunk, 16x16 output tile); A[i][k=b] = L[b][i0+i],
+// B[k=b][j] = R[b][j0+j]: both operands are read straight from the scratch rows (64 B contiguous per 16
+// lanes).  Jobs are derived on the device from the cached formula descriptor + the kernel-argument plan.
+// The extra last block turns the per-tile hinge sums of the fused kernel into losses[].
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeGemmJob* __restrict__ jobs, int n_units,
+__global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDynPlan plan,
+                                                                   const GqeDevFormula* __restrict__ formulas,
                                                                    const float* __restrict__ ws,
                                                                    float* __restrict__ grads, int d,
-                                                                   const GqeDevBatch* __restrict__ batches, int n_batches,
                                                                    const float* __restrict__ tile_loss,
                                                                    float* __restrict__ losses) {
   if (blockIdx.x == gridDim.x - 1) {
     // finalize block: per-batch mean hinge loss (model.py:124-126) and the weighted iteration loss from the
     // per-tile partials of the fused kernel — plain stores, nothing to zero, no atomics.
-    __shared__ float s_w[GQE_MAX_BATCHES];
+    __shared__ float s_w[GQE_LAUNCH_BATCHES];
     const int t = threadIdx.x;
-    if (t < n_batches) {
-      const GqeDevBatch* b = batches + t;
+    if (t < plan.n_batches) {
+      const GqeDynBatch b = plan.b[t];
       float l = 0.f;
-      for (int k = 0; k < b->Bpad / GQE_TQ; ++k) l += tile_loss[b->tile_begin + k];
-      l *= b->inv_B;
-      losses[t] = l;
-      s_w[t] = l * b->loss_weight;
+      for (int k = 0; k < b.Bpad / GQE_TQ; ++k) l += tile_loss[b.tile_begin + k];
+      l *= b.inv_B;
+      losses[b.loss_index] = l;
+      s_w[t] = l * b.loss_weight;
     }
     __syncthreads();
     if (t == 0) {
-      float tot = 0.f;
-      for (int k = 0; k < n_batches; ++k) tot += s_w[k];
-      losses[n_batches] = tot;
+      float tot = plan.first ? 0.f : losses[plan.total_index];
+      for (int k = 0; k < plan.n_batches; ++k) tot += s_w[k];
+      losses[plan.total_index] = tot;
     }
     return;
   }
-  const int wave_global = (int)blockIdx.x * GQE_WAVES + (threadIdx.x >> 6);
-  if (wave_global >= n_units) return;
+  const int unit = (int)blockIdx.x * GQE_WAVES + (threadIdx.x >> 6);
+  if (unit >= plan.units) return;
   const int lane = threadIdx.x & 63;
   const int lq = lane & 15, lk = lane >> 4;
+  int bi = 0;
+#pragma unroll 1
+  while (bi + 1 < plan.n_batches && unit >= plan.b[bi + 1].unit_begin) ++bi;
+  const GqeDynBatch b = plan.b[bi];
+  const GqeDevFormula* __restrict__ f = formulas + b.formula;
   const int tiles_per_dim = d / 16;
   const int tiles = tiles_per_dim * tiles_per_dim;
-  // unit -> (job, chunk, tile): jobs carry a prefix sum of their units
-  int lo = 0;
-  while (jobs[lo].unit_end <= wave_global) ++lo;
-  const GqeGemmJob* job = jobs + lo;
-  const int u = wave_global - job->unit_begin;
+  const int chunks = (b.Bpad + GQE_GEMM_KCHUNK - 1) / GQE_GEMM_KCHUNK;
+  int u = unit - b.unit_begin;
+  const int job = u / (chunks * tiles);
+  u -= job * chunks * tiles;
   const int chunk = u / tiles;
-  const int t = u % tiles;
+  const int t = u - chunk * tiles;
   const int i0 = (t / tiles_per_dim) * 16, j0 = (t % tiles_per_dim) * 16;
   const int k_begin = chunk * GQE_GEMM_KCHUNK;
-  const int k_end = min(job->K, k_begin + GQE_GEMM_KCHUNK);
-  const float* L = ws + job->L_off;
-  const float* R = ws + job->R_off;
+  const int k_end = min(b.Bpad, k_begin + GQE_GEMM_KCHUNK);
+  const size_t slot_floats = (size_t)b.Bpad * d;
+  const float* L = ws + b.scratch_base + (size_t)f->job_L[job] * slot_floats;
+  const float* R = ws + b.scratch_base + (size_t)f->job_R[job] * slot_floats;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int k0 = k_begin; k0 < k_end; k0 += 16) {
     const float* lp = L + (size_t)(k0 + 4 * lk) * d + i0 + lq;
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeGem
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lp[s * d], rp[s * d], acc, 0, 0, 0);
   }
-  float* out = grads + job->param_off + (size_t)(i0 + 4 * lk) * d + j0 + lq;
+  float* out = grads + f->job_param[job] + (size_t)(i0 + 4 * lk) * d + j0 + lq;
 #pragma unroll
   for (int r = 0; r < 4; ++r) unsafeAtomicAdd(out + (size_t)r * d, acc[r]);
 }
@@ -101,11 +108,14 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
                                                              const float* __restrict__ contrib, int d, float lr, float b1,
                                                              float b2, float eps, GqeStepCoef coef, GqeOptActive active) {
   __shared__ long long s_begin[GQE_MAX_SEGS + 1];  // chunk prefix over the universe; inactive tensors get 0 chunks
+  __shared__ long long s_cnt[GQE_MAX_SEGS];
+  if ((int)threadIdx.x < n_segs) s_cnt[threadIdx.x] = (active.group[threadIdx.x] != 0xFF) ? segs[threadIdx.x].n_chunks : 0;
+  __syncthreads();
   if (threadIdx.x == 0) {
     long long run = 0;
     for (int i = 0; i < n_segs; ++i) {
       s_begin[i] = run;
-      if (active.group[i] != 0xFF) run += segs[i].n_chunks;
+      run += s_cnt[i];
     }
     s_begin[n_segs] = run;
   }
@@ -238,11 +248,10 @@ hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a) {
   }
 }
 
-hipError_t gqe_launch_pair_gemm(int n_units, hipStream_t st, const GqeGemmJob* jobs, const float* ws, float* grads, int d,
-                                const GqeDevBatch* batches, int n_batches, const float* tile_loss, float* losses) {
-  const int blocks = (n_units + GQE_WAVES - 1) / GQE_WAVES + 1;  // + the finalize block
-  hipLaunchKernelGGL(gqe_pair_gemm_kernel, dim3(blocks), dim3(GQE_THREADS), 0, st, jobs, n_units, ws, grads, d, batches,
-                     n_batches, tile_loss, losses);
+hipError_t gqe_launch_pair_gemm(const GqeFusedArgs& a, float* losses) {
+  const int blocks = (a.plan.units + GQE_WAVES - 1) / GQE_WAVES + 1;  // + the finalize block
+  hipLaunchKernelGGL(gqe_pair_gemm_kernel, dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.plan, a.formulas, a.ws, a.grads, a.d,
+                     a.tile_loss, losses);
   return hipGetLastError();
 }
 
