@@ -121,17 +121,12 @@ def main():
     args = ap.parse_args()
 
     import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from graphqembed_amd import parallel
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%s: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, os.environ.get("WORLD_SIZE", "1"), args.gpus))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, world, local_rank, dist = parallel.init_from_env("nccl")
 
     from graphqembed_amd import synth
     from graphqembed_amd.engine import Engine
@@ -167,9 +162,8 @@ def main():
     def step(i):
         ps = prepared[i % n_distinct]
         eng.run_margin(ps)
-        if dist is not None:
-            eng.materialize()                                      # per-row gradient lists -> dense arena
-            dist.all_reduce(eng.grads)                             # RCCL sum of the dense gradient arena (xGMI)
+        if dist is not None:                                       # lists -> dense arena, RCCL sum over xGMI
+            parallel.exchange_gradients(eng.grads, dist, engine=eng)
         eng.run_adam(ps["adam"])
 
     def fence():

@@ -231,36 +231,75 @@ __device__ __forceinline__ void rows_finish(RowSet<NC>& rs) {
 // backward of x/||x||:  (g - xhat (xhat.g)) / ||x||.  The row gradient is written ONCE, coalesced, as
 // contribution entry (role, query) and pushed onto the table row's list with one 4-byte atomic exchange;
 // the optimiser pass (or gqe_materialize_grads) sums the lists.  role: 0 target, 1 negative, 2+i anchor i.
+#define GQE_NO_PUSH (-2147483647 - 1)
+
 template <int NC>
 __device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_base, int role, int r, int row,
-                                                 const Vec<NC>& xhat, float nrm, const Vec<NC>& g) {
+                                                 const Vec<NC>& xhat, float nrm, const Vec<NC>& g, int& old_head) {
   const float pg = vdot<NC>(xhat, g);
   const float inv = 1.f / nrm;
   Vec<NC> gx;
   VEC_OP(gx, (g.v[c] - xhat.v[c] * pg) * inv);
   const int64_t entry = e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
   vstore<NC>(e.contrib + entry * e.d, gx, e.d, e.lane);
-  if (e.lane == 0) {
-    const int old = __hip_atomic_exchange(e.head + head_base + row, (int)entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    e.next[entry] = old;
+  // The returned previous head is only needed for next[entry]; that store is deferred to the end of the
+  // kernel (push_links) so that the wave never stalls on the atomic's round trip.
+  if (e.lane == 0) old_head = __hip_atomic_exchange(e.head + head_base + row, (int)entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// next[entry] = previous head, for every contribution this wave pushed
+__device__ __forceinline__ void push_links(const TileEnv& e, const int (&olds)[RPW][2 + GQE_MAX_BRANCH]) {
+  if (e.lane != 0) return;
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+    for (int role = 0; role < 2 + GQE_MAX_BRANCH; ++role)
+      if (olds[rr][role] != GQE_NO_PUSH)
+        e.next[e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + e.wave * RPW + rr)] = olds[rr][role];
+}
+
+// Relation-vector gradients (bilinear-diag / TransE): every wave keeps its partial sums in registers
+// (slot k = 2*branch + hop, 6 = final projection; chains use slot = hop) until the end of the kernel, when
+// one LDS round (the tiles are dead by then) reduces the 8 waves and wave k flushes vector k with one
+// atomic row: two barriers per tile instead of two per vector.
+#define GQE_VG_SLOTS 7
+
+template <int NC>
+struct VecGrads {
+  Vec<NC> g[GQE_VG_SLOTS];
+  int64_t param[GQE_VG_SLOTS];  // -1 = unused (workgroup-uniform)
+};
+
+template <int NC>
+__device__ __forceinline__ void vecgrads_init(VecGrads<NC>& vg) {
+#pragma unroll
+  for (int k = 0; k < GQE_VG_SLOTS; ++k) {
+    vg.g[k] = vzero<NC>();
+    vg.param[k] = -1;
   }
 }
 
-// cross-wave reduction of per-wave partial relation-vector gradients, then one atomic row per block
 template <int NC>
-__device__ __forceinline__ void flush_vec_grad(const TileEnv& e, float* red /*[GQE_FWAVES][d]*/, int64_t param,
-                                               const Vec<NC>& part) {
-  __syncthreads();
-  vstore<NC>(red + e.wave * e.d, part, e.d, e.lane);
-  __syncthreads();
-  if (e.wave == 0) {
-    Vec<NC> s = vload<NC>(red, e.d, e.lane);
+__device__ __forceinline__ void vecgrads_commit(const TileEnv& e, float* lds /* >= SLOTS*8*d floats */, long long* s_param,
+                                                const VecGrads<NC>& vg) {
+  __syncthreads();  // every wave is done with the tiles this staging area overlays
 #pragma unroll
-    for (int w = 1; w < GQE_FWAVES; ++w) {
-      Vec<NC> t = vload<NC>(red + w * e.d, e.d, e.lane);
-      VEC_OP(s, s.v[c] + t.v[c]);
+  for (int k = 0; k < GQE_VG_SLOTS; ++k) {
+    if (vg.param[k] >= 0) vstore<NC>(lds + (size_t)(k * GQE_FWAVES + e.wave) * e.d, vg.g[k], e.d, e.lane);
+    if (threadIdx.x == 0) s_param[k] = vg.param[k];
+  }
+  __syncthreads();
+  if (e.wave < GQE_VG_SLOTS) {
+    const long long param = s_param[e.wave];
+    if (param >= 0) {
+      Vec<NC> s = vload<NC>(lds + (size_t)(e.wave * GQE_FWAVES) * e.d, e.d, e.lane);
+#pragma unroll
+      for (int w = 1; w < GQE_FWAVES; ++w) {
+        Vec<NC> t = vload<NC>(lds + (size_t)(e.wave * GQE_FWAVES + w) * e.d, e.d, e.lane);
+        VEC_OP(s, s.v[c] + t.v[c]);
+      }
+      vatomic_add<NC>(e.grads + param, s, e.d, e.lane);
     }
-    vatomic_add<NC>(e.grads + param, s, e.d, e.lane);
   }
 }
 
@@ -291,9 +330,9 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
   } while (0)
   GQE_STAMP(0);
   const int d = FULL ? 64 * NC : d_arg;
-  int bi = 0;  // which batch owns this tile: the plan is a kernel argument (SGPRs), a few scalar compares
-#pragma unroll 1
-  while (bi + 1 < plan.n_batches && (int)blockIdx.x >= plan.b[bi + 1].tile_begin) ++bi;
+  int bi = 0;  // which batch owns this tile: the plan is a kernel argument (SGPRs), 16 scalar compares
+#pragma unroll
+  for (int k = 1; k < GQE_LAUNCH_BATCHES; ++k) bi += ((int)blockIdx.x >= plan.tile_begin[k]) ? 1 : 0;
   const GqeDynBatch b = plan.b[bi];
   const GqeDevFormula* __restrict__ f = formulas + b.formula;
   TileEnv e;
@@ -366,6 +405,13 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
   const bool is_chain = f->qtype <= 2;
   const float gscale = b.grad_scale;  // loss_weight / B
   float loss_part = 0.f;
+  VecGrads<NC> vg;  // relation-vector gradient partials of this wave (DEC != bilinear)
+  vecgrads_init<NC>(vg);
+  int olds[RPW][2 + GQE_MAX_BRANCH];  // previous list heads returned by this wave's pushes
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+    for (int role = 0; role < 2 + GQE_MAX_BRANCH; ++role) olds[rr][role] = GQE_NO_PUSH;
   GQE_STAMP(2);
 
   if (is_chain) {
@@ -449,9 +495,9 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
             VEC_OP(ga, cp * (up.v[c] * ipp - sp * a.v[c] * iaa) + cn * (un.v[c] * ipn - sn * a.v[c] * iaa));
             VEC_OP(gw_acc, gw_acc.v[c] + gtp.v[c] + gtn.v[c]);
           }
-          scatter_norm_bwd<NC>(e, f->target_head, 0, wave * RPW + rr, RT.row[rr], tp, RT.nrm[rr], gtp);
-          scatter_norm_bwd<NC>(e, f->target_head, 1, wave * RPW + rr, RN.row[rr], tn, RN.nrm[rr], gtn);
-          scatter_norm_bwd<NC>(e, f->anchor_head[0], 2, wave * RPW + rr, RA[0].row[rr], a, RA[0].nrm[rr], ga);
+          scatter_norm_bwd<NC>(e, f->target_head, 0, wave * RPW + rr, RT.row[rr], tp, RT.nrm[rr], gtp, olds[rr][0]);
+          scatter_norm_bwd<NC>(e, f->target_head, 1, wave * RPW + rr, RN.row[rr], tn, RN.nrm[rr], gtn, olds[rr][1]);
+          scatter_norm_bwd<NC>(e, f->anchor_head[0], 2, wave * RPW + rr, RA[0].row[rr], a, RA[0].nrm[rr], ga, olds[rr][2]);
         }
       }
       if (BWD) {
@@ -465,7 +511,8 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
               for (int j = 0; j < GQE_MAX_HOPS; ++j)
                 if (j != h) VEC_OP(part, part.v[c] * w[j].v[c]);
             }
-            flush_vec_grad<NC>(e, red, f->hop_param[0][h], part);
+            vg.g[h] = part;
+            vg.param[h] = f->hop_param[0][h];
           }
         }
       }
@@ -535,7 +582,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
           VEC_OP(ga, ga.v[c] + cf[s] * (u[s].v[c] * iun - a.v[c] * iaa));
           vstore<NC>(cur[s] + r * DP, gu, d, lane);
         }
-        if (act) scatter_norm_bwd<NC>(e, f->anchor_head[0], 2, wave * RPW + rr, RA[0].row[rr], a, RA[0].nrm[rr], ga);
+        if (act) scatter_norm_bwd<NC>(e, f->anchor_head[0], 2, wave * RPW + rr, RA[0].row[rr], a, RA[0].nrm[rr], ga, olds[rr][2]);
       }
       if (BWD) {
         // back through the hops: act_{h+1} = act_h M_h  =>  g_act_h = g_act_{h+1} M_h^T (= M . g per row),
@@ -556,8 +603,8 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
         for (int rr = 0; rr < RPW; ++rr) {
           const int r = wave * RPW + rr;
           if (e.q0 + r >= B) continue;
-          scatter_norm_bwd<NC>(e, f->target_head, 0, r, RT.row[rr], RT.x[rr], RT.nrm[rr], vload<NC>(cur[0] + r * DP, d, lane));
-          scatter_norm_bwd<NC>(e, f->target_head, 1, r, RN.row[rr], RN.x[rr], RN.nrm[rr], vload<NC>(cur[1] + r * DP, d, lane));
+          scatter_norm_bwd<NC>(e, f->target_head, 0, r, RT.row[rr], RT.x[rr], RT.nrm[rr], vload<NC>(cur[0] + r * DP, d, lane), olds[rr][0]);
+          scatter_norm_bwd<NC>(e, f->target_head, 1, r, RN.row[rr], RN.x[rr], RN.nrm[rr], vload<NC>(cur[1] + r * DP, d, lane), olds[rr][1]);
         }
       }
     }
@@ -704,8 +751,8 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
         const float ipp = sp / (ncp * ncp), inn = sn / (ncn * ncn);
         VEC_OP(gtp, cp * (qv.v[c] * ipq - tp.v[c] * ipp));
         VEC_OP(gtn, cn * (qv.v[c] * inq - tn.v[c] * inn));
-        scatter_norm_bwd<NC>(e, f->target_head, 0, wave * RPW + rr, RT.row[rr], tp, RT.nrm[rr], gtp);
-        scatter_norm_bwd<NC>(e, f->target_head, 1, wave * RPW + rr, RN.row[rr], tn, RN.nrm[rr], gtn);
+        scatter_norm_bwd<NC>(e, f->target_head, 0, wave * RPW + rr, RT.row[rr], tp, RT.nrm[rr], gtp, olds[rr][0]);
+        scatter_norm_bwd<NC>(e, f->target_head, 1, wave * RPW + rr, RN.row[rr], tn, RN.nrm[rr], gtn, olds[rr][1]);
       }
     }
     GQE_STAMP(5);
@@ -735,7 +782,8 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
               VEC_OP(gw, gw.v[c] + g.v[c]);
             }
           }
-          flush_vec_grad<NC>(e, red, f->final_param, gw);
+          vg.g[6] = gw;
+          vg.param[6] = f->final_param;
         }
       }
       // ---- backward of Post: g_h -> tacc (h itself is already parked in scratch) ----
@@ -810,7 +858,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
             const int r = wave * RPW + rr;
             if (e.q0 + r >= B) continue;
             scatter_norm_bwd<NC>(e, f->anchor_head[i], 2 + i, r, RA[i].row[rr], RA[i].x[rr], RA[i].nrm[rr],
-                                 vload<NC>(tcur + r * DP, d, lane));
+                                 vload<NC>(tcur + r * DP, d, lane), olds[rr][2 + i]);
           }
           __syncthreads();  // tt / tq are rewritten by the next branch
         } else {
@@ -844,15 +892,21 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
             } else {
               VEC_OP(gw0, gw0.v[c] + g.v[c]);
             }
-            scatter_norm_bwd<NC>(e, f->anchor_head[i], 2 + i, r, RA[i].row[rr], x, RA[i].nrm[rr], g);
+            scatter_norm_bwd<NC>(e, f->anchor_head[i], 2 + i, r, RA[i].row[rr], x, RA[i].nrm[rr], g, olds[rr][2 + i]);
           }
-          flush_vec_grad<NC>(e, red, f->hop_param[i][0], gw0);
-          if (nh > 1) flush_vec_grad<NC>(e, red, f->hop_param[i][1], (DEC == DEC_DIAG) ? gw1 : gw0);
+          vg.g[2 * i] = gw0;
+          vg.param[2 * i] = f->hop_param[i][0];
+          if (nh > 1) {
+            vg.g[2 * i + 1] = (DEC == DEC_DIAG) ? gw1 : gw0;
+            vg.param[2 * i + 1] = f->hop_param[i][1];
+          }
         }
       }
     }
   }
   GQE_STAMP(7);
+  if (BWD && DEC != DEC_BILINEAR) vecgrads_commit<NC>(e, smem, reinterpret_cast<long long*>(s_idx), vg);
+  if (BWD) push_links(e, olds);
   if (BWD) {
     // mean hinge loss of the batch (model.py:124-126) and the weighted iteration loss: reduce the 8 waves in
     // LDS (thousands of same-address device atomics serialise at ~12 ns each) and park one partial per tile.

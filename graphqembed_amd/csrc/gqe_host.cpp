@@ -434,6 +434,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     P.n_batches = nb;
     P.first = b0 == 0;
     P.total_index = n_batches;
+    for (int k = 0; k < GQE_LAUNCH_BATCHES; ++k) P.tile_begin[k] = P.unit_begin[k] = 0x7fffffff;
     int64_t scratch = (int64_t)(L.scratch_off / sizeof(float));
     for (int k = 0; k < nb; ++k) {
       const gqe_batch& s = batches[b0 + k];
@@ -444,9 +445,9 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       b.Bpad = (int)align_up(s.n_queries, GQE_TQ);
       b.idx_offset = s.idx_offset;
       b.out_offset = s.out_offset;
-      b.tile_begin = P.tiles;
+      b.tile_begin = P.tile_begin[k] = P.tiles;
       b.has_neg = bwd ? 1 : 0;
-      b.unit_begin = P.units;
+      b.unit_begin = P.unit_begin[k] = P.units;
       b.entry_base = entry;
       b.scratch_base = scratch;
       b.margin = s.margin;

@@ -36,13 +36,13 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
     }
     return;
   }
-  const int unit = (int)blockIdx.x * GQE_WAVES + (threadIdx.x >> 6);
+  const int unit = (int)blockIdx.x * GQE_WAVES + (threadIdx.x >> 6);  // (batch, job, K chunk, output tile)
   if (unit >= plan.units) return;
   const int lane = threadIdx.x & 63;
   const int lq = lane & 15, lk = lane >> 4;
   int bi = 0;
-#pragma unroll 1
-  while (bi + 1 < plan.n_batches && unit >= plan.b[bi + 1].unit_begin) ++bi;
+#pragma unroll
+  for (int k = 1; k < GQE_LAUNCH_BATCHES; ++k) bi += (unit >= plan.unit_begin[k]) ? 1 : 0;
   const GqeDynBatch b = plan.b[bi];
   const GqeDevFormula* __restrict__ f = formulas + b.formula;
   const int tiles_per_dim = d / 16;
@@ -55,17 +55,29 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
   const int t = u - chunk * tiles;
   const int i0 = (t / tiles_per_dim) * 16, j0 = (t % tiles_per_dim) * 16;
   const int k_begin = chunk * GQE_GEMM_KCHUNK;
-  const int k_end = min(b.Bpad, k_begin + GQE_GEMM_KCHUNK);
   const size_t slot_floats = (size_t)b.Bpad * d;
   const float* L = ws + b.scratch_base + (size_t)f->job_L[job] * slot_floats;
   const float* R = ws + b.scratch_base + (size_t)f->job_R[job] * slot_floats;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = k_begin; k0 < k_end; k0 += 16) {
+  // all operand loads of the unit are issued before the first MFMA (8 k-blocks x 4 rows x 2 operands)
+  constexpr int KBLK = GQE_GEMM_KCHUNK / 16;
+  float la[KBLK][4], ra[KBLK][4];
+#pragma unroll
+  for (int kb = 0; kb < KBLK; ++kb) {
+    const int k0 = k_begin + kb * 16;
+    const bool ok = k0 < b.Bpad;
     const float* lp = L + (size_t)(k0 + 4 * lk) * d + i0 + lq;
     const float* rp = R + (size_t)(k0 + 4 * lk) * d + j0 + lq;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lp[s * d], rp[s * d], acc, 0, 0, 0);
+    for (int s = 0; s < 4; ++s) {
+      la[kb][s] = ok ? lp[s * d] : 0.f;
+      ra[kb][s] = ok ? rp[s * d] : 0.f;
+    }
   }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < KBLK; ++kb)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la[kb][s], ra[kb][s], acc, 0, 0, 0);
   float* out = grads + f->job_param[job] + (size_t)(i0 + 4 * lk) * d + j0 + lq;
 #pragma unroll
   for (int r = 0; r < 4; ++r) unsafeAtomicAdd(out + (size_t)r * d, acc[r]);

@@ -197,8 +197,10 @@ class Graph(object):
         self.full_sets = defaultdict(set)
         self.full_lists = {}
         self.meta_neighs = defaultdict(dict)
+        # built with the same set operations as the reference (graph.py:116-120): the ORDER of full_lists
+        # decides which node ``random.choice`` returns for 1-chain negatives under a given seed
         for rel, adjs in self.adj_lists.items():
-            self.full_sets[rel[0]].update(adjs.keys())
+            self.full_sets[rel[0]] = self.full_sets[rel[0]].union(set(adjs.keys()))
         for mode, nodes in self.full_sets.items():
             self.full_lists[mode] = list(nodes)
         self._refresh_caches()

@@ -1,0 +1,214 @@
+"""-m gpu: the reference-shaped Python API (QueryEncoderDecoder / utils.eval_* / train_helpers.run_train)
+on the golden fixtures the reference itself produced (oracle/make_golden.py)."""
+import json
+import os
+import pickle
+import random
+
+import numpy as np
+import pytest
+
+from golden_utils import GOLDEN, load_tables, to_rels
+
+pytestmark = pytest.mark.gpu
+
+TYPES = ["1-chain", "2-chain", "3-chain", "2-inter", "3-inter", "3-inter_chain", "3-chain_inter"]
+
+
+def build_world(dec, inter, d, fixture):
+    """The tiny graph of the fixtures + a model whose state_dict is the fixture's."""
+    import torch
+    from graphqembed_amd import data_utils, utils
+    from graphqembed_amd.graph import Graph
+    from graphqembed_amd.model import QueryEncoderDecoder
+    rel, adj, ids = data_utils.make_synthetic_graph(data_utils.BIO_TINY_SIZES, edges_per_kind=data_utils.BIO_TINY_EDGES_PER_KIND, seed=0)
+    node_maps = data_utils.make_node_maps(ids)
+    feature_modules = {m: torch.nn.Embedding(len(node_maps[m]) + 1, d) for m in rel}
+    out_dims = {m: d for m in rel}
+    graph = Graph(None, out_dims, rel, adj)
+    enc = utils.get_encoder(0, graph, out_dims, feature_modules, True, node_maps=node_maps)
+    model = QueryEncoderDecoder(graph, enc, utils.get_metapath_decoder(graph, out_dims, dec),
+                                utils.get_intersection_decoder(graph, out_dims, inter))
+    z = np.load(os.path.join(GOLDEN, fixture))
+    sd = {k: torch.from_numpy(v) for k, v in load_tables(d).items()}
+    sd.update({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")})
+    assert set(sd) == set(model.state_dict().keys())          # same state_dict keys as the reference
+    model.load_state_dict(sd)
+    return model, z
+
+
+def rebuild_queries():
+    """The Query objects of the fixtures, negatives in their recorded order."""
+    from graphqembed_amd.graph import Query
+    from collections import defaultdict
+    with open(os.path.join(GOLDEN, "queries_tiny.pkl"), "rb") as f:
+        data = pickle.load(f)
+
+    def mk(info):
+        negs, hard = info[1], info[2]
+        return Query(info[0], negs, hard, neg_sample_max=10 ** 9, keep_graph=True)
+    train = {}
+    for t in TYPES:
+        by = defaultdict(list)
+        for info in data["train"][t]:
+            q = mk(info)
+            by[q.formula].append(q)
+        train[t] = dict(by)
+    test = {}
+    for split, infos in data["test"].items():
+        by = defaultdict(lambda: defaultdict(list))
+        for info in infos:
+            q = mk(info)
+            by[q.formula.query_type][q.formula].append(q)
+        test[split] = by
+    return train, test
+
+
+def test_forward_matches_reference_eval_calls_and_auc():
+    """eval_auc_queries / eval_perc_queries: same negatives (seeded like the reference), same scores,
+    AUC and percentile within 1e-4 / 1e-2 of what the reference logged."""
+    import torch
+    from graphqembed_amd import utils
+    model, z = build_world("bilinear-diag", "min", 32, "eval_bilinear-diag_min_d32.npz")
+    _, test = rebuild_queries()
+    summary = json.loads(str(z["summary"]))
+    for tag, want in summary.items():
+        qtype, hard = (tag[:-5], True) if tag.endswith(".hard") else (tag, False)
+        calls = []
+        orig = model.forward
+
+        def spy(formula, queries, nodes):
+            out = orig(formula, queries, nodes)
+            calls.append(out.detach().cpu().numpy())
+            return out
+        model.forward = spy
+        auc, _ = utils.eval_auc_queries(test["one_neg"][qtype], model, hard_negatives=hard)
+        n_auc = len(calls)
+        perc = utils.eval_perc_queries(test["full_neg"][qtype], model, hard_negatives=hard)
+        model.forward = orig
+        assert n_auc == len(want["auc_calls"]) and len(calls) - n_auc == len(want["perc_calls"]), tag
+        for got, ci in zip(calls, want["auc_calls"] + want["perc_calls"]):
+            np.testing.assert_allclose(got, z["call%d/scores" % ci], atol=2e-5, rtol=1e-4, err_msg=tag)
+        assert abs(auc - want["auc"]) <= 1e-4, (tag, auc, want["auc"])
+        assert abs(perc - want["perc"]) <= 1e-2, (tag, perc, want["perc"])
+
+
+@pytest.mark.parametrize("dec,inter", [("bilinear-diag", "min"), ("bilinear", "mean"), ("transe", "min-simple")])
+def test_margin_loss_backward_with_torch_optim(dec, inter):
+    """Compatibility path: margin_loss -> loss.backward() -> param.grad views, checked against the golden
+    gradients; hard negatives on a chain query raise the reference's exception."""
+    import torch
+    from graphqembed_amd.graph import Formula
+    model, _ = build_world(dec, inter, 32, "train_%s_%s_d32.npz" % (dec, inter))
+    z = np.load(os.path.join(GOLDEN, "model_%s_%s_d32.npz" % (dec, inter)))
+    train, _ = rebuild_queries()
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    for case in ("2-chain", "3-inter", "3-chain_inter.hard"):
+        qtype, hard = (case[:-5], True) if case.endswith(".hard") else (case, False)
+        meta = json.loads(str(z[case + "/meta"]))
+        formula = Formula(qtype, to_rels(meta["rels"]))
+        queries = train[qtype][formula][:len(z[case + "/target"])]
+        rows = model.enc.rows([q.target_node for q in queries], formula.target_mode)
+        assert np.array_equal(rows, z[case + "/target"])        # same queries as the fixture
+        opt.zero_grad()
+        loss = model.margin_loss(formula, queries, hard_negatives=hard)
+        (2.0 * loss).backward()                                 # upstream gradient != 1 on purpose
+        np.testing.assert_allclose(loss.item(), float(z[case + "/loss"]), rtol=1e-4)   # train negatives are fixed (1 per query)
+        for k, p in model.named_parameters():
+            key = case + "/grad/" + k
+            if key in z.files:
+                scale = max(np.abs(z[key]).max(), 1e-12)
+                np.testing.assert_allclose(p.grad.cpu().numpy(), 2.0 * z[key], rtol=2e-3, atol=4e-6 * scale + 1e-9, err_msg=case + " " + k)
+            else:
+                assert p.grad is None or not p.grad.abs().max().item(), (case, k)
+        before = {k: p.detach().clone() for k, p in model.named_parameters()}
+        opt.step()
+        moved = [k for k, p in model.named_parameters() if not torch.equal(before[k], p.detach())]
+        assert set(moved) == set(k[len(case + "/grad/"):] for k in z.files if k.startswith(case + "/grad/"))
+    f1 = next(iter(train["1-chain"]))
+    with pytest.raises(Exception, match="Hard negative examples can only be used with intersection queries"):
+        model.margin_loss(f1, train["1-chain"][f1][:4], hard_negatives=True)
+
+
+@pytest.mark.parametrize("dec,inter,d", [("bilinear-diag", "min", 32), ("bilinear", "mean", 32), ("transe", "min-simple", 32),
+                                         ("bilinear-diag", "min", 128)])
+def test_run_train_reproduces_the_reference_run(dec, inter, d):
+    """train_helpers.run_train with the fused optimiser, seeded like oracle/make_golden.py: the same
+    (formula, slice, negatives) batches in the same order, the same per-iteration losses, per-tensor Adam
+    step counts and final parameters as the reference's own run_train (5 iterations, burn-in 2)."""
+    import torch
+    from graphqembed_amd import train_helpers
+    from graphqembed_amd.model import FusedAdam
+    if d != 32:
+        pytest.skip("query objects are only shipped for the d=32 world")  # the d=128 train fixture is replayed below
+    model, z = build_world(dec, inter, d, "train_%s_%s_d%d.npz" % (dec, inter, d))
+    train, test = rebuild_queries()
+    p0 = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    seen = []
+    orig = model.margin_step
+
+    def spy(items, **kw):
+        out = orig(items, want_scores=False)
+        seen.append((items, out[0]))
+        return out
+    model.margin_step = spy
+
+    class Log(object):
+        lines = []
+
+        def info(self, m):
+            self.lines.append(m)
+    random.seed(41); np.random.seed(41); torch.manual_seed(41)
+    opt = FusedAdam(model, lr=0.01)
+    train_helpers.run_train(model, opt, train, test, test, Log(), max_burn_in=2, batch_size=23, log_every=1, val_every=1000, max_iter=5)
+    assert len(seen) == 5
+    for i, (items, losses) in enumerate(seen):
+        assert len(items) == int(z["it%d/n" % i]), i
+        for j, (f, t, ng, a, w, m) in enumerate(items):
+            meta = json.loads(str(z["it%d/b%d/meta" % (i, j)]))
+            assert f.query_type == meta["type"] and f.rels == to_rels(meta["rels"]), (i, j)
+            assert np.array_equal(t, z["it%d/b%d/target" % (i, j)]) and np.array_equal(ng, z["it%d/b%d/neg" % (i, j)]), (i, j)
+            assert np.array_equal(a, z["it%d/b%d/anchors" % (i, j)]), (i, j)
+        l = losses.cpu().numpy()
+        np.testing.assert_allclose(l[-1], float(z["it%d/loss" % i]), rtol=1e-4 if i == 0 else 3e-2, err_msg="iteration %d" % i)
+    got = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    for k in got:
+        diff = np.abs(got[k].astype(np.float64) - p0[k] - z["delta/" + k])
+        assert diff.max() < 6e-2 and np.median(diff) < 1e-3, (k, diff.max(), np.median(diff))
+        steps = int(z["touched/" + k]) if "touched/" + k in z.files else 0
+        assert model.engine.steps[k] == steps, (k, model.engine.steps[k], steps)       # per-tensor Adam step counters
+    ref_log = json.loads(str(z["log"]))
+    mine = Log.lines
+    assert [l.split(";")[0] for l in mine if l.startswith("Iter")] == [l.split(";")[0] for l in ref_log if l.startswith("Iter")]
+    assert any(l.startswith("Edge converged at iteration 1") for l in mine)
+
+
+def test_train_fixture_replay_d128():
+    """The d=128 run_train fixture replayed batch by batch through margin_step + FusedAdam."""
+    import torch
+    from graphqembed_amd.graph import Formula
+    from graphqembed_amd.model import FusedAdam
+    model, z = build_world("bilinear-diag", "min", 128, "train_bilinear-diag_min_d128.npz")
+    p0 = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    opt = FusedAdam(model, lr=0.01)
+    i = 0
+    while "it%d/n" % i in z.files:
+        items = []
+        for j in range(int(z["it%d/n" % i])):
+            meta = json.loads(str(z["it%d/b%d/meta" % (i, j)]))
+            w = 1.0 if meta["type"] == "1-chain" else (0.005 if "inter" in meta["type"] else 0.01)
+            items.append((Formula(meta["type"], to_rels(meta["rels"])), z["it%d/b%d/target" % (i, j)], z["it%d/b%d/neg" % (i, j)],
+                          z["it%d/b%d/anchors" % (i, j)], w, float(meta["margin"])))
+        opt.zero_grad()
+        losses, _, _ = model.margin_step(items)
+        l = losses.cpu().numpy()
+        for j in range(len(items)):
+            np.testing.assert_allclose(l[j], float(z["it%d/b%d/loss" % (i, j)]), rtol=1e-4 if i == 0 else 5e-2, atol=1e-5, err_msg="it %d batch %d" % (i, j))
+        np.testing.assert_allclose(l[-1], float(z["it%d/loss" % i]), rtol=1e-4 if i == 0 else 3e-2)
+        opt.step()
+        i += 1
+    assert i == 5
+    got = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    for k in got:
+        diff = np.abs(got[k].astype(np.float64) - p0[k] - z["delta/" + k])
+        assert diff.max() < 6e-2 and np.median(diff) < 1e-3, (k, diff.max(), np.median(diff))
