@@ -22,6 +22,9 @@ Fixture schema (all index arrays are TABLE ROWS = node_maps[mode][node] + 1):
        it<i>/n, it<i>/b<j>/{meta,target,neg,anchors,loss}, it<i>/loss,
        delta/<key> (final - initial), touched/<key> = per-tensor Adam step count
   eval_<dec>_<inter>_d<D>.npz      eval_auc_queries / eval_perc_queries captures.
+  reddit_<dec>_<inter>_d32.npz     Reddit-shaped world (post features = nn.EmbeddingBag mean over word ids):
+       param/* (all tables incl. the word table enc.feat-post.weight), bag/post/{ptr,ids} (CSR of the posts'
+       word ids; a post's index row = its bag index), cases as in model_*.npz.
 """
 import json
 import logging
@@ -364,6 +367,128 @@ def dump_queries(world, by_formula, test_queries):
         pickle.dump({"train": train, "test": test}, f, protocol=2)
 
 
+class RedditWorld(object):
+    """Tiny Reddit-shaped graph: users / communities are nn.Embedding tables indexed by id + 1, posts are an
+    nn.EmbeddingBag (mean) over each post's word ids — what reddit/data_utils_new.py:143-182 (load_graph)
+    builds.  That module cannot be imported here (it imports gensim / spacy at module level), so its
+    feature closure (lines 162-169, CPU branch) is restated below; everything downstream (Graph,
+    DirectEncoder, decoders, QueryEncoderDecoder, optim) is the imported reference."""
+
+    RELATIONS = {  # reddit/data_utils_new.py:193-197
+        "user": [("post", "up"), ("post", "down"), ("post", "make"), ("post", "comment"), ("community", "subscribe")],
+        "post": [("user", "up"), ("user", "down"), ("user", "make"), ("user", "comment"), ("community", "belong")],
+        "community": [("post", "belong"), ("user", "subscribe")],
+    }
+
+    def __init__(self, d, n_user=80, n_post=120, n_comm=12, n_words=60, seed=0):
+        from collections import defaultdict
+        from netquery.graph import Graph
+        self.d = d
+        rng = np.random.RandomState(seed)
+        sizes = {"user": n_user, "post": n_post, "community": n_comm}
+        self.relations = self.RELATIONS
+        self.adj_lists = {}
+        for m1, lst in self.relations.items():
+            for (m2, name) in lst:
+                self.adj_lists.setdefault((m1, name, m2), defaultdict(set))
+        for (m1, name, m2) in list(self.adj_lists.keys()):
+            if m1 > m2:
+                continue                                   # fill each undirected kind once
+            n_edges = 500 if "community" not in (m1, m2) else 250
+            for u, v in zip(rng.randint(0, sizes[m1], n_edges).tolist(), rng.randint(0, sizes[m2], n_edges).tolist()):
+                self.adj_lists[(m1, name, m2)][u].add(v)
+                self.adj_lists[(m2, name, m1)][v].add(u)
+        self.post_ids = list(range(n_post))
+        self.post_words_np = {p: rng.randint(0, n_words, size=rng.randint(3, 13)).astype(np.int64) for p in self.post_ids}
+        post_words = {p: torch.LongTensor(w) for p, w in self.post_words_np.items()}
+        seed_all(2000 + d)
+        self.feature_modules = {"post": torch.nn.EmbeddingBag(n_words, d), "user": torch.nn.Embedding(n_user + 1, d),
+                                "community": torch.nn.Embedding(n_comm + 1, d)}
+        for m in self.feature_modules:
+            self.feature_modules[m].weight.data.normal_(0, 1. / d)
+        self._init_tables = {m: self.feature_modules[m].weight.data.clone() for m in self.feature_modules}
+        fm = self.feature_modules
+
+        def _feature_func(nodes, mode):                    # restated: reddit/data_utils_new.py:162-169
+            if mode != "post":
+                return fm[mode](torch.autograd.Variable(torch.LongTensor(nodes) + 1))
+            offsets = np.concatenate(([0], np.cumsum([post_words[post].size()[0] for post in nodes[:-1]])))
+            return fm[mode](torch.autograd.Variable(torch.cat([post_words[post] for post in nodes])),
+                            torch.autograd.Variable(torch.LongTensor(offsets)))
+        self.features = _feature_func
+        self.out_dims = {m: d for m in self.relations}
+        self.graph = Graph(self.features, self.out_dims, self.relations, self.adj_lists)
+        self.bag_ptr = np.concatenate(([0], np.cumsum([len(self.post_words_np[p]) for p in self.post_ids]))).astype(np.int32)
+        self.bag_ids = np.concatenate([self.post_words_np[p] for p in self.post_ids]).astype(np.int32)
+
+    def rows(self, nodes, mode):
+        """posts -> bag index (position in post_ids); users / communities -> id + 1."""
+        if mode == "post":
+            return np.asarray(nodes, dtype=np.int32)
+        return np.asarray(nodes, dtype=np.int32) + 1
+
+    reset_tables = World.reset_tables
+    build_model = World.build_model
+
+
+def gen_reddit_cases(d, B):
+    """margin_loss / backward / 3 Adam steps on the Reddit-shaped world (EmbeddingBag post features)."""
+    from collections import defaultdict
+    from netquery.graph import Query
+    world = RedditWorld(d)
+    seed_all(51)
+    qs = world.graph.sample_queries(2, 500, 1, verbose=False) + world.graph.sample_queries(3, 1000, 1, verbose=False)
+    qs += [Query(("1-chain", e), None, None, keep_graph=True) for e in world.graph.get_all_edges(seed=7)[:500]]
+    by = defaultdict(lambda: defaultdict(list))
+    for q in qs:
+        by[q.formula.query_type][q.formula].append(q)
+    for dec, inter in (("bilinear-diag", "min"), ("bilinear", "mean"), ("transe", "mean-simple")):
+        out = {"bag/post/ptr": world.bag_ptr, "bag/post/ids": world.bag_ids}
+        model = world.build_model(dec, inter)
+        p0 = state_np(model)
+        for k, v in p0.items():
+            out["param/" + k] = v
+        for qtype in ["1-chain", "2-chain", "3-chain", "2-inter", "3-inter", "3-inter_chain", "3-chain_inter"]:
+            # prefer formulas that involve posts on both sides, then the best populated
+            cands = sorted(by[qtype].items(), key=lambda kv: (-(str(kv[0]).count("post")), -len(kv[1]), str(kv[0])))
+            formula, queries = cands[0][0], cands[0][1][:B]
+            for hard in ((False, True) if qtype in ("2-inter", "3-chain_inter") else (False,)):
+                case = qtype + (".hard" if hard else "")
+                model = world.build_model(dec, inter)
+                spy = Spy(model)
+                seed_all(61)
+                model.zero_grad()
+                loss = model.margin_loss(formula, queries, hard_negatives=hard)
+                loss.backward()
+                mc = spy.margin_calls[-1]
+                batch_record(world, mc, case, out)
+                out[case + "/pos"] = mc["pos"]
+                out[case + "/negscore"] = mc["neg"]
+                for k, p in model.named_parameters():
+                    if p.grad is not None:
+                        out[case + "/grad/" + k] = p.grad.detach().numpy().copy()
+                model = world.build_model(dec, inter)
+                spy = Spy(model)
+                opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.01)
+                seed_all(67)
+                negs, losses = [], []
+                for _ in range(3):
+                    opt.zero_grad()
+                    loss = model.margin_loss(formula, queries, hard_negatives=hard)
+                    loss.backward()
+                    opt.step()
+                    negs.append(world.rows(spy.margin_calls[-1]["neg_nodes"], formula.target_mode))
+                    losses.append(spy.margin_calls[-1]["loss"])
+                out[case + "/adam/neg"] = np.stack(negs)
+                out[case + "/adam/loss"] = np.asarray(losses, dtype=np.float64)
+                p3 = state_np(model)
+                for k, p in model.named_parameters():
+                    if p.grad is not None:
+                        out[case + "/adam/delta/" + k] = (p3[k].astype(np.float64) - p0[k].astype(np.float64)).astype(np.float32)
+        np.savez_compressed(os.path.join(OUT, "reddit_%s_%s_d%d.npz" % (dec, inter, d)), **out)
+        print("reddit", dec, inter, d, flush=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     tmp = import_reference()
@@ -395,6 +520,7 @@ def main():
                 if d == 32:
                     gen_eval_case(world, test_queries, dec, inter)
                 print("train/eval", dec, inter, d, flush=True)
+        gen_reddit_cases(32, 23)
         with open(os.path.join(OUT, "META.json"), "w") as f:
             json.dump(meta, f, indent=1)
     finally:

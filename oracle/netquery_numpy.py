@@ -106,18 +106,42 @@ def make_plan(query_type, rels):
 # ----------------------------------------------------------------------------
 # primitive ops, forward + backward
 # ----------------------------------------------------------------------------
+BAGS_KEY = "__bags__"   # params[BAGS_KEY] = {mode: (ptr[n+1], ids[nnz])}: modes whose feature is an EmbeddingBag
+
+
+def _bag(params, mode):
+    bags = params.get(BAGS_KEY)
+    return None if bags is None else bags.get(mode)
+
+
 def _encode(params, mode, rows, dt):
-    """rows of the mode's table, L2-normalised, NO eps (encoders.py:41-43)."""
-    raw = params[table_key(mode)][rows].astype(dt)
+    """rows of the mode's table, L2-normalised, NO eps (encoders.py:41-43).  For a bag mode (Reddit
+    posts: nn.EmbeddingBag, mode 'mean', reddit/data_utils_new.py:155,162-169) ``rows`` are bag indices
+    and the raw vector is the mean of the bag's word rows."""
+    bag = _bag(params, mode)
+    W = params[table_key(mode)]
+    if bag is None:
+        raw = W[rows].astype(dt)
+    else:
+        ptr, ids = bag
+        raw = np.stack([W[ids[ptr[r]:ptr[r + 1]]].astype(dt).mean(axis=0) for r in np.asarray(rows)])
     nrm = np.sqrt((raw * raw).sum(axis=1, keepdims=True))
     return raw / nrm, nrm
 
 
 def _encode_bwd(grads, mode, rows, xhat, nrm, g):
     """d(x/|x|): (g - xhat (xhat.g)) / |x|, scatter-ADD into the dense table grad
-    (duplicate rows accumulate, as a dense nn.Embedding backward does)."""
+    (duplicate rows accumulate, as a dense nn.Embedding backward does); a bag spreads its
+    gradient / len over its word rows (EmbeddingBag mean backward)."""
     gx = (g - xhat * (xhat * g).sum(axis=1, keepdims=True)) / nrm
-    np.add.at(grads[table_key(mode)], rows, gx)
+    bag = _bag(grads, mode)
+    if bag is None:
+        np.add.at(grads[table_key(mode)], rows, gx)
+    else:
+        ptr, ids = bag
+        for b, r in enumerate(np.asarray(rows)):
+            w = ids[ptr[r]:ptr[r + 1]]
+            np.add.at(grads[table_key(mode)], w, np.broadcast_to(gx[b] / len(w), (len(w), gx.shape[1])))
 
 
 def _project(dec, params, rel, v):
@@ -268,7 +292,10 @@ def _query_vector(params, plan, dec, inter, anchor_rows, dtype):
 # fused margin loss forward + backward
 # ----------------------------------------------------------------------------
 def zero_grads_like(params, dtype=np.float64):
-    return {k: np.zeros(v.shape, dtype=dtype) for k, v in params.items()}
+    out = {k: np.zeros(v.shape, dtype=dtype) for k, v in params.items() if k != BAGS_KEY}
+    if BAGS_KEY in params:
+        out[BAGS_KEY] = params[BAGS_KEY]      # the scatter needs the bag structure too
+    return out
 
 
 def margin_fwd_bwd(params, plan, dec, inter, target_rows, neg_rows, anchor_rows,

@@ -20,18 +20,26 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .netquery_numpy import make_plan, pre_key, post_key, rel_key, table_key, CHAIN_TYPES
+from .netquery_numpy import BAGS_KEY, make_plan, pre_key, post_key, rel_key, table_key, CHAIN_TYPES
 
 
 class TorchPort(object):
     def __init__(self, params, dec, inter, lr=0.01):
         self.dec, self.inter = dec, inter
-        self.p = {k: torch.nn.Parameter(torch.from_numpy(np.array(v, dtype=np.float32))) for k, v in params.items()}
+        self.bags = params.get(BAGS_KEY) or {}
+        self.p = {k: torch.nn.Parameter(torch.from_numpy(np.array(v, dtype=np.float32))) for k, v in params.items() if k != BAGS_KEY}
         self.cos = torch.nn.CosineSimilarity(dim=0)
         self.opt = torch.optim.Adam(list(self.p.values()), lr=lr)
 
     def enc(self, mode, rows):
-        e = F.embedding(torch.as_tensor(np.asarray(rows), dtype=torch.long), self.p[table_key(mode)]).t()
+        if mode in self.bags:   # nn.EmbeddingBag(mode='mean') over the bag's word ids (reddit/data_utils_new.py:155,167-169)
+            ptr, ids = self.bags[mode]
+            parts = [ids[ptr[r]:ptr[r + 1]] for r in np.asarray(rows)]
+            offsets = np.concatenate(([0], np.cumsum([len(x) for x in parts[:-1]])))
+            e = F.embedding_bag(torch.as_tensor(np.concatenate(parts), dtype=torch.long), self.p[table_key(mode)],
+                                torch.as_tensor(offsets, dtype=torch.long), mode="mean").t()
+        else:
+            e = F.embedding(torch.as_tensor(np.asarray(rows), dtype=torch.long), self.p[table_key(mode)]).t()
         return e.div(e.norm(p=2, dim=0, keepdim=True).expand_as(e))
 
     def project(self, e, rel):

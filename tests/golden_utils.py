@@ -54,3 +54,19 @@ def load_case(z, case):
         out["adam_neg"] = z[case + "/adam/neg"]
         out["adam_loss"] = z[case + "/adam/loss"]
     return out
+
+
+def reddit_files():
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLDEN, "reddit_*.npz"))):
+        _, dec, inter, dd = os.path.basename(p)[:-4].split("_")
+        out.append((p, dec, inter, int(dd[1:])))
+    return out
+
+
+def load_reddit_params(z, with_bags=True):
+    """All parameters of a reddit_*.npz fixture (+ the oracle's bag registry under '__bags__')."""
+    params = {k[6:]: z[k] for k in z.files if k.startswith("param/")}
+    if with_bags:
+        params["__bags__"] = {"post": (z["bag/post/ptr"], z["bag/post/ids"])}
+    return params

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from golden_utils import GOLDEN, case_names, load_case, load_params, model_files
+from golden_utils import GOLDEN, case_names, load_case, load_params, load_reddit_params, model_files, reddit_files
 from oracle import netquery_numpy as O
 
 # fp32 reference vs fp64 oracle
@@ -113,3 +113,41 @@ def test_torch_port_matches_golden(path, dec, inter, d):
         for k, g in c["grads"].items():
             np.testing.assert_allclose(got[k], g, rtol=1e-4, atol=1e-7 + 1e-5 * np.abs(g).max(), err_msg="%s %s" % (case, k))
         assert set(k for k, g in got.items() if g is not None) == set(c["grads"].keys())
+
+
+@pytest.mark.parametrize("path,dec,inter,d", reddit_files(), ids=lambda v: os.path.basename(v) if isinstance(v, str) and v.endswith(".npz") else None)
+def test_reddit_embedding_bag_cases(path, dec, inter, d):
+    """Posts are an nn.EmbeddingBag (mean over word rows) in the reference: scores, loss, gradients (numpy
+    oracle and torch port) and the 3-step Adam trajectory."""
+    from oracle.netquery_torch import TorchPort
+    z = np.load(path)
+    params = load_reddit_params(z)
+    names = case_names(z)
+    assert len(names) == 9
+    for case in names:
+        c = load_case(z, case)
+        plan = O.make_plan(c["type"], c["rels"])
+        loss, sp, sn, grads = O.margin_fwd_bwd(params, plan, dec, inter, c["target"], c["neg"], c["anchors"], margin=c["margin"])
+        np.testing.assert_allclose(sp, c["pos"], atol=SCORE_ATOL, rtol=1e-5, err_msg=case)
+        np.testing.assert_allclose(sn, c["negscore"], atol=SCORE_ATOL, rtol=1e-5, err_msg=case)
+        np.testing.assert_allclose(loss, c["loss"], rtol=LOSS_RTOL, atol=1e-7, err_msg=case)
+        assert O.touched_keys(plan, dec, inter) == set(c["grads"].keys()), case
+        port = TorchPort(params, dec, inter)
+        tl = port.margin_loss(plan, c["target"], c["neg"], c["anchors"], c["margin"])
+        tl.backward()
+        tg = port.grads()
+        for k, g in c["grads"].items():
+            scale = max(np.abs(g).max(), 1e-12)
+            np.testing.assert_allclose(grads[k], g, rtol=GRAD_RTOL, atol=GRAD_ATOL + 1e-5 * scale, err_msg="%s %s" % (case, k))
+            np.testing.assert_allclose(tg[k], g, rtol=1e-4, atol=1e-7 + 1e-5 * scale, err_msg="torch port %s %s" % (case, k))
+        # Adam trajectory
+        p = {k: (v.astype(np.float64) if k != O.BAGS_KEY else v) for k, v in params.items()}
+        state = {}
+        touched = O.touched_keys(plan, dec, inter)
+        for step in range(3):
+            l, _, _, g = O.margin_fwd_bwd(p, plan, dec, inter, c["target"], c["adam_neg"][step], c["anchors"], margin=c["margin"])
+            np.testing.assert_allclose(l, c["adam_loss"][step], rtol=2e-6 if step == 0 else 3e-2, err_msg=case)
+            O.adam_step(p, g, state, touched)
+        for k, delta in c["adam_delta"].items():
+            diff = np.abs(p[k] - params[k].astype(np.float64) - delta)
+            assert diff.max() < 4e-2 and np.median(diff) < 5e-4, (case, k)
