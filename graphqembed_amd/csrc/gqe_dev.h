@@ -20,6 +20,7 @@
 #define GQE_LAUNCH_BATCHES 16  // batches per fused launch: their dynamic descriptors travel as kernel arguments
 #define GQE_MAX_FORMULAS 2048  // distinct (formula, decoder layout) descriptors cached on the device
 #define GQE_MAX_JOBS 8         // deferred matrix-gradient jobs one batch can generate
+#define GQE_MAX_BAGS 4         // tables whose rows are bags (nn.EmbeddingBag modes)
 
 // Static part of a batch: everything that depends only on the Formula (and the parameter layout).
 // Lives in a device-resident table that grows when a new formula is seen; never re-uploaded otherwise.
@@ -33,6 +34,8 @@ struct GqeDevFormula {
   int64_t final_param, pre_param, post_param;
   int64_t target_head;                    // index of the target table's row 0 in the gradient-list heads
   int64_t anchor_head[GQE_MAX_BRANCH];
+  int32_t target_bag;                     // >= 0: the target mode is a bag mode (index into GqeBagTable), else -1
+  int32_t anchor_bag[GQE_MAX_BRANCH];
   // deferred dM += L^T R jobs: parameter + the two scratch slots
   int64_t job_param[GQE_MAX_JOBS];
   int8_t job_L[GQE_MAX_JOBS], job_R[GQE_MAX_JOBS];
@@ -56,6 +59,13 @@ struct GqeDynBatch {
   int64_t scratch_base;  // float offset of this batch's scratch rows in the workspace
   float margin, grad_scale, inv_B, loss_weight;
   int32_t loss_index, pad;  // where this batch's loss goes in the caller's losses[]
+};
+
+// Bag modes (Reddit posts: nn.EmbeddingBag mean over word rows, reddit/data_utils_new.py:155,162-169):
+// CSR of row ids per bag, borrowed device pointers, passed by value with the launch.
+struct GqeBagTable {
+  const int32_t* ptr[GQE_MAX_BAGS];
+  const int32_t* ids[GQE_MAX_BAGS];
 };
 
 struct GqeDynPlan {
@@ -101,6 +111,8 @@ struct GqeOptArgs {
   int32_t* head;
   const int32_t* next;
   const float* contrib;
+  const int32_t* link_contrib;
+  int32_t max_entries;
   int d;
   float lr, b1, b2, eps;
   GqeStepCoef coef;
@@ -122,9 +134,13 @@ struct GqeFusedArgs {
   bool bwd;
   long long* prof;
   hipStream_t stream;
-  int32_t* head;   // gradient lists: head[table row] -> newest contribution entry (-1 = none)
-  int32_t* next;   // next[entry]
+  int32_t* head;   // gradient lists: head[table row] -> newest node (-1 = none)
+  int32_t* next;   // next[node]; node < max_entries: a contribution entry; else a bag link node
   float* contrib;  // contrib[entry][d]
+  GqeBagTable bags;
+  int32_t* link_contrib;  // link node -> contribution entry it stands for
+  int32_t* link_counter;  // bump allocator of link nodes
+  int32_t max_entries;
 };
 
 hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a);

@@ -35,6 +35,9 @@ struct TileEnv {
   int32_t* head;
   int32_t* next;
   float* contrib;
+  int32_t* link_contrib;
+  int32_t* link_counter;
+  int32_t max_entries;
   int d, DP, wave, lane, q0;  // q0 = first query of this tile
 };
 
@@ -200,6 +203,7 @@ struct RowSet {
   Vec<NC> x[RPW];
   float nrm[RPW];
   int row[RPW];
+  int bag_p0[RPW], bag_len[RPW];  // bag modes: the row is bag `row` = ids[p0 .. p0+len)
 };
 
 template <int NC>
@@ -209,6 +213,38 @@ __device__ __forceinline__ void rows_issue(RowSet<NC>& rs, const TileEnv& e, int
     const int row = s_rows[e.wave * RPW + rr];
     rs.row[rr] = row;
     rs.x[rr] = vload<NC>(e.params + table + (size_t)(row < 0 ? 0 : row) * e.d, e.d, e.lane);
+  }
+}
+
+// bag mode: raw vector = mean of the bag's word rows (nn.EmbeddingBag, mode 'mean'), then normalised like any
+// other row by rows_finish.  Lanes fetch the word ids together, the row loads are then issued back to back.
+template <int NC>
+__device__ __forceinline__ void rows_issue_bag(RowSet<NC>& rs, const TileEnv& e, int64_t table, const int* s_rows,
+                                               const int32_t* __restrict__ ptr, const int32_t* __restrict__ ids) {
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = s_rows[e.wave * RPW + rr];
+    rs.row[rr] = row;
+    Vec<NC> acc = vzero<NC>();
+    int p0 = 0, len = 0;
+    if (row >= 0) {
+      p0 = ptr[row];
+      len = ptr[row + 1] - p0;
+      for (int c0 = 0; c0 < len; c0 += 64) {
+        const int m = min(64, len - c0);
+        const int wid = (e.lane < m) ? ids[p0 + c0 + e.lane] : 0;
+        for (int k = 0; k < m; ++k) {
+          const int w = __builtin_amdgcn_readlane(wid, k);
+          const Vec<NC> v = vload<NC>(e.params + table + (size_t)w * e.d, e.d, e.lane);
+          VEC_OP(acc, acc.v[c] + v.v[c]);
+        }
+      }
+      const float inv = 1.f / (float)len;
+      VEC_OP(acc, acc.v[c] * inv);
+    }
+    rs.bag_p0[rr] = p0;
+    rs.bag_len[rr] = len;
+    rs.x[rr] = acc;
   }
 }
 
@@ -245,6 +281,42 @@ __device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_
   // The returned previous head is only needed for next[entry]; that store is deferred to the end of the
   // kernel (push_links) so that the wave never stalls on the atomic's round trip.
   if (e.lane == 0) old_head = __hip_atomic_exchange(e.head + head_base + row, (int)entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// bag mode: one contribution (already divided by the bag length: EmbeddingBag mean backward) shared by every
+// word row of the bag through link nodes: node -> (contribution entry, next).  Nodes come from a bump allocator.
+template <int NC>
+__device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t head_base, int role, int r, int p0, int len,
+                                                     const int32_t* __restrict__ ids, const Vec<NC>& xhat, float nrm,
+                                                     const Vec<NC>& g) {
+  const float pg = vdot<NC>(xhat, g);
+  const float inv = 1.f / (nrm * (float)len);
+  Vec<NC> gx;
+  VEC_OP(gx, (g.v[c] - xhat.v[c] * pg) * inv);
+  const int64_t entry = e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
+  vstore<NC>(e.contrib + entry * e.d, gx, e.d, e.lane);
+  int base = 0;
+  if (e.lane == 0) base = __hip_atomic_fetch_add(e.link_counter, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  base = __builtin_amdgcn_readfirstlane(base);
+  for (int c0 = 0; c0 < len; c0 += 64) {
+    const int k = c0 + e.lane;
+    if (k < len) {
+      const int node = base + k;
+      const int w = ids[p0 + k];
+      const int old = __hip_atomic_exchange(e.head + head_base + w, e.max_entries + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      e.next[e.max_entries + node] = old;
+      e.link_contrib[node] = (int)entry;
+    }
+  }
+}
+
+template <int NC>
+__device__ __forceinline__ void scatter_row(const TileEnv& e, const GqeBagTable& bags, int bag, int64_t head_base, int role, int r,
+                                            const RowSet<NC>& rs, int rr, const Vec<NC>& g, int& old_head) {
+  if (bag < 0)
+    scatter_norm_bwd<NC>(e, head_base, role, r, rs.row[rr], rs.x[rr], rs.nrm[rr], g, old_head);
+  else
+    scatter_norm_bwd_bag<NC>(e, head_base, role, r, rs.bag_p0[rr], rs.bag_len[rr], bags.ids[bag], rs.x[rr], rs.nrm[rr], g);
 }
 
 // next[entry] = previous head, for every contribution this wave pushed
@@ -321,7 +393,9 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
                                                                 float* __restrict__ tile_loss, float* __restrict__ pos_out,
                                                                 float* __restrict__ neg_out, int inter_min,
                                                                 int32_t* __restrict__ head, int32_t* __restrict__ next,
-                                                                float* __restrict__ contrib,
+                                                                float* __restrict__ contrib, const GqeBagTable bags,
+                                                                int32_t* __restrict__ link_contrib,
+                                                                int32_t* __restrict__ link_counter, int max_entries,
                                                                 long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #define GQE_STAMP(k)                                                                                              \
@@ -344,6 +418,9 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
   e.head = head;
   e.next = next;
   e.contrib = contrib;
+  e.link_contrib = link_contrib;
+  e.link_counter = link_counter;
+  e.max_entries = max_entries;
   e.d = d;
   e.DP = d + 4;
   e.wave = threadIdx.x >> 6;
@@ -382,11 +459,24 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
   __syncthreads();
   GQE_STAMP(1);
   RowSet<NC> RA[GQE_MAX_BRANCH], RT, RN;
-  rows_issue<NC>(RT, e, f->target_table, s_idx);
-  if (has_neg) rows_issue<NC>(RN, e, f->target_table, s_idx + GQE_TQ);
+  const int tbag = f->target_bag;
+  if (tbag < 0) {
+    rows_issue<NC>(RT, e, f->target_table, s_idx);
+    if (has_neg) rows_issue<NC>(RN, e, f->target_table, s_idx + GQE_TQ);
+  } else {
+    rows_issue_bag<NC>(RT, e, f->target_table, s_idx, bags.ptr[tbag], bags.ids[tbag]);
+    if (has_neg) rows_issue_bag<NC>(RN, e, f->target_table, s_idx + GQE_TQ, bags.ptr[tbag], bags.ids[tbag]);
+  }
 #pragma unroll
-  for (int i = 0; i < GQE_MAX_BRANCH; ++i)
-    if (i < n) rows_issue<NC>(RA[i], e, f->anchor_table[i], s_idx + (2 + i) * GQE_TQ);
+  for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
+    if (i < n) {
+      const int ab = f->anchor_bag[i];
+      if (ab < 0)
+        rows_issue<NC>(RA[i], e, f->anchor_table[i], s_idx + (2 + i) * GQE_TQ);
+      else
+        rows_issue_bag<NC>(RA[i], e, f->anchor_table[i], s_idx + (2 + i) * GQE_TQ, bags.ptr[ab], bags.ids[ab]);
+    }
+  }
   rows_finish<NC>(RT);
   if (has_neg) {
     rows_finish<NC>(RN);
@@ -495,9 +585,9 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
             VEC_OP(ga, cp * (up.v[c] * ipp - sp * a.v[c] * iaa) + cn * (un.v[c] * ipn - sn * a.v[c] * iaa));
             VEC_OP(gw_acc, gw_acc.v[c] + gtp.v[c] + gtn.v[c]);
           }
-          scatter_norm_bwd<NC>(e, f->target_head, 0, wave * RPW + rr, RT.row[rr], tp, RT.nrm[rr], gtp, olds[rr][0]);
-          scatter_norm_bwd<NC>(e, f->target_head, 1, wave * RPW + rr, RN.row[rr], tn, RN.nrm[rr], gtn, olds[rr][1]);
-          scatter_norm_bwd<NC>(e, f->anchor_head[0], 2, wave * RPW + rr, RA[0].row[rr], a, RA[0].nrm[rr], ga, olds[rr][2]);
+          scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0]);
+          scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1]);
+          scatter_row<NC>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2]);
         }
       }
       if (BWD) {
@@ -582,7 +672,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
           VEC_OP(ga, ga.v[c] + cf[s] * (u[s].v[c] * iun - a.v[c] * iaa));
           vstore<NC>(cur[s] + r * DP, gu, d, lane);
         }
-        if (act) scatter_norm_bwd<NC>(e, f->anchor_head[0], 2, wave * RPW + rr, RA[0].row[rr], a, RA[0].nrm[rr], ga, olds[rr][2]);
+        if (act) scatter_row<NC>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2]);
       }
       if (BWD) {
         // back through the hops: act_{h+1} = act_h M_h  =>  g_act_h = g_act_{h+1} M_h^T (= M . g per row),
@@ -603,8 +693,8 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
         for (int rr = 0; rr < RPW; ++rr) {
           const int r = wave * RPW + rr;
           if (e.q0 + r >= B) continue;
-          scatter_norm_bwd<NC>(e, f->target_head, 0, r, RT.row[rr], RT.x[rr], RT.nrm[rr], vload<NC>(cur[0] + r * DP, d, lane), olds[rr][0]);
-          scatter_norm_bwd<NC>(e, f->target_head, 1, r, RN.row[rr], RN.x[rr], RN.nrm[rr], vload<NC>(cur[1] + r * DP, d, lane), olds[rr][1]);
+          scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, r, RT, rr, vload<NC>(cur[0] + r * DP, d, lane), olds[rr][0]);
+          scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, r, RN, rr, vload<NC>(cur[1] + r * DP, d, lane), olds[rr][1]);
         }
       }
     }
@@ -751,8 +841,8 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
         const float ipp = sp / (ncp * ncp), inn = sn / (ncn * ncn);
         VEC_OP(gtp, cp * (qv.v[c] * ipq - tp.v[c] * ipp));
         VEC_OP(gtn, cn * (qv.v[c] * inq - tn.v[c] * inn));
-        scatter_norm_bwd<NC>(e, f->target_head, 0, wave * RPW + rr, RT.row[rr], tp, RT.nrm[rr], gtp, olds[rr][0]);
-        scatter_norm_bwd<NC>(e, f->target_head, 1, wave * RPW + rr, RN.row[rr], tn, RN.nrm[rr], gtn, olds[rr][1]);
+        scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0]);
+        scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1]);
       }
     }
     GQE_STAMP(5);
@@ -857,8 +947,8 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
           for (int rr = 0; rr < RPW; ++rr) {
             const int r = wave * RPW + rr;
             if (e.q0 + r >= B) continue;
-            scatter_norm_bwd<NC>(e, f->anchor_head[i], 2 + i, r, RA[i].row[rr], RA[i].x[rr], RA[i].nrm[rr],
-                                 vload<NC>(tcur + r * DP, d, lane), olds[rr][2 + i]);
+            scatter_row<NC>(e, bags, f->anchor_bag[i], f->anchor_head[i], 2 + i, r, RA[i], rr, vload<NC>(tcur + r * DP, d, lane),
+                            olds[rr][2 + i]);
           }
           __syncthreads();  // tt / tq are rewritten by the next branch
         } else {
@@ -892,7 +982,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
             } else {
               VEC_OP(gw0, gw0.v[c] + g.v[c]);
             }
-            scatter_norm_bwd<NC>(e, f->anchor_head[i], 2 + i, r, RA[i].row[rr], x, RA[i].nrm[rr], g, olds[rr][2 + i]);
+            scatter_row<NC>(e, bags, f->anchor_bag[i], f->anchor_head[i], 2 + i, r, RA[i], rr, g, olds[rr][2 + i]);
           }
           vg.g[2 * i] = gw0;
           vg.param[2 * i] = f->hop_param[i][0];
@@ -937,10 +1027,12 @@ static hipError_t launch_fused_v(const GqeFusedArgs& a) {
   const size_t lds = gqe_fused_lds_bytes_impl(a.d);
   if (a.bwd)
     hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true>), dim3(a.plan.tiles), dim3(GQE_FTHREADS), lds, a.stream, a.plan,
-                       a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.prof);
+                       a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags, a.link_contrib, a.link_counter,
+                       a.max_entries, a.prof);
   else
     hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, false>), dim3(a.plan.tiles), dim3(GQE_FTHREADS), lds, a.stream, a.plan,
-                       a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.prof);
+                       a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags, a.link_contrib, a.link_counter,
+                       a.max_entries, a.prof);
   return hipGetLastError();
 }
 

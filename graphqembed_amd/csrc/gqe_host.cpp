@@ -48,10 +48,17 @@ struct Table {
   bool pending;  // has un-consumed gradient lists
 };
 
+struct Bag {
+  int table;  // index into ctx->tables
+  const int32_t *ptr, *ids;
+  int64_t n_bags;
+  int32_t max_len;
+};
+
 struct Layout {  // byte offsets inside the bound workspace
   size_t idx_cap, tloss_off, scratch_off, scratch_cap;  // [staged indices x2 | tile losses | pair scratch]
-  size_t seg_off, formula_off, head_off, next_off, contrib_off, total;
-  int64_t max_entries;
+  size_t seg_off, formula_off, head_off, next_off, contrib_off, linkc_off, counter_off, total;
+  int64_t max_entries, max_links;
 };
 
 }  // namespace
@@ -66,6 +73,8 @@ struct gqe_ctx {
   int32_t cap_batches = 0;
   Layout lay{};
   std::vector<Table> tables;
+  std::vector<Bag> bags;
+  bool links_used = false;  // link nodes were allocated since the last consumption
   int64_t total_rows = 0;
   int64_t entries_used = 0;
   bool dense_dirty = false;  // the dense gradient of some table may be non-zero (after materialize)
@@ -141,8 +150,13 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
   L.head_off = L.formula_off + align_up(sizeof(GqeDevFormula) * GQE_MAX_FORMULAS, 256);
   L.max_entries = rows * kRolesPerQuery;
   L.next_off = L.head_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
-  L.contrib_off = L.next_off + align_up(sizeof(int32_t) * (size_t)L.max_entries, 256);
-  L.total = L.contrib_off + align_up(sizeof(float) * (size_t)L.max_entries * ctx->cfg.dim, 256);
+  int32_t max_len = 0;  // bag modes: every (entry, word) pair needs a link node
+  for (const Bag& bg : ctx->bags) max_len = std::max(max_len, bg.max_len);
+  L.max_links = L.max_entries * max_len;
+  L.contrib_off = L.next_off + align_up(sizeof(int32_t) * (size_t)(L.max_entries + L.max_links), 256);
+  L.linkc_off = L.contrib_off + align_up(sizeof(float) * (size_t)L.max_entries * ctx->cfg.dim, 256);
+  L.counter_off = L.linkc_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(L.max_links, 1), 256);
+  L.total = L.counter_off + 256;
   return L;
 }
 
@@ -244,6 +258,13 @@ int formula_of(gqe_ctx* ctx, const gqe_batch& s, int bi, int* out_id) {
   const int tt = table_of(ctx, s.target_table);
   if (tt < 0) return fail(ctx, GQE_ERR_STATE, "batch %d: target_table %lld is not a registered table (gqe_set_tables)", bi, (long long)s.target_table);
   f.target_head = ctx->tables[tt].head_base;
+  auto bag_of = [&](int table) {
+    for (size_t k = 0; k < ctx->bags.size(); ++k)
+      if (ctx->bags[k].table == table) return (int)k;
+    return -1;
+  };
+  f.target_bag = bag_of(tt);
+  for (int i = 0; i < GQE_MAX_BRANCH; ++i) f.anchor_bag[i] = -1;
   for (int i = 0; i < GQE_MAX_BRANCH; ++i) f.n_hops[i] = 0;
   for (int i = 0; i < na; ++i) {
     if (!off_ok(ctx, s.anchor_table[i], d)) return fail(ctx, GQE_ERR_ARG, "batch %d: anchor_table[%d] outside the arena", bi, i);
@@ -251,6 +272,7 @@ int formula_of(gqe_ctx* ctx, const gqe_batch& s, int bi, int* out_id) {
     const int ta = table_of(ctx, s.anchor_table[i]);
     if (ta < 0) return fail(ctx, GQE_ERR_STATE, "batch %d: anchor_table[%d] is not a registered table (gqe_set_tables)", bi, i);
     f.anchor_head[i] = ctx->tables[ta].head_base;
+    f.anchor_bag[i] = bag_of(ta);
   }
   for (int i = 0; i < nbr; ++i) {
     const int nh = s.n_hops[i];
@@ -424,6 +446,15 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   fa.head = reinterpret_cast<int32_t*>(ctx->ws + L.head_off);
   fa.next = reinterpret_cast<int32_t*>(ctx->ws + L.next_off);
   fa.contrib = reinterpret_cast<float*>(ctx->ws + L.contrib_off);
+  memset(&fa.bags, 0, sizeof fa.bags);
+  for (size_t k = 0; k < ctx->bags.size(); ++k) {
+    fa.bags.ptr[k] = ctx->bags[k].ptr;
+    fa.bags.ids[k] = ctx->bags[k].ids;
+  }
+  fa.link_contrib = reinterpret_cast<int32_t*>(ctx->ws + L.linkc_off);
+  fa.link_counter = reinterpret_cast<int32_t*>(ctx->ws + L.counter_off);
+  fa.max_entries = (int32_t)L.max_entries;
+  if (bwd && !ctx->bags.empty()) ctx->links_used = true;
 
   // ---- launches of <= GQE_LAUNCH_BATCHES batches; per-call data travels as kernel arguments ----
   int64_t entry = ctx->entries_used;
@@ -614,6 +645,8 @@ int run_opt(gqe_ctx* ctx, int mode, const gqe_segment* segs, int32_t n_segs, flo
   oa.head = reinterpret_cast<int32_t*>(ctx->ws + ctx->lay.head_off);
   oa.next = reinterpret_cast<const int32_t*>(ctx->ws + ctx->lay.next_off);
   oa.contrib = reinterpret_cast<const float*>(ctx->ws + ctx->lay.contrib_off);
+  oa.link_contrib = reinterpret_cast<const int32_t*>(ctx->ws + ctx->lay.linkc_off);
+  oa.max_entries = (int32_t)ctx->lay.max_entries;
   oa.d = d;
   oa.lr = lr;
   oa.b1 = b1;
@@ -631,7 +664,13 @@ int run_opt(gqe_ctx* ctx, int mode, const gqe_segment* segs, int32_t n_segs, flo
     if (seen[t]) ctx->tables[t].pending = false;
     any_pending = any_pending || ctx->tables[t].pending;
   }
-  if (!any_pending) ctx->entries_used = 0;
+  if (!any_pending) {
+    ctx->entries_used = 0;
+    if (ctx->links_used) {  // recycle the link nodes of the bag modes
+      HIP_TRY(ctx, hipMemsetAsync(ctx->ws + ctx->lay.counter_off, 0, sizeof(int32_t), st));
+      ctx->links_used = false;
+    }
+  }
   if (mode == GQE_OPT_MATERIALIZE)
     ctx->dense_dirty = true;
   else if (!any_pending)
@@ -709,6 +748,7 @@ int gqe_set_tables(gqe_ctx* ctx, const int64_t* offsets, const int64_t* rows, in
   if (!offsets || !rows || n_tables < 1 || n_tables > GQE_MAX_SEGS) return fail(ctx, GQE_ERR_ARG, "bad table list");
   if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "gradients pending; step or materialize before changing the tables");
   ctx->tables.clear();
+  ctx->bags.clear();
   ctx->total_rows = 0;
   for (int t = 0; t < n_tables; ++t) {
     if (offsets[t] < 0 || (offsets[t] % 4) || rows[t] < 1) return fail(ctx, GQE_ERR_ARG, "table %d: bad offset / rows", t);
@@ -721,6 +761,27 @@ int gqe_set_tables(gqe_ctx* ctx, const int64_t* offsets, const int64_t* rows, in
   ctx->formula_ids.clear();
   ctx->formulas_uploaded = 0;
   ctx->ws = nullptr;  // the workspace layout depends on the tables: it must be bound again
+  return GQE_OK;
+}
+
+int gqe_set_bag(gqe_ctx* ctx, int64_t table_offset, const int32_t* bag_ptr, const int32_t* bag_ids, int64_t n_bags, int32_t max_len) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (!bag_ptr || !bag_ids || n_bags < 1 || max_len < 1) return fail(ctx, GQE_ERR_ARG, "bad bag description");
+  if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "gradients pending; step or materialize before changing the bags");
+  const int t = table_of(ctx, table_offset);
+  if (t < 0) return fail(ctx, GQE_ERR_STATE, "gqe_set_bag: offset %lld is not a registered table", (long long)table_offset);
+  for (Bag& bg : ctx->bags)
+    if (bg.table == t) {
+      bg = Bag{t, bag_ptr, bag_ids, n_bags, max_len};
+      ctx->ws = nullptr;
+      return GQE_OK;
+    }
+  if (ctx->bags.size() >= GQE_MAX_BAGS) return fail(ctx, GQE_ERR_ARG, "more than %d bag tables", GQE_MAX_BAGS);
+  ctx->bags.push_back(Bag{t, bag_ptr, bag_ids, n_bags, max_len});
+  ctx->formulas.clear();
+  ctx->formula_ids.clear();
+  ctx->formulas_uploaded = 0;
+  ctx->ws = nullptr;  // the workspace layout depends on the bags: it must be bound again
   return GQE_OK;
 }
 
@@ -744,8 +805,10 @@ int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* strea
   ctx->lay = L;
   ctx->universe_uploaded = 0;
   ctx->formulas_uploaded = 0;
-  // empty gradient lists: head[row] = -1
+  // empty gradient lists: head[row] = -1; link-node allocator at 0
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.head_off, 0xff, L.next_off - L.head_off, reinterpret_cast<hipStream_t>(stream)));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.counter_off, 0, sizeof(int32_t), reinterpret_cast<hipStream_t>(stream)));
+  ctx->links_used = false;
   for (auto& t : ctx->tables) t.pending = false;
   return GQE_OK;
 }

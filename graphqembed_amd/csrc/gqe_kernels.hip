@@ -117,8 +117,10 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
                                                              float* __restrict__ g, float* __restrict__ m,
                                                              float* __restrict__ v, int32_t* __restrict__ head,
                                                              const int32_t* __restrict__ next,
-                                                             const float* __restrict__ contrib, int d, float lr, float b1,
-                                                             float b2, float eps, GqeStepCoef coef, GqeOptActive active) {
+                                                             const float* __restrict__ contrib,
+                                                             const int32_t* __restrict__ link_contrib, int max_entries,
+                                                             int d, float lr, float b1, float b2, float eps,
+                                                             GqeStepCoef coef, GqeOptActive active) {
   __shared__ long long s_begin[GQE_MAX_SEGS + 1];  // chunk prefix over the universe; inactive tensors get 0 chunks
   __shared__ long long s_cnt[GQE_MAX_SEGS];
   if ((int)threadIdx.x < n_segs) s_cnt[threadIdx.x] = (active.group[threadIdx.x] != 0xFF) ? segs[threadIdx.x].n_chunks : 0;
@@ -159,7 +161,8 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
         had = h >= 0;
         float4 acc = zero4;
         while (h >= 0) {
-          const float4 c = *reinterpret_cast<const float4*>(contrib + (size_t)h * d + c4);
+          const int ce = (h < max_entries) ? h : link_contrib[h - max_entries];  // bag link node -> its contribution
+          const float4 c = *reinterpret_cast<const float4*>(contrib + (size_t)ce * d + c4);
           acc.x += c.x;
           acc.y += c.y;
           acc.z += c.z;
@@ -271,7 +274,8 @@ template <int MODE>
 static void launch_opt_mode(const GqeOptArgs& a, unsigned blocks) {
 #define GO(L, D)                                                                                                          \
   hipLaunchKernelGGL((gqe_opt_kernel<MODE, L, D>), dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.n_segs,          \
-                     a.total_chunks, a.p, a.g, a.m, a.v, a.head, a.next, a.contrib, a.d, a.lr, a.b1, a.b2, a.eps, a.coef, a.active)
+                     a.total_chunks, a.p, a.g, a.m, a.v, a.head, a.next, a.contrib, a.link_contrib, a.max_entries, a.d, a.lr, a.b1,  \
+                     a.b2, a.eps, a.coef, a.active)
   if (a.lists) {
     if (a.dense_tables) GO(true, true); else GO(true, false);
   } else {

@@ -19,7 +19,10 @@ class DirectEncoder(nn.Module):
     ``features`` closure; without it rows are ``node_id + 1`` (utils.py:19-20).
     """
 
-    def __init__(self, features, feature_modules, node_maps=None):
+    def __init__(self, features, feature_modules, node_maps=None, bags=None):
+        """``bags``: {mode: {node_id: sequence of row ids}} for modes whose feature module is an
+        ``nn.EmbeddingBag`` (Reddit posts = mean of word rows, reddit/data_utils_new.py:155,162-169);
+        what the reference keeps in its ``post_words`` dict."""
         super(DirectEncoder, self).__init__()
         for name, module in feature_modules.items():
             self.add_module("feat-" + name, module)
@@ -27,6 +30,23 @@ class DirectEncoder(nn.Module):
         self.modes = list(feature_modules.keys())
         self.node_maps = node_maps
         self._lut = {}
+        self.bag_csr = {}       # mode -> (ptr int32[n+1], ids int32[nnz]); a node's "row" is its bag index
+        self._bag_index = {}
+        for mode, module in feature_modules.items():
+            if isinstance(module, nn.EmbeddingBag):
+                if bags is None or mode not in bags:
+                    raise Exception("mode %r is an EmbeddingBag: pass bags={%r: {node: row ids}}" % (mode, mode))
+                if module.mode != "mean":
+                    raise Exception("only EmbeddingBag(mode='mean') is supported (the reference's default)")
+                nodes = list(bags[mode].keys())
+                lens = [len(bags[mode][n]) for n in nodes]
+                if min(lens) < 1:
+                    raise Exception("empty bag in mode %r" % mode)
+                ptr = np.zeros(len(nodes) + 1, dtype=np.int32)
+                ptr[1:] = np.cumsum(lens)
+                ids = np.concatenate([np.asarray(bags[mode][n], dtype=np.int32) for n in nodes])
+                self.bag_csr[mode] = (ptr, ids)
+                self._bag_index[mode] = {n: i for i, n in enumerate(nodes)}
 
     def table(self, mode):
         return getattr(self, "feat-" + mode)
@@ -46,6 +66,9 @@ class DirectEncoder(nn.Module):
 
     def rows(self, nodes, mode):
         """Vectorised node ids -> int32 table rows (node -1 -> the dummy row 0)."""
+        if mode in self._bag_index:
+            idx = self._bag_index[mode]
+            return np.fromiter((idx[n] for n in nodes), dtype=np.int32, count=len(nodes))
         nodes = np.asarray(nodes, dtype=np.int64)
         if self.node_maps is None:
             return (nodes + 1).astype(np.int32)

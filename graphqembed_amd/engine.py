@@ -67,6 +67,7 @@ SYMBOLS = OrderedDict([
     ("gqe_destroy", (C.c_int, [_P])),
     ("gqe_bind_arena", (C.c_int, [_P, _P, _P, _P, _P, C.c_int64])),
     ("gqe_set_tables", (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32])),
+    ("gqe_set_bag", (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int32])),
     ("gqe_workspace_bytes", (C.c_int64, [_P, C.c_int64, C.c_int32])),
     ("gqe_bind_workspace", (C.c_int, [_P, _P, C.c_int64, _P])),
     ("gqe_materialize_grads", (C.c_int, [_P, _P])),
@@ -142,7 +143,9 @@ class ArenaLayout(object):
 class Engine(object):
     """One gqe_ctx + the tensors it borrows."""
 
-    def __init__(self, dim, decoder, inter_decoder, layout, device=None, max_queries=8192, max_batches=16):
+    def __init__(self, dim, decoder, inter_decoder, layout, device=None, max_queries=8192, max_batches=16, bags=None):
+        """``bags``: {table key: (ptr int32[n+1], ids int32[nnz])} for modes whose feature is an
+        nn.EmbeddingBag (mean over table rows) — an index into such a mode is a bag index."""
         import torch
         if not torch.cuda.is_available():
             raise GqeLibraryError("no HIP device visible to torch; the query path only runs on an MI355X "
@@ -171,6 +174,14 @@ class Engine(object):
             offs = (C.c_int64 * len(tables))(*[t[0] for t in tables])
             rows = (C.c_int64 * len(tables))(*[t[1] for t in tables])
             self._check(self.lib.gqe_set_tables(self.ctx, offs, rows, len(tables)))
+        self._bags = {}
+        for key, (ptr, ids) in (bags or {}).items():
+            ptr = np.ascontiguousarray(ptr, dtype=np.int32)
+            ids = np.ascontiguousarray(ids, dtype=np.int32)
+            dp, di = torch.from_numpy(ptr).to(self.device), torch.from_numpy(ids).to(self.device)
+            self._bags[key] = (dp, di)      # keep the borrowed device buffers alive
+            self._check(self.lib.gqe_set_bag(self.ctx, layout.offset(key), dp.data_ptr(), di.data_ptr(), len(ptr) - 1,
+                                             int(np.diff(ptr).max())))
         self.workspace = None
         self.max_queries = self.max_batches = 0
         self.reserve(max_queries, max_batches)

@@ -68,8 +68,9 @@ class QueryEncoderDecoder(nn.Module):
             raise Exception("the fused path needs one embedding dimension for every mode, got %s" % sorted(dims))
         self.dim = dims.pop()
         self.layout = layout
+        bags = {"enc.feat-%s.weight" % m: csr for m, csr in getattr(enc, "bag_csr", {}).items()}
         self.engine = Engine(self.dim, path_dec.kind, inter_dec.kind, layout, device=device,
-                             max_queries=max_queries, max_batches=max_batches)
+                             max_queries=max_queries, max_batches=max_batches, bags=bags)
         # re-home every parameter into the arena (state_dict keys and values unchanged)
         for name, p in self.named_parameters():
             view = layout.view(self.engine.params, name)

@@ -22,13 +22,13 @@ from .decoders import (BilinearDiagMetapathDecoder, BilinearMetapathDecoder, Set
 from .encoders import DirectEncoder
 
 
-def get_encoder(depth, graph, out_dims, feature_modules, cuda=True, node_maps=None):
+def get_encoder(depth, graph, out_dims, feature_modules, cuda=True, node_maps=None, bags=None):
     if depth < 0 or depth > 3:
         raise Exception("Depth must be between 0 and 3 (inclusive)")
     if depth != 0:
         raise Exception("only the depth-0 DirectEncoder is on the MI355X fast path "
                         "(GraphSAGE-style encoders of netquery/encoders.py:47-129 are out of scope)")
-    return DirectEncoder(graph.features, feature_modules, node_maps=node_maps)
+    return DirectEncoder(graph.features, feature_modules, node_maps=node_maps, bags=bags)
 
 
 def get_metapath_decoder(graph, out_dims, decoder):

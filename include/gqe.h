@@ -125,6 +125,12 @@ int gqe_bind_arena(gqe_ctx* ctx, float* params, float* grads, float* exp_avg, fl
  * of d float atomics) that the optimiser pass consumes directly; must precede gqe_workspace_bytes. */
 int gqe_set_tables(gqe_ctx* ctx, const int64_t* offsets, const int64_t* rows, int32_t n_tables);
 
+/* Declare a registered table as a BAG mode: an index into that mode is a bag i whose vector is the mean of the
+ * table rows bag_ids[bag_ptr[i] .. bag_ptr[i+1]) (device pointers, borrowed) — replaces the reference's
+ * nn.EmbeddingBag feature function for Reddit posts (reddit/data_utils_new.py:155,162-169).  max_len bounds the
+ * bag length (sizes the link nodes of the gradient lists).  Must precede gqe_workspace_bytes. */
+int gqe_set_bag(gqe_ctx* ctx, int64_t table_offset, const int32_t* bag_ptr, const int32_t* bag_ids, int64_t n_bags, int32_t max_len);
+
 /* Workspace the kernels need for up to `max_queries` queries / `max_batches` batches between two
  * optimiser steps (bytes); gqe_bind_workspace binds a buffer of at least that size (256-byte aligned)
  * and resets the gradient lists on `stream`.  The capacities given here are remembered by the ctx. */

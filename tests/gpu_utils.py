@@ -9,7 +9,10 @@ def engine_from_params(params, d, dec, inter, **kw):
     from graphqembed_amd.engine import ArenaLayout, Engine
     layout = ArenaLayout()
     for k, v in params.items():
-        layout.add(k, v.shape)
+        if k != O.BAGS_KEY:
+            layout.add(k, v.shape)
+    if O.BAGS_KEY in params:
+        kw["bags"] = {O.table_key(m): csr for m, csr in params[O.BAGS_KEY].items()}
     eng = Engine(d, dec, inter, layout, **kw)
     load_params(eng, params)
     return eng
@@ -18,6 +21,8 @@ def engine_from_params(params, d, dec, inter, **kw):
 def load_params(eng, params):
     import torch
     for k, v in params.items():
+        if k == O.BAGS_KEY:
+            continue
         eng.layout.view(eng.params, k).copy_(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)))
 
 

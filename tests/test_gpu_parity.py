@@ -4,7 +4,7 @@ arbitrary order): scores atol 2e-5, loss rtol 1e-4, gradients rtol 2e-3 + atol 1
 import numpy as np
 import pytest
 
-from golden_utils import case_names, load_case, load_params, model_files
+from golden_utils import case_names, load_case, load_params, load_reddit_params, model_files, reddit_files
 from oracle import netquery_numpy as O
 
 pytestmark = pytest.mark.gpu
@@ -97,6 +97,47 @@ def test_golden_adam_three_steps(path, dec, inter, d):
             assert diff.max() < 4e-2 and np.median(diff) < 5e-4, (case, k, diff.max(), np.median(diff))
         for k in set(got) - set(c["adam_delta"]):
             assert np.array_equal(got[k], p0[k]), (case, k)
+    eng.close()
+
+
+@pytest.mark.parametrize("path,dec,inter,d", reddit_files(), ids=_ids)
+def test_golden_reddit_embedding_bag(path, dec, inter, d):
+    """Bag modes (Reddit posts = nn.EmbeddingBag mean over word rows): scores, loss, gradients of the word
+    table and everything else, then the 3-step Adam trajectory, against the reference's own outputs."""
+    from gpu_utils import engine_from_params, load_params as put, plan_for, read_arena
+    from graphqembed_amd.tensorize import pack_forward_batches, pack_margin_batches
+    z = np.load(path)
+    params = load_reddit_params(z)
+    eng = engine_from_params(params, d, dec, inter)
+    for case in case_names(z):
+        c = load_case(z, case)
+        plan = plan_for(eng, c["type"], c["rels"])
+        put(eng, params)
+        eng.exp_avg.zero_(); eng.exp_avg_sq.zero_(); eng.zero_grads(list(eng.layout.entries))
+        eng.steps = {k: 0 for k in eng.steps}
+        descs, idx, n = pack_forward_batches([(plan, c["target"], c["anchors"]), (plan, c["neg"], c["anchors"])])
+        s = eng.forward(descs, idx, n).cpu().numpy()
+        B = len(c["target"])
+        np.testing.assert_allclose(s[:B], c["pos"], atol=SCORE_ATOL, rtol=1e-4, err_msg=case)
+        np.testing.assert_allclose(s[B:], c["negscore"], atol=SCORE_ATOL, rtol=1e-4, err_msg=case)
+        descs, idx, n = pack_margin_batches([(plan, c["target"], c["neg"], c["anchors"], 1.0, c["margin"])])
+        losses, pos, neg = eng.margin_fwd_bwd(descs, idx, n, want_scores=True)
+        np.testing.assert_allclose(losses.cpu().numpy()[0], c["loss"], rtol=LOSS_RTOL, err_msg=case)
+        got = read_arena(eng, eng.grads)
+        assert_grads_close(got, c["grads"], case)
+        for k in set(got) - set(c["grads"]):
+            assert not got[k].any(), (case, k)
+        # Adam: lists (incl. bag link nodes) consumed directly by the optimiser pass
+        eng.zero_grads(list(eng.layout.entries))
+        for step in range(3):
+            descs, idx, n = pack_margin_batches([(plan, c["target"], c["adam_neg"][step], c["anchors"], 1.0, c["margin"])])
+            losses, _, _ = eng.margin_fwd_bwd(descs, idx, n)
+            np.testing.assert_allclose(losses.cpu().numpy()[0], c["adam_loss"][step], rtol=LOSS_RTOL if step == 0 else 6e-2, err_msg=case)
+            eng.adam_step(plan.touched)
+        now = read_arena(eng, eng.params)
+        for k, delta in c["adam_delta"].items():
+            diff = np.abs(now[k].astype(np.float64) - params[k] - delta)
+            assert diff.max() < 4e-2 and np.median(diff) < 5e-4, (case, k, diff.max(), np.median(diff))
     eng.close()
 
 
