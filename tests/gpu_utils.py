@@ -44,10 +44,20 @@ def plan_for(eng, qtype, rels):
     return FormulaPlan(Formula(qtype, rels), eng.layout, eng.inter_decoder)
 
 
-def random_params(rng, d, dec, inter, sizes, kinds):
-    """Parameters with the reference's shapes/initial distributions for a small schema."""
+def random_params(rng, d, dec, inter, sizes, kinds, bag_modes=(), n_words=64):
+    """Parameters with the reference's shapes/initial distributions for a small schema.  Modes listed in
+    ``bag_modes`` get an EmbeddingBag feature: a word table [n_words, d] and a CSR of 3-12 word ids per node
+    (row index of node i of such a mode = bag i + 1, bag 0 being a dummy so that toy_batch's 1-based rows work)."""
     params = {}
+    bags = {}
     for m, n in sizes.items():
+        if m in bag_modes:
+            params[O.table_key(m)] = rng.normal(0, 1.0 / d, (n_words, d)).astype(np.float32)
+            lens = rng.randint(3, 13, size=n + 2)
+            ptr = np.zeros(n + 3, dtype=np.int32)
+            ptr[1:] = np.cumsum(lens)
+            bags[m] = (ptr, rng.randint(0, n_words, size=int(ptr[-1])).astype(np.int32))
+            continue
         params[O.table_key(m)] = rng.normal(0, 1.0 / d, (n + 2, d)).astype(np.float32)
     rels = []
     for (a, name, b) in kinds:
@@ -65,6 +75,8 @@ def random_params(rng, d, dec, inter, sizes, kinds):
         for m in sizes:
             params[O.pre_key(m)] = rng.uniform(-lim, lim, (d, d)).astype(np.float32)
             params[O.post_key(m)] = rng.uniform(-lim, lim, (d, d)).astype(np.float32)
+    if bags:
+        params[O.BAGS_KEY] = bags
     return params
 
 

@@ -232,19 +232,29 @@ def test_random_schema_vs_oracle(dec, inter, d):
     eng.close()
 
 
-def test_full_batch_512_d128_device_resident_indices():
-    """BASELINE-size batches (B=512, d=128, bilinear-diag + SetIntersection-min, the 9-batch full
-    mix) with the index feed already in HBM; checked against the fp64 oracle."""
+FULL_MIX = [("1-chain", 1.0), ("2-chain", 0.01), ("3-chain", 0.01), ("2-inter", 0.005), ("2-inter", 0.005),
+            ("3-inter", 0.005), ("3-inter", 0.005), ("3-inter_chain", 0.005), ("3-inter_chain", 0.005)]
+BASELINE_CONFIGS = {
+    # BASELINE.json configs at their full batch size (B=512 per batch); the toy schema keeps the oracle fast
+    "config1_bio_2chain_2inter_diag_d128": ("bilinear-diag", "min", 128, (), [("1-chain", 1.0), ("2-chain", 0.01), ("2-inter", 0.005), ("2-inter", 0.005)]),
+    "config2_bio_full_mix_diag_d128": ("bilinear-diag", "min", 128, (), FULL_MIX),
+    "config3_bio_full_mix_bilinear_d128": ("bilinear", "mean", 128, (), FULL_MIX),
+    "config4_reddit_full_mix_d256_bags": ("bilinear-diag", "min", 256, ("b",), FULL_MIX + [("3-chain_inter", 0.005)]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BASELINE_CONFIGS))
+def test_baseline_configs_full_batches(name):
+    """Every BASELINE.json configuration at B=512 per batch, one grouped launch with the index feed already in
+    HBM, against the fp64 oracle (config 4: d=256 with an EmbeddingBag mode, as Reddit posts)."""
     import torch
     from gpu_utils import (TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for,
                            random_params, read_arena, toy_batch)
     from graphqembed_amd.tensorize import pack_margin_batches
-    rng = np.random.RandomState(5)
-    d, dec, inter = 128, "bilinear-diag", "min"
-    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
-    eng = engine_from_params(params, d, dec, inter, max_queries=4608, max_batches=9)
-    mix = [("1-chain", 1.0), ("2-chain", 0.01), ("3-chain", 0.01), ("2-inter", 0.005), ("2-inter", 0.005),
-           ("3-inter", 0.005), ("3-inter", 0.005), ("3-inter_chain", 0.005), ("3-inter_chain", 0.005)]
+    dec, inter, d, bag_modes, mix = BASELINE_CONFIGS[name]
+    rng = np.random.RandomState(len(name))
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS, bag_modes=bag_modes)
+    eng = engine_from_params(params, d, dec, inter, max_queries=512 * len(mix), max_batches=len(mix))
     items, grads, want_l = [], O.zero_grads_like(params), []
     grads32 = O.zero_grads_like(params, np.float32)
     for qtype, w in mix:
@@ -257,7 +267,13 @@ def test_full_batch_512_d128_device_resident_indices():
     didx = torch.from_numpy(idx).cuda()
     losses, _, _ = eng.margin_fwd_bwd(descs, didx, n)
     np.testing.assert_allclose(losses.cpu().numpy()[:-1], want_l, rtol=LOSS_RTOL)
-    assert_grads_close(read_arena(eng, eng.grads), grads, "full mix", want32=grads32)
+    keys = [k for k in grads if k != O.BAGS_KEY]
+    assert_grads_close(read_arena(eng, eng.grads), {k: grads[k] for k in keys}, name, want32={k: grads32[k] for k in keys})
+    # size-independent property: a fused Adam step right after must leave no gradient anywhere
+    losses, _, _ = eng.margin_fwd_bwd(descs, didx, n)
+    eng.adam_step(set().union(*[it[0].touched for it in items]))
+    eng.materialize()
+    assert float(eng.grads.abs().max()) == 0.0
     eng.close()
 
 
