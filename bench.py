@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--inter-decoder", default="min")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to "
+                    "smoke-test the multi-rank path on a single GPU)")
+    ap.add_argument("--check-replicas", action="store_true", help="after the run, verify that all ranks hold identical parameters")
     args = ap.parse_args()
 
     import torch
@@ -147,8 +150,9 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%s: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, os.environ.get("WORLD_SIZE", "1"), args.gpus))
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    rank, world, local_rank, dist = parallel.init_from_env("nccl")
+    n_dev = torch.cuda.device_count()
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(n_dev, 1))
+    rank, world, local_rank, dist = parallel.init_from_env(args.backend)
 
     from graphqembed_amd import synth
     from graphqembed_amd.engine import Engine
@@ -253,6 +257,12 @@ def main():
         out["cpu_baseline"] = cpu_baseline(eng, args.decoder, args.inter_decoder, item_sets[:8], args.cpu_seconds, qpi)
     elif rank == 0:
         out["cpu_baseline"] = None
+    if args.check_replicas and dist is not None:
+        mine = eng.params.double().sum().reshape(1).cpu()
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        out["replicas_identical"] = bool(lo.item() == hi.item())
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -58,7 +58,8 @@ struct GqeDynBatch {
   int64_t entry_base;    // first contribution entry of this batch: [role][query]
   int64_t scratch_base;  // float offset of this batch's scratch rows in the workspace
   float margin, grad_scale, inv_B, loss_weight;
-  int32_t loss_index, pad;  // where this batch's loss goes in the caller's losses[]
+  int32_t loss_index;    // where this batch's loss goes in the caller's losses[]
+  int32_t n_candidates;  // > 0: evaluation against candidate lists (forward only)
 };
 
 // Bag modes (Reddit posts: nn.EmbeddingBag mean over word rows, reddit/data_utils_new.py:155,162-169):

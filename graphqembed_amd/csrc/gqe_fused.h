@@ -248,6 +248,33 @@ __device__ __forceinline__ void rows_issue_bag(RowSet<NC>& rs, const TileEnv& e,
   }
 }
 
+// one candidate target row (evaluation against candidate lists): gather (direct or bag) + normalise
+template <int NC>
+__device__ __forceinline__ Vec<NC> candidate_row(const TileEnv& e, const GqeBagTable& bags, int bag, int64_t table, int row) {
+  Vec<NC> x = vzero<NC>();
+  if (bag < 0) {
+    x = vload<NC>(e.params + table + (size_t)row * e.d, e.d, e.lane);
+  } else {
+    const int32_t* __restrict__ ptr = bags.ptr[bag];
+    const int32_t* __restrict__ ids = bags.ids[bag];
+    const int p0 = ptr[row], len = ptr[row + 1] - p0;
+    for (int c0 = 0; c0 < len; c0 += 64) {
+      const int m = min(64, len - c0);
+      const int wid = (e.lane < m) ? ids[p0 + c0 + e.lane] : 0;
+      for (int k = 0; k < m; ++k) {
+        const int w = __builtin_amdgcn_readlane(wid, k);
+        const Vec<NC> v = vload<NC>(e.params + table + (size_t)w * e.d, e.d, e.lane);
+        VEC_OP(x, x.v[c] + v.v[c]);
+      }
+    }
+    const float il = 1.f / (float)len;
+    VEC_OP(x, x.v[c] * il);
+  }
+  const float inv = 1.f / sqrtf(vdot<NC>(x, x));
+  VEC_OP(x, x.v[c] * inv);
+  return x;
+}
+
 template <int NC>
 __device__ __forceinline__ void rows_finish(RowSet<NC>& rs) {
 #pragma unroll
@@ -430,6 +457,12 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
   const int B = b.B;
   const bool has_neg = b.has_neg != 0;
   const int n = f->n_anchors;
+  // evaluation against candidate lists (forward only): index layout anchors[n][B] | cand_ptr[B+1] | cand_rows[..];
+  // every query is scored against its own list, the query side being computed once (the reference re-encodes
+  // and re-projects the anchors for every candidate, utils.py:50-60,78-88)
+  const bool eval_mode = !BWD && b.n_candidates > 0;
+  const int32_t* __restrict__ cand_ptr = idx + b.idx_offset + (size_t)n * B;
+  const int32_t* __restrict__ cand_rows = cand_ptr + B + 1;
 
   // ---- LDS carve: 7 float tiles [16][DP] + meta tile + red[8][d] + index block ----
   float* te[GQE_MAX_BRANCH];
@@ -449,9 +482,9 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
     const int role = threadIdx.x / GQE_TQ, r = threadIdx.x % GQE_TQ;
     const int q = e.q0 + r;
     int v = -1;
-    const bool used = (role == 0) || (role == 1 && has_neg) || (role >= 2 && role - 2 < n);
+    const bool used = (role == 0 && !eval_mode) || (role == 1 && has_neg) || (role >= 2 && role - 2 < n);
     if (used && q < B) {
-      const int src = (role == 0) ? 0 : (role == 1) ? 1 : (has_neg ? role : role - 1);
+      const int src = (role == 0) ? 0 : (role == 1) ? 1 : (has_neg ? role : (eval_mode ? role - 2 : role - 1));
       v = idx[b.idx_offset + (size_t)src * B + q];
     }
     s_idx[threadIdx.x] = v;
@@ -558,6 +591,25 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
             nun = fmaxf(sqrtf(vdot<NC>(un, un)), COS_EPS);
             sn = vdot<NC>(a, un) / (nap * nun);
           }
+        }
+        if (eval_mode) {
+          for (int ci = cand_ptr[q]; ci < cand_ptr[q + 1]; ++ci) {
+            const Vec<NC> t = candidate_row<NC>(e, bags, f->target_bag, f->target_table, cand_rows[ci]);
+            float sc;
+            if (DEC == DEC_DIAG) {
+              Vec<NC> u = t;
+#pragma unroll
+              for (int h = 0; h < GQE_MAX_HOPS; ++h)
+                if (h < K) VEC_OP(u, u.v[c] * w[h].v[c]);
+              sc = vdot<NC>(u, a);
+            } else {
+              Vec<NC> u;
+              VEC_OP(u, t.v[c] + wcomb.v[c]);
+              sc = vdot<NC>(a, u) / (nap * fmaxf(sqrtf(vdot<NC>(u, u)), COS_EPS));
+            }
+            if (lane == 0) pos_out[b.out_offset + ci] = sc;
+          }
+          continue;
         }
         if (lane == 0) {
           if (pos_out) pos_out[b.out_offset + q] = sp;
@@ -818,6 +870,17 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
       const int q = e.q0 + r;
       Vec<NC> qv = vload<NC>(tqq + r * DP, d, lane);
       const float nq = fmaxf(sqrtf(vdot<NC>(qv, qv)), COS_EPS);
+      if (eval_mode) {
+        if (q < B) {
+          for (int ci = cand_ptr[q]; ci < cand_ptr[q + 1]; ++ci) {
+            const Vec<NC> t = candidate_row<NC>(e, bags, f->target_bag, f->target_table, cand_rows[ci]);
+            const float nt = fmaxf(sqrtf(vdot<NC>(t, t)), COS_EPS);
+            const float sc = vdot<NC>(t, qv) / (nt * nq);
+            if (lane == 0) pos_out[b.out_offset + ci] = sc;
+          }
+        }
+        continue;
+      }
       const Vec<NC>& tp = RT.x[rr];
       const Vec<NC>& tn = RN.x[rr];
       const float ncp = fmaxf(sqrtf(vdot<NC>(tp, tp)), COS_EPS);

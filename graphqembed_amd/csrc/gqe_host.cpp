@@ -373,7 +373,12 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     int rc = formula_of(ctx, s, bi, &fid[bi]);
     if (rc != GQE_OK) return rc;
     const int na = ctx->formulas[fid[bi]].n_anchors;
-    const int64_t need_idx = (int64_t)s.idx_offset + (int64_t)(na + (bwd ? 2 : 1)) * s.n_queries;
+    if (s.n_candidates < 0 || (bwd && s.n_candidates != 0)) return fail(ctx, GQE_ERR_ARG, "batch %d: candidate lists are for gqe_forward only", bi);
+    if (s.n_candidates > 0 && ctx->cfg.decoder == GQE_DEC_BILINEAR && s.qtype <= GQE_Q_3CHAIN)
+      return fail(ctx, GQE_ERR_ARG, "batch %d: candidate lists are not available for Bilinear chain queries (expand the candidates)", bi);
+    const int64_t need_idx = s.n_candidates > 0
+        ? (int64_t)s.idx_offset + (int64_t)na * s.n_queries + s.n_queries + 1 + s.n_candidates
+        : (int64_t)s.idx_offset + (int64_t)(na + (bwd ? 2 : 1)) * s.n_queries;
     if (s.idx_offset < 0 || need_idx > n_idx) return fail(ctx, GQE_ERR_ARG, "batch %d: index range [%d,%lld) exceeds the %lld indices given", bi, s.idx_offset, (long long)need_idx, (long long)n_idx);
     entries += (int64_t)(2 + na) * s.n_queries;
     total_tiles += (s.n_queries + GQE_TQ - 1) / GQE_TQ;
@@ -486,6 +491,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       b.inv_B = 1.0f / (float)s.n_queries;
       b.grad_scale = s.loss_weight / (float)s.n_queries;
       b.loss_index = b0 + k;
+      b.n_candidates = s.n_candidates;
       P.tiles += b.Bpad / GQE_TQ;
       if (bwd) {
         entry += (int64_t)(2 + f.n_anchors) * s.n_queries;
@@ -653,11 +659,16 @@ int run_opt(gqe_ctx* ctx, int mode, const gqe_segment* segs, int32_t n_segs, flo
   oa.b2 = b2;
   oa.eps = eps;
   oa.stream = st;
-  rc = timing_begin(ctx, 2, st);
-  if (rc != GQE_OK) return rc;
+  const bool timed = mode != GQE_OPT_MATERIALIZE && mode != GQE_OPT_ZERO;  // kernel 2 = the optimiser step proper
+  if (timed) {
+    rc = timing_begin(ctx, 2, st);
+    if (rc != GQE_OK) return rc;
+  }
   HIP_TRY(ctx, gqe_launch_opt(oa));
-  rc = timing_end(ctx, 2, st);
-  if (rc != GQE_OK) return rc;
+  if (timed) {
+    rc = timing_end(ctx, 2, st);
+    if (rc != GQE_OK) return rc;
+  }
   // bookkeeping: which lists are consumed now
   bool any_pending = false;
   for (size_t t = 0; t < ctx->tables.size(); ++t) {

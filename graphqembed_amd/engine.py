@@ -51,7 +51,7 @@ class gqe_batch(C.Structure):
                 ("hop_param", (C.c_int64 * MAX_HOPS) * MAX_BRANCH),
                 ("final_param", C.c_int64), ("pre_param", C.c_int64), ("post_param", C.c_int64),
                 ("margin", C.c_float), ("loss_weight", C.c_float),
-                ("out_offset", C.c_int32), ("reserved", C.c_int32)]
+                ("out_offset", C.c_int32), ("n_candidates", C.c_int32)]
 
 
 class gqe_segment(C.Structure):
@@ -243,6 +243,7 @@ class Engine(object):
             b.margin = dsc.get("margin", 1.0)
             b.loss_weight = dsc.get("weight", 1.0)
             b.out_offset = dsc["out_offset"]
+            b.n_candidates = dsc.get("n_candidates", 0)
         return arr
 
     def _idx_arg(self, idx):
@@ -257,7 +258,8 @@ class Engine(object):
     def forward(self, descs, idx, n_scores, out=None):
         """gqe_forward: scores[n_scores] for the listed batches."""
         total = sum(dsc["n"] for dsc in descs)
-        self.reserve(total, len(descs))
+        n_all = int(idx.size if isinstance(idx, np.ndarray) else idx.numel())
+        self.reserve(max(total, (n_all + 4) // 5), len(descs))      # candidate lists can dwarf the query count
         arr = self.make_batches(descs)
         keep, ptr, n_idx, on_dev = self._idx_arg(idx)
         scores = out if out is not None else self.torch.empty(n_scores, dtype=self.torch.float32, device=self.device)

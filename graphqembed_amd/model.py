@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from .engine import ArenaLayout, Engine
-from .tensorize import (FormulaPlan, pack_forward_batches, pack_margin_batches,
+from .tensorize import (FormulaPlan, pack_candidate_batches, pack_forward_batches, pack_margin_batches,
                         reference_negative_nodes)
 
 
@@ -149,6 +149,24 @@ class QueryEncoderDecoder(nn.Module):
         for p in packed:
             self._mark_touched(p[0].touched)
         return out
+
+    def forward_candidates(self, formula, queries, candidate_nodes):
+        """Scores of every node of ``candidate_nodes[i]`` as the target of ``queries[i]`` — the fused
+        replacement of the reference's evaluation trick of repeating a query once per candidate
+        (utils.py:58-60, 86-88): the anchors are encoded / projected / intersected once per query.
+        Returns (scores flat in list order, ptr[n+1])."""
+        lens = [len(c) for c in candidate_nodes]
+        ptr = np.zeros(len(queries) + 1, dtype=np.int32)
+        ptr[1:] = np.cumsum(lens)
+        flat = [x for c in candidate_nodes for x in c]
+        if self.path_dec.kind == "bilinear" and formula.query_type.endswith("chain") and "inter" not in formula.query_type:
+            rep = [q for q, k in zip(queries, lens) for _ in range(k)]       # act = t^T M.. is per candidate anyway
+            return self.forward(formula, rep, flat), ptr
+        rows = self.enc.rows(flat, formula.target_mode)
+        anchors = np.stack([self.enc.rows([q.anchor_nodes[i] for q in queries], m)
+                            for i, m in enumerate(formula.anchor_modes)])
+        descs, idx, n = pack_candidate_batches([(self.plan(formula), anchors, ptr, rows)])
+        return self.engine.forward(descs, idx, n), ptr
 
     def score_batches(self, items):
         """items: [(formula, target_rows, anchor_rows)] -> one scores tensor (concatenated)."""

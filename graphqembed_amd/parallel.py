@@ -33,6 +33,8 @@ def init_from_env(backend=None):
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
         kwargs["device_id"] = torch.device("cuda", local_rank)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
     return rank, world, local_rank, dist
 

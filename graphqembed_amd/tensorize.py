@@ -114,6 +114,22 @@ def pack_forward_batches(items):
     return descs, np.concatenate(chunks), out
 
 
+def pack_candidate_batches(items):
+    """items: [(plan, anchors[k,n], cand_ptr[n+1], cand_rows[nnz])] -> (descs, idx, n_scores): evaluation
+    against candidate lists; per batch the index layout is anchors | cand_ptr | cand_rows and the scores come
+    back flat in candidate order."""
+    descs, chunks, off, out = [], [], 0, 0
+    for plan, anchors, ptr, rows in items:
+        n = len(ptr) - 1
+        d = plan.batch(n, off, out)
+        d["n_candidates"] = int(len(rows))
+        descs.append(d)
+        chunks.extend((np.asarray(anchors, np.int32).reshape(-1), np.asarray(ptr, np.int32), np.asarray(rows, np.int32)))
+        off += plan.static["n_anchors"] * n + n + 1 + len(rows)
+        out += len(rows)
+    return descs, np.concatenate(chunks), out
+
+
 class FormulaQueries(object):
     """All queries of one Formula as int32 row arrays (+ CSR negatives)."""
 

@@ -112,13 +112,24 @@ def eval_auc_queries(test_queries, enc_dec, batch_size=1000, hard_negatives=Fals
     return _auc(labels, np.nan_to_num(predictions)), formula_aucs
 
 
-def eval_perc_queries(test_queries, enc_dec, batch_size=1000, hard_negatives=False):
-    """Mean percentile rank of the true target among ALL stored negatives of its query."""
+def eval_perc_queries(test_queries, enc_dec, batch_size=1000, hard_negatives=False, fused=None):
+    """Mean percentile rank of the true target among ALL stored negatives of its query.
+    ``fused`` (default: whenever the model offers ``forward_candidates``): score each query against its
+    candidate list [target] + negatives in one fused evaluation launch instead of repeating the query per
+    negative as the reference does; same scores, the query side is computed once."""
     perc_scores = []
+    if fused is None:
+        fused = hasattr(enc_dec, "forward_candidates")
     for formula in test_queries:
         for batch in _chunks(test_queries[formula], batch_size):
             lists = [q.hard_neg_samples if hard_negatives else q.neg_samples for q in batch]
             lengths = [len(l) for l in lists]
+            if fused:
+                scores, ptr = enc_dec.forward_candidates(formula, batch, [[q.target_node] + list(l) for q, l in zip(batch, lists)])
+                scores = scores.detach().cpu().numpy()
+                for i in range(len(batch)):
+                    perc_scores.append(_percentile_of_score(scores[ptr[i] + 1:ptr[i + 1]], scores[ptr[i]]))
+                continue
             negatives = [n for l in lists for n in l]
             rep = [q for q, k in zip(batch, lengths) for _ in range(k)]
             scores = enc_dec.forward(formula, batch + rep, [q.target_node for q in batch] + negatives)

@@ -95,8 +95,14 @@ typedef struct {
   float loss_weight;                              /* weight of this batch's mean loss in the
                                                      iteration loss (train_helpers.py:51,69-72);
                                                      gradients are scaled by it              */
-  int32_t out_offset;                             /* where this batch's B scores go          */
-  int32_t reserved;
+  int32_t out_offset;                             /* where this batch's scores go            */
+  int32_t n_candidates;                           /* gqe_forward only; 0 = score target[B].  > 0 = evaluation
+                                                     against candidate lists: the index layout is
+                                                     anchor_0[B] | .. | cand_ptr[B+1] | cand_rows[n_candidates]
+                                                     and scores[out_offset + c] is the score of candidate c
+                                                     (cand_ptr[q] <= c < cand_ptr[q+1]) as the target of query q;
+                                                     not available for the full-Bilinear decoder on chain
+                                                     queries (GQE_ERR_ARG: expand the candidates instead)      */
 } gqe_batch;
 
 /* One parameter tensor for the optimiser (torch.optim semantics: a tensor with no gradient
@@ -139,7 +145,9 @@ int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* strea
 
 /* replaces: QueryEncoderDecoder.forward (model.py:70-109) for n_batches formulas at once.
  * idx: int32 index buffer (device pointer if idx_on_device, else host pointer: copied through
- * the ctx's pinned staging ring with hipMemcpyAsync).  scores: device, sum of B floats. */
+ * the ctx's pinned staging ring with hipMemcpyAsync).  scores: device, sum of B floats (or of
+ * n_candidates for evaluation batches, which also replace the inner loops of eval_auc_queries /
+ * eval_perc_queries, utils.py:35-91: the query side is computed once per query). */
 int gqe_forward(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches,
                 const int32_t* idx, int64_t n_idx, int32_t idx_on_device,
                 float* scores, void* stream);

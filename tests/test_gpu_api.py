@@ -84,8 +84,11 @@ def test_forward_matches_reference_eval_calls_and_auc():
         model.forward = spy
         auc, _ = utils.eval_auc_queries(test["one_neg"][qtype], model, hard_negatives=hard)
         n_auc = len(calls)
-        perc = utils.eval_perc_queries(test["full_neg"][qtype], model, hard_negatives=hard)
+        perc = utils.eval_perc_queries(test["full_neg"][qtype], model, hard_negatives=hard, fused=False)
         model.forward = orig
+        # the fused candidate-list evaluation (query side computed once) gives the same statistic
+        perc_fused = utils.eval_perc_queries(test["full_neg"][qtype], model, hard_negatives=hard)
+        assert abs(perc_fused - perc) < 1e-6, (tag, perc_fused, perc)
         assert n_auc == len(want["auc_calls"]) and len(calls) - n_auc == len(want["perc_calls"]), tag
         for got, ci in zip(calls, want["auc_calls"] + want["perc_calls"]):
             np.testing.assert_allclose(got, z["call%d/scores" % ci], atol=2e-5, rtol=1e-4, err_msg=tag)

@@ -277,6 +277,47 @@ def test_baseline_configs_full_batches(name):
     eng.close()
 
 
+@pytest.mark.parametrize("dec,inter,d,bag_modes", [("bilinear-diag", "min", 128, ()), ("transe", "mean", 64, ()),
+                                                    ("bilinear", "mean-simple", 32, ()), ("bilinear-diag", "min", 256, ("a", "c"))])
+def test_candidate_list_evaluation_matches_expanded_forward(dec, inter, d, bag_modes):
+    """gqe_forward with candidate lists (fused evaluation) == scoring every (query, candidate)
+    pair as its own forward query, for every query type, ragged lists (0..37 candidates), several batches."""
+    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, toy_batch
+    from graphqembed_amd.engine import GqeError
+    from graphqembed_amd.tensorize import pack_candidate_batches, pack_forward_batches
+    rng = np.random.RandomState(d)
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS, bag_modes=bag_modes)
+    eng = engine_from_params(params, d, dec, inter)
+    cand_items, fwd_items = [], []
+    for j, qtype in enumerate(TOY_FORMULAS):
+        B = [1, 16, 21, 40, 7, 33, 18][j]
+        plan = plan_for(eng, qtype, TOY_FORMULAS[qtype])
+        _, _, a = toy_batch(rng, qtype, B)
+        nt = TOY_SIZES[O.make_plan(qtype, TOY_FORMULAS[qtype])["target_mode"]]
+        lens = rng.randint(0, 38, size=B)
+        lens[0] = 37
+        ptr = np.zeros(B + 1, dtype=np.int32)
+        ptr[1:] = np.cumsum(lens)
+        rows = rng.randint(1, nt + 1, size=int(ptr[-1])).astype(np.int32)
+        cand_items.append((plan, a, ptr, rows))
+        rep = np.repeat(np.arange(B), lens)
+        fwd_items.append((plan, rows, a[:, rep]))
+    descs, idx, n = pack_forward_batches(fwd_items)
+    want = eng.forward(descs, idx, n).cpu().numpy()
+    if dec == "bilinear":
+        with pytest.raises(GqeError):        # chain + full Bilinear: per-candidate matvecs, not offered as lists
+            d0, i0, n0 = pack_candidate_batches(cand_items[:1])
+            eng.forward(d0, i0, n0)
+        keep = [k for k, qt in enumerate(TOY_FORMULAS) if "inter" in qt]
+        cand_items = [cand_items[k] for k in keep]
+        offs = np.cumsum([0] + [len(it[1]) for it in fwd_items])
+        want = np.concatenate([want[offs[k]:offs[k + 1]] for k in keep])
+    descs, idx, n = pack_candidate_batches(cand_items)
+    got = eng.forward(descs, idx, n).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=2e-6, rtol=1e-5)
+    eng.close()
+
+
 def test_error_paths():
     from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, toy_batch
     from graphqembed_amd.engine import GqeError
