@@ -60,6 +60,8 @@ struct GqeDynBatch {
   float margin, grad_scale, inv_B, loss_weight;
   int32_t loss_index;    // where this batch's loss goes in the caller's losses[]
   int32_t n_candidates;  // > 0: evaluation against candidate lists (forward only)
+  int32_t eval_splits;   // evaluation: workgroups per query tile (each takes a slice of every candidate list)
+  int32_t pad;
 };
 
 // Bag modes (Reddit posts: nn.EmbeddingBag mean over word rows, reddit/data_utils_new.py:155,162-169):

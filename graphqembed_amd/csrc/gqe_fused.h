@@ -275,6 +275,62 @@ __device__ __forceinline__ Vec<NC> candidate_row(const TileEnv& e, const GqeBagT
   return x;
 }
 
+// Evaluation against candidate lists: the 16 query-side vectors of the tile are in an LDS tile; every wave of
+// the workgroup takes GQE_EVAL_U consecutive candidates of the current query at a time, fetches their row ids
+// with one load, issues all row gathers back to back and scores them.
+//   KIND 0: cos(t, v) with |v| in s_scal (intersections)      KIND 1: dot(t, v) (bilinear-diag chains, v = a (.) prod w)
+//   KIND 2: cos(v, t + wsum) with |v| in s_scal (TransE chains, v = a)
+#define GQE_EVAL_U 8
+template <int NC, int KIND>
+__device__ __forceinline__ void eval_candidates(const TileEnv& e, const GqeBagTable& bags, const float* __restrict__ tv,
+                                                const float* __restrict__ s_scal, const Vec<NC>& wsum,
+                                                const int32_t* __restrict__ cand_ptr, const int32_t* __restrict__ cand_rows,
+                                                int split, int nsplit, float* __restrict__ out) {
+  const int bag = e.f->target_bag;
+  const int64_t table = e.f->target_table;
+  for (int r = 0; r < GQE_TQ; ++r) {
+    const int q = e.q0 + r;
+    if (q >= e.b.B) break;
+    const Vec<NC> qv = vload<NC>(tv + r * e.DP, e.d, e.lane);
+    const float qs = s_scal[r];
+    const int c0 = cand_ptr[q];
+    const long long len = cand_ptr[q + 1] - c0;
+    const int cb = c0 + (int)(len * split / nsplit), ce = c0 + (int)(len * (split + 1) / nsplit);
+    for (int ci = cb + e.wave * GQE_EVAL_U; ci < ce; ci += GQE_FWAVES * GQE_EVAL_U) {
+      const int m = min(GQE_EVAL_U, ce - ci);
+      Vec<NC> x[GQE_EVAL_U];
+      if (bag < 0) {
+        const int idv = (e.lane < m) ? cand_rows[ci + e.lane] : 0;
+#pragma unroll
+        for (int u = 0; u < GQE_EVAL_U; ++u)
+          if (u < m) x[u] = vload<NC>(e.params + table + (size_t)__builtin_amdgcn_readlane(idv, u) * e.d, e.d, e.lane);
+      }
+#pragma unroll
+      for (int u = 0; u < GQE_EVAL_U; ++u) {
+        if (u >= m) continue;
+        Vec<NC> t;
+        if (bag < 0) {
+          const float inv = 1.f / sqrtf(vdot<NC>(x[u], x[u]));   // encoders.py:41-43
+          VEC_OP(t, x[u].v[c] * inv);
+        } else {
+          t = candidate_row<NC>(e, bags, bag, table, cand_rows[ci + u]);
+        }
+        float sc;
+        if (KIND == 0) {
+          sc = vdot<NC>(t, qv) / (fmaxf(sqrtf(vdot<NC>(t, t)), COS_EPS) * qs);
+        } else if (KIND == 1) {
+          sc = vdot<NC>(t, qv);
+        } else {
+          Vec<NC> uu;
+          VEC_OP(uu, t.v[c] + wsum.v[c]);
+          sc = vdot<NC>(qv, uu) / (qs * fmaxf(sqrtf(vdot<NC>(uu, uu)), COS_EPS));
+        }
+        if (e.lane == 0) out[e.b.out_offset + ci + u] = sc;
+      }
+    }
+  }
+}
+
 template <int NC>
 __device__ __forceinline__ void rows_finish(RowSet<NC>& rs) {
 #pragma unroll
@@ -452,7 +508,10 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
   e.DP = d + 4;
   e.wave = threadIdx.x >> 6;
   e.lane = threadIdx.x & 63;
-  e.q0 = ((int)blockIdx.x - b.tile_begin) * GQE_TQ;
+  const int nsplit = b.eval_splits > 1 ? b.eval_splits : 1;  // evaluation: several workgroups share one query tile
+  const int local_tile = (int)blockIdx.x - b.tile_begin;
+  const int eval_split = local_tile % nsplit;
+  e.q0 = (local_tile / nsplit) * GQE_TQ;
   const int DP = e.DP, lane = e.lane, wave = e.wave;
   const int B = b.B;
   const bool has_neg = b.has_neg != 0;
@@ -592,23 +651,11 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
             sn = vdot<NC>(a, un) / (nap * nun);
           }
         }
-        if (eval_mode) {
-          for (int ci = cand_ptr[q]; ci < cand_ptr[q + 1]; ++ci) {
-            const Vec<NC> t = candidate_row<NC>(e, bags, f->target_bag, f->target_table, cand_rows[ci]);
-            float sc;
-            if (DEC == DEC_DIAG) {
-              Vec<NC> u = t;
-#pragma unroll
-              for (int h = 0; h < GQE_MAX_HOPS; ++h)
-                if (h < K) VEC_OP(u, u.v[c] * w[h].v[c]);
-              sc = vdot<NC>(u, a);
-            } else {
-              Vec<NC> u;
-              VEC_OP(u, t.v[c] + wcomb.v[c]);
-              sc = vdot<NC>(a, u) / (nap * fmaxf(sqrtf(vdot<NC>(u, u)), COS_EPS));
-            }
-            if (lane == 0) pos_out[b.out_offset + ci] = sc;
-          }
+        if (eval_mode) {  // park the query-side vector of this row for the candidate loop below
+          Vec<NC> v = a;
+          if (DEC == DEC_DIAG) VEC_OP(v, a.v[c] * wcomb.v[c]);
+          vstore<NC>(te[0] + (wave * RPW + rr) * DP, v, d, lane);
+          if (lane == 0) red[wave * RPW + rr] = nap;
           continue;
         }
         if (lane == 0) {
@@ -641,6 +688,13 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
           scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1]);
           scatter_row<NC>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2]);
         }
+      }
+      if (eval_mode) {
+        __syncthreads();
+        if (DEC == DEC_DIAG)
+          eval_candidates<NC, 1>(e, bags, te[0], red, wcomb, cand_ptr, cand_rows, eval_split, nsplit, pos_out);
+        else
+          eval_candidates<NC, 2>(e, bags, te[0], red, wcomb, cand_ptr, cand_rows, eval_split, nsplit, pos_out);
       }
       if (BWD) {
 #pragma unroll
@@ -871,14 +925,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
       Vec<NC> qv = vload<NC>(tqq + r * DP, d, lane);
       const float nq = fmaxf(sqrtf(vdot<NC>(qv, qv)), COS_EPS);
       if (eval_mode) {
-        if (q < B) {
-          for (int ci = cand_ptr[q]; ci < cand_ptr[q + 1]; ++ci) {
-            const Vec<NC> t = candidate_row<NC>(e, bags, f->target_bag, f->target_table, cand_rows[ci]);
-            const float nt = fmaxf(sqrtf(vdot<NC>(t, t)), COS_EPS);
-            const float sc = vdot<NC>(t, qv) / (nt * nq);
-            if (lane == 0) pos_out[b.out_offset + ci] = sc;
-          }
-        }
+        if (lane == 0) red[r] = nq;
         continue;
       }
       const Vec<NC>& tp = RT.x[rr];
@@ -907,6 +954,10 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
         scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0]);
         scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1]);
       }
+    }
+    if (eval_mode) {
+      __syncthreads();
+      eval_candidates<NC, 0>(e, bags, tqq, red, vzero<NC>(), cand_ptr, cand_rows, eval_split, nsplit, pos_out);
     }
     GQE_STAMP(5);
     if (BWD) {

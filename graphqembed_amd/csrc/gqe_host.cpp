@@ -492,7 +492,17 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       b.grad_scale = s.loss_weight / (float)s.n_queries;
       b.loss_index = b0 + k;
       b.n_candidates = s.n_candidates;
-      P.tiles += b.Bpad / GQE_TQ;
+      b.eval_splits = 1;
+      if (s.n_candidates > 0) {
+        // long candidate lists: several workgroups per query tile so that a 1000-query evaluation fills 256 CUs
+        const int tiles_q = b.Bpad / GQE_TQ;
+        const int64_t per_tile = (int64_t)s.n_candidates / tiles_q;
+        int want = (512 + tiles_q - 1) / tiles_q;
+        if (want > 32) want = 32;
+        while (want > 1 && per_tile / want < 8 * GQE_FWAVES * 8) --want;   // keep >= 8 rounds of work per workgroup
+        b.eval_splits = want;
+      }
+      P.tiles += (b.Bpad / GQE_TQ) * b.eval_splits;
       if (bwd) {
         entry += (int64_t)(2 + f.n_anchors) * s.n_queries;
         scratch += (int64_t)f.n_slots * b.Bpad * d;
