@@ -103,6 +103,34 @@ struct gqe_ctx {
   std::vector<TimedLaunch> event_pool;  // recycled hipEvent pairs (creation is not free)
 };
 
+
+// ------------------------------------------------------------------------------------------
+// native training feed (first half): per-formula query pools live on the host as int32
+// row arrays; an iteration = draw a formula per batch (probability ~ pool size), slice it with the
+// reference's wrap-around rule (train_helpers.py:100-105), draw negatives (1-chain: any node of the target
+// mode, model.py:118; otherwise the stored negative / hard negative), pack, launch, step — no Python per
+// iteration.
+// ------------------------------------------------------------------------------------------
+struct FeederPool {
+  gqe_batch proto;  // static fields of the formula
+  int64_t n;
+  std::vector<int32_t> target, anchors /*[k][n]*/, neg, hard;
+};
+
+struct gqe_feeder {
+  gqe_ctx* ctx;
+  uint64_t rng[2];
+  int32_t batch_size;
+  float path_weight, inter_weight;
+  std::vector<FeederPool> pools;
+  std::vector<int> by_type[7];                          // pool indices per query type
+  std::vector<double> cum[7];                           // cumulative pool sizes per type
+  std::map<int64_t, std::vector<int32_t>> mode_rows;    // table offset -> rows to draw 1-chain negatives from
+  std::vector<int32_t> idx;
+  std::vector<gqe_batch> batches;
+  std::vector<gqe_segment> segs;
+};
+
 namespace {
 
 int fail(gqe_ctx* ctx, int code, const char* fmt, ...) {
@@ -859,6 +887,183 @@ int gqe_sgd_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, float lr
 
 int gqe_zero_grads(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, void* stream) {
   return run_opt(ctx, GQE_OPT_ZERO, segs, n_segs, 0.f, 0.f, 0.f, 0.f, stream);
+}
+
+
+// ---- native training feed -------------------------------------------------------------------
+static inline uint64_t feeder_next(gqe_feeder* f) {  // xoroshiro128+
+  const uint64_t s0 = f->rng[0];
+  uint64_t s1 = f->rng[1];
+  const uint64_t r = s0 + s1;
+  s1 ^= s0;
+  f->rng[0] = ((s0 << 24) | (s0 >> 40)) ^ s1 ^ (s1 << 16);
+  f->rng[1] = (s1 << 37) | (s1 >> 27);
+  return r;
+}
+
+int gqe_feeder_create(gqe_ctx* ctx, uint64_t seed, int32_t batch_size, float path_weight, float inter_weight, gqe_feeder** out) {
+  if (!ctx || !out) return GQE_ERR_ARG;
+  if (batch_size < 1) return fail(ctx, GQE_ERR_ARG, "batch_size must be >= 1");
+  gqe_feeder* f = new gqe_feeder();
+  f->ctx = ctx;
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull;  // splitmix64 seeding
+  for (int k = 0; k < 2; ++k) {
+    z += 0x9E3779B97F4A7C15ull;
+    uint64_t x = z;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    f->rng[k] = x ^ (x >> 31);
+  }
+  f->batch_size = batch_size;
+  f->path_weight = path_weight;
+  f->inter_weight = inter_weight;
+  *out = f;
+  return GQE_OK;
+}
+
+int gqe_feeder_destroy(gqe_feeder* f) {
+  delete f;
+  return GQE_OK;
+}
+
+int gqe_feeder_add_pool(gqe_feeder* f, const gqe_batch* formula, int64_t n, const int32_t* target, const int32_t* anchors,
+                        const int32_t* neg, const int32_t* hard) {
+  if (!f) return GQE_ERR_ARG;
+  gqe_ctx* ctx = f->ctx;
+  if (!formula || n < 1 || !target || !anchors) return fail(ctx, GQE_ERR_ARG, "bad pool");
+  const int na = anchors_of(formula->qtype);
+  if (na < 0 || na != formula->n_anchors) return fail(ctx, GQE_ERR_ARG, "pool: bad query type / anchor count");
+  if (formula->qtype != GQE_Q_1CHAIN && !neg) return fail(ctx, GQE_ERR_ARG, "pool: stored negatives are required except for 1-chain");
+  int fid;
+  gqe_batch probe = *formula;
+  probe.n_queries = 1;
+  int rc = formula_of(ctx, probe, (int)f->pools.size(), &fid);  // validates the static fields
+  if (rc != GQE_OK) return rc;
+  FeederPool p;
+  p.proto = *formula;
+  p.n = n;
+  p.target.assign(target, target + n);
+  p.anchors.assign(anchors, anchors + (size_t)na * n);
+  if (neg) p.neg.assign(neg, neg + n);
+  if (hard) p.hard.assign(hard, hard + n);
+  f->pools.push_back(std::move(p));
+  const int t = formula->qtype;
+  f->by_type[t].push_back((int)f->pools.size() - 1);
+  f->cum[t].push_back((f->cum[t].empty() ? 0.0 : f->cum[t].back()) + (double)n);
+  return GQE_OK;
+}
+
+int gqe_feeder_set_mode_rows(gqe_feeder* f, int64_t table_offset, const int32_t* rows, int64_t n) {
+  if (!f) return GQE_ERR_ARG;
+  if (!rows || n < 1) return fail(f->ctx, GQE_ERR_ARG, "bad row list");
+  f->mode_rows[table_offset].assign(rows, rows + n);
+  return GQE_OK;
+}
+
+// one (formula, slice) batch appended to f->batches / f->idx
+static int feeder_batch(gqe_feeder* f, int qtype, int64_t it, float weight, bool hard) {
+  gqe_ctx* ctx = f->ctx;
+  const std::vector<int>& cand = f->by_type[qtype];
+  if (cand.empty()) return GQE_OK;
+  size_t pick = 0;
+  if (cand.size() > 1) {
+    const double u = (double)(feeder_next(f) >> 11) * (1.0 / 9007199254740992.0) * f->cum[qtype].back();
+    pick = std::lower_bound(f->cum[qtype].begin(), f->cum[qtype].end(), u) - f->cum[qtype].begin();
+    if (pick >= cand.size()) pick = cand.size() - 1;
+  }
+  const FeederPool& p = f->pools[cand[pick]];
+  if (hard && p.hard.empty()) return fail(ctx, GQE_ERR_ARG, "pool of query type %d has no hard negatives", qtype);
+  const int64_t n = p.n, B = f->batch_size;
+  const int64_t start = (it * B) % n;
+  int64_t end = std::min(((it + 1) * B) % n, n);
+  if (end <= start) end = n;
+  const int64_t m = end - start;
+  gqe_batch b = p.proto;
+  b.n_queries = (int32_t)m;
+  b.idx_offset = (int32_t)f->idx.size();
+  b.out_offset = 0;
+  b.margin = 1.f;
+  b.loss_weight = weight;
+  b.n_candidates = 0;
+  f->idx.insert(f->idx.end(), p.target.begin() + start, p.target.begin() + end);
+  if (qtype == GQE_Q_1CHAIN) {
+    auto it_rows = f->mode_rows.find(p.proto.target_table);
+    if (it_rows == f->mode_rows.end()) return fail(ctx, GQE_ERR_STATE, "gqe_feeder_set_mode_rows missing for the 1-chain target table");
+    const std::vector<int32_t>& rows = it_rows->second;
+    for (int64_t k = 0; k < m; ++k) f->idx.push_back(rows[feeder_next(f) % rows.size()]);
+  } else {
+    const std::vector<int32_t>& src = hard ? p.hard : p.neg;
+    f->idx.insert(f->idx.end(), src.begin() + start, src.begin() + end);
+  }
+  for (int a = 0; a < p.proto.n_anchors; ++a)
+    f->idx.insert(f->idx.end(), p.anchors.begin() + (size_t)a * n + start, p.anchors.begin() + (size_t)a * n + end);
+  f->batches.push_back(b);
+  return GQE_OK;
+}
+
+static void feeder_touch(gqe_feeder* f, int64_t offset, int64_t numel) {
+  if (offset < 0) return;
+  for (const gqe_segment& s : f->segs)
+    if (s.offset == offset) return;
+  gqe_segment s;
+  s.offset = offset;
+  s.numel = numel;
+  s.step = 0;  // library-kept Adam step counters
+  s.reserved = 0;
+  f->segs.push_back(s);
+}
+
+int gqe_feeder_run(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations, int32_t burn_in, float lr, float beta1,
+                   float beta2, float eps, float* losses, void* stream) {
+  if (!f) return GQE_ERR_ARG;
+  gqe_ctx* ctx = f->ctx;
+  if (n_iterations < 1 || !losses) return fail(ctx, GQE_ERR_ARG, "bad arguments");
+  const int d = ctx->cfg.dim;
+  const bool bil = ctx->cfg.decoder == GQE_DEC_BILINEAR;
+  const int64_t vec = bil ? (int64_t)d * d : d;
+  for (int64_t it = first_iteration; it < first_iteration + n_iterations; ++it) {
+    f->batches.clear();
+    f->idx.clear();
+    f->segs.clear();
+    // the reference's schedule (train_helpers.py:50-72): 1-chain always; after burn-in every other type,
+    // chains once (path_weight), intersections with regular and with hard negatives (inter_weight each)
+    int rc = feeder_batch(f, GQE_Q_1CHAIN, it, 1.f, false);
+    if (rc != GQE_OK) return rc;
+    if (it >= burn_in) {
+      for (int t = GQE_Q_2CHAIN; t <= GQE_Q_3CHAIN_INTER; ++t) {
+        if (f->by_type[t].empty()) continue;
+        const bool inter = t >= GQE_Q_2INTER;
+        rc = feeder_batch(f, t, it, inter ? f->inter_weight : f->path_weight, false);
+        if (rc != GQE_OK) return rc;
+        if (inter) {
+          rc = feeder_batch(f, t, it, f->inter_weight, true);
+          if (rc != GQE_OK) return rc;
+        }
+      }
+    }
+    if (f->batches.empty()) return fail(ctx, GQE_ERR_STATE, "feeder has no 1-chain pool");
+    rc = run_queries(ctx, f->batches.data(), (int32_t)f->batches.size(), f->idx.data(), (int64_t)f->idx.size(), 0, true, losses,
+                     nullptr, nullptr, stream);
+    if (rc != GQE_OK) return rc;
+    for (const gqe_batch& b : f->batches) {
+      const int tt = table_of(ctx, b.target_table);
+      feeder_touch(f, b.target_table, ctx->tables[tt].rows * d);
+      const bool chain = b.qtype <= GQE_Q_3CHAIN;
+      for (int a = 0; a < b.n_anchors; ++a) feeder_touch(f, b.anchor_table[a], ctx->tables[table_of(ctx, b.anchor_table[a])].rows * d);
+      for (int i = 0; i < (chain ? 1 : b.n_anchors); ++i)
+        for (int h = 0; h < b.n_hops[i]; ++h) feeder_touch(f, b.hop_param[i][h], vec);
+      if (!chain) {
+        if (b.n_final) feeder_touch(f, b.final_param, vec);
+        if (is_mlp(ctx)) {
+          feeder_touch(f, b.pre_param, (int64_t)d * d);
+          feeder_touch(f, b.post_param, (int64_t)d * d);
+        }
+      }
+    }
+    rc = run_opt(ctx, GQE_OPT_ADAM, f->segs.data(), (int32_t)f->segs.size(), lr, beta1, beta2, eps, stream);
+    if (rc != GQE_OK) return rc;
+  }
+  return GQE_OK;
 }
 
 int gqe_debug_profile(gqe_ctx* ctx, long long* stamps) {

@@ -76,6 +76,11 @@ SYMBOLS = OrderedDict([
     ("gqe_adam_step", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P])),
     ("gqe_sgd_step", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, C.c_float, _P])),
     ("gqe_zero_grads", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, _P])),
+    ("gqe_feeder_create", (C.c_int, [_P, C.c_uint64, C.c_int32, C.c_float, C.c_float, C.POINTER(_P)])),
+    ("gqe_feeder_destroy", (C.c_int, [_P])),
+    ("gqe_feeder_add_pool", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int64, _P, _P, _P, _P])),
+    ("gqe_feeder_set_mode_rows", (C.c_int, [_P, C.c_int64, _P, C.c_int64])),
+    ("gqe_feeder_run", (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P])),
     ("gqe_timing_enable", (C.c_int, [_P, C.c_int32])),
     ("gqe_debug_profile", (C.c_int, [_P, _P])),
     ("gqe_timing_read", (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)])),
@@ -344,6 +349,33 @@ class Engine(object):
             return
         arr = self._segments(keys, False)
         self._check(self.lib.gqe_zero_grads(self.ctx, arr, len(keys), self._stream()))
+
+    # -- native training feed ---------------------------------------------------------
+    def make_feeder(self, pools_by_plan, mode_rows, batch_size=512, path_weight=0.01, inter_weight=0.005, seed=0):
+        """pools_by_plan: [(FormulaPlan, pool)] with pool.target[n], pool.anchors[k,n], pool.neg[n] or None,
+        pool.hard[n] or None (int32 rows); mode_rows: {table key: int32 rows} for 1-chain negatives."""
+        h = _P()
+        self._check(self.lib.gqe_feeder_create(self.ctx, seed, batch_size, path_weight, inter_weight, C.byref(h)))
+        for plan, pool in pools_by_plan:
+            arr = self.make_batches([plan.batch(1, 0, 0)])
+            c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+            t, a, ng, hd = c(pool.target), c(pool.anchors), c(getattr(pool, "neg", None)), c(getattr(pool, "hard", None))
+            p = lambda x: None if x is None else C.c_void_p(x.ctypes.data)
+            self._check(self.lib.gqe_feeder_add_pool(h, arr, len(t), p(t), p(a), p(ng), p(hd)))
+        for key, rows in mode_rows.items():
+            rows = np.ascontiguousarray(rows, dtype=np.int32)
+            self._check(self.lib.gqe_feeder_set_mode_rows(h, self.layout.offset(key), C.c_void_p(rows.ctypes.data), len(rows)))
+        return h
+
+    def feeder_run(self, feeder, first_iteration, n_iterations, burn_in=0, lr=0.01, betas=(0.9, 0.999), eps=1e-8, losses=None):
+        if losses is None:
+            losses = self.torch.zeros(MAX_BATCHES + 1, dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.gqe_feeder_run(feeder, first_iteration, n_iterations, burn_in, lr, betas[0], betas[1], eps,
+                                            losses.data_ptr(), self._stream()))
+        return losses
+
+    def feeder_destroy(self, feeder):
+        self.lib.gqe_feeder_destroy(feeder)
 
     # -- timing (bench.py roofline) ------------------------------------------------
     def timing_enable(self, stride):

@@ -1,0 +1,108 @@
+"""Tensorised trainer: the reference's training schedule (train_helpers.py:40-107) driven from int32
+structure-of-arrays instead of Python ``Query`` objects.
+
+``run_train`` keeps the reference's exact object-walking flow (and RNG call order) for drop-in use and
+parity; this class is the production feed: a formula's queries live once as contiguous row arrays
+(``tensorize.FormulaQueries`` built from Query lists, or ``synth.QueryPool``), a batch is a slice, negatives
+are drawn with a vectorised RNG, the nine (formula, slice) batches of an iteration are packed into ONE int32
+buffer that libgqe uploads on its side stream while the previous iteration computes, and the loss is only
+read back when it is logged.  Sampling stays on the host cores (north star); nothing here is on the GPU.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from .tensorize import pack_margin_batches
+
+
+class PoolView(object):
+    """Uniform view of one formula's queries: target[n], anchors[k,n], negatives (fixed array or CSR)."""
+
+    def __init__(self, pool):
+        self.formula = pool.formula
+        self.n = pool.n
+        self.target = pool.target
+        self.anchors = pool.anchors
+        self.neg_fixed = getattr(pool, "neg", None)
+        self.hard_fixed = getattr(pool, "hard", None)
+        self.csr = pool if hasattr(pool, "sample_negatives") else None
+
+    def negatives(self, start, end, hard, rng, all_rows):
+        if all_rows is not None:                      # 1-chain: any node of the target mode (model.py:118)
+            return all_rows[rng.randint(0, len(all_rows), size=end - start)]
+        if self.csr is not None:
+            return self.csr.sample_negatives(start, end, hard, rng)
+        arr = self.hard_fixed if hard else self.neg_fixed
+        if arr is None:
+            raise Exception("queries of formula %s carry no %snegative samples" % (self.formula, "hard " if hard else ""))
+        return arr[start:end]
+
+
+class TensorizedTrainer(object):
+    def __init__(self, model_or_engine, optimizer, pools_by_type, all_rows_by_mode, batch_size=512, inter_weight=0.005,
+                 path_weight=0.01, seed=0, plan_of=None):
+        """pools_by_type: {query_type: [pool, ...]} (one pool per formula); all_rows_by_mode: {mode: int32 rows}
+        to draw 1-chain negatives from.  ``model_or_engine``: a QueryEncoderDecoder (``margin_step``) — or any
+        object with the same ``margin_step(items)`` method."""
+        self.model = model_or_engine
+        self.opt = optimizer
+        self.types = list(pools_by_type.keys())
+        self.pools = {t: [PoolView(p) for p in pools_by_type[t]] for t in self.types}
+        self.probs = {t: np.array([p.n for p in self.pools[t]], dtype=np.float64) for t in self.types}
+        for t in self.types:
+            self.probs[t] /= self.probs[t].sum()
+        self.all_rows = all_rows_by_mode
+        self.B = batch_size
+        self.inter_weight, self.path_weight = inter_weight, path_weight
+        self.rng = np.random.RandomState(seed)
+        self.ema_loss = None
+        self.iterations = 0
+        self.queries_seen = 0
+
+    def _batch(self, qtype, it, weight, hard=False):
+        """formula drawn in proportion to its number of queries, slice by the reference's wrap-around rule."""
+        plist = self.pools[qtype]
+        p = plist[int(self.rng.choice(len(plist), p=self.probs[qtype]))] if len(plist) > 1 else plist[0]
+        n, B = p.n, self.B
+        start = (it * B) % n
+        end = min(((it + 1) * B) % n, n)
+        end = n if end <= start else end
+        all_rows = self.all_rows[p.formula.target_mode] if qtype == "1-chain" else None
+        neg = p.negatives(start, end, hard, self.rng, all_rows)
+        return (p.formula, p.target[start:end], neg, p.anchors[:, start:end], weight, 1.0)
+
+    def items(self, it, edge_conv=True):
+        out = [self._batch("1-chain", it, 1.0)]
+        if edge_conv:
+            for t in self.types:
+                if t == "1-chain":
+                    continue
+                if "inter" in t:
+                    out.append(self._batch(t, it, self.inter_weight))
+                    out.append(self._batch(t, it, self.inter_weight, hard=True))
+                else:
+                    out.append(self._batch(t, it, self.path_weight))
+        return out
+
+    def step(self, it, edge_conv=True):
+        """One iteration: sample on the host, one grouped fused launch, one fused optimiser pass."""
+        items = self.items(it, edge_conv)
+        losses, _, _ = self.model.margin_step(items)
+        self.opt.step()
+        self.iterations += 1
+        self.queries_seen += sum(len(x[1]) for x in items)
+        return losses
+
+    def run(self, max_iter, burn_in=0, log_every=100, logger=None):
+        t0 = time.time()
+        losses = None
+        for it in range(max_iter):
+            losses = self.step(it, edge_conv=it >= burn_in)
+            if log_every and it % log_every == 0:
+                val = float(losses[-1].item())        # the only host sync of the loop
+                self.ema_loss = val if self.ema_loss is None else 0.99 * self.ema_loss + 0.01 * val
+                if logger is not None:
+                    logger.info("Iter: {:d}; loss: {:f}; {:.0f} queries/s".format(it, val, self.queries_seen / max(time.time() - t0, 1e-9)))
+        return losses

@@ -177,6 +177,23 @@ int gqe_sgd_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, float lr
 /* replaces: optimizer.zero_grad() alone */
 int gqe_zero_grads(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, void* stream);
 
+/* ---- native training feed: replaces run_train's per-iteration Python (train_helpers.py:48-79,
+ * 95-107 + model.py:113-120) once the queries are tensorised.  Pools are HOST int32 row arrays (copied):
+ * target[n], anchors[k][n], one stored negative and (intersections) one hard negative per query, as the
+ * reference's training files carry them (data_utils.py:71 neg_sample_max=1); `formula` supplies the static
+ * fields of gqe_batch.  gqe_feeder_run performs n_iterations of: draw a formula per batch (probability
+ * proportional to pool size), slice by the reference's wrap-around rule, draw 1-chain negatives uniformly from
+ * the rows given by gqe_feeder_set_mode_rows, pack, gqe_margin_fwd_bwd, gqe_adam_step on the touched tensors.
+ * losses (device, >= GQE_MAX_BATCHES+1 floats) holds the last iteration's losses. */
+typedef struct gqe_feeder gqe_feeder;
+int gqe_feeder_create(gqe_ctx* ctx, uint64_t seed, int32_t batch_size, float path_weight, float inter_weight, gqe_feeder** out);
+int gqe_feeder_destroy(gqe_feeder* f);
+int gqe_feeder_add_pool(gqe_feeder* f, const gqe_batch* formula, int64_t n, const int32_t* target, const int32_t* anchors,
+                        const int32_t* neg, const int32_t* hard);
+int gqe_feeder_set_mode_rows(gqe_feeder* f, int64_t table_offset, const int32_t* rows, int64_t n);
+int gqe_feeder_run(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations, int32_t burn_in, float lr, float beta1,
+                   float beta2, float eps, float* losses, void* stream);
+
 /* Timing of the most recent launches of each kernel on the stream they ran on, measured with
  * hipEvents recorded by the library when enabled (bench.py's roofline block uses this:
  * torch.cuda.Event cannot see a raw hipStream).  kernel: 0 = fused fwd/bwd, 1 = param-grad

@@ -339,3 +339,57 @@ def test_error_paths():
     with pytest.raises(GqeError):
         eng.adam_step([])  if False else eng._check(eng.lib.gqe_adam_step(eng.ctx, None, 0, 0.01, 0.9, 0.999, 1e-8, None))
     eng.close()
+
+
+def test_native_feeder_matches_python_driven_iterations():
+    """gqe_feeder_run (C++ sampling + packing + launch + step) against the same iterations driven
+    from Python: one pool per query type (so the formula draw is forced), 1-chain negatives drawn from a
+    single-row list (so the RNG cannot matter), batch size that wraps around the pools."""
+    import torch
+    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, read_arena, toy_batch
+
+    class Pool(object):
+        pass
+    rng = np.random.RandomState(11)
+    d, dec, inter, B = 64, "bilinear-diag", "min", 48
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
+    engs = [engine_from_params(params, d, dec, inter) for _ in range(2)]
+    pools = []
+    for qtype in ("1-chain", "2-chain", "2-inter", "3-inter_chain", "3-chain_inter"):
+        t, g, a = toy_batch(rng, qtype, 100)
+        p = Pool()
+        p.target, p.anchors, p.neg, p.hard = t, a, g, (np.roll(g, 1) if "inter" in qtype else None)
+        pools.append((qtype, p))
+    one_row = {O.table_key("a"): np.array([7], dtype=np.int32)}
+    plans0 = [(plan_for(engs[0], qt, TOY_FORMULAS[qt]), p) for qt, p in pools]
+    feeder = engs[0].make_feeder(plans0, one_row, batch_size=B, path_weight=0.01, inter_weight=0.005, seed=1)
+    losses_f = engs[0].feeder_run(feeder, 0, 3, burn_in=1).cpu().numpy()
+    engs[0].feeder_destroy(feeder)
+    # the same three iterations from Python on the second engine
+    from graphqembed_amd.tensorize import pack_margin_batches
+    e1 = engs[1]
+    for it in range(3):
+        items = []
+        for qt, p in pools:
+            if it < 1 and qt != "1-chain":
+                continue
+            plan = plan_for(e1, qt, TOY_FORMULAS[qt])
+            n = 100
+            s = (it * B) % n
+            e = min(((it + 1) * B) % n, n)
+            e = n if e <= s else e
+            for hard in ((False, True) if "inter" in qt else (False,)):
+                neg = np.full(e - s, 7, dtype=np.int32) if qt == "1-chain" else (p.hard if hard else p.neg)[s:e]
+                w = 1.0 if qt == "1-chain" else (0.005 if "inter" in qt else 0.01)
+                items.append((plan, p.target[s:e], neg, p.anchors[:, s:e], w, 1.0))
+        descs, idx, n_s = pack_margin_batches(items)
+        losses_p, _, _ = e1.margin_fwd_bwd(descs, idx, n_s)
+        e1.adam_step(set().union(*[i[0].touched for i in items]))
+    lp = losses_p.cpu().numpy()
+    np.testing.assert_allclose(losses_f[:len(lp) - 1], lp[:-1], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(losses_f[len(lp) - 1], lp[-1], rtol=1e-5)
+    pf, pp = read_arena(engs[0], engs[0].params), read_arena(e1, e1.params)
+    for k in pf:
+        np.testing.assert_allclose(pf[k], pp[k], rtol=0, atol=5e-6, err_msg=k)
+    for e in engs:
+        e.close()
