@@ -393,3 +393,98 @@ def test_native_feeder_matches_python_driven_iterations():
         np.testing.assert_allclose(pf[k], pp[k], rtol=0, atol=5e-6, err_msg=k)
     for e in engs:
         e.close()
+
+
+def test_gradient_bookkeeping_state_machine():
+    """Lists + dense arena bookkeeping: accumulate over calls, materialise in the middle, zero_grads drops pending
+    lists, more than 16 batches in one call (several launches), long bags (> 64 words), contribution-buffer
+    overflow is an error, not corruption."""
+    import torch
+    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, read_arena, toy_batch
+    from graphqembed_amd.engine import GqeError
+    from graphqembed_amd.tensorize import pack_margin_batches
+    rng = np.random.RandomState(23)
+    d, dec, inter = 32, "bilinear-diag", "mean"
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS, bag_modes=("c",))
+    ptr, ids = params[O.BAGS_KEY]["c"]                       # make two bags long: 70 and 150 words
+    lens = np.diff(ptr).copy(); lens[3] = 70; lens[5] = 150
+    ptr2 = np.zeros_like(ptr); ptr2[1:] = np.cumsum(lens)
+    params[O.BAGS_KEY]["c"] = (ptr2, rng.randint(0, 64, size=int(ptr2[-1])).astype(np.int32))
+    eng = engine_from_params(params, d, dec, inter, max_queries=64, max_batches=4)
+    types = list(TOY_FORMULAS)
+    batches = []
+    for j in range(20):                                       # 20 batches -> 2 launches inside one call
+        qt = types[j % len(types)]
+        t, g, a = toy_batch(rng, qt, 3 + j)
+        plan_o = O.make_plan(qt, TOY_FORMULAS[qt])
+        for arr, mode in [(t, plan_o["target_mode"]), (g, plan_o["target_mode"])] + [(a[i], m) for i, m in enumerate(plan_o["anchor_modes"])]:
+            if mode == "c":
+                arr[:2] = (3, 5)                              # hit the long bags
+        batches.append((qt, t, g, a, 0.1 * (j + 1)))
+    want = O.zero_grads_like(params)
+    want_l = []
+    for qt, t, g, a, w in batches:
+        l, _, _, _ = O.margin_fwd_bwd(params, O.make_plan(qt, TOY_FORMULAS[qt]), dec, inter, t, g, a, weight=w, grads=want)
+        want_l.append(l)
+    keys = [k for k in want if k != O.BAGS_KEY]
+    items = [(plan_for(eng, qt, TOY_FORMULAS[qt]), t, g, a, w, 1.0) for qt, t, g, a, w in batches]
+
+    def check(what):
+        got = read_arena(eng, eng.grads)
+        for k in keys:
+            scale = max(np.abs(want[k]).max(), 1e-12)
+            np.testing.assert_allclose(got[k], want[k], rtol=2e-3, atol=3e-6 * scale + 1e-9, err_msg="%s %s" % (what, k))
+        eng.zero_grads(list(eng.layout.entries))
+        assert float(eng.grads.abs().max()) == 0.0
+
+    # (1) all 20 batches in ONE call
+    descs, idx, n = pack_margin_batches(items)
+    losses, _, _ = eng.margin_fwd_bwd(descs, idx, n)
+    l = losses.cpu().numpy()
+    np.testing.assert_allclose(l[:20], want_l, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(l[20], sum(w * x for (_, _, _, _, w), x in zip(batches, want_l)), rtol=1e-4)
+    check("one call")
+    # (2) one call per batch, a materialise in the middle, the optimiser-free read at the end
+    for j, it in enumerate(items):
+        descs, idx, n = pack_margin_batches([it])
+        eng.margin_fwd_bwd(descs, idx, n)
+        if j == 9:
+            eng.materialize()
+    check("accumulated")
+    # (3) zero_grads drops what is pending in the lists
+    descs, idx, n = pack_margin_batches(items[:5])
+    eng.margin_fwd_bwd(descs, idx, n)
+    eng.zero_grads(list(eng.layout.entries))
+    got = read_arena(eng, eng.grads)
+    assert all(not got[k].any() for k in keys)
+    # (4) lists + dense gradient consumed together by one Adam step == everything at once
+    p0 = read_arena(eng, eng.params)
+    descs, idx, n = pack_margin_batches(items[:10])
+    eng.margin_fwd_bwd(descs, idx, n)
+    eng.materialize()
+    descs, idx, n = pack_margin_batches(items[10:])
+    eng.margin_fwd_bwd(descs, idx, n)
+    touched = set().union(*[it[0].touched for it in items])
+    eng.adam_step(touched)
+    ref = {k: v.astype(np.float64) for k, v in params.items() if k != O.BAGS_KEY}
+    O.adam_step(ref, {k: want[k] for k in keys}, {}, [k for k in keys if k in touched])
+    got = read_arena(eng, eng.params)
+    for k in keys:
+        diff = np.abs(got[k] - ref[k])
+        # first Adam step: |dp| = lr for every non-zero gradient; rounding-noise gradients may differ (see oracle tests)
+        assert np.median(diff) < 1e-5 and (diff > 1e-3).mean() < 0.02, (k, np.median(diff), (diff > 1e-3).mean())
+    assert float(eng.grads.abs().max()) == 0.0
+    # (5) the contribution buffer is bounded: overflow is reported, nothing is corrupted
+    small = engine_from_params(params, d, dec, inter, max_queries=32, max_batches=2)
+    it5 = (plan_for(small, "3-inter", TOY_FORMULAS["3-inter"]),) + tuple(toy_batch(rng, "3-inter", 30)) + (1.0, 1.0)
+    descs, idx, n = pack_margin_batches([it5])
+    with pytest.raises(GqeError, match="contribution buffer full"):
+        for _ in range(10):
+            small.lib.gqe_margin_fwd_bwd  # noqa: B018  (the call below goes through the binding)
+            arr = small.make_batches(descs)
+            keep, ptr_, n_idx, on_dev = small._idx_arg(idx)
+            losses_ = torch.empty(2, device="cuda")
+            small._check(small.lib.gqe_margin_fwd_bwd(small.ctx, arr, 1, ptr_, n_idx, on_dev, losses_.data_ptr(), None, None, small._stream()))
+    small.materialize()
+    small.close()
+    eng.close()
