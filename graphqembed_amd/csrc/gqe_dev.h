@@ -15,6 +15,7 @@
 #define GQE_OPT_CHUNK 1024   // floats per optimiser chunk (256 threads x float4)
 #define GQE_MAX_SEGS 96
 #define GQE_GEMM_KCHUNK 128  // queries per pair-GEMM unit
+#define GQE_GEMM_MT 64       // edge of the gradient block one pair-GEMM unit produces
 #define GQE_PROF_SLOTS 16     // wall_clock64 stamps per workgroup (debug profile)
 
 #define GQE_LAUNCH_BATCHES 16  // batches per fused launch: their dynamic descriptors travel as kernel arguments

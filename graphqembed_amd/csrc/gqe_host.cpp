@@ -389,7 +389,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int d = ctx->cfg.dim;
   const Layout& L = ctx->lay;
-  const int tiles_sq = (d / 16) * (d / 16);
+  const int macros_sq = ((d + GQE_GEMM_MT - 1) / GQE_GEMM_MT) * ((d + GQE_GEMM_MT - 1) / GQE_GEMM_MT);
 
   // ---- validate everything and resolve the formula descriptors before anything is enqueued ----
   std::vector<int> fid(n_batches);
@@ -534,7 +534,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       if (bwd) {
         entry += (int64_t)(2 + f.n_anchors) * s.n_queries;
         scratch += (int64_t)f.n_slots * b.Bpad * d;
-        P.units += f.n_jobs * ((b.Bpad + GQE_GEMM_KCHUNK - 1) / GQE_GEMM_KCHUNK) * tiles_sq;
+        P.units += f.n_jobs * ((b.Bpad + GQE_GEMM_KCHUNK - 1) / GQE_GEMM_KCHUNK) * macros_sq;
       }
     }
     if ((size_t)(scratch * (int64_t)sizeof(float)) > L.scratch_off + L.scratch_cap)

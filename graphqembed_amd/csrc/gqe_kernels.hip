@@ -15,18 +15,21 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
                                                                    float* __restrict__ grads, int d,
                                                                    const float* __restrict__ tile_loss,
                                                                    float* __restrict__ losses) {
-  if (blockIdx.x == gridDim.x - 1) {
-    // finalize block: per-batch mean hinge loss (model.py:124-126) and the weighted iteration loss from the
+  if (blockIdx.x == 0) {
+    // finalize block (first, so that it is not queued behind the GEMM units): per-batch mean hinge loss (model.py:124-126) and the weighted iteration loss from the
     // per-tile partials of the fused kernel — plain stores, nothing to zero, no atomics.
     __shared__ float s_w[GQE_LAUNCH_BATCHES];
     const int t = threadIdx.x;
-    if (t < plan.n_batches) {
-      const GqeDynBatch b = plan.b[t];
+    // one wave per batch: lanes stride the tile partials (independent loads), DPP-reduce
+    for (int k = t >> 6; k < plan.n_batches; k += GQE_WAVES) {
+      const GqeDynBatch b = plan.b[k];
       float l = 0.f;
-      for (int k = 0; k < b.Bpad / GQE_TQ; ++k) l += tile_loss[b.tile_begin + k];
-      l *= b.inv_B;
-      losses[b.loss_index] = l;
-      s_w[t] = l * b.loss_weight;
+      for (int i = t & 63; i < b.Bpad / GQE_TQ; i += 64) l += tile_loss[b.tile_begin + i];
+      l = wave_sum(l) * b.inv_B;
+      if ((t & 63) == 0) {
+        losses[b.loss_index] = l;
+        s_w[k] = l * b.loss_weight;
+      }
     }
     __syncthreads();
     if (t == 0) {
@@ -36,51 +39,94 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
     }
     return;
   }
-  const int unit = (int)blockIdx.x * GQE_WAVES + (threadIdx.x >> 6);  // (batch, job, K chunk, output tile)
+  // one workgroup = one unit (batch, job, K chunk of GQE_GEMM_KCHUNK queries, 64x64 block of the d x d gradient).
+  // Both operand panels go through LDS in 64-query halves (float4 global loads, 80-float rows: the four k-rows an
+  // MFMA step reads land 16 banks apart); each wave owns a 2x2 group of 16x16 MFMA tiles.
+  const int unit = (int)blockIdx.x - 1;
   if (unit >= plan.units) return;
-  const int lane = threadIdx.x & 63;
+  constexpr int MT = GQE_GEMM_MT, KS = 64, STR = MT + 16;
+  __shared__ float sL[KS * STR], sR[KS * STR];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lq = lane & 15, lk = lane >> 4;
   int bi = 0;
 #pragma unroll
   for (int k = 1; k < GQE_LAUNCH_BATCHES; ++k) bi += (unit >= plan.unit_begin[k]) ? 1 : 0;
   const GqeDynBatch b = plan.b[bi];
   const GqeDevFormula* __restrict__ f = formulas + b.formula;
-  const int tiles_per_dim = d / 16;
-  const int tiles = tiles_per_dim * tiles_per_dim;
+  const int mper = (d + MT - 1) / MT, macros = mper * mper;
   const int chunks = (b.Bpad + GQE_GEMM_KCHUNK - 1) / GQE_GEMM_KCHUNK;
   int u = unit - b.unit_begin;
-  const int job = u / (chunks * tiles);
-  u -= job * chunks * tiles;
-  const int chunk = u / tiles;
-  const int t = u - chunk * tiles;
-  const int i0 = (t / tiles_per_dim) * 16, j0 = (t % tiles_per_dim) * 16;
+  const int job = u / (chunks * macros);
+  u -= job * chunks * macros;
+  const int chunk = u / macros;
+  const int mt = u - chunk * macros;
+  const int i0 = (mt / mper) * MT, j0 = (mt % mper) * MT;
+  const int nib = (min(d - i0, MT)) >> 4, njb = (min(d - j0, MT)) >> 4;  // 16-wide tile columns present in this block
   const int k_begin = chunk * GQE_GEMM_KCHUNK;
   const size_t slot_floats = (size_t)b.Bpad * d;
   const float* L = ws + b.scratch_base + (size_t)f->job_L[job] * slot_floats;
   const float* R = ws + b.scratch_base + (size_t)f->job_R[job] * slot_floats;
-  // all operand loads of the unit are issued before the first MFMA (8 k-blocks x 4 rows x 2 operands)
-  constexpr int KBLK = GQE_GEMM_KCHUNK / 16;
-  float la[KBLK][4], ra[KBLK][4];
+  const int ib0 = (wave >> 1) * 2, jb0 = (wave & 1) * 2;
+  f32x4 acc[2][2];
 #pragma unroll
-  for (int kb = 0; kb < KBLK; ++kb) {
-    const int k0 = k_begin + kb * 16;
-    const bool ok = k0 < b.Bpad;
-    const float* lp = L + (size_t)(k0 + 4 * lk) * d + i0 + lq;
-    const float* rp = R + (size_t)(k0 + 4 * lk) * d + j0 + lq;
+  for (int x = 0; x < 2; ++x)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      la[kb][s] = ok ? lp[s * d] : 0.f;
-      ra[kb][s] = ok ? rp[s * d] : 0.f;
+    for (int y = 0; y < 2; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // the whole K chunk is requested up front (16 float4 per thread) and fed through the LDS panels half by half.
+  // Out-of-range lanes read the panel's first floats (always mapped) and are zeroed afterwards: a predicated load
+  // would fence each load behind its own wait.
+  constexpr int NQ = GQE_GEMM_KCHUNK * 16 / GQE_THREADS;  // float4 per thread per operand
+  float4 vl[NQ], vr[NQ];
+  unsigned okm = 0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int idx = tid + q * GQE_THREADS, row = idx >> 4, c4 = (idx & 15) * 4;
+    const int k = k_begin + row;
+    const bool okk = k < b.Bpad;
+    const bool okl = okk && i0 + c4 < d, okr = okk && j0 + c4 < d;
+    vl[q] = *reinterpret_cast<const float4*>(L + (okl ? (size_t)k * d + i0 + c4 : 0));
+    vr[q] = *reinterpret_cast<const float4*>(R + (okr ? (size_t)k * d + j0 + c4 : 0));
+    okm |= (okl ? 1u : 0u) << (2 * q) | (okr ? 2u : 0u) << (2 * q);
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if (!(okm >> (2 * q) & 1u)) vl[q] = zero4;
+    if (!(okm >> (2 * q) & 2u)) vr[q] = zero4;
+  }
+#pragma unroll
+  for (int h = 0; h < GQE_GEMM_KCHUNK / KS; ++h) {
+    if (h) __syncthreads();  // the previous half is consumed
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + q * GQE_THREADS, row = idx >> 4, c4 = (idx & 15) * 4;
+      *reinterpret_cast<float4*>(sL + row * STR + c4) = vl[h * 4 + q];
+      *reinterpret_cast<float4*>(sR + row * STR + c4) = vr[h * 4 + q];
+    }
+    __syncthreads();
+    if (ib0 < nib && jb0 < njb) {
+#pragma unroll 4
+      for (int s = 0; s < KS / 4; ++s) {
+        const float* pl = sL + (s * 4 + lk) * STR + lq;
+        const float* pr = sR + (s * 4 + lk) * STR + lq;
+        const float a0 = pl[ib0 * 16], a1 = pl[ib0 * 16 + 16];
+        const float b0 = pr[jb0 * 16], b1 = pr[jb0 * 16 + 16];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
     }
   }
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int kb = 0; kb < KBLK; ++kb)
+  for (int x = 0; x < 2; ++x)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la[kb][s], ra[kb][s], acc, 0, 0, 0);
-  float* out = grads + f->job_param[job] + (size_t)(i0 + 4 * lk) * d + j0 + lq;
+    for (int y = 0; y < 2; ++y) {
+      if (ib0 + x >= nib || jb0 + y >= njb) continue;
+      float* out = grads + f->job_param[job] + (size_t)(i0 + (ib0 + x) * 16 + 4 * lk) * d + j0 + (jb0 + y) * 16 + lq;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) unsafeAtomicAdd(out + (size_t)r * d, acc[r]);
+      for (int r = 0; r < 4; ++r) unsafeAtomicAdd(out + (size_t)r * d, acc[x][y][r]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -264,7 +310,7 @@ hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a) {
 }
 
 hipError_t gqe_launch_pair_gemm(const GqeFusedArgs& a, float* losses) {
-  const int blocks = (a.plan.units + GQE_WAVES - 1) / GQE_WAVES + 1;  // + the finalize block
+  const int blocks = a.plan.units + 1;  // + the finalize block
   hipLaunchKernelGGL(gqe_pair_gemm_kernel, dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.plan, a.formulas, a.ws, a.grads, a.d,
                      a.tile_loss, losses);
   return hipGetLastError();
