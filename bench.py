@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to "
                     "smoke-test the multi-rank path on a single GPU)")
+    ap.add_argument("--exchange", default="sparse", choices=["sparse", "dense"],
+                    help="--gpus > 1: all-gather the gradient contribution entries (sparse) or all-reduce the dense arena")
     ap.add_argument("--check-replicas", action="store_true", help="after the run, verify that all ranks hold identical parameters")
     args = ap.parse_args()
 
@@ -163,7 +165,10 @@ def main():
     layout = build_layout(g, d, args.decoder, args.inter_decoder)
     mix = synth.FULL_MIX
     qpi = B * len(mix)                                             # queries per iteration per GPU
-    eng = Engine(d, args.decoder, args.inter_decoder, layout, max_queries=qpi, max_batches=len(mix))
+    sparse = world > 1 and args.exchange == "sparse"
+    eng = Engine(d, args.decoder, args.inter_decoder, layout, max_queries=qpi, max_batches=len(mix),
+                 rank=rank if sparse else 0, world=world if sparse else 1)
+    spans = parallel.dense_spans(layout, lambda k, shape: k.startswith("enc."))
     init_params(eng, d, seed=0)                                    # same seed on every rank: replicas start equal
     pools = synth.make_pools(g, sorted(set(m[0] for m in mix)), formulas_per_type=6, pool_size=max(16 * B, 8192), seed=0)
 
@@ -181,14 +186,26 @@ def main():
         descs, idx, _ = pack_margin_batches(packed)
         ps = eng.prepare_margin(descs, torch.from_numpy(idx).to(eng.device))
         ps["adam"] = eng.prepare_adam(set().union(*[p[0].touched for p in packed]))
+        ps["n_entries"] = sum((2 + a.shape[0]) * len(t) for (_, t, _, a, _, _) in items)
         ps["aq_bytes"] = sum(algorithmic_bytes_per_query(f.query_type, d) * len(t) for (f, t, _, _, _, _) in items)
         ps["p_touched"] = sum(layout.numel(k) for k in ps["adam"]["keys"])
         prepared.append(ps)
 
+    mode = {"sparse": sparse}
+
     def step(i):
         ps = prepared[i % n_distinct]
         eng.run_margin(ps)
-        if dist is not None:                                       # lists -> dense arena, RCCL sum over xGMI
+        if mode["sparse"]:                                         # contribution entries all-gathered over xGMI
+            try:
+                parallel.exchange_sparse(eng, dist, spans)
+            except Exception as e:                                 # argument-level refusal by the backend: same on all ranks
+                if i != 0:
+                    raise
+                sys.stderr.write("bench: sparse exchange refused (%s); falling back to the dense all-reduce\n" % e)
+                mode["sparse"] = False
+                parallel.exchange_gradients(eng.grads, dist, engine=eng)
+        elif dist is not None:                                     # lists -> dense arena, RCCL sum over xGMI
             parallel.exchange_gradients(eng.grads, dist, engine=eng)
         eng.run_adam(ps["adam"])
 
@@ -238,7 +255,10 @@ def main():
                                % (len(mix), B, d, args.decoder, args.inter_decoder, layout.total),
                    "graph": "5 modes, 97000 nodes, 14 directed relations, 60000 edges/kind, seed 0",
                    "queries_per_step_per_gpu": qpi, "parallelism": "dp%d" % world,
-                   "gradient_exchange": "none" if world == 1 else "RCCL all-reduce of the %d-float gradient arena" % layout.total},
+                   "gradient_exchange": "none" if world == 1 else
+                   ("all-gather of the contribution entries (%d x (%d floats + row id) per rank per step) + all-reduce of the "
+                    "%d dense relation/Pre/Post floats" % (prepared[0]["n_entries"], d, sum(e - b for b, e in spans))) if mode["sparse"] else
+                   "all-reduce of the %d-float gradient arena" % layout.total},
         "roofline": {"bound": "hbm", "kernel": "gqe_opt_kernel<ADAM> (fused Adam + grad re-zero)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -258,11 +278,11 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if args.check_replicas and dist is not None:
-        mine = eng.params.double().sum().reshape(1).cpu()
-        lo, hi = mine.clone(), mine.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        out["replicas_identical"] = bool(lo.item() == hi.item())
+        ref = eng.params.clone()
+        dist.broadcast(ref, 0)
+        same = torch.tensor([int(torch.equal(ref, eng.params))], device=eng.device)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        out["replicas_identical"] = bool(same.item() == 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -107,6 +107,7 @@ struct GqeStepCoef {
 struct GqeOptArgs {
   int mode;
   bool lists;         // some table has pending gradient lists
+  bool sorted;        // sum each list in ascending node id (bit-identical across data-parallel replicas)
   bool dense_tables;  // the dense gradient of the tables has to be read (and re-zeroed) too
   const GqeDevSeg* segs;
   int n_segs;
@@ -150,5 +151,6 @@ struct GqeFusedArgs {
 hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a);
 hipError_t gqe_launch_pair_gemm(const GqeFusedArgs& a, float* losses);
 hipError_t gqe_launch_opt(const GqeOptArgs& a);
+hipError_t gqe_launch_import(int32_t* head, int32_t* next, int32_t max_entries, int32_t n, int rank, int world, hipStream_t stream);
 
 #endif

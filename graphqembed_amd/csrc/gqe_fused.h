@@ -363,7 +363,10 @@ __device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_
   vstore<NC>(e.contrib + entry * e.d, gx, e.d, e.lane);
   // The returned previous head is only needed for next[entry]; that store is deferred to the end of the
   // kernel (push_links) so that the wave never stalls on the atomic's round trip.
-  if (e.lane == 0) old_head = __hip_atomic_exchange(e.head + head_base + row, (int)entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (e.lane == 0) {
+    old_head = __hip_atomic_exchange(e.head + head_base + row, (int)entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    e.next[entry - e.max_entries] = (int)(head_base + row);  // entry -> list head, for the data-parallel exchange
+  }
 }
 
 // bag mode: one contribution (already divided by the bag length: EmbeddingBag mean backward) shared by every

@@ -57,8 +57,8 @@ struct Bag {
 
 struct Layout {  // byte offsets inside the bound workspace
   size_t idx_cap, tloss_off, scratch_off, scratch_cap;  // [staged indices x2 | tile losses | pair scratch]
-  size_t seg_off, formula_off, head_off, next_off, contrib_off, linkc_off, counter_off, total;
-  int64_t max_entries, max_links;
+  size_t seg_off, formula_off, head_off, rows_off, next_off, contrib_off, linkc_off, counter_off, total;
+  int64_t max_entries, max_links;  // max_entries = per-rank capacity x world (the exchange gathers every rank's entries)
 };
 
 }  // namespace
@@ -77,6 +77,9 @@ struct gqe_ctx {
   bool links_used = false;  // link nodes were allocated since the last consumption
   int64_t total_rows = 0;
   int64_t entries_used = 0;
+  int rank = 0, world = 1;     // gqe_set_exchange: data-parallel replica id / count
+  int64_t step_entries = 0;    // world > 1: slab size (entries per rank) of the pending margin call
+  int64_t slab_hint = 0;       // gqe_exchange_reserve: slab size for the next margin call (0 = its own entry count)
   bool dense_dirty = false;  // the dense gradient of some table may be non-zero (after materialize)
   RingSlot ring[kRing];
   int ring_next = 0;
@@ -176,8 +179,11 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
   L.seg_off = L.scratch_off + L.scratch_cap;
   L.formula_off = L.seg_off + align_up(sizeof(GqeDevSeg) * GQE_MAX_SEGS, 256);
   L.head_off = L.formula_off + align_up(sizeof(GqeDevFormula) * GQE_MAX_FORMULAS, 256);
-  L.max_entries = rows * kRolesPerQuery;
-  L.next_off = L.head_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
+  L.max_entries = (int64_t)align_up((size_t)(rows * kRolesPerQuery), 64) * ctx->world;
+  // entry -> list head it was pushed on (-1: not pushed); sits exactly max_entries ints below next[], so the
+  // kernels address it as next[entry - max_entries]
+  L.rows_off = L.head_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
+  L.next_off = L.rows_off + sizeof(int32_t) * (size_t)L.max_entries;
   int32_t max_len = 0;  // bag modes: every (entry, word) pair needs a link node
   for (const Bag& bg : ctx->bags) max_len = std::max(max_len, bg.max_len);
   L.max_links = L.max_entries * max_len;
@@ -417,6 +423,14 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   }
   const size_t idx_bytes = idx_on_device ? 0 : (size_t)n_idx * sizeof(int32_t);
   if (idx_bytes > L.idx_cap) return fail(ctx, GQE_ERR_WORKSPACE, "index feed of %lld entries exceeds the bound workspace (%lld queries)", (long long)n_idx, (long long)ctx->cap_queries);
+  if (bwd && ctx->world > 1) {
+    if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "exchange mode: one gqe_margin_fwd_bwd per optimiser step (gradients of the previous call are still pending)");
+    if (!ctx->bags.empty()) return fail(ctx, GQE_ERR_STATE, "exchange mode is not available with bag modes: use gqe_materialize_grads + a dense all-reduce");
+    const int64_t slab = ctx->slab_hint ? ctx->slab_hint : entries;
+    if (entries > slab) return fail(ctx, GQE_ERR_ARG, "this call produces %lld gradient entries, more than the reserved slab of %lld", (long long)entries, (long long)slab);
+    if (slab * ctx->world > L.max_entries)
+      return fail(ctx, GQE_ERR_WORKSPACE, "gradient contribution buffer too small for %d ranks x %lld entries", ctx->world, (long long)slab);
+  }
   if (bwd && ctx->entries_used + entries > L.max_entries)
     return fail(ctx, GQE_ERR_WORKSPACE, "gradient contribution buffer full (%lld + %lld > %lld entries): step or "
                 "gqe_materialize_grads first", (long long)ctx->entries_used, (long long)entries, (long long)L.max_entries);
@@ -491,6 +505,13 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
 
   // ---- launches of <= GQE_LAUNCH_BATCHES batches; per-call data travels as kernel arguments ----
   int64_t entry = ctx->entries_used;
+  if (bwd && ctx->world > 1) {
+    // this rank's slab of the gathered entry space; entries that are not pushed (inactive hinge) must read -1
+    const int64_t slab = ctx->slab_hint ? ctx->slab_hint : entries;
+    entry = (int64_t)ctx->rank * slab;
+    ctx->step_entries = slab;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.rows_off + sizeof(int32_t) * (size_t)entry, 0xff, sizeof(int32_t) * (size_t)slab, st));
+  }
   for (int b0 = 0; b0 < n_batches; b0 += GQE_LAUNCH_BATCHES) {
     const int nb = std::min(GQE_LAUNCH_BATCHES, n_batches - b0);
     GqeDynPlan& P = fa.plan;
@@ -555,7 +576,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     }
   }
   if (bwd) {
-    ctx->entries_used = entry;
+    ctx->entries_used = ctx->world > 1 ? ctx->step_entries * ctx->world : entry;
     for (int t : touched_tables) ctx->tables[t].pending = true;
   }
   if (buf >= 0) {
@@ -678,6 +699,7 @@ int run_opt(gqe_ctx* ctx, int mode, const gqe_segment* segs, int32_t n_segs, flo
   }
   oa.mode = mode;
   oa.lists = lists;
+  oa.sorted = ctx->world > 1;  // replicas must sum a row's contributions in the same order
   oa.dense_tables = ctx->dense_dirty || mode == GQE_OPT_ZERO;
   oa.segs = reinterpret_cast<const GqeDevSeg*>(ctx->ws + ctx->lay.seg_off);
   oa.n_segs = (int)ctx->universe.size();
@@ -855,10 +877,48 @@ int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* strea
   ctx->universe_uploaded = 0;
   ctx->formulas_uploaded = 0;
   // empty gradient lists: head[row] = -1; link-node allocator at 0
-  HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.head_off, 0xff, L.next_off - L.head_off, reinterpret_cast<hipStream_t>(stream)));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.head_off, 0xff, L.rows_off - L.head_off, reinterpret_cast<hipStream_t>(stream)));
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.counter_off, 0, sizeof(int32_t), reinterpret_cast<hipStream_t>(stream)));
   ctx->links_used = false;
   for (auto& t : ctx->tables) t.pending = false;
+  return GQE_OK;
+}
+
+int gqe_set_exchange(gqe_ctx* ctx, int32_t rank, int32_t world) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (world < 1 || world > 1024 || rank < 0 || rank >= world) return fail(ctx, GQE_ERR_ARG, "need 0 <= rank < world <= 1024, got rank %d world %d", rank, world);
+  if (ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_set_exchange must precede gqe_workspace_bytes / gqe_bind_workspace");
+  ctx->rank = rank;
+  ctx->world = world;
+  return GQE_OK;
+}
+
+int gqe_exchange_reserve(gqe_ctx* ctx, int64_t slab_entries) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (slab_entries < 0) return fail(ctx, GQE_ERR_ARG, "slab_entries must be >= 0");
+  ctx->slab_hint = slab_entries;
+  return GQE_OK;
+}
+
+int gqe_exchange_info(gqe_ctx* ctx, int64_t* n_entries, int64_t* contrib_offset, int64_t* rows_offset) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
+  if (n_entries) *n_entries = ctx->world > 1 ? ctx->step_entries : ctx->entries_used;
+  if (contrib_offset) *contrib_offset = (int64_t)ctx->lay.contrib_off;
+  if (rows_offset) *rows_offset = (int64_t)ctx->lay.rows_off;
+  return GQE_OK;
+}
+
+int gqe_import_entries(gqe_ctx* ctx, int64_t n_entries, void* stream) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
+  if (ctx->world < 2) return fail(ctx, GQE_ERR_STATE, "gqe_set_exchange(world > 1) has not been called");
+  if (n_entries != ctx->step_entries || ctx->entries_used == 0)
+    return fail(ctx, GQE_ERR_ARG, "import of %lld entries per rank, but the pending margin call produced %lld", (long long)n_entries, (long long)ctx->step_entries);
+  const Layout& L = ctx->lay;
+  HIP_TRY(ctx, gqe_launch_import(reinterpret_cast<int32_t*>(ctx->ws + L.head_off), reinterpret_cast<int32_t*>(ctx->ws + L.next_off),
+                                 (int32_t)L.max_entries, (int32_t)n_entries, ctx->rank, ctx->world, reinterpret_cast<hipStream_t>(stream)));
+  ctx->step_entries = 0;  // imported: a second import of the same step is refused
   return GQE_OK;
 }
 

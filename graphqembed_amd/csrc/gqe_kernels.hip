@@ -157,7 +157,7 @@ __device__ __forceinline__ void opt_update(float4& pp, float4& mm, float4& vv, c
   }
 }
 
-template <int MODE, bool LISTS, bool DENSE_T>
+template <int MODE, bool LISTS, bool DENSE_T, bool SORTED>
 __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* __restrict__ segs, int n_segs,
                                                              long long total_chunks, float* __restrict__ p,
                                                              float* __restrict__ g, float* __restrict__ m,
@@ -203,9 +203,11 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
       }
       bool had = false;
       if (LISTS) {
-        int h = head[sg.head_base + row];
+        const int h0 = head[sg.head_base + row];
+        int h = h0;
         had = h >= 0;
         float4 acc = zero4;
+        int len = 0;
         while (h >= 0) {
           const int ce = (h < max_entries) ? h : link_contrib[h - max_entries];  // bag link node -> its contribution
           const float4 c = *reinterpret_cast<const float4*>(contrib + (size_t)ce * d + c4);
@@ -214,6 +216,25 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
           acc.z += c.z;
           acc.w += c.w;
           h = next[h];
+          ++len;
+        }
+        if (SORTED && len > 2) {
+          // list order = arrival order of the atomic exchanges, which differs between replicas; a + b commutes,
+          // longer lists are re-summed in ascending node id (selection walk: lists this long are rare)
+          acc = zero4;
+          int prev = -1;
+          for (int k = 0; k < len; ++k) {
+            int best = 0x7fffffff;
+            for (int x = h0; x >= 0; x = next[x])
+              if (x > prev && x < best) best = x;
+            const int ce = (best < max_entries) ? best : link_contrib[best - max_entries];
+            const float4 c = *reinterpret_cast<const float4*>(contrib + (size_t)ce * d + c4);
+            acc.x += c.x;
+            acc.y += c.y;
+            acc.z += c.z;
+            acc.w += c.w;
+            prev = best;
+          }
         }
         if (had && c4 == 0) head[sg.head_base + row] = -1;
         if (MODE == GQE_OPT_ZERO) continue;
@@ -318,16 +339,44 @@ hipError_t gqe_launch_pair_gemm(const GqeFusedArgs& a, float* losses) {
 
 template <int MODE>
 static void launch_opt_mode(const GqeOptArgs& a, unsigned blocks) {
-#define GO(L, D)                                                                                                          \
-  hipLaunchKernelGGL((gqe_opt_kernel<MODE, L, D>), dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.n_segs,          \
+#define GO(L, D, S)                                                                                                       \
+  hipLaunchKernelGGL((gqe_opt_kernel<MODE, L, D, S>), dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.n_segs,       \
                      a.total_chunks, a.p, a.g, a.m, a.v, a.head, a.next, a.contrib, a.link_contrib, a.max_entries, a.d, a.lr, a.b1,  \
                      a.b2, a.eps, a.coef, a.active)
   if (a.lists) {
-    if (a.dense_tables) GO(true, true); else GO(true, false);
+    if (a.sorted) {
+      if (a.dense_tables) GO(true, true, true); else GO(true, false, true);
+    } else {
+      if (a.dense_tables) GO(true, true, false); else GO(true, false, false);
+    }
   } else {
-    if (a.dense_tables) GO(false, true); else GO(false, false);
+    if (a.dense_tables) GO(false, true, false); else GO(false, false, false);
   }
 #undef GO
+}
+
+// data-parallel exchange: after the all-gather, rank r holds every rank's contribution vectors and entry -> list
+// head map (slab k = entries [k*n, (k+1)*n)); its own slab is already linked, the others are pushed here.
+__global__ __launch_bounds__(GQE_THREADS) void gqe_import_kernel(int32_t* __restrict__ head, int32_t* __restrict__ next,
+                                                                int32_t max_entries, int32_t n, int rank, int world) {
+  const long long t = (long long)blockIdx.x * GQE_THREADS + threadIdx.x;
+  if (t >= (long long)n * (world - 1)) return;
+  int slab = (int)(t / n);
+  const int i = (int)(t - (long long)slab * n);
+  if (slab >= rank) ++slab;
+  const int e = slab * n + i;
+  const int h = next[(long long)e - max_entries];  // entry -> list head (-1: the producer did not push it)
+  if (h < 0) return;
+  next[e] = __hip_atomic_exchange(head + h, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+hipError_t gqe_launch_import(int32_t* head, int32_t* next, int32_t max_entries, int32_t n, int rank, int world,
+                             hipStream_t stream) {
+  const long long total = (long long)n * (world - 1);
+  if (total < 1) return hipSuccess;
+  hipLaunchKernelGGL(gqe_import_kernel, dim3((unsigned)((total + GQE_THREADS - 1) / GQE_THREADS)), dim3(GQE_THREADS), 0, stream,
+                     head, next, max_entries, n, rank, world);
+  return hipGetLastError();
 }
 
 hipError_t gqe_launch_opt(const GqeOptArgs& a) {

@@ -71,6 +71,10 @@ SYMBOLS = OrderedDict([
     ("gqe_workspace_bytes", (C.c_int64, [_P, C.c_int64, C.c_int32])),
     ("gqe_bind_workspace", (C.c_int, [_P, _P, C.c_int64, _P])),
     ("gqe_materialize_grads", (C.c_int, [_P, _P])),
+    ("gqe_set_exchange", (C.c_int, [_P, C.c_int32, C.c_int32])),
+    ("gqe_exchange_reserve", (C.c_int, [_P, C.c_int64])),
+    ("gqe_exchange_info", (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)])),
+    ("gqe_import_entries", (C.c_int, [_P, C.c_int64, _P])),
     ("gqe_forward", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P])),
     ("gqe_margin_fwd_bwd", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P, _P, _P])),
     ("gqe_adam_step", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P])),
@@ -148,9 +152,12 @@ class ArenaLayout(object):
 class Engine(object):
     """One gqe_ctx + the tensors it borrows."""
 
-    def __init__(self, dim, decoder, inter_decoder, layout, device=None, max_queries=8192, max_batches=16, bags=None):
+    def __init__(self, dim, decoder, inter_decoder, layout, device=None, max_queries=8192, max_batches=16, bags=None,
+                 rank=0, world=1):
         """``bags``: {table key: (ptr int32[n+1], ids int32[nnz])} for modes whose feature is an
-        nn.EmbeddingBag (mean over table rows) — an index into such a mode is a bag index."""
+        nn.EmbeddingBag (mean over table rows) — an index into such a mode is a bag index.
+        ``world`` > 1 (and no bags): size the gradient-entry space for the data-parallel exchange
+        (include/gqe.h, gqe_set_exchange) and make the optimiser sum lists in a replica-independent order."""
         import torch
         if not torch.cuda.is_available():
             raise GqeLibraryError("no HIP device visible to torch; the query path only runs on an MI355X "
@@ -187,6 +194,10 @@ class Engine(object):
             self._bags[key] = (dp, di)      # keep the borrowed device buffers alive
             self._check(self.lib.gqe_set_bag(self.ctx, layout.offset(key), dp.data_ptr(), di.data_ptr(), len(ptr) - 1,
                                              int(np.diff(ptr).max())))
+        self.rank, self.world = int(rank), int(world)
+        self.sparse_exchange = self.world > 1 and not self._bags
+        if self.sparse_exchange:
+            self._check(self.lib.gqe_set_exchange(self.ctx, self.rank, self.world))
         self.workspace = None
         self.max_queries = self.max_batches = 0
         self.reserve(max_queries, max_batches)
@@ -214,6 +225,25 @@ class Engine(object):
         self.workspace = self.torch.empty(int(nbytes) + 256, dtype=self.torch.uint8, device=self.device)
         ptr = _align(self.workspace.data_ptr(), 256)
         self._check(self.lib.gqe_bind_workspace(self.ctx, ptr, int(nbytes), self._stream()))
+
+    # -- data-parallel exchange (gqe_set_exchange) ---------------------------------------------
+    def exchange_reserve(self, slab_entries):
+        """Entries per rank slab for the following margin calls (0: each call's own count, equal on all ranks)."""
+        self._check(self.lib.gqe_exchange_reserve(self.ctx, int(slab_entries)))
+
+    def exchange_buffers(self):
+        """(n, contrib float32[world*n, dim], rows int32[world*n]) — views of the workspace holding every
+        rank's slab of the pending margin call; this rank's slab is [rank*n, (rank+1)*n)."""
+        n, c_off, r_off = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.lib.gqe_exchange_info(self.ctx, C.byref(n), C.byref(c_off), C.byref(r_off)))
+        n = int(n.value)
+        base = _align(self.workspace.data_ptr(), 256) - self.workspace.data_ptr()
+        cb = self.workspace[base + c_off.value: base + c_off.value + 4 * self.world * n * self.dim]
+        rb = self.workspace[base + r_off.value: base + r_off.value + 4 * self.world * n]
+        return n, cb.view(self.torch.float32).view(self.world * n, self.dim), rb.view(self.torch.int32)
+
+    def import_entries(self, n):
+        self._check(self.lib.gqe_import_entries(self.ctx, int(n), self._stream()))
 
     def close(self):
         if getattr(self, "ctx", None):

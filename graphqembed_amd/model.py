@@ -53,7 +53,7 @@ class _MarginLossFn(torch.autograd.Function):
 class QueryEncoderDecoder(nn.Module):
     """Encoder-decoder that scores conjunctive queries (edges, metapaths, intersections)."""
 
-    def __init__(self, graph, enc, path_dec, inter_dec, device=None, max_queries=8192, max_batches=16):
+    def __init__(self, graph, enc, path_dec, inter_dec, device=None, max_queries=8192, max_batches=16, rank=0, world=1):
         super(QueryEncoderDecoder, self).__init__()
         self.enc = enc
         self.path_dec = path_dec
@@ -70,7 +70,8 @@ class QueryEncoderDecoder(nn.Module):
         self.layout = layout
         bags = {"enc.feat-%s.weight" % m: csr for m, csr in getattr(enc, "bag_csr", {}).items()}
         self.engine = Engine(self.dim, path_dec.kind, inter_dec.kind, layout, device=device,
-                             max_queries=max_queries, max_batches=max_batches, bags=bags)
+                             max_queries=max_queries, max_batches=max_batches, bags=bags,
+                             rank=rank, world=world)
         # re-home every parameter into the arena (state_dict keys and values unchanged)
         for name, p in self.named_parameters():
             view = layout.view(self.engine.params, name)

@@ -8,8 +8,17 @@ applies the identical fused Adam step.  The reference has no counterpart (single
 the definition of correctness is: W ranks x batch b == 1 rank x batch W*b on the
 concatenated queries (tests/test_parallel_gloo.py, 2 gloo ranks on CPU).
 
-The collective is ``torch.distributed.all_reduce`` — backend "nccl" is RCCL over xGMI on
-ROCm, "gloo" in the CPU tests.
+Two exchange forms (both leave bit-identical replicas):
+  dense  : fold the per-row gradient lists into the dense arena, all-reduce all P floats
+           (what the north star names; the only form for bag modes).
+  sparse : all-gather the contribution entries the fused kernel wrote (d floats + a row id per
+           (query, role): ~A_q bytes per query instead of 4 P per step), link the other ranks'
+           entries into the local lists (gqe_import_entries) and all-reduce only the small dense
+           relation / Pre / Post gradients.  At the Bio d=128 full mix this moves 9.4 MB per rank
+           instead of 50 MB through the xGMI links.
+
+The collectives are ``torch.distributed`` ones — backend "nccl" is RCCL over xGMI on ROCm,
+"gloo" in the CPU tests.
 """
 from __future__ import annotations
 
@@ -53,6 +62,37 @@ def rank_slice(n_queries, batch_size, step, rank, world):
 def dp_weight(loss_weight, world):
     """Per-rank loss weight: the W per-rank mean losses average to the global mean."""
     return loss_weight / float(world)
+
+
+def dense_spans(layout, is_table):
+    """Contiguous [begin, end) float spans of the arena covering the tensors that are NOT embedding tables."""
+    spans = []
+    for key, (off, shape) in layout.entries.items():
+        if is_table(key, shape):
+            continue
+        n = 1
+        for x in shape:
+            n *= int(x)
+        end = off + (n + layout.ALIGN - 1) // layout.ALIGN * layout.ALIGN
+        if spans and spans[-1][1] == off:
+            spans[-1][1] = end
+        else:
+            spans.append([off, end])
+    return [tuple(x) for x in spans]
+
+
+def exchange_sparse(engine, dist, spans):
+    """Sparse form (module docstring).  ``spans``: dense_spans() of the layout.  Call between the margin
+    launch and the optimiser step; every rank must have produced the same number of entries per slab
+    (same formulas and batch sizes, or Engine.exchange_reserve)."""
+    n, contrib, rows = engine.exchange_buffers()
+    r = engine.rank
+    if n > 0:
+        dist.all_gather_into_tensor(contrib, contrib[r * n:(r + 1) * n])
+        dist.all_gather_into_tensor(rows, rows[r * n:(r + 1) * n])
+        engine.import_entries(n)
+    for b, e in spans:
+        dist.all_reduce(engine.grads[b:e])
 
 
 def exchange_gradients(flat_grads, dist, engine=None):

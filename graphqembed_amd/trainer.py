@@ -14,6 +14,7 @@ import time
 
 import numpy as np
 
+from . import parallel
 from .tensorize import pack_margin_batches
 
 
@@ -42,10 +43,15 @@ class PoolView(object):
 
 class TensorizedTrainer(object):
     def __init__(self, model_or_engine, optimizer, pools_by_type, all_rows_by_mode, batch_size=512, inter_weight=0.005,
-                 path_weight=0.01, seed=0, plan_of=None):
+                 path_weight=0.01, seed=0, plan_of=None, dist=None, rank=0, world=1, engine=None):
         """pools_by_type: {query_type: [pool, ...]} (one pool per formula); all_rows_by_mode: {mode: int32 rows}
         to draw 1-chain negatives from.  ``model_or_engine``: a QueryEncoderDecoder (``margin_step``) — or any
-        object with the same ``margin_step(items)`` method."""
+        object with the same ``margin_step(items)`` method.
+
+        Data parallel: pass ``dist`` (torch.distributed), ``rank``, ``world`` and build the model /
+        Engine with the same rank and world.  Every rank draws the same formula per batch, trains on slice
+        ``it*world + rank`` of it with loss weight n_rank / n_all_ranks, and the gradients are exchanged between the
+        margin launch and the optimiser step (parallel.exchange_sparse, or the dense all-reduce for bag modes)."""
         self.model = model_or_engine
         self.opt = optimizer
         self.types = list(pools_by_type.keys())
@@ -56,7 +62,14 @@ class TensorizedTrainer(object):
         self.all_rows = all_rows_by_mode
         self.B = batch_size
         self.inter_weight, self.path_weight = inter_weight, path_weight
-        self.rng = np.random.RandomState(seed)
+        self.rng = np.random.RandomState(seed)                 # formula draws: the same stream on every rank
+        self.neg_rng = self.rng if world == 1 else np.random.RandomState([seed, 1 + rank])
+        self.dist, self.rank, self.world = dist, int(rank), int(world)
+        self.engine = engine if engine is not None else getattr(model_or_engine, "engine", None)
+        if self.world > 1 and (self.dist is None or self.engine is None):
+            raise Exception("data-parallel training needs dist= and an Engine (model.engine or engine=)")
+        self._spans = None
+        self._slab = 0
         self.ema_loss = None
         self.iterations = 0
         self.queries_seen = 0
@@ -66,11 +79,12 @@ class TensorizedTrainer(object):
         plist = self.pools[qtype]
         p = plist[int(self.rng.choice(len(plist), p=self.probs[qtype]))] if len(plist) > 1 else plist[0]
         n, B = p.n, self.B
-        start = (it * B) % n
-        end = min(((it + 1) * B) % n, n)
-        end = n if end <= start else end
+        start, end = parallel.rank_slice(n, B, it, self.rank, self.world)
+        if self.world > 1:   # mean over the global batch = sum_r (n_r / n_all) * mean_r
+            n_all = sum(e - s for s, e in (parallel.rank_slice(n, B, it, r, self.world) for r in range(self.world)))
+            weight = weight * (end - start) / float(n_all)
         all_rows = self.all_rows[p.formula.target_mode] if qtype == "1-chain" else None
-        neg = p.negatives(start, end, hard, self.rng, all_rows)
+        neg = p.negatives(start, end, hard, self.neg_rng, all_rows)
         return (p.formula, p.target[start:end], neg, p.anchors[:, start:end], weight, 1.0)
 
     def items(self, it, edge_conv=True):
@@ -89,7 +103,19 @@ class TensorizedTrainer(object):
     def step(self, it, edge_conv=True):
         """One iteration: sample on the host, one grouped fused launch, one fused optimiser pass."""
         items = self.items(it, edge_conv)
+        if self.world > 1 and self.engine.sparse_exchange:
+            slab = sum((2 + x[3].shape[0]) * self.B for x in items)     # the most entries any rank can produce
+            if slab != self._slab:
+                self.engine.exchange_reserve(slab)
+                self._slab = slab
         losses, _, _ = self.model.margin_step(items)
+        if self.world > 1:
+            if self.engine.sparse_exchange:
+                if self._spans is None:
+                    self._spans = parallel.dense_spans(self.engine.layout, lambda k, shape: k.startswith("enc."))
+                parallel.exchange_sparse(self.engine, self.dist, self._spans)
+            else:
+                parallel.exchange_gradients(self.engine.grads, self.dist, engine=self.engine)
         self.opt.step()
         self.iterations += 1
         self.queries_seen += sum(len(x[1]) for x in items)
