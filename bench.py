@@ -168,7 +168,6 @@ def main():
     sparse = world > 1 and args.exchange == "sparse"
     eng = Engine(d, args.decoder, args.inter_decoder, layout, max_queries=qpi, max_batches=len(mix),
                  rank=rank if sparse else 0, world=world if sparse else 1)
-    spans = parallel.dense_spans(layout, lambda k, shape: k.startswith("enc."))
     init_params(eng, d, seed=0)                                    # same seed on every rank: replicas start equal
     pools = synth.make_pools(g, sorted(set(m[0] for m in mix)), formulas_per_type=6, pool_size=max(16 * B, 8192), seed=0)
 
@@ -198,7 +197,7 @@ def main():
         eng.run_margin(ps)
         if mode["sparse"]:                                         # contribution entries all-gathered over xGMI
             try:
-                parallel.exchange_sparse(eng, dist, spans)
+                parallel.exchange_sparse(eng, dist)
             except Exception as e:                                 # argument-level refusal by the backend: same on all ranks
                 if i != 0:
                     raise
@@ -256,8 +255,8 @@ def main():
                    "graph": "5 modes, 97000 nodes, 14 directed relations, 60000 edges/kind, seed 0",
                    "queries_per_step_per_gpu": qpi, "parallelism": "dp%d" % world,
                    "gradient_exchange": "none" if world == 1 else
-                   ("all-gather of the contribution entries (%d x (%d floats + row id) per rank per step) + all-reduce of the "
-                    "%d dense relation/Pre/Post floats" % (prepared[0]["n_entries"], d, sum(e - b for b, e in spans))) if mode["sparse"] else
+                   ("one all-gather per step of per-rank slabs: %d contribution entries x (%d floats + row id) + the dense "
+                    "relation/Pre/Post gradients" % (prepared[0]["n_entries"], d)) if mode["sparse"] else
                    "all-reduce of the %d-float gradient arena" % layout.total},
         "roofline": {"bound": "hbm", "kernel": "gqe_opt_kernel<ADAM> (fused Adam + grad re-zero)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

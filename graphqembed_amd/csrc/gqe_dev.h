@@ -151,6 +151,14 @@ struct GqeFusedArgs {
 hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a);
 hipError_t gqe_launch_pair_gemm(const GqeFusedArgs& a, float* losses);
 hipError_t gqe_launch_opt(const GqeOptArgs& a);
-hipError_t gqe_launch_import(int32_t* head, int32_t* next, int32_t max_entries, int32_t n, int rank, int world, hipStream_t stream);
+// non-table floats of the arena (dense gradients that travel with the exchanged slab)
+struct GqeSpans {
+  int n;  // < 0: more than 8 spans (unsupported)
+  long long off[8], len[8], total;
+};
+hipError_t gqe_launch_export(float* contrib, const int32_t* rows, const float* grads, int d, long long slab_base, int32_t n,
+                             const GqeSpans& sp, hipStream_t stream);
+hipError_t gqe_launch_import(int32_t* head, int32_t* next, const float* contrib, float* grads, int d, long long slab, int32_t n,
+                             int rank, int world, const GqeSpans& sp, hipStream_t stream);
 
 #endif

@@ -78,7 +78,9 @@ struct gqe_ctx {
   int64_t total_rows = 0;
   int64_t entries_used = 0;
   int rank = 0, world = 1;     // gqe_set_exchange: data-parallel replica id / count
-  int64_t step_entries = 0;    // world > 1: slab size (entries per rank) of the pending margin call
+  int64_t step_entries = 0;    // world > 1: contribution entries per rank slab of the pending margin call (n)
+  int64_t step_slab = 0;       // ... and the slab size in entries: n + row-id tail + dense-gradient tail (S)
+  bool step_exported = false;
   int64_t slab_hint = 0;       // gqe_exchange_reserve: slab size for the next margin call (0 = its own entry count)
   bool dense_dirty = false;  // the dense gradient of some table may be non-zero (after materialize)
   RingSlot ring[kRing];
@@ -169,6 +171,38 @@ int anchors_of(int qtype) {
   }
 }
 
+// the arena floats that are NOT embedding tables (relation vectors / matrices, Pre / Post), as <= 8 spans
+GqeSpans dense_spans(const gqe_ctx* ctx) {
+  GqeSpans sp;
+  memset(&sp, 0, sizeof sp);
+  std::vector<std::pair<int64_t, int64_t>> t;
+  for (const Table& tb : ctx->tables) t.emplace_back(tb.offset, tb.rows * (int64_t)ctx->cfg.dim);
+  std::sort(t.begin(), t.end());
+  int64_t at = 0;
+  auto add = [&](int64_t b, int64_t e) {
+    if (e <= b) return;
+    if (sp.n == 8) { sp.n = -1; return; }
+    sp.off[sp.n] = b;
+    sp.len[sp.n] = e - b;
+    sp.total += e - b;
+    ++sp.n;
+  };
+  for (auto& x : t) {
+    if (sp.n < 0) break;
+    add(at, x.first);
+    at = std::max(at, x.first + x.second);
+  }
+  if (sp.n >= 0) add(at, ctx->n_arena);
+  return sp;
+}
+
+// slab of one rank in the exchanged entry space, in entries of dim floats: n contributions, the row ids of those
+// entries (int32, packed), the dense gradient spans
+int64_t slab_entries(const gqe_ctx* ctx, int64_t n, int64_t dense_floats) {
+  const int64_t d = ctx->cfg.dim;
+  return n + (n + d - 1) / d + (dense_floats + d - 1) / d;
+}
+
 Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches) {
   Layout L;
   const int64_t rows = max_queries + (int64_t)GQE_TQ * max_batches;  // queries incl. tile padding
@@ -179,7 +213,11 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
   L.seg_off = L.scratch_off + L.scratch_cap;
   L.formula_off = L.seg_off + align_up(sizeof(GqeDevSeg) * GQE_MAX_SEGS, 256);
   L.head_off = L.formula_off + align_up(sizeof(GqeDevFormula) * GQE_MAX_FORMULAS, 256);
-  L.max_entries = (int64_t)align_up((size_t)(rows * kRolesPerQuery), 64) * ctx->world;
+  L.max_entries = (int64_t)align_up((size_t)(rows * kRolesPerQuery), 64);
+  if (ctx->world > 1) {
+    const GqeSpans sp = dense_spans(ctx);
+    L.max_entries = (int64_t)align_up((size_t)slab_entries(ctx, L.max_entries, sp.n < 0 ? 0 : sp.total), 64) * ctx->world;
+  }
   // entry -> list head it was pushed on (-1: not pushed); sits exactly max_entries ints below next[], so the
   // kernels address it as next[entry - max_entries]
   L.rows_off = L.head_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
@@ -428,7 +466,9 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     if (!ctx->bags.empty()) return fail(ctx, GQE_ERR_STATE, "exchange mode is not available with bag modes: use gqe_materialize_grads + a dense all-reduce");
     const int64_t slab = ctx->slab_hint ? ctx->slab_hint : entries;
     if (entries > slab) return fail(ctx, GQE_ERR_ARG, "this call produces %lld gradient entries, more than the reserved slab of %lld", (long long)entries, (long long)slab);
-    if (slab * ctx->world > L.max_entries)
+    const GqeSpans sp = dense_spans(ctx);
+    if (sp.n < 0) return fail(ctx, GQE_ERR_STATE, "exchange mode: the non-table parameters form more than 8 spans of the arena");
+    if (slab_entries(ctx, slab, sp.total) * ctx->world > L.max_entries)
       return fail(ctx, GQE_ERR_WORKSPACE, "gradient contribution buffer too small for %d ranks x %lld entries", ctx->world, (long long)slab);
   }
   if (bwd && ctx->entries_used + entries > L.max_entries)
@@ -508,8 +548,10 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   if (bwd && ctx->world > 1) {
     // this rank's slab of the gathered entry space; entries that are not pushed (inactive hinge) must read -1
     const int64_t slab = ctx->slab_hint ? ctx->slab_hint : entries;
-    entry = (int64_t)ctx->rank * slab;
     ctx->step_entries = slab;
+    ctx->step_slab = slab_entries(ctx, slab, dense_spans(ctx).total);
+    ctx->step_exported = false;
+    entry = (int64_t)ctx->rank * ctx->step_slab;
     HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.rows_off + sizeof(int32_t) * (size_t)entry, 0xff, sizeof(int32_t) * (size_t)slab, st));
   }
   for (int b0 = 0; b0 < n_batches; b0 += GQE_LAUNCH_BATCHES) {
@@ -576,7 +618,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     }
   }
   if (bwd) {
-    ctx->entries_used = ctx->world > 1 ? ctx->step_entries * ctx->world : entry;
+    ctx->entries_used = ctx->world > 1 ? ctx->step_slab * ctx->world : entry;
     for (int t : touched_tables) ctx->tables[t].pending = true;
   }
   if (buf >= 0) {
@@ -900,25 +942,37 @@ int gqe_exchange_reserve(gqe_ctx* ctx, int64_t slab_entries) {
   return GQE_OK;
 }
 
-int gqe_exchange_info(gqe_ctx* ctx, int64_t* n_entries, int64_t* contrib_offset, int64_t* rows_offset) {
-  if (!ctx) return GQE_ERR_ARG;
-  if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
-  if (n_entries) *n_entries = ctx->world > 1 ? ctx->step_entries : ctx->entries_used;
-  if (contrib_offset) *contrib_offset = (int64_t)ctx->lay.contrib_off;
-  if (rows_offset) *rows_offset = (int64_t)ctx->lay.rows_off;
-  return GQE_OK;
-}
-
-int gqe_import_entries(gqe_ctx* ctx, int64_t n_entries, void* stream) {
+int gqe_export_entries(gqe_ctx* ctx, int64_t* slab_entries_out, int64_t* contrib_offset, void* stream) {
   if (!ctx) return GQE_ERR_ARG;
   if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
   if (ctx->world < 2) return fail(ctx, GQE_ERR_STATE, "gqe_set_exchange(world > 1) has not been called");
-  if (n_entries != ctx->step_entries || ctx->entries_used == 0)
-    return fail(ctx, GQE_ERR_ARG, "import of %lld entries per rank, but the pending margin call produced %lld", (long long)n_entries, (long long)ctx->step_entries);
+  if (ctx->entries_used == 0 || ctx->step_slab == 0) return fail(ctx, GQE_ERR_STATE, "no margin call is pending");
+  const Layout& L = ctx->lay;
+  if (!ctx->step_exported) {
+    // flush the deferred work that still adds into the dense gradients, then pack the slab's tails
+    HIP_TRY(ctx, gqe_launch_export(reinterpret_cast<float*>(ctx->ws + L.contrib_off), reinterpret_cast<const int32_t*>(ctx->ws + L.rows_off),
+                                   ctx->grads, ctx->cfg.dim, (long long)ctx->rank * ctx->step_slab, (int32_t)ctx->step_entries,
+                                   dense_spans(ctx), reinterpret_cast<hipStream_t>(stream)));
+    ctx->step_exported = true;
+  }
+  if (slab_entries_out) *slab_entries_out = ctx->step_slab;
+  if (contrib_offset) *contrib_offset = (int64_t)L.contrib_off;
+  return GQE_OK;
+}
+
+int gqe_import_entries(gqe_ctx* ctx, int64_t slab, void* stream) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
+  if (ctx->world < 2) return fail(ctx, GQE_ERR_STATE, "gqe_set_exchange(world > 1) has not been called");
+  if (!ctx->step_exported || slab != ctx->step_slab || ctx->entries_used == 0)
+    return fail(ctx, GQE_ERR_ARG, "import of %lld-entry slabs, but the exported slab of the pending margin call has %lld (0: none exported)",
+                (long long)slab, (long long)(ctx->step_exported ? ctx->step_slab : 0));
   const Layout& L = ctx->lay;
   HIP_TRY(ctx, gqe_launch_import(reinterpret_cast<int32_t*>(ctx->ws + L.head_off), reinterpret_cast<int32_t*>(ctx->ws + L.next_off),
-                                 (int32_t)L.max_entries, (int32_t)n_entries, ctx->rank, ctx->world, reinterpret_cast<hipStream_t>(stream)));
-  ctx->step_entries = 0;  // imported: a second import of the same step is refused
+                                 reinterpret_cast<const float*>(ctx->ws + L.contrib_off), ctx->grads, ctx->cfg.dim, (long long)slab,
+                                 (int32_t)ctx->step_entries, ctx->rank, ctx->world, dense_spans(ctx), reinterpret_cast<hipStream_t>(stream)));
+  ctx->step_exported = false;  // imported: a second import of the same step is refused
+  ctx->step_slab = 0;
   return GQE_OK;
 }
 

@@ -355,27 +355,76 @@ static void launch_opt_mode(const GqeOptArgs& a, unsigned blocks) {
 #undef GO
 }
 
-// data-parallel exchange: after the all-gather, rank r holds every rank's contribution vectors and entry -> list
-// head map (slab k = entries [k*n, (k+1)*n)); its own slab is already linked, the others are pushed here.
-__global__ __launch_bounds__(GQE_THREADS) void gqe_import_kernel(int32_t* __restrict__ head, int32_t* __restrict__ next,
-                                                                int32_t max_entries, int32_t n, int rank, int world) {
-  const long long t = (long long)blockIdx.x * GQE_THREADS + threadIdx.x;
-  if (t >= (long long)n * (world - 1)) return;
-  int slab = (int)(t / n);
-  const int i = (int)(t - (long long)slab * n);
-  if (slab >= rank) ++slab;
-  const int e = slab * n + i;
-  const int h = next[(long long)e - max_entries];  // entry -> list head (-1: the producer did not push it)
-  if (h < 0) return;
-  next[e] = __hip_atomic_exchange(head + h, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// ------------------------------------------------------------------------------------------
+// data-parallel exchange.  Entry space = world slabs of S entries (d floats each); slab k:
+//   [0, n)            contribution vectors of rank k (written by its fused kernel)
+//   [n, n + R)        int32 list head of each contribution (-1: not pushed), R = ceil(n / d)
+//   [n + R, S)        rank k's dense gradient spans (relation vectors / matrices, Pre / Post)
+// export packs the two tails of the own slab; after ONE all-gather of the slabs, import links the other ranks'
+// contributions into the local lists and replaces the dense gradients by the sum over the slabs in rank order
+// (the same order on every replica).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long span_address(const GqeSpans& sp, long long j) {
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+    if (k == i && i + 1 < sp.n && j >= sp.len[i]) {
+      j -= sp.len[i];
+      ++k;
+    }
+  return sp.off[k] + j;
 }
 
-hipError_t gqe_launch_import(int32_t* head, int32_t* next, int32_t max_entries, int32_t n, int rank, int world,
-                             hipStream_t stream) {
-  const long long total = (long long)n * (world - 1);
+__global__ __launch_bounds__(GQE_THREADS) void gqe_export_kernel(float* __restrict__ contrib, const int32_t* __restrict__ rows,
+                                                                const float* __restrict__ grads, int d, long long slab_base,
+                                                                int32_t n, const GqeSpans sp) {
+  const long long t = (long long)blockIdx.x * GQE_THREADS + threadIdx.x;
+  const long long R = (n + d - 1) / d;
+  if (t < n) {
+    reinterpret_cast<int32_t*>(contrib + (slab_base + n) * d)[t] = rows[slab_base + t];
+  } else if (t - n < sp.total) {
+    const long long j = t - n;
+    contrib[(slab_base + n + R) * d + j] = grads[span_address(sp, j)];
+  }
+}
+
+__global__ __launch_bounds__(GQE_THREADS) void gqe_import_kernel(int32_t* __restrict__ head, int32_t* __restrict__ next,
+                                                                const float* __restrict__ contrib, float* __restrict__ grads, int d,
+                                                                long long slab, int32_t n, int rank, int world, const GqeSpans sp) {
+  const long long t = (long long)blockIdx.x * GQE_THREADS + threadIdx.x;
+  const long long links = (long long)n * (world - 1);
+  const long long R = (n + d - 1) / d;
+  if (t < links) {
+    int k = (int)(t / n);
+    const int i = (int)(t - (long long)k * n);
+    if (k >= rank) ++k;
+    const int h = reinterpret_cast<const int32_t*>(contrib + (k * slab + n) * d)[i];
+    if (h < 0) return;
+    const int e = (int)(k * slab + i);
+    next[e] = __hip_atomic_exchange(head + h, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (t - links < sp.total) {
+    const long long j = t - links;
+    float sum = 0.f;
+    for (int k = 0; k < world; ++k) sum += contrib[(k * slab + n + R) * d + j];
+    grads[span_address(sp, j)] = sum;
+  }
+}
+
+hipError_t gqe_launch_export(float* contrib, const int32_t* rows, const float* grads, int d, long long slab_base, int32_t n,
+                             const GqeSpans& sp, hipStream_t stream) {
+  const long long total = (long long)n + sp.total;
+  if (total < 1) return hipSuccess;
+  hipLaunchKernelGGL(gqe_export_kernel, dim3((unsigned)((total + GQE_THREADS - 1) / GQE_THREADS)), dim3(GQE_THREADS), 0, stream,
+                     contrib, rows, grads, d, slab_base, n, sp);
+  return hipGetLastError();
+}
+
+hipError_t gqe_launch_import(int32_t* head, int32_t* next, const float* contrib, float* grads, int d, long long slab, int32_t n,
+                             int rank, int world, const GqeSpans& sp, hipStream_t stream) {
+  const long long total = (long long)n * (world - 1) + sp.total;
   if (total < 1) return hipSuccess;
   hipLaunchKernelGGL(gqe_import_kernel, dim3((unsigned)((total + GQE_THREADS - 1) / GQE_THREADS)), dim3(GQE_THREADS), 0, stream,
-                     head, next, max_entries, n, rank, world);
+                     head, next, contrib, grads, d, slab, n, rank, world, sp);
   return hipGetLastError();
 }
 

@@ -73,7 +73,7 @@ SYMBOLS = OrderedDict([
     ("gqe_materialize_grads", (C.c_int, [_P, _P])),
     ("gqe_set_exchange", (C.c_int, [_P, C.c_int32, C.c_int32])),
     ("gqe_exchange_reserve", (C.c_int, [_P, C.c_int64])),
-    ("gqe_exchange_info", (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)])),
+    ("gqe_export_entries", (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P])),
     ("gqe_import_entries", (C.c_int, [_P, C.c_int64, _P])),
     ("gqe_forward", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P])),
     ("gqe_margin_fwd_bwd", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P, _P, _P])),
@@ -228,19 +228,19 @@ class Engine(object):
 
     # -- data-parallel exchange (gqe_set_exchange) ---------------------------------------------
     def exchange_reserve(self, slab_entries):
-        """Entries per rank slab for the following margin calls (0: each call's own count, equal on all ranks)."""
+        """Contribution entries per rank slab for the following margin calls (0: each call's own count, which
+        then has to be equal on all ranks)."""
         self._check(self.lib.gqe_exchange_reserve(self.ctx, int(slab_entries)))
 
-    def exchange_buffers(self):
-        """(n, contrib float32[world*n, dim], rows int32[world*n]) — views of the workspace holding every
-        rank's slab of the pending margin call; this rank's slab is [rank*n, (rank+1)*n)."""
-        n, c_off, r_off = C.c_int64(), C.c_int64(), C.c_int64()
-        self._check(self.lib.gqe_exchange_info(self.ctx, C.byref(n), C.byref(c_off), C.byref(r_off)))
-        n = int(n.value)
+    def export_entries(self):
+        """Pack this rank's slab of the pending margin call and return (S, slabs float32[world*S, dim]) — a view of
+        the workspace's entry space; this rank's slab is rows [rank*S, (rank+1)*S) (include/gqe.h)."""
+        S, c_off = C.c_int64(), C.c_int64()
+        self._check(self.lib.gqe_export_entries(self.ctx, C.byref(S), C.byref(c_off), self._stream()))
+        S = int(S.value)
         base = _align(self.workspace.data_ptr(), 256) - self.workspace.data_ptr()
-        cb = self.workspace[base + c_off.value: base + c_off.value + 4 * self.world * n * self.dim]
-        rb = self.workspace[base + r_off.value: base + r_off.value + 4 * self.world * n]
-        return n, cb.view(self.torch.float32).view(self.world * n, self.dim), rb.view(self.torch.int32)
+        cb = self.workspace[base + c_off.value: base + c_off.value + 4 * self.world * S * self.dim]
+        return S, cb.view(self.torch.float32).view(self.world * S, self.dim)
 
     def import_entries(self, n):
         self._check(self.lib.gqe_import_entries(self.ctx, int(n), self._stream()))

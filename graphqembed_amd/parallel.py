@@ -11,11 +11,11 @@ concatenated queries (tests/test_parallel_gloo.py, 2 gloo ranks on CPU).
 Two exchange forms (both leave bit-identical replicas):
   dense  : fold the per-row gradient lists into the dense arena, all-reduce all P floats
            (what the north star names; the only form for bag modes).
-  sparse : all-gather the contribution entries the fused kernel wrote (d floats + a row id per
-           (query, role): ~A_q bytes per query instead of 4 P per step), link the other ranks'
-           entries into the local lists (gqe_import_entries) and all-reduce only the small dense
-           relation / Pre / Post gradients.  At the Bio d=128 full mix this moves 9.4 MB per rank
-           instead of 50 MB through the xGMI links.
+  sparse : ONE all-gather of per-rank slabs = the contribution entries the fused kernel wrote
+           (d floats + a row id per (query, role)) followed by the small dense relation / Pre /
+           Post gradients; the other ranks' entries are linked into the local lists and the dense
+           parts summed in rank order (gqe_import_entries).  At the Bio d=128 full mix a slab is
+           ~10 MB per rank instead of the 50 MB arena.
 
 The collectives are ``torch.distributed`` ones — backend "nccl" is RCCL over xGMI on ROCm,
 "gloo" in the CPU tests.
@@ -64,35 +64,14 @@ def dp_weight(loss_weight, world):
     return loss_weight / float(world)
 
 
-def dense_spans(layout, is_table):
-    """Contiguous [begin, end) float spans of the arena covering the tensors that are NOT embedding tables."""
-    spans = []
-    for key, (off, shape) in layout.entries.items():
-        if is_table(key, shape):
-            continue
-        n = 1
-        for x in shape:
-            n *= int(x)
-        end = off + (n + layout.ALIGN - 1) // layout.ALIGN * layout.ALIGN
-        if spans and spans[-1][1] == off:
-            spans[-1][1] = end
-        else:
-            spans.append([off, end])
-    return [tuple(x) for x in spans]
-
-
-def exchange_sparse(engine, dist, spans):
-    """Sparse form (module docstring).  ``spans``: dense_spans() of the layout.  Call between the margin
-    launch and the optimiser step; every rank must have produced the same number of entries per slab
-    (same formulas and batch sizes, or Engine.exchange_reserve)."""
-    n, contrib, rows = engine.exchange_buffers()
+def exchange_sparse(engine, dist):
+    """Sparse form (module docstring): ONE in-place all-gather of the ranks' slabs.  Call between the margin
+    launch and the optimiser step; every rank must use the same slab size (same formulas and batch sizes, or
+    Engine.exchange_reserve)."""
+    S, slabs = engine.export_entries()
     r = engine.rank
-    if n > 0:
-        dist.all_gather_into_tensor(contrib, contrib[r * n:(r + 1) * n])
-        dist.all_gather_into_tensor(rows, rows[r * n:(r + 1) * n])
-        engine.import_entries(n)
-    for b, e in spans:
-        dist.all_reduce(engine.grads[b:e])
+    dist.all_gather_into_tensor(slabs, slabs[r * S:(r + 1) * S])
+    engine.import_entries(S)
 
 
 def exchange_gradients(flat_grads, dist, engine=None):

@@ -68,7 +68,6 @@ class TensorizedTrainer(object):
         self.engine = engine if engine is not None else getattr(model_or_engine, "engine", None)
         if self.world > 1 and (self.dist is None or self.engine is None):
             raise Exception("data-parallel training needs dist= and an Engine (model.engine or engine=)")
-        self._spans = None
         self._slab = 0
         self.ema_loss = None
         self.iterations = 0
@@ -111,9 +110,7 @@ class TensorizedTrainer(object):
         losses, _, _ = self.model.margin_step(items)
         if self.world > 1:
             if self.engine.sparse_exchange:
-                if self._spans is None:
-                    self._spans = parallel.dense_spans(self.engine.layout, lambda k, shape: k.startswith("enc."))
-                parallel.exchange_sparse(self.engine, self.dist, self._spans)
+                parallel.exchange_sparse(self.engine, self.dist)
             else:
                 parallel.exchange_gradients(self.engine.grads, self.dist, engine=self.engine)
         self.opt.step()

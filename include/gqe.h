@@ -168,26 +168,27 @@ int gqe_margin_fwd_bwd(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches
 int gqe_materialize_grads(gqe_ctx* ctx, void* stream);
 
 /* ---- data-parallel gradient exchange (the reference is single-process) -------------------
- * Replicas exchange the embedding-row gradients in the form the fused kernel produces them: contribution
- * entries (d floats + the list head they belong to) instead of the dense P-float table gradients.  Rank r writes
- * its entries into slab r of the workspace's entry space; the host all-gathers the slabs (RCCL / any transport)
- * in place, gqe_import_entries links the other ranks' entries into the local per-row lists, and the optimiser
- * pass — which then sums every list in ascending entry id, so that all replicas round identically — steps as
- * usual.  Relation / Pre / Post gradients stay dense in the grads arena: all-reduce those segments.
+ * Replicas exchange the gradients in the form the fused kernel produces them — contribution entries (dim floats
+ * + the list head they belong to) — instead of the dense P-float table gradients.  The workspace's entry space is
+ * `world` slabs of S entries (dim floats each); slab k = [ n contributions of rank k | their int32 list heads |
+ * rank k's dense relation / Pre / Post gradients ].  Rank r's fused kernel writes its contributions straight into
+ * slab r; gqe_export_entries packs the two tails; the host moves the slabs with ONE in-place all-gather (RCCL or
+ * any transport); gqe_import_entries links the other ranks' entries into the local per-row lists and replaces
+ * the dense gradients by the sum over the slabs in rank order.  The optimiser pass then sums every list in
+ * ascending entry id, so all replicas round identically and stay bit-equal.
  *
  *   gqe_set_exchange(ctx, rank, world)      once, before gqe_workspace_bytes (sizes the entry space x world)
- *   [gqe_exchange_reserve(ctx, n_slab)]     slab size when ranks may produce different entry counts
+ *   [gqe_exchange_reserve(ctx, n)]          contributions per slab when ranks may produce different counts
  *   gqe_margin_fwd_bwd(...)                 exactly one per optimiser step in this mode; no bag modes
- *   gqe_exchange_info(ctx, &n, &c_off, &r_off)
- *        all-gather  float[world][n][dim] at workspace + c_off   (this rank's slab: [rank*n, (rank+1)*n))
- *        all-gather  int32[world][n]      at workspace + r_off
- *   gqe_import_entries(ctx, n, stream)
+ *   gqe_export_entries(ctx, &S, &off, st)   all-gather float[world][S][dim] at workspace + off,
+ *                                           this rank's part being [rank*S, (rank+1)*S)
+ *   gqe_import_entries(ctx, S, stream)
  *   gqe_adam_step / gqe_sgd_step
  */
 int gqe_set_exchange(gqe_ctx* ctx, int32_t rank, int32_t world);
-int gqe_exchange_reserve(gqe_ctx* ctx, int64_t slab_entries);
-int gqe_exchange_info(gqe_ctx* ctx, int64_t* n_entries, int64_t* contrib_offset, int64_t* rows_offset);
-int gqe_import_entries(gqe_ctx* ctx, int64_t n_entries, void* stream);
+int gqe_exchange_reserve(gqe_ctx* ctx, int64_t n_contributions);
+int gqe_export_entries(gqe_ctx* ctx, int64_t* slab_entries, int64_t* contrib_offset, void* stream);
+int gqe_import_entries(gqe_ctx* ctx, int64_t slab_entries, void* stream);
 
 /* replaces: optimizer.step() + optimizer.zero_grad() for torch.optim.Adam
  * (bio/train.py:62, train_helpers.py:50,79): one fused pass p,g,m,v -> p,m,v and g := 0
