@@ -437,7 +437,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
 
   // ---- validate everything and resolve the formula descriptors before anything is enqueued ----
   std::vector<int> fid(n_batches);
-  int64_t entries = 0, total_tiles = 0;
+  int64_t entries = 0;
   std::vector<int> touched_tables;
   for (int bi = 0; bi < n_batches; ++bi) {
     const gqe_batch& s = batches[bi];
@@ -453,7 +453,6 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
         : (int64_t)s.idx_offset + (int64_t)(na + (bwd ? 2 : 1)) * s.n_queries;
     if (s.idx_offset < 0 || need_idx > n_idx) return fail(ctx, GQE_ERR_ARG, "batch %d: index range [%d,%lld) exceeds the %lld indices given", bi, s.idx_offset, (long long)need_idx, (long long)n_idx);
     entries += (int64_t)(2 + na) * s.n_queries;
-    total_tiles += (s.n_queries + GQE_TQ - 1) / GQE_TQ;
     if (bwd) {
       touched_tables.push_back(table_of(ctx, s.target_table));
       for (int i = 0; i < na; ++i) touched_tables.push_back(table_of(ctx, s.anchor_table[i]));

@@ -1,0 +1,292 @@
+"""Native (C++) query sampler — drop-in for the sampling half of ``netquery.graph.Graph``.
+
+``Graph.sample_queries`` / ``sample_test_queries`` / ``get_negative_samples`` (netquery/graph.py:185-434) walk
+Python sets; ``NativeSampler`` hands the same graph to libgqe's host-side sampler (include/gqe_sampler.h: CSR
+adjacency, bitset answer sets, one RNG stream per thread) and returns either the reference's ``Query`` objects or
+int32 structure-of-arrays pools the trainer slices batches from.  Sampling stays on the host cores (north star).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .engine import QTYPES, load_library
+from .graph import Formula, Query, _reverse_relation
+
+_P = C.c_void_p
+QNAMES = {v: k for k, v in QTYPES.items()}
+ANY = -1
+
+
+class _GraphDesc(C.Structure):
+    _fields_ = [("n_modes", C.c_int32), ("mode_sizes", C.POINTER(C.c_int64)), ("n_rels", C.c_int32),
+                ("rel_src_mode", C.POINTER(C.c_int32)), ("rel_dst_mode", C.POINTER(C.c_int32)),
+                ("rel_reverse", C.POINTER(C.c_int32)), ("rel_ptr", C.POINTER(C.POINTER(C.c_int64))),
+                ("rel_idx", C.POINTER(C.POINTER(C.c_int32))), ("mode_present", C.POINTER(C.POINTER(C.c_uint8)))]
+
+
+class _QueryBatch(C.Structure):
+    _fields_ = [("n", C.c_int64), ("qtype", C.POINTER(C.c_int32)), ("edges", C.POINTER(C.c_int32)),
+                ("neg_ptr", C.POINTER(C.c_int64)), ("neg_idx", C.POINTER(C.c_int32)),
+                ("hard_ptr", C.POINTER(C.c_int64)), ("hard_idx", C.POINTER(C.c_int32)), ("attempts", C.c_int64)]
+
+
+SAMPLER_SYMBOLS = {
+    "gqe_sampler_create": (C.c_int, [C.POINTER(_GraphDesc), C.POINTER(_P)]),
+    "gqe_sampler_destroy": (C.c_int, [_P]),
+    "gqe_sampler_sample": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_uint64, C.c_int32, C.c_int64,
+                                     C.POINTER(C.POINTER(_QueryBatch))]),
+    "gqe_query_batch_free": (C.c_int, [C.POINTER(_QueryBatch)]),
+    "gqe_sampler_check": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
+    "gqe_sampler_last_error": (C.c_char_p, []),
+}
+
+
+def _lib():
+    lib = load_library()
+    if not getattr(lib, "_sampler_typed", False):
+        for name, (res, args) in SAMPLER_SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        lib._sampler_typed = True
+    return lib
+
+
+class SampledQueries(object):
+    """One ``sample`` call: ``qtype[n]``, ``edges[n,3,3]`` ((src, rel id, dst) local indices, -1 padding) and the CSR
+    negative / hard-negative lists (local indices in the target mode)."""
+
+    def __init__(self, sampler, qtype, edges, neg_ptr, neg_idx, hard_ptr, hard_idx, attempts):
+        self.sampler = sampler
+        self.qtype, self.edges = qtype, edges
+        self.neg_ptr, self.neg_idx, self.hard_ptr, self.hard_idx = neg_ptr, neg_idx, hard_ptr, hard_idx
+        self.attempts = attempts
+        self.n = len(qtype)
+
+    def query_graph(self, i):
+        """The reference's nested tuple form (graph.py:38-54) with real node ids."""
+        s = self.sampler
+        qt = QNAMES[int(self.qtype[i])]
+        e = []
+        for k in range(2 if qt.startswith("2") else 3):
+            u, r, v = (int(x) for x in self.edges[i, k])
+            rel = s.rels[r]
+            e.append((s.node_of[rel[0]][u], rel, s.node_of[rel[2]][v]))
+        if qt in ("3-inter_chain", "3-chain_inter"):
+            return (qt, e[0], (e[1], e[2]))
+        return (qt,) + tuple(e)
+
+    def to_queries(self, keep_graph=True):
+        """[Query] — the objects ``Graph.sample_queries`` returns (negatives already sub-sampled natively)."""
+        s = self.sampler
+        out = []
+        for i in range(self.n):
+            qg = self.query_graph(i)
+            ids = s.node_of[qg[1][1][0]]
+            negs = [ids[j] for j in self.neg_idx[self.neg_ptr[i]:self.neg_ptr[i + 1]]]
+            hard = None
+            if "inter" in qg[0]:
+                hard = [ids[j] for j in self.hard_idx[self.hard_ptr[i]:self.hard_ptr[i + 1]]]
+            out.append(Query(qg, negs, hard, neg_sample_max=1 << 62, keep_graph=keep_graph))
+        return out
+
+    def formulas(self):
+        """Formula of every query + the anchors' (edge, end) positions, vectorised per query type."""
+        s = self.sampler
+        out = [None] * self.n
+        for i in range(self.n):
+            qt = QNAMES[int(self.qtype[i])]
+            r = [s.rels[int(self.edges[i, k, 1])] for k in range(2 if qt.startswith("2") else 3)]
+            rels = (r[0], (r[1], r[2])) if qt in ("3-inter_chain", "3-chain_inter") else tuple(r)
+            out[i] = Formula(qt, rels)
+        return out
+
+    def pools(self):
+        """{query_type: [FormulaPool]}: the queries grouped by formula as int32 TABLE-ROW arrays (row = local
+        index + 1, the DirectEncoder convention), ready for ``trainer.TensorizedTrainer``."""
+        forms = self.formulas()
+        groups = {}
+        for i, f in enumerate(forms):
+            groups.setdefault(f, []).append(i)
+        out = {}
+        for f, rows in groups.items():
+            rows = np.asarray(rows)
+            qt = f.query_type
+            e = self.edges[rows]
+            if qt in ("2-chain", "3-chain"):
+                anchors = e[:, -1 if qt == "3-chain" else 1, 2][None, :]
+            elif qt in ("2-inter", "3-inter"):
+                anchors = np.stack([e[:, k, 2] for k in range(int(qt[0]))])
+            elif qt == "3-inter_chain":
+                anchors = np.stack([e[:, 0, 2], e[:, 2, 2]])
+            else:
+                anchors = np.stack([e[:, 1, 2], e[:, 2, 2]])
+            out.setdefault(qt, []).append(FormulaPool(f, e[:, 0, 0] + 1, anchors + 1,
+                                                     *_take_csr(self.neg_ptr, self.neg_idx, rows),
+                                                     *_take_csr(self.hard_ptr, self.hard_idx, rows)))
+        return out
+
+
+def _take_csr(ptr, idx, rows):
+    lens = ptr[rows + 1] - ptr[rows]
+    new_ptr = np.zeros(len(rows) + 1, dtype=np.int64)
+    new_ptr[1:] = np.cumsum(lens)
+    if new_ptr[-1] == 0:
+        return new_ptr, np.zeros(0, dtype=np.int32)
+    take = np.concatenate([np.arange(ptr[r], ptr[r + 1]) for r in rows])
+    return new_ptr, (idx[take] + 1).astype(np.int32)
+
+
+class FormulaPool(object):
+    """All sampled queries of one formula as table rows (+ CSR negatives); what ``trainer.PoolView`` reads."""
+
+    def __init__(self, formula, target, anchors, neg_ptr, neg_rows, hard_ptr, hard_rows):
+        self.formula = formula
+        self.n = len(target)
+        self.target = np.ascontiguousarray(target, dtype=np.int32)
+        self.anchors = np.ascontiguousarray(anchors, dtype=np.int32)
+        self.neg_ptr, self.neg_rows, self.hard_ptr, self.hard_rows = neg_ptr, neg_rows, hard_ptr, hard_rows
+
+    def sample_negatives(self, start, end, hard, rng):
+        ptr, rows = (self.hard_ptr, self.hard_rows) if hard else (self.neg_ptr, self.neg_rows)
+        lo = ptr[start:end]
+        cnt = ptr[start + 1:end + 1] - lo
+        if (cnt < 1).any():
+            raise Exception("queries of formula %s carry no %snegative samples" % (self.formula, "hard " if hard else ""))
+        return rows[lo + (rng.random_sample(end - start) * cnt).astype(np.int64)]
+
+
+class NativeSampler(object):
+    def __init__(self, graph, node_maps=None):
+        """``graph``: a ``graphqembed_amd.graph.Graph`` (``relations``, ``adj_lists``, ``full_sets``).
+        ``node_maps``: {mode: {node id: index}} (bio/data_utils.py:12) fixes the local index of every node — and
+        with it the embedding-table row (index + 1); without it the nodes of a mode are indexed in sorted order."""
+        self.lib = _lib()
+        self.modes = sorted(graph.relations.keys())
+        mode_id = {m: i for i, m in enumerate(self.modes)}
+        self.rels = []
+        for m in self.modes:
+            for to, name in graph.relations[m]:
+                if (m, name, to) not in self.rels:
+                    self.rels.append((m, name, to))
+        for rel in list(self.rels):
+            if _reverse_relation(rel) not in self.rels:
+                self.rels.append(_reverse_relation(rel))
+        rel_id = {r: i for i, r in enumerate(self.rels)}
+        nodes = {m: set(graph.full_sets.get(m, ())) for m in self.modes}
+        for rel in self.rels:
+            for u, neigh in graph.adj_lists.get(rel, {}).items():
+                nodes[rel[0]].add(u)
+                nodes[rel[2]].update(neigh)
+        if node_maps is None:
+            self.index_of = {m: {n: i for i, n in enumerate(sorted(nodes[m]))} for m in self.modes}
+        else:
+            self.index_of = {m: {n: i for n, i in node_maps[m].items() if n >= 0 and i >= 0} for m in self.modes}
+            for m in self.modes:
+                missing = [n for n in nodes[m] if n not in self.index_of[m]]
+                if missing:
+                    raise KeyError("node %r of mode %r is not in node_maps" % (missing[0], m))
+        self.sizes = [max(self.index_of[m].values()) + 1 if self.index_of[m] else 1 for m in self.modes]
+        self.node_of = {}
+        for m, size in zip(self.modes, self.sizes):
+            arr = np.full(size, -1, dtype=np.int64)
+            for n, i in self.index_of[m].items():
+                if i >= 0:
+                    arr[i] = n
+            self.node_of[m] = arr.tolist()
+        keep = []
+        ptrs, idxs = [], []
+        for rel in self.rels:
+            src, dst = self.index_of[rel[0]], self.index_of[rel[2]]
+            adj = graph.adj_lists.get(rel, {})
+            deg = np.zeros(self.sizes[mode_id[rel[0]]] + 1, dtype=np.int64)
+            for u, neigh in adj.items():
+                deg[src[u] + 1] = len(neigh)
+            ptr = np.cumsum(deg)
+            idx = np.zeros(int(ptr[-1]), dtype=np.int32)
+            for u, neigh in adj.items():
+                if neigh:
+                    p = ptr[src[u]]
+                    idx[p:p + len(neigh)] = sorted(dst[v] for v in neigh)
+            ptrs.append(np.ascontiguousarray(ptr))
+            idxs.append(idx)
+        present = []
+        for m, size in zip(self.modes, self.sizes):
+            pr = np.zeros(size, dtype=np.uint8)
+            for n in graph.full_sets.get(m, ()):
+                pr[self.index_of[m][n]] = 1
+            present.append(pr)
+        keep += ptrs + idxs + present
+        n_rels = len(self.rels)
+        sizes = (C.c_int64 * len(self.modes))(*self.sizes)
+        src_m = (C.c_int32 * n_rels)(*[mode_id[r[0]] for r in self.rels])
+        dst_m = (C.c_int32 * n_rels)(*[mode_id[r[2]] for r in self.rels])
+        rev = (C.c_int32 * n_rels)(*[rel_id[_reverse_relation(r)] for r in self.rels])
+        pp = (C.POINTER(C.c_int64) * n_rels)(*[p.ctypes.data_as(C.POINTER(C.c_int64)) for p in ptrs])
+        ip = (C.POINTER(C.c_int32) * n_rels)(*[i.ctypes.data_as(C.POINTER(C.c_int32)) for i in idxs])
+        prp = (C.POINTER(C.c_uint8) * len(self.modes))(*[p.ctypes.data_as(C.POINTER(C.c_uint8)) for p in present])
+        desc = _GraphDesc(len(self.modes), sizes, n_rels, src_m, dst_m, rev, pp, ip, prp)
+        handle = _P()
+        rc = self.lib.gqe_sampler_create(C.byref(desc), C.byref(handle))
+        if rc != 0:
+            raise ValueError("gqe_sampler_create: " + (self.lib.gqe_sampler_last_error() or b"").decode())
+        self.handle = handle
+        self.rel_id = rel_id
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gqe_sampler_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def sample(self, n, q_type=None, arity=None, neg_sample_max=100, seed=0, threads=1, train=None, max_attempts=0):
+        """n accepted queries of ``q_type`` (or of the reference's random shapes for ``arity`` 2 / 3)."""
+        if q_type is None and arity not in (2, 3):
+            raise Exception("Only arity of at most 3 is supported for queries")
+        if q_type is not None and (q_type not in QTYPES or q_type == "1-chain"):
+            raise ValueError("cannot sample query type %r" % (q_type,))
+        out = C.POINTER(_QueryBatch)()
+        rc = self.lib.gqe_sampler_sample(self.handle, train.handle if train is not None else None,
+                                         QTYPES[q_type] if q_type is not None else ANY, int(arity or 0), int(n),
+                                         int(neg_sample_max), int(seed), int(threads), int(max_attempts), C.byref(out))
+        if rc != 0:
+            raise RuntimeError("gqe_sampler_sample: " + (self.lib.gqe_sampler_last_error() or b"").decode())
+        b = out.contents
+        try:
+            k = int(b.n)
+            take = lambda p, cnt, dt: np.ctypeslib.as_array(p, shape=(max(cnt, 1),))[:cnt].astype(dt, copy=True)
+            neg_ptr = take(b.neg_ptr, k + 1, np.int64)
+            hard_ptr = take(b.hard_ptr, k + 1, np.int64)
+            res = SampledQueries(self, take(b.qtype, k, np.int32), take(b.edges, 9 * k, np.int32).reshape(k, 3, 3),
+                                 neg_ptr, take(b.neg_idx, int(neg_ptr[-1]), np.int32),
+                                 hard_ptr, take(b.hard_idx, int(hard_ptr[-1]), np.int32), int(b.attempts))
+        finally:
+            self.lib.gqe_query_batch_free(out)
+        return res
+
+    # -- the reference's entry points (graph.py:185-238) ---------------------------------------------
+    def sample_queries(self, arity, num_samples, neg_sample_max, verbose=False, seed=0, threads=1):
+        return self.sample(num_samples, arity=arity, neg_sample_max=neg_sample_max, seed=seed, threads=threads).to_queries()
+
+    def sample_test_queries(self, train_sampler, q_types, samples_per_type, neg_sample_max, verbose=False, seed=0, threads=1):
+        out = []
+        for k, q_type in enumerate(q_types):
+            out.extend(self.sample(samples_per_type, q_type=q_type, neg_sample_max=neg_sample_max, seed=seed + k,
+                                   threads=threads, train=train_sampler).to_queries())
+        return out
+
+    def check(self, query_graph, node):
+        """bit 0: _is_subgraph; bit 1: ``node`` is a negative; bit 2: a hard negative (graph.py:447-534)."""
+        qt = query_graph[0]
+        flat = list(query_graph[1:])
+        if qt in ("3-inter_chain", "3-chain_inter"):
+            flat = [query_graph[1], query_graph[2][0], query_graph[2][1]]
+        e9 = (C.c_int32 * 9)(*([-1] * 9))
+        for k, (u, rel, v) in enumerate(flat):
+            if rel not in self.rel_id or u not in self.index_of[rel[0]] or v not in self.index_of[rel[2]]:
+                return 0
+            e9[3 * k], e9[3 * k + 1], e9[3 * k + 2] = self.index_of[rel[0]][u], self.rel_id[rel], self.index_of[rel[2]][v]
+        tm = flat[0][1][0]
+        return int(self.lib.gqe_sampler_check(self.handle, QTYPES[qt], e9, self.index_of[tm].get(node, -1)))

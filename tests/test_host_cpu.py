@@ -30,6 +30,13 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert getattr(lib, name) is not None
     assert lib.gqe_abi_version() == engine.ABI_VERSION
+    # the host-side sampler's header (include/gqe_sampler.h) is served by the same library
+    from graphqembed_amd import sampler
+    header = open(os.path.join(ROOT, "include", "gqe_sampler.h")).read()
+    declared = set(re.findall(r"\b(gqe_[a-z_]+)\s*\(", header))
+    assert declared == set(sampler.SAMPLER_SYMBOLS), declared ^ set(sampler.SAMPLER_SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
 
 
 def test_no_gpu_means_loud_failure():
