@@ -195,7 +195,6 @@ class NativeSampler(object):
                 if i >= 0:
                     arr[i] = n
             self.node_of[m] = arr.tolist()
-        keep = []
         ptrs, idxs = [], []
         for rel in self.rels:
             src, dst = self.index_of[rel[0]], self.index_of[rel[2]]
@@ -217,7 +216,35 @@ class NativeSampler(object):
             for n in graph.full_sets.get(m, ()):
                 pr[self.index_of[m][n]] = 1
             present.append(pr)
-        keep += ptrs + idxs + present
+        self._create(ptrs, idxs, present)
+
+    @classmethod
+    def from_flat(cls, flat):
+        """From a ``flatdata.FlatGraph`` (the converter's graph.npz): the CSR arrays go to the library as they are."""
+        self = cls.__new__(cls)
+        self.lib = _lib()
+        self.modes = list(flat.modes)
+        self.rels = [tuple(r) for r in flat.relations]
+        self.sizes = [max(int(s), 1) for s in flat.sizes]
+        self.node_of = {m: [int(x) for x in flat.node_ids[k]] for k, m in enumerate(self.modes)}
+        self.index_of = {m: {n: i for i, n in enumerate(self.node_of[m]) if n >= 0} for m in self.modes}
+        present = []
+        for k, m in enumerate(self.modes):           # Graph.full_sets: nodes that are the source of some edge
+            pr = np.zeros(self.sizes[k], dtype=np.uint8)
+            for r, rel in enumerate(self.rels):
+                if rel[0] == m:
+                    pr[np.nonzero(np.diff(flat.ptr[r]))[0]] = 1
+            present.append(pr)
+        self._create([np.ascontiguousarray(p, dtype=np.int64) for p in flat.ptr],
+                     [np.ascontiguousarray(i, dtype=np.int32) for i in flat.idx], present)
+        return self
+
+    def _create(self, ptrs, idxs, present):
+        mode_id = {m: i for i, m in enumerate(self.modes)}
+        rel_id = {r: i for i, r in enumerate(self.rels)}
+        for r in self.rels:
+            if _reverse_relation(r) not in rel_id:
+                raise ValueError("relation %r has no stored reverse" % (r,))
         n_rels = len(self.rels)
         sizes = (C.c_int64 * len(self.modes))(*self.sizes)
         src_m = (C.c_int32 * n_rels)(*[mode_id[r[0]] for r in self.rels])
