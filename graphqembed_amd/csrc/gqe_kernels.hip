@@ -219,22 +219,42 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
           ++len;
         }
         if (SORTED && len > 2) {
-          // list order = arrival order of the atomic exchanges, which differs between replicas; a + b commutes,
-          // longer lists are re-summed in ascending node id (selection walk: lists this long are rare)
-          acc = zero4;
-          int prev = -1;
-          for (int k = 0; k < len; ++k) {
-            int best = 0x7fffffff;
-            for (int x = h0; x >= 0; x = next[x])
-              if (x > prev && x < best) best = x;
-            const int ce = (best < max_entries) ? best : link_contrib[best - max_entries];
+          // list order = arrival order of the atomic exchanges, which differs between replicas.  a + b commutes;
+          // longer lists are re-summed order-independently: every term is scaled by a power of two chosen from
+          // the list's largest magnitude (a max is order-independent, the scaling exact), rounded to a 64-bit
+          // integer with 40 fraction bits below that magnitude, and the integers are added (associative).
+          float4 mx = zero4;
+          for (int x = h0; x >= 0; x = next[x]) {
+            const int ce = (x < max_entries) ? x : link_contrib[x - max_entries];
             const float4 c = *reinterpret_cast<const float4*>(contrib + (size_t)ce * d + c4);
-            acc.x += c.x;
-            acc.y += c.y;
-            acc.z += c.z;
-            acc.w += c.w;
-            prev = best;
+            mx.x = fmaxf(mx.x, fabsf(c.x));
+            mx.y = fmaxf(mx.y, fabsf(c.y));
+            mx.z = fmaxf(mx.z, fabsf(c.z));
+            mx.w = fmaxf(mx.w, fabsf(c.w));
           }
+          int ex, ey, ez, ew;
+          frexpf(mx.x, &ex);
+          frexpf(mx.y, &ey);
+          frexpf(mx.z, &ez);
+          frexpf(mx.w, &ew);
+          ex = max(ex, -80);  // keeps 2^(40 - e) finite for vanishing gradients
+          ey = max(ey, -80);
+          ez = max(ez, -80);
+          ew = max(ew, -80);
+          const float sx = ldexpf(1.f, 40 - ex), sy = ldexpf(1.f, 40 - ey), sz = ldexpf(1.f, 40 - ez), sw = ldexpf(1.f, 40 - ew);
+          long long ax = 0, ay = 0, az = 0, aw = 0;
+          for (int x = h0; x >= 0; x = next[x]) {
+            const int ce = (x < max_entries) ? x : link_contrib[x - max_entries];
+            const float4 c = *reinterpret_cast<const float4*>(contrib + (size_t)ce * d + c4);
+            ax += __float2ll_rn(c.x * sx);
+            ay += __float2ll_rn(c.y * sy);
+            az += __float2ll_rn(c.z * sz);
+            aw += __float2ll_rn(c.w * sw);
+          }
+          acc.x = (float)ldexp((double)ax, ex - 40);
+          acc.y = (float)ldexp((double)ay, ey - 40);
+          acc.z = (float)ldexp((double)az, ez - 40);
+          acc.w = (float)ldexp((double)aw, ew - 40);
         }
         if (had && c4 == 0) head[sg.head_base + row] = -1;
         if (MODE == GQE_OPT_ZERO) continue;

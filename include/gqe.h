@@ -174,8 +174,8 @@ int gqe_materialize_grads(gqe_ctx* ctx, void* stream);
  * rank k's dense relation / Pre / Post gradients ].  Rank r's fused kernel writes its contributions straight into
  * slab r; gqe_export_entries packs the two tails; the host moves the slabs with ONE in-place all-gather (RCCL or
  * any transport); gqe_import_entries links the other ranks' entries into the local per-row lists and replaces
- * the dense gradients by the sum over the slabs in rank order.  The optimiser pass then sums every list in
- * ascending entry id, so all replicas round identically and stay bit-equal.
+ * the dense gradients by the sum over the slabs in rank order.  The optimiser pass then sums every list
+ * order-independently (integer accumulation), so all replicas round identically and stay bit-equal.
  *
  *   gqe_set_exchange(ctx, rank, world)      once, before gqe_workspace_bytes (sizes the entry space x world)
  *   [gqe_exchange_reserve(ctx, n)]          contributions per slab when ranks may produce different counts

@@ -46,7 +46,7 @@ def _worker(rank, world, port, out_dir, dec, inter):
     full = O.zero_grads_like(params)
     items = []
     for qtype, wgt in mix:
-        t, g, a = toy_batch(rng, qtype, n_pool)
+        t, g, a = toy_batch(rng, qtype, n_pool, hub=(qtype == "2-inter"))     # hub rows: lists of ~100 entries
         # step 2 wraps around the pool: rank 0 gets a short slice (16 queries), rank 1 a full one -> unequal entry
         # counts (Engine.exchange_reserve) and loss weights n_r / n_total instead of 1 / world
         s, e = parallel.rank_slice(n_pool, B, 2, r, w)
@@ -82,7 +82,9 @@ def _worker(rank, world, port, out_dir, dec, inter):
     longest = 0
     for qtype, t, g, a, _ in items:
         longest = max(longest, int(np.bincount(np.concatenate([t, g])).max()))
-    assert longest > 2
+    longest = torch.tensor([longest])
+    dist.all_reduce(longest, op=dist.ReduceOp.MAX)
+    assert int(longest.item()) > 40
     for step in range(3):
         if step:
             launch(sparse)
