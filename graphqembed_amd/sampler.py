@@ -317,3 +317,85 @@ class NativeSampler(object):
             e9[3 * k], e9[3 * k + 1], e9[3 * k + 2] = self.index_of[rel[0]][u], self.rel_id[rel], self.index_of[rel[2]][v]
         tm = flat[0][1][0]
         return int(self.lib.gqe_sampler_check(self.handle, QTYPES[qt], e9, self.index_of[tm].get(node, -1)))
+
+
+class OnlinePools(object):
+    """Fresh query pools while training runs: a background thread keeps sampling the next generation of
+    ``{query_type: [FormulaPool]}`` with the native sampler (the C call releases the GIL, so the host cores sample
+    while the main thread feeds the GPU) and ``current()`` swaps it in when it is ready — the reference samples its
+    training queries once, offline, because its sampler is too slow to do otherwise (graph.py:185-238).
+
+        online = OnlinePools(sampler, {"2-chain": 20000, "2-inter": 20000, ...}, neg_sample_max=100, threads=16)
+        pools = online.current()           # blocks only for the very first generation
+        ...                                # every few thousand iterations: pools = online.current()
+        online.close()
+    """
+
+    def __init__(self, sampler, per_type, neg_sample_max=100, threads=1, seed=0, edges=None):
+        """per_type: {query_type: queries per generation}; ``edges``: optional ready-made 1-chain pools (edges are
+        not sampled, they are the graph itself) that are passed through unchanged in every generation."""
+        import threading
+        self.sampler, self.per_type, self.neg_sample_max, self.threads = sampler, dict(per_type), neg_sample_max, threads
+        self.edges = edges
+        self.generation = 0
+        self._seed = seed
+        self._ready = None
+        self._error = None
+        self._cv = threading.Condition()
+        self._stop = False
+        self._want = True
+        self._thread = threading.Thread(target=self._work, daemon=True)
+        self._thread.start()
+
+    def _sample_generation(self, gen):
+        pools = {}
+        for k, (qt, n) in enumerate(sorted(self.per_type.items())):
+            res = self.sampler.sample(n, q_type=qt, neg_sample_max=self.neg_sample_max, threads=self.threads,
+                                      seed=self._seed + 7919 * gen + k)
+            pools.update(res.pools())
+        if self.edges is not None:
+            pools["1-chain"] = self.edges
+        return pools
+
+    def _work(self):
+        gen = 0
+        while True:
+            with self._cv:
+                while not self._want and not self._stop:
+                    self._cv.wait()
+                if self._stop:
+                    return
+                self._want = False
+            try:
+                pools = self._sample_generation(gen)
+            except Exception as e:          # surfaced by the next current()
+                with self._cv:
+                    self._error = e
+                    self._cv.notify_all()
+                return
+            gen += 1
+            with self._cv:
+                self._ready = pools
+                self._cv.notify_all()
+
+    def current(self, wait=False):
+        """The newest finished generation (None never: the first call waits for generation 0).  Taking a generation
+        starts the sampling of the next one; ``wait=True`` blocks until a NEW generation is there."""
+        with self._cv:
+            while self._error is None and (self._ready is None and (wait or self.generation == 0)):
+                self._cv.wait()
+            if self._error is not None:
+                raise self._error
+            if self._ready is not None:
+                self._pools = self._ready
+                self._ready = None
+                self.generation += 1
+                self._want = True
+                self._cv.notify_all()
+            return self._pools
+
+    def close(self):
+        with self._cv:
+            self._stop = True
+            self._cv.notify_all()
+        self._thread.join(timeout=60)

@@ -243,3 +243,53 @@ def test_training_improves_auc_end_to_end():
     assert np.mean(list(after.values())) > np.mean(list(before.values())) + 0.03, (before, after)
     sd = model.state_dict()
     assert all(torch.isfinite(v).all() for v in sd.values())
+
+
+def test_native_sampler_to_trainer_to_eval():
+    """The whole host-to-device pipeline on the tiny graph: C++ sampler (train pools + held-out test queries that
+    the training graph cannot answer) -> TensorizedTrainer (grouped fused launches, fused Adam) -> the reference's
+    AUC protocol on the sampled test queries.  Training must lower the loss and raise the AUC."""
+    import torch
+    from graphqembed_amd import data_utils, flatdata, utils
+    from graphqembed_amd.graph import Graph
+    from graphqembed_amd.model import FusedAdam, QueryEncoderDecoder
+    from graphqembed_amd.sampler import NativeSampler
+    from graphqembed_amd.trainer import TensorizedTrainer
+    d = 32
+    rel, adj, ids = data_utils.make_synthetic_graph(data_utils.BIO_TINY_SIZES, edges_per_kind=data_utils.BIO_TINY_EDGES_PER_KIND, seed=0)
+    node_maps = data_utils.make_node_maps(ids)
+    full = Graph(None, {m: d for m in rel}, rel, adj)
+    rel2, adj2, _ = data_utils.make_synthetic_graph(data_utils.BIO_TINY_SIZES, edges_per_kind=data_utils.BIO_TINY_EDGES_PER_KIND, seed=0)
+    train_graph = Graph(None, {m: d for m in rel2}, rel2, adj2)
+    held_out = train_graph.get_all_edges(seed=2)
+    train_graph.remove_edges(held_out[: len(held_out) // 10])
+    s_full, s_train = NativeSampler(full, node_maps), NativeSampler(train_graph, node_maps)
+    types = ["2-chain", "3-chain", "2-inter", "3-inter", "3-inter_chain"]
+    pools = {}
+    for k, t in enumerate(types):
+        pools.update(s_train.sample(3000, q_type=t, neg_sample_max=20, seed=k, threads=2).pools())
+    # 1-chain pools: the training graph's edges, grouped by relation
+    edge_queries = [("1-chain", (u, r, v)) for (u, r, v) in train_graph.get_all_edges(seed=0)]
+    from graphqembed_amd.graph import Query
+    flat = flatdata.FlatGraph.from_reference(rel2, adj2, node_maps)
+    luts = {m: {int(n): i + 1 for i, n in enumerate(flat.node_ids[k]) if n >= 0} for k, m in enumerate(flat.modes)}
+    row_of = lambda nodes, mode: np.fromiter((luts[mode][n] for n in nodes), dtype=np.int32, count=len(nodes))
+    pools.update(flatdata.pools_from_queries([Query(qg, None, None) for qg in edge_queries], row_of))
+    test_queries = s_full.sample_test_queries(s_train, ["2-chain", "2-inter", "3-inter_chain"], 150, 1, seed=9)
+    by_type = data_utils.group_by_formula(test_queries)
+
+    feature_modules = {m: torch.nn.Embedding(len(node_maps[m]) + 1, d) for m in rel}
+    for m in feature_modules.values():
+        m.weight.data.normal_(0, 1.0 / d)
+    enc = utils.get_encoder(0, train_graph, {m: d for m in rel}, feature_modules, True, node_maps=node_maps)
+    model = QueryEncoderDecoder(train_graph, enc, utils.get_metapath_decoder(train_graph, {m: d for m in rel}, "bilinear-diag"),
+                                utils.get_intersection_decoder(train_graph, {m: d for m in rel}, "min"), max_queries=9 * 64)
+    all_rows = flat.all_rows()
+    tr = TensorizedTrainer(model, FusedAdam(model, lr=0.01), pools, all_rows, batch_size=64, seed=1)
+    random.seed(0)
+    before = {t: utils.eval_auc_queries(by_type[t], model)[0] for t in by_type}
+    first = float(tr.run(5, log_every=0)[-1].item())
+    last = float(tr.run(600, log_every=0)[-1].item())
+    after = {t: utils.eval_auc_queries(by_type[t], model)[0] for t in by_type}
+    assert np.isfinite(last) and last < 0.95 * first, (first, last)
+    assert np.mean(list(after.values())) > np.mean(list(before.values())) + 0.02, (before, after)

@@ -175,3 +175,26 @@ def test_error_paths(world):
     with pytest.raises(RuntimeError, match="gave up"):
         tiny.sample(3, q_type="3-inter", max_attempts=50)
     assert s.sample(0, q_type="2-chain").n == 0
+
+
+def test_online_pools_refresh_in_the_background(world):
+    from graphqembed_amd.sampler import OnlinePools
+    g, s, _ = world
+    online = OnlinePools(s, {"2-chain": 300, "3-inter": 200}, neg_sample_max=10, threads=2, seed=3)
+    try:
+        first = online.current()
+        assert online.generation == 1 and set(first) == {"2-chain", "3-inter"}
+        assert sum(p.n for p in first["2-chain"]) == 300 and sum(p.n for p in first["3-inter"]) == 200
+        second = online.current(wait=True)
+        assert online.generation == 2 and second is not first
+        a = np.concatenate([p.target for p in first["3-inter"]])
+        b = np.concatenate([p.target for p in second["3-inter"]])
+        assert not np.array_equal(np.sort(a), np.sort(b))            # a different draw
+        again = online.current()                                     # non-blocking: newest finished generation
+        assert again is second or online.generation == 3
+    finally:
+        online.close()
+    bad = OnlinePools(s, {"1-chain": 5})
+    with pytest.raises(ValueError):
+        bad.current()
+    bad.close()
