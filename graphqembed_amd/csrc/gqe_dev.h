@@ -99,6 +99,45 @@ struct GqeStepCoef {
   float bc2_sqrt[GQE_MAX_STEP_GROUPS];   // sqrt(1 - b2^t)
 };
 
+// ---- lazy rows (gqe_set_lazy_adam; see gqe_kernels.hip) ----
+#define GQE_LAZY_RING 64        // per-table ring of (step_size, bc2_sqrt) of the last 64 Adam steps
+#define GQE_LAZY_TABLES 8
+#define GQE_LAZY_SEGS 96        // index-feed segments one rows launch can cover
+struct GqeLazyTabs {
+  long long offset[GQE_LAZY_TABLES], head_base[GQE_LAZY_TABLES];
+  int target[GQE_LAZY_TABLES];     // bring rows to this Adam step count of their table
+  int grad_step[GQE_LAZY_TABLES];  // the step that consumes the row's gradient list (== target), or -1: replay only
+  float step_size[GQE_LAZY_TABLES], bc2_sqrt[GQE_LAZY_TABLES];  // coefficients of grad_step
+};
+struct GqeLazyArgs {      // rides along with the optimiser launch
+  int32_t* last;          // [total rows] step count each row is current for
+  float2* ring;           // [GQE_LAZY_TABLES][GQE_LAZY_RING]
+  GqeLazyTabs t;
+  int8_t table_of_seg[GQE_MAX_SEGS];  // universe entry -> slot in t (tables only)
+};
+struct GqeRowSegs {       // the table rows named by an index feed: segment k = idx[idx_begin[k] .. +count) of table tid[k]
+  int n, total;
+  int begin[GQE_LAZY_SEGS + 1];  // prefix sums of the counts
+  int idx_begin[GQE_LAZY_SEGS];
+  int8_t tid[GQE_LAZY_SEGS];
+};
+struct GqeRowsArgs {
+  GqeRowSegs segs;
+  GqeLazyTabs t;
+  const int32_t* idx;
+  int32_t* last;
+  float2* ring;
+  float *p, *m, *v;
+  int32_t* head;
+  const int32_t* next;
+  const float* contrib;
+  int32_t max_entries;
+  int d;
+  float b1, b2, eps;
+  bool with_grad, sorted;
+  hipStream_t stream;
+};
+
 #define GQE_OPT_ADAM 0
 #define GQE_OPT_SGD 1
 #define GQE_OPT_ZERO 2
@@ -122,6 +161,8 @@ struct GqeOptArgs {
   float lr, b1, b2, eps;
   GqeStepCoef coef;
   GqeOptActive active;
+  bool lazy;          // tables carry per-row step counts (GqeLazyArgs)
+  GqeLazyArgs lz;
   hipStream_t stream;
 };
 
@@ -151,6 +192,7 @@ struct GqeFusedArgs {
 hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a);
 hipError_t gqe_launch_pair_gemm(const GqeFusedArgs& a, float* losses);
 hipError_t gqe_launch_opt(const GqeOptArgs& a);
+hipError_t gqe_launch_rows(const GqeRowsArgs& a);
 // non-table floats of the arena (dense gradients that travel with the exchanged slab)
 struct GqeSpans {
   int n;  // < 0: more than 8 spans (unsupported)

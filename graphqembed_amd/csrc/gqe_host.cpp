@@ -46,6 +46,14 @@ struct TimedLaunch {
 struct Table {
   int64_t offset, rows, head_base;
   bool pending;  // has un-consumed gradient lists
+  // lazy Adam (gqe_set_lazy_adam): lstep = Adam steps applied to the table so far (rows are current for <= lstep),
+  // since_full = steps since every row was brought to lstep (bounded by the coefficient ring), dirty = some rows lag
+  int lstep = 0, since_full = 0;
+  bool dirty = false;
+};
+
+struct SavedFeed {  // the table rows of the pending margin call, for the sparse optimiser launch
+  GqeRowSegs segs;
 };
 
 struct Bag {
@@ -57,7 +65,7 @@ struct Bag {
 
 struct Layout {  // byte offsets inside the bound workspace
   size_t idx_cap, tloss_off, scratch_off, scratch_cap;  // [staged indices x2 | tile losses | pair scratch]
-  size_t seg_off, formula_off, head_off, rows_off, next_off, contrib_off, linkc_off, counter_off, total;
+  size_t seg_off, formula_off, head_off, rows_off, next_off, contrib_off, linkc_off, counter_off, last_off, ring_off, total;
   int64_t max_entries, max_links;  // max_entries = per-rank capacity x world (the exchange gathers every rank's entries)
 };
 
@@ -77,6 +85,13 @@ struct gqe_ctx {
   bool links_used = false;  // link nodes were allocated since the last consumption
   int64_t total_rows = 0;
   int64_t entries_used = 0;
+  bool lazy = false;                 // gqe_set_lazy_adam
+  std::vector<SavedFeed> feed;       // index segments of the pending margin call ...
+  const int32_t* feed_idx = nullptr; // ... and where its (device) index feed lives
+  int feed_buf = -1;                 // staging buffer holding it (-1: caller's device buffer)
+  bool feed_valid = false;           // the pending gradient lists come from exactly that call
+  float lz_lr = 0.f, lz_b1 = 0.f, lz_b2 = 0.f, lz_eps = 0.f;  // hyper-parameters the coefficient ring was written with
+  bool lz_hyper = false;
   int rank = 0, world = 1;     // gqe_set_exchange: data-parallel replica id / count
   int64_t step_entries = 0;    // world > 1: contribution entries per rank slab of the pending margin call (n)
   int64_t step_slab = 0;       // ... and the slab size in entries: n + row-id tail + dense-gradient tail (S)
@@ -102,9 +117,9 @@ struct gqe_ctx {
   std::vector<GqeDevSeg> universe;             // every tensor ever stepped (device copy at lay.seg_off)
   size_t universe_uploaded = 0;                // entries of `universe` the device table already holds
   int timing = 0;                              // record every `timing`-th launch of each kernel (0 = off)
-  long long timing_calls[3] = {0, 0, 0};
-  bool timing_open[3] = {false, false, false};
-  std::vector<TimedLaunch> timed[3];
+  long long timing_calls[5] = {0, 0, 0, 0, 0};
+  bool timing_open[5] = {false, false, false, false, false};
+  std::vector<TimedLaunch> timed[5];  // 0 fused, 1 pair GEMM, 2 optimiser (tables), 3 lazy: small tensors, 4 lazy: catch-up before a read
   std::vector<TimedLaunch> event_pool;  // recycled hipEvent pairs (creation is not free)
 };
 
@@ -228,7 +243,9 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
   L.contrib_off = L.next_off + align_up(sizeof(int32_t) * (size_t)(L.max_entries + L.max_links), 256);
   L.linkc_off = L.contrib_off + align_up(sizeof(float) * (size_t)L.max_entries * ctx->cfg.dim, 256);
   L.counter_off = L.linkc_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(L.max_links, 1), 256);
-  L.total = L.counter_off + 256;
+  L.last_off = L.counter_off + 256;  // lazy Adam: per-row step counts + per-table coefficient rings
+  L.ring_off = L.last_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
+  L.total = L.ring_off + align_up(sizeof(float) * 2 * GQE_LAZY_TABLES * GQE_LAZY_RING, 256);
   return L;
 }
 
@@ -421,6 +438,83 @@ int formula_of(gqe_ctx* ctx, const gqe_batch& s, int bi, int* out_id) {
   return GQE_OK;
 }
 
+// ---- lazy Adam helpers -------------------------------------------------------------------------------
+bool lazy_table_ok(const gqe_ctx* ctx, int t) {
+  if (t < 0 || t >= GQE_LAZY_TABLES) return false;
+  for (const Bag& bg : ctx->bags)
+    if (bg.table == t) return false;
+  return true;
+}
+
+// which runs of the index feed name rows of which table (the layout of gqe_batch's index block)
+void build_feed(const gqe_ctx* ctx, const gqe_batch* batches, int n_batches, bool bwd, const std::vector<int>& fid,
+                std::vector<SavedFeed>& out) {
+  out.clear();
+  SavedFeed cur;
+  memset(&cur, 0, sizeof cur);
+  auto push = [&](int64_t idx_begin, int64_t count, int64_t table_offset) {
+    if (count <= 0) return;
+    if (cur.segs.n == GQE_LAZY_SEGS) {
+      out.push_back(cur);
+      memset(&cur, 0, sizeof cur);
+    }
+    GqeRowSegs& g = cur.segs;
+    const int t = table_of(ctx, table_offset);
+    g.idx_begin[g.n] = (int)idx_begin;
+    g.tid[g.n] = (int8_t)(lazy_table_ok(ctx, t) ? t : -1);
+    g.begin[g.n] = g.total;
+    g.total += (int)count;
+    g.begin[++g.n] = g.total;
+  };
+  for (int bi = 0; bi < n_batches; ++bi) {
+    const gqe_batch& s = batches[bi];
+    const GqeDevFormula& f = ctx->formulas[fid[bi]];
+    const int64_t B = s.n_queries, o = s.idx_offset;
+    if (s.n_candidates > 0) {
+      for (int i = 0; i < f.n_anchors; ++i) push(o + i * B, B, f.anchor_table[i]);
+      push(o + f.n_anchors * B + B + 1, s.n_candidates, f.target_table);
+    } else {
+      const int lead = bwd ? 2 : 1;
+      push(o, B * lead, f.target_table);  // target [| negative]: the same table
+      for (int i = 0; i < f.n_anchors; ++i) push(o + (lead + i) * B, B, f.anchor_table[i]);
+    }
+  }
+  if (cur.segs.n) out.push_back(cur);
+}
+
+void lazy_rows_args(const gqe_ctx* ctx, GqeRowsArgs& ra, hipStream_t st) {
+  const Layout& L = ctx->lay;
+  memset(&ra.t, 0, sizeof ra.t);
+  for (size_t t = 0; t < ctx->tables.size() && t < GQE_LAZY_TABLES; ++t) {
+    ra.t.offset[t] = ctx->tables[t].offset;
+    ra.t.head_base[t] = ctx->tables[t].head_base;
+    ra.t.target[t] = ctx->tables[t].lstep;
+    ra.t.grad_step[t] = -1;
+  }
+  ra.last = reinterpret_cast<int32_t*>(ctx->ws + L.last_off);
+  ra.ring = reinterpret_cast<float2*>(ctx->ws + L.ring_off);
+  ra.p = ctx->params;
+  ra.m = ctx->m;
+  ra.v = ctx->v;
+  ra.head = reinterpret_cast<int32_t*>(ctx->ws + L.head_off);
+  ra.next = reinterpret_cast<const int32_t*>(ctx->ws + L.next_off);
+  ra.contrib = reinterpret_cast<const float*>(ctx->ws + L.contrib_off);
+  ra.max_entries = (int32_t)L.max_entries;
+  ra.d = ctx->cfg.dim;
+  ra.b1 = ctx->lz_b1;
+  ra.b2 = ctx->lz_b2;
+  ra.eps = ctx->lz_eps;
+  ra.with_grad = false;
+  ra.sorted = false;
+  ra.stream = st;
+}
+
+bool lazy_any_dirty(const gqe_ctx* ctx) {
+  for (const Table& t : ctx->tables)
+    if (t.dirty) return true;
+  return false;
+}
+
 int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx,
                 int32_t idx_on_device, bool bwd, float* losses, float* pos, float* neg, void* stream) {
   if (!ctx) return GQE_ERR_ARG;
@@ -513,6 +607,32 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     HIP_TRY(ctx, hipEventRecord(ctx->plan_ready[buf], ctx->up));
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->plan_ready[buf], 0));
     d_idx = reinterpret_cast<const int32_t*>(dev);
+  }
+
+  if (ctx->lazy) {
+    // rows this call reads must be current: replay their deferred zero-gradient Adam steps first
+    std::vector<SavedFeed> feed;
+    const bool dirty = lazy_any_dirty(ctx);
+    if (dirty || bwd) build_feed(ctx, batches, n_batches, bwd, fid, feed);
+    if (dirty) {
+      GqeRowsArgs ra;
+      lazy_rows_args(ctx, ra, st);
+      ra.idx = d_idx;
+      rc = timing_begin(ctx, 4, st);
+      if (rc != GQE_OK) return rc;
+      for (const SavedFeed& sf : feed) {
+        ra.segs = sf.segs;
+        HIP_TRY(ctx, gqe_launch_rows(ra));
+      }
+      rc = timing_end(ctx, 4, st);
+      if (rc != GQE_OK) return rc;
+    }
+    if (bwd) {
+      ctx->feed_valid = ctx->entries_used == 0;  // lists pending from an earlier call: the feed no longer names them all
+      ctx->feed.swap(feed);
+      ctx->feed_idx = d_idx;
+      ctx->feed_buf = buf;
+    }
   }
 
   GqeFusedArgs fa;
@@ -650,15 +770,39 @@ int universe_index(gqe_ctx* ctx, int64_t offset, int64_t numel, int table) {
 }
 
 // mode: GQE_OPT_ADAM / SGD / ZERO / MATERIALIZE (gqe_dev.h)
-int run_opt(gqe_ctx* ctx, int mode, const gqe_segment* segs, int32_t n_segs, float lr, float b1, float b2, float eps,
+int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, float lr, float b1, float b2, float eps,
+            void* stream);
+
+#define GQE_OPT_FLUSH 4  // internal: lazy Adam, bring every lagging row of the dirty tables to its table's step
+
+int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, float lr, float b1, float b2, float eps,
             void* stream) {
   if (!ctx) return GQE_ERR_ARG;
+  const bool flush = mode_in == GQE_OPT_FLUSH;
+  const int mode = flush ? GQE_OPT_ADAM : mode_in;
   if (!ctx->params || !ctx->grads) return fail(ctx, GQE_ERR_STATE, "parameter / gradient arenas not bound");
   if (mode == GQE_OPT_ADAM && (!ctx->m || !ctx->v)) return fail(ctx, GQE_ERR_STATE, "Adam moment arenas not bound");
   if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int d = ctx->cfg.dim;
+  if (flush && !lazy_any_dirty(ctx)) return GQE_OK;
+  if (ctx->lazy && !flush && lazy_any_dirty(ctx) &&
+      (mode == GQE_OPT_SGD || (mode == GQE_OPT_ADAM && ctx->lz_hyper &&
+                               (lr != ctx->lz_lr || b1 != ctx->lz_b1 || b2 != ctx->lz_b2 || eps != ctx->lz_eps)))) {
+    // deferred steps were recorded with the previous hyper-parameters (or SGD would move rows that still owe
+    // Adam steps): settle them first
+    int rcf = run_opt(ctx, GQE_OPT_FLUSH, nullptr, 0, ctx->lz_lr, ctx->lz_b1, ctx->lz_b2, ctx->lz_eps, stream);
+    if (rcf != GQE_OK) return rcf;
+  }
+  if (flush) {
+    lr = ctx->lz_lr;
+    b1 = ctx->lz_b1;
+    b2 = ctx->lz_b2;
+    eps = ctx->lz_eps;
+  }
   GqeOptArgs oa;
+  oa.lazy = false;
+  memset(&oa.lz, 0, sizeof oa.lz);
   memset(oa.active.group, 0xFF, sizeof oa.active.group);
   long long chunks = 0;
   std::vector<char> seen(ctx->tables.size(), 0);
@@ -694,7 +838,14 @@ int run_opt(gqe_ctx* ctx, int mode, const gqe_segment* segs, int32_t n_segs, flo
     return GQE_OK;
   };
   int rc;
-  if (mode == GQE_OPT_MATERIALIZE) {
+  if (flush) {
+    for (size_t t = 0; t < ctx->tables.size(); ++t)
+      if (ctx->tables[t].dirty) {
+        rc = activate(ctx->tables[t].offset, ctx->tables[t].rows * d, 1, (int)t);
+        if (rc != GQE_OK) return rc;
+      }
+    lists = false;
+  } else if (mode == GQE_OPT_MATERIALIZE) {
     bool any = false;
     for (size_t t = 0; t < ctx->tables.size(); ++t)
       if (ctx->tables[t].pending) {
@@ -760,16 +911,122 @@ int run_opt(gqe_ctx* ctx, int mode, const gqe_segment* segs, int32_t n_segs, flo
   oa.b2 = b2;
   oa.eps = eps;
   oa.stream = st;
-  const bool timed = mode != GQE_OPT_MATERIALIZE && mode != GQE_OPT_ZERO;  // kernel 2 = the optimiser step proper
-  if (timed) {
-    rc = timing_begin(ctx, 2, st);
-    if (rc != GQE_OK) return rc;
+  const bool timed = !flush && mode != GQE_OPT_MATERIALIZE && mode != GQE_OPT_ZERO;  // kernel 2 = the optimiser step proper
+  bool sparse = false;
+  if (ctx->lazy && mode == GQE_OPT_ADAM) {
+    const Layout& L = ctx->lay;
+    // ---- lazy Adam: per-row step counts.  Either the sparse launch over the rows of the pending margin call, or
+    // the full pass (which also replays whatever any row is behind).
+    if (!flush) {
+      for (size_t t = 0; t < ctx->tables.size(); ++t)
+        if (seen[t] && ctx->adam_steps[ctx->tables[t].offset] != ctx->tables[t].lstep + 1)
+          return fail(ctx, GQE_ERR_ARG, "lazy Adam: table at offset %lld is at step %d, cannot apply step %d",
+                      (long long)ctx->tables[t].offset, ctx->tables[t].lstep, ctx->adam_steps[ctx->tables[t].offset]);
+      ctx->lz_lr = lr;
+      ctx->lz_b1 = b1;
+      ctx->lz_b2 = b2;
+      ctx->lz_eps = eps;
+      ctx->lz_hyper = true;
+      sparse = lists && ctx->feed_valid && !ctx->dense_dirty && ctx->world == 1 && ctx->bags.empty() &&
+               (int)ctx->tables.size() <= GQE_LAZY_TABLES && (64 % (d / 4)) == 0;
+      for (size_t t = 0; t < ctx->tables.size() && sparse; ++t)
+        if (seen[t] && ctx->tables[t].since_full >= GQE_LAZY_RING - 2) sparse = false;  // ring slot about to be reused
+    }
+    auto coef_of = [&](size_t t, float* ss, float* bc) {
+      for (size_t ui = 0; ui < ctx->universe.size(); ++ui)
+        if (ctx->universe[ui].is_table && ctx->universe[ui].offset == ctx->tables[t].offset) {
+          const int gi = oa.active.group[ui];
+          *ss = oa.coef.step_size[gi];
+          *bc = oa.coef.bc2_sqrt[gi];
+        }
+    };
+    if (sparse) {
+      GqeRowsArgs ra;
+      lazy_rows_args(ctx, ra, st);
+      ra.with_grad = true;
+      ra.sorted = oa.sorted;
+      ra.idx = ctx->feed_idx;
+      for (size_t t = 0; t < ctx->tables.size(); ++t)
+        if (seen[t]) {
+          ra.t.target[t] = ra.t.grad_step[t] = ctx->tables[t].lstep + 1;
+          coef_of(t, &ra.t.step_size[t], &ra.t.bc2_sqrt[t]);
+        }
+      rc = timing_begin(ctx, 2, st);
+      if (rc != GQE_OK) return rc;
+      for (const SavedFeed& sf : ctx->feed) {
+        ra.segs = sf.segs;
+        HIP_TRY(ctx, gqe_launch_rows(ra));
+      }
+      rc = timing_end(ctx, 2, st);
+      if (rc != GQE_OK) return rc;
+      if (ctx->feed_buf >= 0) HIP_TRY(ctx, hipEventRecord(ctx->plan_free[ctx->feed_buf], st));  // the staged feed may go now
+      // the small dense tensors: the ordinary pass, tables masked out
+      long long dense_chunks = 0;
+      for (size_t ui = 0; ui < ctx->universe.size(); ++ui) {
+        if (oa.active.group[ui] == 0xFF) continue;
+        if (ctx->universe[ui].is_table) oa.active.group[ui] = 0xFF;
+        else dense_chunks += ctx->universe[ui].n_chunks;
+      }
+      if (dense_chunks > 0) {
+        oa.total_chunks = dense_chunks;
+        oa.lists = false;
+        oa.dense_tables = false;
+        rc = timing_begin(ctx, 3, st);
+        if (rc != GQE_OK) return rc;
+        HIP_TRY(ctx, gqe_launch_opt(oa));
+        rc = timing_end(ctx, 3, st);
+        if (rc != GQE_OK) return rc;
+      }
+      for (size_t t = 0; t < ctx->tables.size(); ++t)
+        if (seen[t]) {
+          ++ctx->tables[t].lstep;
+          ++ctx->tables[t].since_full;
+          ctx->tables[t].dirty = true;
+        }
+    } else {
+      oa.lazy = true;
+      oa.lz.last = reinterpret_cast<int32_t*>(ctx->ws + L.last_off);
+      oa.lz.ring = reinterpret_cast<float2*>(ctx->ws + L.ring_off);
+      memset(oa.lz.table_of_seg, 0, sizeof oa.lz.table_of_seg);
+      if ((int)ctx->tables.size() > GQE_LAZY_TABLES) return fail(ctx, GQE_ERR_STATE, "lazy Adam supports at most %d tables", GQE_LAZY_TABLES);
+      for (size_t t = 0; t < ctx->tables.size(); ++t) {
+        oa.lz.t.target[t] = ctx->tables[t].lstep + ((seen[t] && !flush) ? 1 : 0);
+        oa.lz.t.grad_step[t] = (seen[t] && !flush) ? ctx->tables[t].lstep + 1 : -1;
+      }
+      for (size_t ui = 0; ui < ctx->universe.size(); ++ui)
+        if (ctx->universe[ui].is_table) oa.lz.table_of_seg[ui] = (int8_t)table_of(ctx, ctx->universe[ui].offset);
+      if (timed) {
+        rc = timing_begin(ctx, 2, st);
+        if (rc != GQE_OK) return rc;
+      }
+      HIP_TRY(ctx, gqe_launch_opt(oa));
+      if (timed) {
+        rc = timing_end(ctx, 2, st);
+        if (rc != GQE_OK) return rc;
+      }
+      for (size_t t = 0; t < ctx->tables.size(); ++t)
+        if (seen[t]) {
+          if (!flush) ++ctx->tables[t].lstep;
+          ctx->tables[t].since_full = 0;
+          ctx->tables[t].dirty = false;
+        }
+    }
+    if (flush) return GQE_OK;
+  } else {
+    if (timed) {
+      rc = timing_begin(ctx, 2, st);
+      if (rc != GQE_OK) return rc;
+    }
+    HIP_TRY(ctx, gqe_launch_opt(oa));
+    if (timed) {
+      rc = timing_end(ctx, 2, st);
+      if (rc != GQE_OK) return rc;
+    }
+    if (mode == GQE_OPT_ADAM)
+      for (size_t t = 0; t < ctx->tables.size(); ++t)
+        if (seen[t]) ctx->tables[t].lstep = ctx->adam_steps[ctx->tables[t].offset];  // keeps gqe_set_lazy_adam(1) possible later
   }
-  HIP_TRY(ctx, gqe_launch_opt(oa));
-  if (timed) {
-    rc = timing_end(ctx, 2, st);
-    if (rc != GQE_OK) return rc;
-  }
+  if (mode != GQE_OPT_ADAM) ctx->feed_valid = false;  // lists were dropped / folded: the saved feed no longer describes them
   // bookkeeping: which lists are consumed now
   bool any_pending = false;
   for (size_t t = 0; t < ctx->tables.size(); ++t) {
@@ -864,7 +1121,14 @@ int gqe_set_tables(gqe_ctx* ctx, const int64_t* offsets, const int64_t* rows, in
   ctx->total_rows = 0;
   for (int t = 0; t < n_tables; ++t) {
     if (offsets[t] < 0 || (offsets[t] % 4) || rows[t] < 1) return fail(ctx, GQE_ERR_ARG, "table %d: bad offset / rows", t);
-    ctx->tables.push_back(Table{offsets[t], rows[t], ctx->total_rows, false});
+    {
+      Table tb;
+      tb.offset = offsets[t];
+      tb.rows = rows[t];
+      tb.head_base = ctx->total_rows;
+      tb.pending = false;
+      ctx->tables.push_back(tb);
+    }
     ctx->total_rows += rows[t];
   }
   ctx->universe.clear();
@@ -910,6 +1174,7 @@ int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* strea
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(ctx, GQE_ERR_ARG, "workspace must be 256-byte aligned");
   if (ctx->cap_queries < 1) return fail(ctx, GQE_ERR_STATE, "call gqe_workspace_bytes first");
   if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "gradients pending; step or materialize before re-binding the workspace");
+  if (lazy_any_dirty(ctx)) return fail(ctx, GQE_ERR_STATE, "lazy Adam: call gqe_optimizer_sync before re-binding the workspace");
   const Layout L = make_layout(ctx, ctx->cap_queries, ctx->cap_batches);
   if ((int64_t)L.total > bytes) return fail(ctx, GQE_ERR_WORKSPACE, "workspace has %lld bytes, %zu needed", (long long)bytes, L.total);
   ctx->ws = static_cast<char*>(workspace);
@@ -921,12 +1186,40 @@ int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* strea
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.head_off, 0xff, L.rows_off - L.head_off, reinterpret_cast<hipStream_t>(stream)));
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.counter_off, 0, sizeof(int32_t), reinterpret_cast<hipStream_t>(stream)));
   ctx->links_used = false;
-  for (auto& t : ctx->tables) t.pending = false;
+  // lazy Adam: every row is current for its table's step count, empty rings
+  HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.ring_off, 0, L.total - L.ring_off, reinterpret_cast<hipStream_t>(stream)));
+  for (auto& t : ctx->tables) {
+    t.pending = false;
+    t.since_full = 0;
+    HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->ws + L.last_off + sizeof(int32_t) * (size_t)t.head_base),
+                                   t.lstep, (size_t)t.rows, reinterpret_cast<hipStream_t>(stream)));
+  }
+  ctx->feed_valid = false;
   return GQE_OK;
+}
+
+int gqe_set_lazy_adam(gqe_ctx* ctx, int32_t enable) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (enable) {
+    if ((int)ctx->tables.size() > GQE_LAZY_TABLES) return fail(ctx, GQE_ERR_ARG, "lazy Adam supports at most %d tables", GQE_LAZY_TABLES);
+    if (ctx->world > 1) return fail(ctx, GQE_ERR_STATE, "lazy Adam is not available together with gqe_set_exchange");
+    if (ctx->dense_dirty || ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "gradients pending: step first");
+  } else if (lazy_any_dirty(ctx)) {
+    return fail(ctx, GQE_ERR_STATE, "rows still owe Adam steps: call gqe_optimizer_sync before leaving lazy mode");
+  }
+  ctx->lazy = enable != 0;
+  return GQE_OK;
+}
+
+int gqe_optimizer_sync(gqe_ctx* ctx, void* stream) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (!ctx->lazy || !ctx->ws) return GQE_OK;
+  return run_opt(ctx, GQE_OPT_FLUSH, nullptr, 0, 0.f, 0.f, 0.f, 0.f, stream);
 }
 
 int gqe_set_exchange(gqe_ctx* ctx, int32_t rank, int32_t world) {
   if (!ctx) return GQE_ERR_ARG;
+  if (ctx->lazy && world > 1) return fail(ctx, GQE_ERR_STATE, "gqe_set_exchange is not available in lazy Adam mode");
   if (world < 1 || world > 1024 || rank < 0 || rank >= world) return fail(ctx, GQE_ERR_ARG, "need 0 <= rank < world <= 1024, got rank %d world %d", rank, world);
   if (ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_set_exchange must precede gqe_workspace_bytes / gqe_bind_workspace");
   ctx->rank = rank;
@@ -1188,12 +1481,12 @@ int gqe_debug_profile(gqe_ctx* ctx, long long* stamps) {
 int gqe_timing_enable(gqe_ctx* ctx, int32_t stride) {
   if (!ctx) return GQE_ERR_ARG;
   ctx->timing = stride > 0 ? stride : 0;
-  for (int k = 0; k < 3; ++k) ctx->timing_calls[k] = 0;
+  for (int k = 0; k < 5; ++k) ctx->timing_calls[k] = 0;
   return GQE_OK;
 }
 
 int gqe_timing_read(gqe_ctx* ctx, int32_t kernel, float* avg_ms, int32_t* count) {
-  if (!ctx || kernel < 0 || kernel > 2 || !avg_ms || !count) return GQE_ERR_ARG;
+  if (!ctx || kernel < 0 || kernel > 4 || !avg_ms || !count) return GQE_ERR_ARG;
   double total = 0;
   int n = 0;
   for (auto& t : ctx->timed[kernel]) {

@@ -139,16 +139,27 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
 //       at 24 B/param, the dense table gradient is neither read nor re-zeroed.
 //   MODE = ADAM | SGD | ZERO (drop gradients) | MATERIALIZE (fold the lists into the dense gradient).
 // ------------------------------------------------------------------------------------------
+// One Adam step of one element, torch.optim.Adam's formulas (exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2 v + (1-b2) g g;
+// p -= step_size * exp_avg / (sqrt(exp_avg_sq) / bc2_sqrt + eps)).  Every operation is spelled out with its rounding so
+// that the eager pass and the replay of deferred steps (lazy rows, below) execute the SAME sequence and agree bit
+// for bit — with contraction left to the compiler the two call sites could fuse differently.
+__device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, float step_size, float bc2_sqrt, float b1c,
+                                      float b2, float b2c, float eps) {
+  m = __fmaf_rn(b1c, __fsub_rn(g, m), m);
+  v = __fmaf_rn(__fmul_rn(b2c, g), g, __fmul_rn(v, b2));
+  const float den = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);
+  p = __fmaf_rn(-step_size, __fdiv_rn(m, den), p);
+}
+
 template <int MODE>
 __device__ __forceinline__ void opt_update(float4& pp, float4& mm, float4& vv, const float4& gg, float step_size,
                                            float bc2_sqrt, float lr, float b1, float b2, float eps) {
   if (MODE == GQE_OPT_ADAM) {
-#define ADAM1(x)                                 \
-  mm.x = mm.x + (1.f - b1) * (gg.x - mm.x);      \
-  vv.x = vv.x * b2 + (1.f - b2) * gg.x * gg.x;   \
-  pp.x = pp.x - step_size * (mm.x / (sqrtf(vv.x) / bc2_sqrt + eps));
-    ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
-#undef ADAM1
+    const float b1c = 1.f - b1, b2c = 1.f - b2;
+    adam1(pp.x, mm.x, vv.x, gg.x, step_size, bc2_sqrt, b1c, b2, b2c, eps);
+    adam1(pp.y, mm.y, vv.y, gg.y, step_size, bc2_sqrt, b1c, b2, b2c, eps);
+    adam1(pp.z, mm.z, vv.z, gg.z, step_size, bc2_sqrt, b1c, b2, b2c, eps);
+    adam1(pp.w, mm.w, vv.w, gg.w, step_size, bc2_sqrt, b1c, b2, b2c, eps);
   } else {
     pp.x -= lr * gg.x;
     pp.y -= lr * gg.y;
@@ -157,7 +168,93 @@ __device__ __forceinline__ void opt_update(float4& pp, float4& mm, float4& vv, c
   }
 }
 
-template <int MODE, bool LISTS, bool DENSE_T, bool SORTED>
+// Sum of a row's gradient list (float4 slice c4 of every contribution).  len = number of nodes walked.
+template <bool SORTED>
+__device__ __forceinline__ float4 list_gradient(int h0, const int32_t* __restrict__ next, const float* __restrict__ contrib,
+                                                const int32_t* __restrict__ link_contrib, int max_entries, int d, int c4) {
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc = zero4;
+  int len = 0;
+  for (int h = h0; h >= 0; h = next[h]) {
+    const int ce = (h < max_entries) ? h : link_contrib[h - max_entries];  // bag link node -> its contribution
+    const float4 c = *reinterpret_cast<const float4*>(contrib + (size_t)ce * d + c4);
+    acc.x += c.x;
+    acc.y += c.y;
+    acc.z += c.z;
+    acc.w += c.w;
+    ++len;
+  }
+  if (SORTED && len > 2) {
+    // list order = arrival order of the atomic exchanges, which differs between replicas.  a + b commutes;
+    // longer lists are re-summed order-independently: every term is scaled by a power of two chosen from
+    // the list's largest magnitude (a max is order-independent, the scaling exact), rounded to a 64-bit
+    // integer with 40 fraction bits below that magnitude, and the integers are added (associative).
+    float4 mx = zero4;
+    for (int x = h0; x >= 0; x = next[x]) {
+      const int ce = (x < max_entries) ? x : link_contrib[x - max_entries];
+      const float4 c = *reinterpret_cast<const float4*>(contrib + (size_t)ce * d + c4);
+      mx.x = fmaxf(mx.x, fabsf(c.x));
+      mx.y = fmaxf(mx.y, fabsf(c.y));
+      mx.z = fmaxf(mx.z, fabsf(c.z));
+      mx.w = fmaxf(mx.w, fabsf(c.w));
+    }
+    int ex, ey, ez, ew;
+    frexpf(mx.x, &ex);
+    frexpf(mx.y, &ey);
+    frexpf(mx.z, &ez);
+    frexpf(mx.w, &ew);
+    ex = max(ex, -80);  // keeps 2^(40 - e) finite for vanishing gradients
+    ey = max(ey, -80);
+    ez = max(ez, -80);
+    ew = max(ew, -80);
+    const float sx = ldexpf(1.f, 40 - ex), sy = ldexpf(1.f, 40 - ey), sz = ldexpf(1.f, 40 - ez), sw = ldexpf(1.f, 40 - ew);
+    long long ax = 0, ay = 0, az = 0, aw = 0;
+    for (int x = h0; x >= 0; x = next[x]) {
+      const int ce = (x < max_entries) ? x : link_contrib[x - max_entries];
+      const float4 c = *reinterpret_cast<const float4*>(contrib + (size_t)ce * d + c4);
+      ax += __float2ll_rn(c.x * sx);
+      ay += __float2ll_rn(c.y * sy);
+      az += __float2ll_rn(c.z * sz);
+      aw += __float2ll_rn(c.w * sw);
+    }
+    acc.x = (float)ldexp((double)ax, ex - 40);
+    acc.y = (float)ldexp((double)ay, ey - 40);
+    acc.z = (float)ldexp((double)az, ez - 40);
+    acc.w = (float)ldexp((double)aw, ew - 40);
+  }
+  return acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Lazy rows (gqe_set_lazy_adam).  A row without a gradient still moves under Adam (its momentum decays), which
+// is why the eager pass streams every row of every stepped table each iteration.  But those zero-gradient steps
+// depend on nothing except the row's own (p, m, v) and the step number: they can be REPLAYED later, in registers,
+// with exactly the arithmetic the eager pass would have executed (adam1), the first time the row is needed
+// again — by a forward that reads it, or by the step that gives it a gradient.  last[row] = the table's Adam
+// step count the row is current for; the per-step bias-correction pair of the last 64 steps of each table sits
+// in a device ring (older steps cannot be pending: the host runs a full pass before a ring slot is reused).
+// Result: bit-identical parameters, HBM traffic proportional to the rows a step touches.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lazy_advance(float4& pp, float4& mm, float4& vv, const float4& gg, int from, int target,
+                                             int grad_step, const float2* __restrict__ ring, float step_size_now,
+                                             float bc2_now, int now_step, float b1, float b2, float eps) {
+  const float b1c = 1.f - b1, b2c = 1.f - b2;
+  for (int j = from + 1; j <= target; ++j) {
+    float ss = step_size_now, bc = bc2_now;
+    if (j != now_step) {
+      const float2 c = ring[j & (GQE_LAZY_RING - 1)];
+      ss = c.x;
+      bc = c.y;
+    }
+    const bool gs = j == grad_step;
+    adam1(pp.x, mm.x, vv.x, gs ? gg.x : 0.f, ss, bc, b1c, b2, b2c, eps);
+    adam1(pp.y, mm.y, vv.y, gs ? gg.y : 0.f, ss, bc, b1c, b2, b2c, eps);
+    adam1(pp.z, mm.z, vv.z, gs ? gg.z : 0.f, ss, bc, b1c, b2, b2c, eps);
+    adam1(pp.w, mm.w, vv.w, gs ? gg.w : 0.f, ss, bc, b1c, b2, b2c, eps);
+  }
+}
+
+template <int MODE, bool LISTS, bool DENSE_T, bool SORTED, bool LAZY>
 __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* __restrict__ segs, int n_segs,
                                                              long long total_chunks, float* __restrict__ p,
                                                              float* __restrict__ g, float* __restrict__ m,
@@ -166,7 +263,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
                                                              const float* __restrict__ contrib,
                                                              const int32_t* __restrict__ link_contrib, int max_entries,
                                                              int d, float lr, float b1, float b2, float eps,
-                                                             GqeStepCoef coef, GqeOptActive active) {
+                                                             GqeStepCoef coef, GqeOptActive active, GqeLazyArgs lazy) {
   __shared__ long long s_begin[GQE_MAX_SEGS + 1];  // chunk prefix over the universe; inactive tensors get 0 chunks
   __shared__ long long s_cnt[GQE_MAX_SEGS];
   if ((int)threadIdx.x < n_segs) s_cnt[threadIdx.x] = (active.group[threadIdx.x] != 0xFF) ? segs[threadIdx.x].n_chunks : 0;
@@ -204,58 +301,8 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
       bool had = false;
       if (LISTS) {
         const int h0 = head[sg.head_base + row];
-        int h = h0;
-        had = h >= 0;
-        float4 acc = zero4;
-        int len = 0;
-        while (h >= 0) {
-          const int ce = (h < max_entries) ? h : link_contrib[h - max_entries];  // bag link node -> its contribution
-          const float4 c = *reinterpret_cast<const float4*>(contrib + (size_t)ce * d + c4);
-          acc.x += c.x;
-          acc.y += c.y;
-          acc.z += c.z;
-          acc.w += c.w;
-          h = next[h];
-          ++len;
-        }
-        if (SORTED && len > 2) {
-          // list order = arrival order of the atomic exchanges, which differs between replicas.  a + b commutes;
-          // longer lists are re-summed order-independently: every term is scaled by a power of two chosen from
-          // the list's largest magnitude (a max is order-independent, the scaling exact), rounded to a 64-bit
-          // integer with 40 fraction bits below that magnitude, and the integers are added (associative).
-          float4 mx = zero4;
-          for (int x = h0; x >= 0; x = next[x]) {
-            const int ce = (x < max_entries) ? x : link_contrib[x - max_entries];
-            const float4 c = *reinterpret_cast<const float4*>(contrib + (size_t)ce * d + c4);
-            mx.x = fmaxf(mx.x, fabsf(c.x));
-            mx.y = fmaxf(mx.y, fabsf(c.y));
-            mx.z = fmaxf(mx.z, fabsf(c.z));
-            mx.w = fmaxf(mx.w, fabsf(c.w));
-          }
-          int ex, ey, ez, ew;
-          frexpf(mx.x, &ex);
-          frexpf(mx.y, &ey);
-          frexpf(mx.z, &ez);
-          frexpf(mx.w, &ew);
-          ex = max(ex, -80);  // keeps 2^(40 - e) finite for vanishing gradients
-          ey = max(ey, -80);
-          ez = max(ez, -80);
-          ew = max(ew, -80);
-          const float sx = ldexpf(1.f, 40 - ex), sy = ldexpf(1.f, 40 - ey), sz = ldexpf(1.f, 40 - ez), sw = ldexpf(1.f, 40 - ew);
-          long long ax = 0, ay = 0, az = 0, aw = 0;
-          for (int x = h0; x >= 0; x = next[x]) {
-            const int ce = (x < max_entries) ? x : link_contrib[x - max_entries];
-            const float4 c = *reinterpret_cast<const float4*>(contrib + (size_t)ce * d + c4);
-            ax += __float2ll_rn(c.x * sx);
-            ay += __float2ll_rn(c.y * sy);
-            az += __float2ll_rn(c.z * sz);
-            aw += __float2ll_rn(c.w * sw);
-          }
-          acc.x = (float)ldexp((double)ax, ex - 40);
-          acc.y = (float)ldexp((double)ay, ey - 40);
-          acc.z = (float)ldexp((double)az, ez - 40);
-          acc.w = (float)ldexp((double)aw, ew - 40);
-        }
+        had = h0 >= 0;
+        const float4 acc = list_gradient<SORTED>(h0, next, contrib, link_contrib, max_entries, d, c4);
         if (had && c4 == 0) head[sg.head_base + row] = -1;
         if (MODE == GQE_OPT_ZERO) continue;
         gg.x += acc.x;
@@ -282,6 +329,23 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
       if (MODE == GQE_OPT_ADAM) {
         mm = *reinterpret_cast<const float4*>(m + off);
         vv = *reinterpret_cast<const float4*>(v + off);
+      }
+      if (LAZY && MODE == GQE_OPT_ADAM) {
+        // full pass in lazy mode: replay what the row is behind, then (grad_step == target) the step with gradient
+        const int lt = lazy.table_of_seg[si];
+        const int from = lazy.last[sg.head_base + row];
+        const int target = lazy.t.target[lt];
+        if (from < target) {
+          lazy_advance(pp, mm, vv, gg, from, target, lazy.t.grad_step[lt], lazy.ring + lt * GQE_LAZY_RING, step_size, bc2_sqrt,
+                       lazy.t.grad_step[lt], b1, b2, eps);
+          if (c4 == 0) lazy.last[sg.head_base + row] = target;
+          *reinterpret_cast<float4*>(m + off) = mm;
+          *reinterpret_cast<float4*>(v + off) = vv;
+          *reinterpret_cast<float4*>(p + off) = pp;
+        }
+        if (ch == chunk_begin && threadIdx.x == 0 && lazy.t.grad_step[lt] > 0)
+          lazy.ring[lt * GQE_LAZY_RING + (lazy.t.grad_step[lt] & (GQE_LAZY_RING - 1))] = make_float2(step_size, bc2_sqrt);
+        continue;
       }
       opt_update<MODE>(pp, mm, vv, gg, step_size, bc2_sqrt, lr, b1, b2, eps);
       if (MODE == GQE_OPT_ADAM) {
@@ -319,11 +383,11 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
         g[o] = 0.f;
         if (MODE == GQE_OPT_ZERO) continue;
         if (MODE == GQE_OPT_ADAM) {
-          const float mm = m[o] + (1.f - b1) * (gg - m[o]);
-          const float vv = v[o] * b2 + (1.f - b2) * gg * gg;
+          float pp = p[o], mm = m[o], vv = v[o];
+          adam1(pp, mm, vv, gg, step_size, bc2_sqrt, 1.f - b1, b2, 1.f - b2, eps);
           m[o] = mm;
           v[o] = vv;
-          p[o] = p[o] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+          p[o] = pp;
         } else {
           p[o] -= lr * gg;
         }
@@ -359,20 +423,95 @@ hipError_t gqe_launch_pair_gemm(const GqeFusedArgs& a, float* losses) {
 
 template <int MODE>
 static void launch_opt_mode(const GqeOptArgs& a, unsigned blocks) {
-#define GO(L, D, S)                                                                                                       \
-  hipLaunchKernelGGL((gqe_opt_kernel<MODE, L, D, S>), dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.n_segs,       \
+#define GO(L, D, S, Z)                                                                                                    \
+  hipLaunchKernelGGL((gqe_opt_kernel<MODE, L, D, S, Z>), dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.n_segs,    \
                      a.total_chunks, a.p, a.g, a.m, a.v, a.head, a.next, a.contrib, a.link_contrib, a.max_entries, a.d, a.lr, a.b1,  \
-                     a.b2, a.eps, a.coef, a.active)
-  if (a.lists) {
-    if (a.sorted) {
-      if (a.dense_tables) GO(true, true, true); else GO(true, false, true);
+                     a.b2, a.eps, a.coef, a.active, a.lz)
+  if (a.lazy && MODE == GQE_OPT_ADAM) {  // lazy full pass: lists are summed order-independently only when asked to
+    if (a.lists) {
+      if (a.dense_tables) GO(true, true, false, true); else GO(true, false, false, true);
     } else {
-      if (a.dense_tables) GO(true, true, false); else GO(true, false, false);
+      if (a.dense_tables) GO(false, true, false, true); else GO(false, false, false, true);
+    }
+  } else if (a.lists) {
+    if (a.sorted) {
+      if (a.dense_tables) GO(true, true, true, false); else GO(true, false, true, false);
+    } else {
+      if (a.dense_tables) GO(true, true, false, false); else GO(true, false, false, false);
     }
   } else {
-    if (a.dense_tables) GO(false, true, false); else GO(false, false, false);
+    if (a.dense_tables) GO(false, true, false, false); else GO(false, false, false, false);
   }
 #undef GO
+}
+
+// ------------------------------------------------------------------------------------------
+// lazy rows: advance exactly the table rows an index feed names (duplicates are resolved by an atomic max on the
+// row's step count: the first arrival owns the work).  WITH_GRAD: the final step consumes the row's gradient
+// list — the launch that replaces the full-table pass after a fused forward/backward; without: replay only —
+// the launch that makes the rows current before a forward reads them.
+// ------------------------------------------------------------------------------------------
+template <bool WITH_GRAD, bool SORTED>
+__global__ __launch_bounds__(GQE_THREADS) void gqe_rows_kernel(const GqeRowSegs segs, const GqeLazyTabs t,
+                                                              const int32_t* __restrict__ idx, int32_t* __restrict__ last,
+                                                              float2* __restrict__ ring, float* __restrict__ p,
+                                                              float* __restrict__ m, float* __restrict__ v,
+                                                              int32_t* __restrict__ head, const int32_t* __restrict__ next,
+                                                              const float* __restrict__ contrib, int max_entries, int d,
+                                                              float b1, float b2, float eps) {
+  if (WITH_GRAD && blockIdx.x == 0 && threadIdx.x < GQE_LAZY_TABLES && t.grad_step[threadIdx.x] > 0)
+    ring[threadIdx.x * GQE_LAZY_RING + (t.grad_step[threadIdx.x] & (GQE_LAZY_RING - 1))] =
+        make_float2(t.step_size[threadIdx.x], t.bc2_sqrt[threadIdx.x]);
+  const int tpr = d >> 2;  // threads per row (a divisor of 64: the group never straddles a wave)
+  const int e = (int)(((long long)blockIdx.x * GQE_THREADS + threadIdx.x) / tpr);
+  if (e >= segs.total) return;
+  const int c4 = (threadIdx.x % tpr) * 4;
+  int k = 0;  // segment of entry e: begin[k] <= e < begin[k+1]
+  for (int step = 64; step > 0; step >>= 1)
+    if (k + step < segs.n && segs.begin[k + step] <= e) k += step;
+  const int lt = segs.tid[k];
+  if (lt < 0) return;
+  const int row = idx[segs.idx_begin[k] + (e - segs.begin[k])];
+  if (row < 0) return;  // padding query
+  const int target = t.target[lt];
+  const long long hrow = t.head_base[lt] + row;
+  int from = 0;
+  if (c4 == 0) from = __hip_atomic_fetch_max(last + hrow, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  from = __shfl(from, (threadIdx.x & 63) / tpr * tpr);
+  if (from >= target) return;  // someone else brought (or is bringing) the row there
+  const long long off = t.offset[lt] + (long long)row * d + c4;
+  float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (WITH_GRAD) {
+    const int h0 = head[hrow];
+    if (h0 >= 0) {
+      gg = list_gradient<SORTED>(h0, next, contrib, nullptr, max_entries, d, c4);
+      if (c4 == 0) head[hrow] = -1;
+    }
+  }
+  float4 pp = *reinterpret_cast<const float4*>(p + off);
+  float4 mm = *reinterpret_cast<const float4*>(m + off);
+  float4 vv = *reinterpret_cast<const float4*>(v + off);
+  lazy_advance(pp, mm, vv, gg, from, target, t.grad_step[lt], ring + lt * GQE_LAZY_RING, t.step_size[lt], t.bc2_sqrt[lt],
+               t.grad_step[lt], b1, b2, eps);
+  *reinterpret_cast<float4*>(m + off) = mm;
+  *reinterpret_cast<float4*>(v + off) = vv;
+  *reinterpret_cast<float4*>(p + off) = pp;
+}
+
+hipError_t gqe_launch_rows(const GqeRowsArgs& a) {
+  if (a.segs.total < 1) return hipSuccess;
+  const long long threads = (long long)a.segs.total * (a.d >> 2);
+  const unsigned blocks = (unsigned)((threads + GQE_THREADS - 1) / GQE_THREADS);
+#define GO(G, S)                                                                                                          \
+  hipLaunchKernelGGL((gqe_rows_kernel<G, S>), dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.t, a.idx, a.last,     \
+                     a.ring, a.p, a.m, a.v, a.head, a.next, a.contrib, a.max_entries, a.d, a.b1, a.b2, a.eps)
+  if (a.with_grad) {
+    if (a.sorted) GO(true, true); else GO(true, false);
+  } else {
+    GO(false, false);
+  }
+#undef GO
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------

@@ -71,6 +71,8 @@ SYMBOLS = OrderedDict([
     ("gqe_workspace_bytes", (C.c_int64, [_P, C.c_int64, C.c_int32])),
     ("gqe_bind_workspace", (C.c_int, [_P, _P, C.c_int64, _P])),
     ("gqe_materialize_grads", (C.c_int, [_P, _P])),
+    ("gqe_set_lazy_adam", (C.c_int, [_P, C.c_int32])),
+    ("gqe_optimizer_sync", (C.c_int, [_P, _P])),
     ("gqe_set_exchange", (C.c_int, [_P, C.c_int32, C.c_int32])),
     ("gqe_exchange_reserve", (C.c_int, [_P, C.c_int64])),
     ("gqe_export_entries", (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P])),
@@ -153,11 +155,13 @@ class Engine(object):
     """One gqe_ctx + the tensors it borrows."""
 
     def __init__(self, dim, decoder, inter_decoder, layout, device=None, max_queries=8192, max_batches=16, bags=None,
-                 rank=0, world=1):
+                 rank=0, world=1, lazy_adam=False):
         """``bags``: {table key: (ptr int32[n+1], ids int32[nnz])} for modes whose feature is an
         nn.EmbeddingBag (mean over table rows) — an index into such a mode is a bag index.
         ``world`` > 1 (and no bags): size the gradient-entry space for the data-parallel exchange
-        (include/gqe.h, gqe_set_exchange) and make the optimiser sum lists in a replica-independent order."""
+        (include/gqe.h, gqe_set_exchange) and make the optimiser sum lists in a replica-independent order.
+        ``lazy_adam``: deferred bit-exact Adam (include/gqe.h, gqe_set_lazy_adam); ``params`` / ``exp_avg`` /
+        ``exp_avg_sq`` then synchronise on access."""
         import torch
         if not torch.cuda.is_available():
             raise GqeLibraryError("no HIP device visible to torch; the query path only runs on an MI355X "
@@ -177,9 +181,10 @@ class Engine(object):
         self.ctx = handle
         n = max(layout.total, 64)
         z = lambda: torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.params, self.grads, self.exp_avg, self.exp_avg_sq = z(), z(), z(), z()
-        self._check(self.lib.gqe_bind_arena(self.ctx, self.params.data_ptr(), self.grads.data_ptr(),
-                                            self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), n))
+        self.lazy_adam = False
+        self._params, self.grads, self._exp_avg, self._exp_avg_sq = z(), z(), z(), z()
+        self._check(self.lib.gqe_bind_arena(self.ctx, self._params.data_ptr(), self.grads.data_ptr(),
+                                            self._exp_avg.data_ptr(), self._exp_avg_sq.data_ptr(), n))
         tables = [(off, shape[0]) for k, (off, shape) in layout.entries.items()
                   if k.startswith("enc.") and len(shape) == 2 and shape[1] == self.dim]
         if tables:
@@ -198,6 +203,9 @@ class Engine(object):
         self.sparse_exchange = self.world > 1 and not self._bags
         if self.sparse_exchange:
             self._check(self.lib.gqe_set_exchange(self.ctx, self.rank, self.world))
+        if lazy_adam:
+            self._check(self.lib.gqe_set_lazy_adam(self.ctx, 1))
+            self.lazy_adam = True
         self.workspace = None
         self.max_queries = self.max_batches = 0
         self.reserve(max_queries, max_batches)
@@ -207,6 +215,26 @@ class Engine(object):
     def _check(self, rc):
         if rc != 0:
             raise GqeError(rc, (self.lib.gqe_last_error(self.ctx) or b"").decode())
+
+    # the arenas as the caller sees them: in lazy-Adam mode rows may owe deferred steps until synchronised
+    def sync(self):
+        if self.lazy_adam and self.workspace is not None:
+            self._check(self.lib.gqe_optimizer_sync(self.ctx, self._stream()))
+
+    @property
+    def params(self):
+        self.sync()
+        return self._params
+
+    @property
+    def exp_avg(self):
+        self.sync()
+        return self._exp_avg
+
+    @property
+    def exp_avg_sq(self):
+        self.sync()
+        return self._exp_avg_sq
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
@@ -218,6 +246,7 @@ class Engine(object):
         self.max_batches = max(max_batches, self.max_batches)
         if self.workspace is not None:
             self.materialize()            # pending gradient lists live in the old workspace
+            self.sync()                   # ... and so do the per-row step counts of lazy Adam
         nbytes = self.lib.gqe_workspace_bytes(self.ctx, self.max_queries, min(self.max_batches, MAX_BATCHES))
         if nbytes < 0:
             raise GqeError(int(nbytes), "gqe_workspace_bytes")

@@ -53,7 +53,8 @@ class _MarginLossFn(torch.autograd.Function):
 class QueryEncoderDecoder(nn.Module):
     """Encoder-decoder that scores conjunctive queries (edges, metapaths, intersections)."""
 
-    def __init__(self, graph, enc, path_dec, inter_dec, device=None, max_queries=8192, max_batches=16, rank=0, world=1):
+    def __init__(self, graph, enc, path_dec, inter_dec, device=None, max_queries=8192, max_batches=16, rank=0, world=1,
+                 lazy_adam=False):
         super(QueryEncoderDecoder, self).__init__()
         self.enc = enc
         self.path_dec = path_dec
@@ -71,7 +72,7 @@ class QueryEncoderDecoder(nn.Module):
         bags = {"enc.feat-%s.weight" % m: csr for m, csr in getattr(enc, "bag_csr", {}).items()}
         self.engine = Engine(self.dim, path_dec.kind, inter_dec.kind, layout, device=device,
                              max_queries=max_queries, max_batches=max_batches, bags=bags,
-                             rank=rank, world=world)
+                             rank=rank, world=world, lazy_adam=lazy_adam)
         # re-home every parameter into the arena (state_dict keys and values unchanged)
         for name, p in self.named_parameters():
             view = layout.view(self.engine.params, name)
@@ -83,6 +84,15 @@ class QueryEncoderDecoder(nn.Module):
         self._autograd_anchor = torch.zeros((), device=self.engine.device, requires_grad=True)
 
     # -- helpers ----------------------------------------------------------------
+    def sync(self):
+        """Lazy Adam (Engine(lazy_adam=True)): settle the deferred steps so that the ``nn.Parameter`` views show the
+        current values.  ``state_dict()`` does it implicitly."""
+        self.engine.sync()
+
+    def state_dict(self, *args, **kwargs):
+        self.engine.sync()
+        return super(QueryEncoderDecoder, self).state_dict(*args, **kwargs)
+
     def plan(self, formula):
         p = self._plans.get(formula)
         if p is None:

@@ -167,6 +167,23 @@ int gqe_margin_fwd_bwd(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches
  * The next optimiser pass then also reads (and re-zeroes) the dense table gradient. */
 int gqe_materialize_grads(gqe_ctx* ctx, void* stream);
 
+/* ---- lazy (deferred, bit-exact) Adam ---------------------------------------------------------------------
+ * torch.optim.Adam on a dense embedding gradient moves EVERY row each step — a row without a gradient still
+ * follows its decaying momentum — which is why gqe_adam_step streams 24 B per parameter per iteration.  Those
+ * zero-gradient steps depend only on the row's own (p, m, v) and the step number, so they can be replayed later
+ * with exactly the same arithmetic: in lazy mode gqe_adam_step updates only the rows the pending margin call
+ * touched and records, per row, the step count it is current for; gqe_forward / gqe_margin_fwd_bwd first replay
+ * the missing steps of the rows they are about to read (and only those), and a full pass runs whenever the
+ * 64-step coefficient ring of a table is about to wrap.  The parameters every kernel reads, and the arena after
+ * gqe_optimizer_sync, are bit-identical to the eager schedule (tests/test_gpu_parity.py::test_lazy_adam_*).
+ * Not available together with gqe_set_exchange; tables of bag modes always take the full pass.
+ *
+ * gqe_set_lazy_adam(ctx, 1)     switch on (any time no gradients are pending); 0 switches off (sync first)
+ * gqe_optimizer_sync(ctx, st)   bring every row up to date — before the caller reads or writes the parameter /
+ *                               moment arenas directly (checkpoints, state_dict, tests) */
+int gqe_set_lazy_adam(gqe_ctx* ctx, int32_t enable);
+int gqe_optimizer_sync(gqe_ctx* ctx, void* stream);
+
 /* ---- data-parallel gradient exchange (the reference is single-process) -------------------
  * Replicas exchange the gradients in the form the fused kernel produces them — contribution entries (dim floats
  * + the list head they belong to) — instead of the dense P-float table gradients.  The workspace's entry space is
@@ -220,7 +237,8 @@ int gqe_feeder_run(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations,
 /* Timing of the most recent launches of each kernel on the stream they ran on, measured with
  * hipEvents recorded by the library when enabled (bench.py's roofline block uses this:
  * torch.cuda.Event cannot see a raw hipStream).  kernel: 0 = fused fwd/bwd, 1 = param-grad
- * GEMM, 2 = optimiser.  Returns the average milliseconds over the recorded launches and
+ * GEMM, 2 = optimiser (table pass, or the sparse row launch in lazy mode), 3 = lazy mode: small dense tensors,
+ * 4 = lazy mode: catch-up launch before a read.  Returns the average milliseconds over the recorded launches and
  * their count, then clears the record. */
 int gqe_timing_enable(gqe_ctx* ctx, int32_t stride);   /* record every stride-th launch; 0 = off */
 /* Debug: when `stamps` (device, 16 int64 per workgroup of the next fused launches) is non-NULL the fused

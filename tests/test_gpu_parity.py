@@ -488,3 +488,123 @@ def test_gradient_bookkeeping_state_machine():
     small.materialize()
     small.close()
     eng.close()
+
+
+def _disjoint_batch(rng, qtype, B, lo_frac, hi_frac):
+    from gpu_utils import TOY_FORMULAS, TOY_SIZES
+    """A batch in which no table row occurs twice (so gradient lists hold one entry and every sum is
+    order-free), drawn from the [lo_frac, hi_frac) part of each table."""
+    plan = O.make_plan(qtype, TOY_FORMULAS[qtype])
+    pools = {}
+
+    def take(mode, n):
+        if mode not in pools:
+            size = TOY_SIZES[mode]
+            lo, hi = 1 + int(lo_frac * size), 1 + int(hi_frac * size)
+            pools[mode] = list(rng.permutation(np.arange(lo, hi)))
+        out = [pools[mode].pop() for _ in range(n)]
+        return np.asarray(out, dtype=np.int32)
+    t = take(plan["target_mode"], B)
+    g = take(plan["target_mode"], B)
+    a = np.stack([take(m, B) for m in plan["anchor_modes"]])
+    return t, g, a
+
+
+@pytest.mark.parametrize("dec,inter", [("bilinear-diag", "min"), ("bilinear", "mean"), ("transe", "min-simple")])
+def test_lazy_adam_is_bit_identical_to_the_eager_schedule(dec, inter):
+    """gqe_set_lazy_adam: rows without a gradient are not streamed every step; their zero-gradient Adam steps are
+    replayed when the row is next read or stepped.  150 iterations on two engines (eager / lazy) with batches built
+    so that every reduction is order-free: scores read along the way and the final (p, m, v) arenas must agree BIT
+    FOR BIT.  The row ranges move in phases, so rows lag for more steps than the 64-entry coefficient ring holds
+    (forcing the interleaved full pass) and come back later."""
+    import torch
+    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params
+    from graphqembed_amd.tensorize import pack_forward_batches, pack_margin_batches
+    rng = np.random.RandomState(5)
+    d = 32
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
+    eager = engine_from_params(params, d, dec, inter)
+    lazy = engine_from_params(params, d, dec, inter, lazy_adam=True)
+    assert lazy.lazy_adam and not eager.lazy_adam
+    # no 3-inter: its three branches add into the same Pre gradient with atomics, the only order-dependent sum
+    # left at one tile per launch — a run-to-run effect that has nothing to do with the optimiser mode
+    types = ["1-chain", "2-inter", "2-chain", "3-inter_chain", "3-chain", "3-chain_inter"]
+    B = 6
+    n_steps = 150
+    for step in range(n_steps):
+        qt = types[step % len(types)]
+        # phase A: low third of every table; phase B (after 80 steps): upper two thirds; phase C: everything
+        lo, hi = (0.0, 0.4) if step < 80 else ((0.35, 1.0) if step < 120 else (0.0, 1.0))
+        t, g, a = _disjoint_batch(rng, qt, B, lo, hi)
+        outs = []
+        for eng in (eager, lazy):
+            plan = plan_for(eng, qt, TOY_FORMULAS[qt])
+            descs, idx, n_scores = pack_margin_batches([(plan, t, g, a, 1.0, 1.0)])
+            losses, pos, neg = eng.margin_fwd_bwd(descs, idx, n_scores, want_scores=True)
+            eng.adam_step(plan.touched, 0.01)
+            outs.append((losses.clone(), pos.clone(), neg.clone()))
+        for x, y in zip(*outs):
+            assert torch.equal(x, y), "step %d (%s): forward differs between eager and lazy" % (step, qt)
+        if step % 37 == 5:      # a forward-only read of rows that may lag (replayed by the catch-up launch)
+            tt, _, aa = _disjoint_batch(rng, "2-inter", B, 0.0, 1.0)
+            sc = []
+            for eng in (eager, lazy):
+                descs, idx, n = pack_forward_batches([(plan_for(eng, "2-inter", TOY_FORMULAS["2-inter"]), tt, aa)])
+                sc.append(eng.forward(descs, idx, n).clone())
+            assert torch.equal(sc[0], sc[1])
+    torch.cuda.synchronize()
+    # lazy really was lazy: before the sync its arena differs from the eager one ...
+    assert not torch.equal(lazy._params, eager._params)
+    # ... and after it (the properties synchronise) everything is bit-identical
+    assert torch.equal(lazy.params, eager.params)
+    assert torch.equal(lazy.exp_avg, eager.exp_avg)
+    assert torch.equal(lazy.exp_avg_sq, eager.exp_avg_sq)
+    for e in (eager, lazy):
+        e.close()
+
+
+def test_lazy_adam_state_machine():
+    import torch
+    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params
+    from graphqembed_amd.engine import GqeError
+    from graphqembed_amd.tensorize import pack_margin_batches
+    rng = np.random.RandomState(2)      # min-simple: two margin calls accumulating into a Pre gradient would add in atomic order
+    d = 32
+    params = random_params(rng, d, "bilinear-diag", "min-simple", TOY_SIZES, TOY_KINDS)
+    eng = engine_from_params(params, d, "bilinear-diag", "min-simple", lazy_adam=True)
+    ref = engine_from_params(params, d, "bilinear-diag", "min-simple")
+    plan_l, plan_r = plan_for(eng, "2-inter", TOY_FORMULAS["2-inter"]), plan_for(ref, "2-inter", TOY_FORMULAS["2-inter"])
+    for step in range(5):
+        t, g, a = _disjoint_batch(rng, "2-inter", 8, 0.0, 0.5)
+        for e, pl in ((eng, plan_l), (ref, plan_r)):
+            descs, idx, n = pack_margin_batches([(pl, t, g, a, 1.0, 1.0)])
+            e.margin_fwd_bwd(descs, idx, n)
+            # a different learning rate half way: the deferred steps are settled with the old one first
+            e.adam_step(pl.touched, 0.01 if step < 3 else 0.003)
+    # two margin calls before one step: the lists of the first are not named by the second call's feed -> full pass
+    for _ in range(2):
+        t, g, a = _disjoint_batch(rng, "2-inter", 8, 0.5, 1.0)
+        for e, pl in ((eng, plan_l), (ref, plan_r)):
+            descs, idx, n = pack_margin_batches([(pl, t, g, a, 1.0, 1.0)])
+            e.margin_fwd_bwd(descs, idx, n)
+    for e, pl in ((eng, plan_l), (ref, plan_r)):
+        e.adam_step(pl.touched, 0.003)
+    # SGD after Adam: rows settle their Adam debt first
+    t, g, a = _disjoint_batch(rng, "2-inter", 8, 0.0, 1.0)
+    for e, pl in ((eng, plan_l), (ref, plan_r)):
+        descs, idx, n = pack_margin_batches([(pl, t, g, a, 1.0, 1.0)])
+        e.margin_fwd_bwd(descs, idx, n)
+        e.sgd_step(pl.touched, 0.05)
+    assert torch.equal(eng.params, ref.params) and torch.equal(eng.exp_avg_sq, ref.exp_avg_sq)
+    # leaving lazy mode needs a sync; the exchange mode refuses lazy engines
+    t, g, a = _disjoint_batch(rng, "2-inter", 8, 0.0, 0.5)
+    descs, idx, n = pack_margin_batches([(plan_l, t, g, a, 1.0, 1.0)])
+    eng.margin_fwd_bwd(descs, idx, n)
+    eng.adam_step(plan_l.touched, 0.003)
+    assert eng.lib.gqe_set_lazy_adam(eng.ctx, 0) != 0
+    eng.sync()
+    assert eng.lib.gqe_set_lazy_adam(eng.ctx, 0) == 0
+    with pytest.raises(GqeError):
+        engine_from_params(params, d, "bilinear-diag", "min-simple", lazy_adam=True, rank=0, world=2)
+    eng.close()
+    ref.close()
