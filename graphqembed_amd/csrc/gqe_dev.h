@@ -101,6 +101,7 @@ struct GqeStepCoef {
 
 // ---- lazy rows (gqe_set_lazy_adam; see gqe_kernels.hip) ----
 #define GQE_LAZY_RING 64        // per-table ring of (step_size, bc2_sqrt) of the last 64 Adam steps
+#define GQE_LAZY_PERIOD 32      // a full pass at least this often per table: bounds how many steps a row can owe
 #define GQE_LAZY_TABLES 8
 #define GQE_LAZY_SEGS 96        // index-feed segments one rows launch can cover
 struct GqeLazyTabs {
@@ -127,14 +128,20 @@ struct GqeRowsArgs {
   const int32_t* idx;
   int32_t* last;
   float2* ring;
-  float *p, *m, *v;
+  float *p, *g, *m, *v;
   int32_t* head;
   const int32_t* next;
   const float* contrib;
   int32_t max_entries;
   int d;
-  float b1, b2, eps;
+  float lr, b1, b2, eps;
   bool with_grad, sorted;
+  // the step's small dense tensors ride in extra workgroups of the same launch (dense_chunks == 0: none)
+  const GqeDevSeg* dsegs;
+  int n_dsegs;
+  long long dense_chunks;
+  GqeStepCoef dcoef;
+  GqeOptActive dactive;
   hipStream_t stream;
 };
 

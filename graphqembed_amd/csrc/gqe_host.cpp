@@ -494,8 +494,15 @@ void lazy_rows_args(const gqe_ctx* ctx, GqeRowsArgs& ra, hipStream_t st) {
   ra.last = reinterpret_cast<int32_t*>(ctx->ws + L.last_off);
   ra.ring = reinterpret_cast<float2*>(ctx->ws + L.ring_off);
   ra.p = ctx->params;
+  ra.g = ctx->grads;
   ra.m = ctx->m;
   ra.v = ctx->v;
+  ra.lr = ctx->lz_lr;
+  ra.dsegs = nullptr;
+  ra.n_dsegs = 0;
+  ra.dense_chunks = 0;
+  memset(&ra.dcoef, 0, sizeof ra.dcoef);
+  memset(ra.dactive.group, 0xFF, sizeof ra.dactive.group);
   ra.head = reinterpret_cast<int32_t*>(ctx->ws + L.head_off);
   ra.next = reinterpret_cast<const int32_t*>(ctx->ws + L.next_off);
   ra.contrib = reinterpret_cast<const float*>(ctx->ws + L.contrib_off);
@@ -930,7 +937,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       sparse = lists && ctx->feed_valid && !ctx->dense_dirty && ctx->world == 1 && ctx->bags.empty() &&
                (int)ctx->tables.size() <= GQE_LAZY_TABLES && (64 % (d / 4)) == 0;
       for (size_t t = 0; t < ctx->tables.size() && sparse; ++t)
-        if (seen[t] && ctx->tables[t].since_full >= GQE_LAZY_RING - 2) sparse = false;  // ring slot about to be reused
+        if (seen[t] && ctx->tables[t].since_full >= GQE_LAZY_PERIOD) sparse = false;  // bound the replay depth of any row
     }
     auto coef_of = [&](size_t t, float* ss, float* bc) {
       for (size_t ui = 0; ui < ctx->universe.size(); ++ui)
@@ -951,32 +958,28 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
           ra.t.target[t] = ra.t.grad_step[t] = ctx->tables[t].lstep + 1;
           coef_of(t, &ra.t.step_size[t], &ra.t.bc2_sqrt[t]);
         }
-      rc = timing_begin(ctx, 2, st);
-      if (rc != GQE_OK) return rc;
-      for (const SavedFeed& sf : ctx->feed) {
-        ra.segs = sf.segs;
-        HIP_TRY(ctx, gqe_launch_rows(ra));
-      }
-      rc = timing_end(ctx, 2, st);
-      if (rc != GQE_OK) return rc;
-      if (ctx->feed_buf >= 0) HIP_TRY(ctx, hipEventRecord(ctx->plan_free[ctx->feed_buf], st));  // the staged feed may go now
-      // the small dense tensors: the ordinary pass, tables masked out
+      // the small dense tensors ride in extra workgroups of the (first) row launch: the ordinary pass, tables masked out
       long long dense_chunks = 0;
       for (size_t ui = 0; ui < ctx->universe.size(); ++ui) {
         if (oa.active.group[ui] == 0xFF) continue;
         if (ctx->universe[ui].is_table) oa.active.group[ui] = 0xFF;
         else dense_chunks += ctx->universe[ui].n_chunks;
       }
-      if (dense_chunks > 0) {
-        oa.total_chunks = dense_chunks;
-        oa.lists = false;
-        oa.dense_tables = false;
-        rc = timing_begin(ctx, 3, st);
-        if (rc != GQE_OK) return rc;
-        HIP_TRY(ctx, gqe_launch_opt(oa));
-        rc = timing_end(ctx, 3, st);
-        if (rc != GQE_OK) return rc;
+      ra.dsegs = oa.segs;
+      ra.n_dsegs = oa.n_segs;
+      ra.dense_chunks = dense_chunks;
+      ra.dcoef = oa.coef;
+      ra.dactive = oa.active;
+      rc = timing_begin(ctx, 2, st);
+      if (rc != GQE_OK) return rc;
+      for (const SavedFeed& sf : ctx->feed) {
+        ra.segs = sf.segs;
+        HIP_TRY(ctx, gqe_launch_rows(ra));
+        ra.dense_chunks = 0;
       }
+      rc = timing_end(ctx, 2, st);
+      if (rc != GQE_OK) return rc;
+      if (ctx->feed_buf >= 0) HIP_TRY(ctx, hipEventRecord(ctx->plan_free[ctx->feed_buf], st));  // the staged feed may go now
       for (size_t t = 0; t < ctx->tables.size(); ++t)
         if (seen[t]) {
           ++ctx->tables[t].lstep;

@@ -140,26 +140,30 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
 //   MODE = ADAM | SGD | ZERO (drop gradients) | MATERIALIZE (fold the lists into the dense gradient).
 // ------------------------------------------------------------------------------------------
 // One Adam step of one element, torch.optim.Adam's formulas (exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2 v + (1-b2) g g;
-// p -= step_size * exp_avg / (sqrt(exp_avg_sq) / bc2_sqrt + eps)).  Every operation is spelled out with its rounding so
-// that the eager pass and the replay of deferred steps (lazy rows, below) execute the SAME sequence and agree bit
-// for bit — with contraction left to the compiler the two call sites could fuse differently.
-__device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, float step_size, float bc2_sqrt, float b1c,
+// p -= step_size * exp_avg / (sqrt(exp_avg_sq) / bc2_sqrt + eps)).  Every operation is spelled out — fused
+// multiply-adds where they are wanted, the hardware's v_sqrt_f32 / v_rcp_f32 (1 ulp) for the root and the two
+// divisions — so that the eager pass and the replay of deferred steps (lazy rows, below) execute the SAME
+// instruction sequence and agree bit for bit; left to the compiler, two call sites may contract differently.  The
+// 1-ulp primitives keep a replayed step at ~15 instructions per element (the IEEE expansions are 3x that and sit
+// on the critical path of a row that owes dozens of steps); against torch's IEEE result the update differs in the
+// last bit or two, far inside the tolerance of every parity test (and of fp32 training itself).
+__device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, float step_size, float inv_bc2, float b1c,
                                       float b2, float b2c, float eps) {
   m = __fmaf_rn(b1c, __fsub_rn(g, m), m);
   v = __fmaf_rn(__fmul_rn(b2c, g), g, __fmul_rn(v, b2));
-  const float den = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);
-  p = __fmaf_rn(-step_size, __fdiv_rn(m, den), p);
+  const float den = __fmaf_rn(__builtin_amdgcn_sqrtf(v), inv_bc2, eps);
+  p = __fmaf_rn(-step_size, __fmul_rn(m, __builtin_amdgcn_rcpf(den)), p);
 }
 
 template <int MODE>
 __device__ __forceinline__ void opt_update(float4& pp, float4& mm, float4& vv, const float4& gg, float step_size,
                                            float bc2_sqrt, float lr, float b1, float b2, float eps) {
   if (MODE == GQE_OPT_ADAM) {
-    const float b1c = 1.f - b1, b2c = 1.f - b2;
-    adam1(pp.x, mm.x, vv.x, gg.x, step_size, bc2_sqrt, b1c, b2, b2c, eps);
-    adam1(pp.y, mm.y, vv.y, gg.y, step_size, bc2_sqrt, b1c, b2, b2c, eps);
-    adam1(pp.z, mm.z, vv.z, gg.z, step_size, bc2_sqrt, b1c, b2, b2c, eps);
-    adam1(pp.w, mm.w, vv.w, gg.w, step_size, bc2_sqrt, b1c, b2, b2c, eps);
+    const float b1c = 1.f - b1, b2c = 1.f - b2, ibc = __builtin_amdgcn_rcpf(bc2_sqrt);
+    adam1(pp.x, mm.x, vv.x, gg.x, step_size, ibc, b1c, b2, b2c, eps);
+    adam1(pp.y, mm.y, vv.y, gg.y, step_size, ibc, b1c, b2, b2c, eps);
+    adam1(pp.z, mm.z, vv.z, gg.z, step_size, ibc, b1c, b2, b2c, eps);
+    adam1(pp.w, mm.w, vv.w, gg.w, step_size, ibc, b1c, b2, b2c, eps);
   } else {
     pp.x -= lr * gg.x;
     pp.y -= lr * gg.y;
@@ -247,15 +251,17 @@ __device__ __forceinline__ void lazy_advance(float4& pp, float4& mm, float4& vv,
       bc = c.y;
     }
     const bool gs = j == grad_step;
-    adam1(pp.x, mm.x, vv.x, gs ? gg.x : 0.f, ss, bc, b1c, b2, b2c, eps);
-    adam1(pp.y, mm.y, vv.y, gs ? gg.y : 0.f, ss, bc, b1c, b2, b2c, eps);
-    adam1(pp.z, mm.z, vv.z, gs ? gg.z : 0.f, ss, bc, b1c, b2, b2c, eps);
-    adam1(pp.w, mm.w, vv.w, gs ? gg.w : 0.f, ss, bc, b1c, b2, b2c, eps);
+    const float ibc = __builtin_amdgcn_rcpf(bc);
+    adam1(pp.x, mm.x, vv.x, gs ? gg.x : 0.f, ss, ibc, b1c, b2, b2c, eps);
+    adam1(pp.y, mm.y, vv.y, gs ? gg.y : 0.f, ss, ibc, b1c, b2, b2c, eps);
+    adam1(pp.z, mm.z, vv.z, gs ? gg.z : 0.f, ss, ibc, b1c, b2, b2c, eps);
+    adam1(pp.w, mm.w, vv.w, gs ? gg.w : 0.f, ss, ibc, b1c, b2, b2c, eps);
   }
 }
 
 template <int MODE, bool LISTS, bool DENSE_T, bool SORTED, bool LAZY>
-__global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* __restrict__ segs, int n_segs,
+__device__ __forceinline__ void opt_body(const long long first_chunk, const long long chunk_stride,
+                                         const GqeDevSeg* __restrict__ segs, int n_segs,
                                                              long long total_chunks, float* __restrict__ p,
                                                              float* __restrict__ g, float* __restrict__ m,
                                                              float* __restrict__ v, int32_t* __restrict__ head,
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
                                                              const float* __restrict__ contrib,
                                                              const int32_t* __restrict__ link_contrib, int max_entries,
                                                              int d, float lr, float b1, float b2, float eps,
-                                                             GqeStepCoef coef, GqeOptActive active, GqeLazyArgs lazy) {
+                                                             const GqeStepCoef& coef, const GqeOptActive& active, const GqeLazyArgs& lazy) {
   __shared__ long long s_begin[GQE_MAX_SEGS + 1];  // chunk prefix over the universe; inactive tensors get 0 chunks
   __shared__ long long s_cnt[GQE_MAX_SEGS];
   if ((int)threadIdx.x < n_segs) s_cnt[threadIdx.x] = (active.group[threadIdx.x] != 0xFF) ? segs[threadIdx.x].n_chunks : 0;
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
   const int c4 = (threadIdx.x - lr_row * tpr) * 4;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   int si = 0;
-  for (long long ch = blockIdx.x; ch < total_chunks; ch += gridDim.x) {
+  for (long long ch = first_chunk; ch < total_chunks; ch += chunk_stride) {
     while (s_begin[si + 1] <= ch) ++si;  // chunks are visited in increasing order
     const GqeDevSeg sg = segs[si];
     const long long chunk_begin = s_begin[si];
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
         if (MODE == GQE_OPT_ZERO) continue;
         if (MODE == GQE_OPT_ADAM) {
           float pp = p[o], mm = m[o], vv = v[o];
-          adam1(pp, mm, vv, gg, step_size, bc2_sqrt, 1.f - b1, b2, 1.f - b2, eps);
+          adam1(pp, mm, vv, gg, step_size, __builtin_amdgcn_rcpf(bc2_sqrt), 1.f - b1, b2, 1.f - b2, eps);
           m[o] = mm;
           v[o] = vv;
           p[o] = pp;
@@ -394,6 +400,20 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
       }
     }
   }
+}
+
+template <int MODE, bool LISTS, bool DENSE_T, bool SORTED, bool LAZY>
+__global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* __restrict__ segs, int n_segs,
+                                                             long long total_chunks, float* __restrict__ p,
+                                                             float* __restrict__ g, float* __restrict__ m,
+                                                             float* __restrict__ v, int32_t* __restrict__ head,
+                                                             const int32_t* __restrict__ next,
+                                                             const float* __restrict__ contrib,
+                                                             const int32_t* __restrict__ link_contrib, int max_entries,
+                                                             int d, float lr, float b1, float b2, float eps,
+                                                             GqeStepCoef coef, GqeOptActive active, GqeLazyArgs lazy) {
+  opt_body<MODE, LISTS, DENSE_T, SORTED, LAZY>(blockIdx.x, gridDim.x, segs, n_segs, total_chunks, p, g, m, v, head, next,
+                                                contrib, link_contrib, max_entries, d, lr, b1, b2, eps, coef, active, lazy);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -455,10 +475,27 @@ template <bool WITH_GRAD, bool SORTED>
 __global__ __launch_bounds__(GQE_THREADS) void gqe_rows_kernel(const GqeRowSegs segs, const GqeLazyTabs t,
                                                               const int32_t* __restrict__ idx, int32_t* __restrict__ last,
                                                               float2* __restrict__ ring, float* __restrict__ p,
-                                                              float* __restrict__ m, float* __restrict__ v,
-                                                              int32_t* __restrict__ head, const int32_t* __restrict__ next,
+                                                              float* __restrict__ g, float* __restrict__ m,
+                                                              float* __restrict__ v, int32_t* __restrict__ head,
+                                                              const int32_t* __restrict__ next,
                                                               const float* __restrict__ contrib, int max_entries, int d,
-                                                              float b1, float b2, float eps) {
+                                                              float lr, float b1, float b2, float eps, int n_row_blocks,
+                                                              const GqeDevSeg* __restrict__ dsegs, int n_dsegs,
+                                                              long long dense_chunks, GqeStepCoef dcoef, GqeOptActive dactive) {
+  if ((int)blockIdx.x >= n_row_blocks) {
+    // the step's small dense tensors (relation vectors / matrices, Pre / Post): the ordinary chunk loop
+    GqeLazyArgs none;
+    none.last = nullptr;
+    none.ring = nullptr;
+    opt_body<GQE_OPT_ADAM, false, false, false, false>((long long)blockIdx.x - n_row_blocks, (long long)gridDim.x - n_row_blocks,
+                                                       dsegs, n_dsegs, dense_chunks, p, g, m, v, head, next, contrib, nullptr,
+                                                       max_entries, d, lr, b1, b2, eps, dcoef, dactive, none);
+    return;
+  }
+  // the coefficient rings go through LDS: a replay of k steps would otherwise chain k dependent global loads
+  __shared__ float2 s_ring[GQE_LAZY_TABLES * GQE_LAZY_RING];
+  for (int i = threadIdx.x; i < GQE_LAZY_TABLES * GQE_LAZY_RING; i += GQE_THREADS) s_ring[i] = ring[i];
+  __syncthreads();
   if (WITH_GRAD && blockIdx.x == 0 && threadIdx.x < GQE_LAZY_TABLES && t.grad_step[threadIdx.x] > 0)
     ring[threadIdx.x * GQE_LAZY_RING + (t.grad_step[threadIdx.x] & (GQE_LAZY_RING - 1))] =
         make_float2(t.step_size[threadIdx.x], t.bc2_sqrt[threadIdx.x]);
@@ -466,32 +503,30 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_rows_kernel(const GqeRowSegs 
   const int e = (int)(((long long)blockIdx.x * GQE_THREADS + threadIdx.x) / tpr);
   if (e >= segs.total) return;
   const int c4 = (threadIdx.x % tpr) * 4;
-  int k = 0;  // segment of entry e: begin[k] <= e < begin[k+1]
-  for (int step = 64; step > 0; step >>= 1)
-    if (k + step < segs.n && segs.begin[k + step] <= e) k += step;
+  int k = 0;  // segment of entry e: begin[k] <= e < begin[k+1]; a scan with uniform (scalar) loads of the kernel
+  for (int i = 1; i < segs.n; ++i) k += (e >= segs.begin[i]) ? 1 : 0;  // arguments, not a per-lane search through memory
   const int lt = segs.tid[k];
   if (lt < 0) return;
   const int row = idx[segs.idx_begin[k] + (e - segs.begin[k])];
   if (row < 0) return;  // padding query
   const int target = t.target[lt];
   const long long hrow = t.head_base[lt] + row;
+  const long long off = t.offset[lt] + (long long)row * d + c4;
+  // everything the update needs is requested before the claim's round trip is awaited
   int from = 0;
   if (c4 == 0) from = __hip_atomic_fetch_max(last + hrow, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  from = __shfl(from, (threadIdx.x & 63) / tpr * tpr);
-  if (from >= target) return;  // someone else brought (or is bringing) the row there
-  const long long off = t.offset[lt] + (long long)row * d + c4;
-  float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (WITH_GRAD) {
-    const int h0 = head[hrow];
-    if (h0 >= 0) {
-      gg = list_gradient<SORTED>(h0, next, contrib, nullptr, max_entries, d, c4);
-      if (c4 == 0) head[hrow] = -1;
-    }
-  }
   float4 pp = *reinterpret_cast<const float4*>(p + off);
   float4 mm = *reinterpret_cast<const float4*>(m + off);
   float4 vv = *reinterpret_cast<const float4*>(v + off);
-  lazy_advance(pp, mm, vv, gg, from, target, t.grad_step[lt], ring + lt * GQE_LAZY_RING, t.step_size[lt], t.bc2_sqrt[lt],
+  const int h0 = WITH_GRAD ? head[hrow] : -1;
+  from = __shfl(from, (threadIdx.x & 63) / tpr * tpr);
+  if (from >= target) return;  // someone else brought (or is bringing) the row there
+  float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (WITH_GRAD && h0 >= 0) {
+    gg = list_gradient<SORTED>(h0, next, contrib, nullptr, max_entries, d, c4);
+    if (c4 == 0) head[hrow] = -1;
+  }
+  lazy_advance(pp, mm, vv, gg, from, target, t.grad_step[lt], s_ring + lt * GQE_LAZY_RING, t.step_size[lt], t.bc2_sqrt[lt],
                t.grad_step[lt], b1, b2, eps);
   *reinterpret_cast<float4*>(m + off) = mm;
   *reinterpret_cast<float4*>(v + off) = vv;
@@ -499,12 +534,14 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_rows_kernel(const GqeRowSegs 
 }
 
 hipError_t gqe_launch_rows(const GqeRowsArgs& a) {
-  if (a.segs.total < 1) return hipSuccess;
+  if (a.segs.total < 1 && a.dense_chunks < 1) return hipSuccess;
   const long long threads = (long long)a.segs.total * (a.d >> 2);
-  const unsigned blocks = (unsigned)((threads + GQE_THREADS - 1) / GQE_THREADS);
+  const unsigned row_blocks = (unsigned)((threads + GQE_THREADS - 1) / GQE_THREADS);
+  const unsigned dense_blocks = (unsigned)(a.dense_chunks < 512 ? a.dense_chunks : 512);
 #define GO(G, S)                                                                                                          \
-  hipLaunchKernelGGL((gqe_rows_kernel<G, S>), dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.t, a.idx, a.last,     \
-                     a.ring, a.p, a.m, a.v, a.head, a.next, a.contrib, a.max_entries, a.d, a.b1, a.b2, a.eps)
+  hipLaunchKernelGGL((gqe_rows_kernel<G, S>), dim3(row_blocks + dense_blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.t,  \
+                     a.idx, a.last, a.ring, a.p, a.g, a.m, a.v, a.head, a.next, a.contrib, a.max_entries, a.d, a.lr, a.b1,   \
+                     a.b2, a.eps, (int)row_blocks, a.dsegs, a.n_dsegs, a.dense_chunks, a.dcoef, a.dactive)
   if (a.with_grad) {
     if (a.sorted) GO(true, true); else GO(true, false);
   } else {
