@@ -1,6 +1,7 @@
 // gqe_kernels.hip — pair-GEMM (deferred matrix gradients), fused optimiser pass and the dispatcher of
 // the fused query kernel (gqe_fused.h, instantiated per decoder variant in gqe_fused_inst.hip).
 #include "gqe_common.h"
+#include "gqe_adam.h"
 
 // ------------------------------------------------------------------------------------------
 // deferred matrix gradients:  dM[i][j] += sum_b L[b][i] * R[b][j]   (rank-B update on the matrix cores)
@@ -139,31 +140,15 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
 //       at 24 B/param, the dense table gradient is neither read nor re-zeroed.
 //   MODE = ADAM | SGD | ZERO (drop gradients) | MATERIALIZE (fold the lists into the dense gradient).
 // ------------------------------------------------------------------------------------------
-// One Adam step of one element, torch.optim.Adam's formulas (exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2 v + (1-b2) g g;
-// p -= step_size * exp_avg / (sqrt(exp_avg_sq) / bc2_sqrt + eps)).  Every operation is spelled out — fused
-// multiply-adds where they are wanted, the hardware's v_sqrt_f32 / v_rcp_f32 (1 ulp) for the root and the two
-// divisions — so that the eager pass and the replay of deferred steps (lazy rows, below) execute the SAME
-// instruction sequence and agree bit for bit; left to the compiler, two call sites may contract differently.  The
-// 1-ulp primitives keep a replayed step at ~15 instructions per element (the IEEE expansions are 3x that and sit
-// on the critical path of a row that owes dozens of steps); against torch's IEEE result the update differs in the
-// last bit or two, far inside the tolerance of every parity test (and of fp32 training itself).
-__device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, float step_size, float inv_bc2, float b1c,
-                                      float b2, float b2c, float eps) {
-  m = __fmaf_rn(b1c, __fsub_rn(g, m), m);
-  v = __fmaf_rn(__fmul_rn(b2c, g), g, __fmul_rn(v, b2));
-  const float den = __fmaf_rn(__builtin_amdgcn_sqrtf(v), inv_bc2, eps);
-  p = __fmaf_rn(-step_size, __fmul_rn(m, __builtin_amdgcn_rcpf(den)), p);
-}
-
 template <int MODE>
 __device__ __forceinline__ void opt_update(float4& pp, float4& mm, float4& vv, const float4& gg, float step_size,
                                            float bc2_sqrt, float lr, float b1, float b2, float eps) {
   if (MODE == GQE_OPT_ADAM) {
     const float b1c = 1.f - b1, b2c = 1.f - b2, ibc = __builtin_amdgcn_rcpf(bc2_sqrt);
-    adam1(pp.x, mm.x, vv.x, gg.x, step_size, ibc, b1c, b2, b2c, eps);
-    adam1(pp.y, mm.y, vv.y, gg.y, step_size, ibc, b1c, b2, b2c, eps);
-    adam1(pp.z, mm.z, vv.z, gg.z, step_size, ibc, b1c, b2, b2c, eps);
-    adam1(pp.w, mm.w, vv.w, gg.w, step_size, ibc, b1c, b2, b2c, eps);
+    gqe_adam1(pp.x, mm.x, vv.x, gg.x, step_size, ibc, b1c, b2, b2c, eps);
+    gqe_adam1(pp.y, mm.y, vv.y, gg.y, step_size, ibc, b1c, b2, b2c, eps);
+    gqe_adam1(pp.z, mm.z, vv.z, gg.z, step_size, ibc, b1c, b2, b2c, eps);
+    gqe_adam1(pp.w, mm.w, vv.w, gg.w, step_size, ibc, b1c, b2, b2c, eps);
   } else {
     pp.x -= lr * gg.x;
     pp.y -= lr * gg.y;
@@ -252,10 +237,10 @@ __device__ __forceinline__ void lazy_advance(float4& pp, float4& mm, float4& vv,
     }
     const bool gs = j == grad_step;
     const float ibc = __builtin_amdgcn_rcpf(bc);
-    adam1(pp.x, mm.x, vv.x, gs ? gg.x : 0.f, ss, ibc, b1c, b2, b2c, eps);
-    adam1(pp.y, mm.y, vv.y, gs ? gg.y : 0.f, ss, ibc, b1c, b2, b2c, eps);
-    adam1(pp.z, mm.z, vv.z, gs ? gg.z : 0.f, ss, ibc, b1c, b2, b2c, eps);
-    adam1(pp.w, mm.w, vv.w, gs ? gg.w : 0.f, ss, ibc, b1c, b2, b2c, eps);
+    gqe_adam1(pp.x, mm.x, vv.x, gs ? gg.x : 0.f, ss, ibc, b1c, b2, b2c, eps);
+    gqe_adam1(pp.y, mm.y, vv.y, gs ? gg.y : 0.f, ss, ibc, b1c, b2, b2c, eps);
+    gqe_adam1(pp.z, mm.z, vv.z, gs ? gg.z : 0.f, ss, ibc, b1c, b2, b2c, eps);
+    gqe_adam1(pp.w, mm.w, vv.w, gs ? gg.w : 0.f, ss, ibc, b1c, b2, b2c, eps);
   }
 }
 
@@ -390,7 +375,7 @@ __device__ __forceinline__ void opt_body(const long long first_chunk, const long
         if (MODE == GQE_OPT_ZERO) continue;
         if (MODE == GQE_OPT_ADAM) {
           float pp = p[o], mm = m[o], vv = v[o];
-          adam1(pp, mm, vv, gg, step_size, __builtin_amdgcn_rcpf(bc2_sqrt), 1.f - b1, b2, 1.f - b2, eps);
+          gqe_adam1(pp, mm, vv, gg, step_size, __builtin_amdgcn_rcpf(bc2_sqrt), 1.f - b1, b2, 1.f - b2, eps);
           m[o] = mm;
           v[o] = vv;
           p[o] = pp;

@@ -510,8 +510,9 @@ def _disjoint_batch(rng, qtype, B, lo_frac, hi_frac):
     return t, g, a
 
 
-@pytest.mark.parametrize("dec,inter", [("bilinear-diag", "min"), ("bilinear", "mean"), ("transe", "min-simple")])
-def test_lazy_adam_is_bit_identical_to_the_eager_schedule(dec, inter):
+@pytest.mark.parametrize("dec,inter,d", [("bilinear-diag", "min", 32), ("bilinear", "mean", 32), ("transe", "min-simple", 32),
+                                         ("bilinear-diag", "min", 64), ("bilinear", "mean", 64), ("transe", "mean", 128)])
+def test_lazy_adam_is_bit_identical_to_the_eager_schedule(dec, inter, d):
     """gqe_set_lazy_adam: rows without a gradient are not streamed every step; their zero-gradient Adam steps are
     replayed when the row is next read or stepped.  150 iterations on two engines (eager / lazy) with batches built
     so that every reduction is order-free: scores read along the way and the final (p, m, v) arenas must agree BIT
@@ -521,7 +522,6 @@ def test_lazy_adam_is_bit_identical_to_the_eager_schedule(dec, inter):
     from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params
     from graphqembed_amd.tensorize import pack_forward_batches, pack_margin_batches
     rng = np.random.RandomState(5)
-    d = 32
     params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
     eager = engine_from_params(params, d, dec, inter)
     lazy = engine_from_params(params, d, dec, inter, lazy_adam=True)
