@@ -608,3 +608,63 @@ def test_lazy_adam_state_machine():
         engine_from_params(params, d, "bilinear-diag", "min-simple", lazy_adam=True, rank=0, world=2)
     eng.close()
     ref.close()
+
+
+@pytest.mark.parametrize("dec,inter", [("bilinear-diag", "min"), ("bilinear", "mean")])
+def test_full_size_properties(dec, inter):
+    """Size-independent properties at the BASELINE sizes (full mix, B=512, d=128), no oracle involved:
+      * linearity: loss weights x2 -> every gradient x2 (a power of two: only summation order can differ);
+      * batching: the same batches twice in one grouped launch == one launch called twice == 2 x the gradient;
+      * permutation: shuffling the queries of a batch permutes its scores and leaves loss and gradients alone;
+      * a forward of the same queries reproduces the margin call's positive scores."""
+    import torch
+    from gpu_utils import (TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, read_arena,
+                           toy_batch)
+    from graphqembed_amd.tensorize import pack_forward_batches, pack_margin_batches
+    d, B = 128, 512
+    mix = [("1-chain", 1.0), ("2-chain", 0.01), ("3-chain", 0.01), ("2-inter", 0.005), ("3-inter", 0.005), ("3-inter_chain", 0.005),
+           ("3-chain_inter", 0.005)]
+    rng = np.random.RandomState(17)
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
+    eng = engine_from_params(params, d, dec, inter, max_queries=2 * B * len(mix), max_batches=2 * len(mix))
+    base = []
+    for qt, w in mix:
+        t, g, a = toy_batch(rng, qt, B)
+        base.append((plan_for(eng, qt, TOY_FORMULAS[qt]), t, g, a, w, 1.0))
+
+    def run(items):
+        eng.zero_grads(list(eng.layout.entries))
+        descs, idx, n = pack_margin_batches(items)
+        losses, pos, neg = eng.margin_fwd_bwd(descs, torch.from_numpy(idx).cuda(), n, want_scores=True)
+        grads = read_arena(eng, eng.grads)
+        return losses.cpu().numpy(), pos.cpu().numpy(), neg.cpu().numpy(), grads
+
+    def close(a, b, what, factor=1.0):
+        for k in a:
+            scale = max(1e-12, float(np.abs(b[k]).max()))
+            np.testing.assert_allclose(a[k], factor * b[k], rtol=0, atol=3e-5 * factor * scale, err_msg="%s %s" % (what, k))
+
+    l1, p1, n1, g1 = run(base)
+    # linearity in the loss weight
+    l2, p2, n2, g2 = run([(pl, t, g, a, 2.0 * w, m) for (pl, t, g, a, w, m) in base])
+    assert np.array_equal(p1, p2) and np.array_equal(n1, n2)
+    np.testing.assert_allclose(l2[:-1], l1[:-1], rtol=1e-6)          # per-batch mean losses do not carry the weight
+    np.testing.assert_allclose(l2[-1], 2.0 * l1[-1], rtol=1e-5)
+    close(g2, g1, "weights x2", 2.0)
+    # the batches twice in one grouped launch
+    l3, p3, n3, g3 = run(base + base)
+    assert np.array_equal(p3[: len(p1)], p1) and np.array_equal(p3[len(p1):], p1)
+    close(g3, g1, "batches twice", 2.0)
+    # permutation of the queries inside every batch
+    perms = [rng.permutation(B) for _ in base]
+    l4, p4, n4, g4 = run([(pl, t[pm], g[pm], a[:, pm], w, m) for (pl, t, g, a, w, m), pm in zip(base, perms)])
+    off = 0
+    for pm in perms:
+        assert np.array_equal(p4[off:off + B], p1[off:off + B][pm]) and np.array_equal(n4[off:off + B], n1[off:off + B][pm])
+        off += B
+    np.testing.assert_allclose(l4, l1, rtol=2e-6)
+    close(g4, g1, "permuted queries")
+    # forward() of the same (target, anchors) = the positive scores of the margin call
+    descs, idx, n = pack_forward_batches([(pl, t, a) for (pl, t, g, a, w, m) in base])
+    np.testing.assert_allclose(eng.forward(descs, idx, n).cpu().numpy(), p1, rtol=0, atol=1e-6)   # (the training variant
+    eng.close()                                                             # of the Bilinear chain contracts in another order)
