@@ -341,8 +341,9 @@ def test_error_paths():
     eng.close()
 
 
-def test_native_feeder_matches_python_driven_iterations():
-    """gqe_feeder_run (C++ sampling + packing + launch + step) against the same iterations driven
+@pytest.mark.parametrize("lazy", [False, True])
+def test_native_feeder_matches_python_driven_iterations(lazy):
+    """(lazy=True: the feeder engine runs in lazy-Adam mode, the Python-driven one eagerly.)  gqe_feeder_run (C++ sampling + packing + launch + step) against the same iterations driven
     from Python: one pool per query type (so the formula draw is forced), 1-chain negatives drawn from a
     single-row list (so the RNG cannot matter), batch size that wraps around the pools."""
     import torch
@@ -353,7 +354,7 @@ def test_native_feeder_matches_python_driven_iterations():
     rng = np.random.RandomState(11)
     d, dec, inter, B = 64, "bilinear-diag", "min", 48
     params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
-    engs = [engine_from_params(params, d, dec, inter) for _ in range(2)]
+    engs = [engine_from_params(params, d, dec, inter, lazy_adam=lazy), engine_from_params(params, d, dec, inter)]
     pools = []
     for qtype in ("1-chain", "2-chain", "2-inter", "3-inter_chain", "3-chain_inter"):
         t, g, a = toy_batch(rng, qtype, 100)
