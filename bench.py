@@ -198,6 +198,8 @@ def main():
                     "smoke-test the multi-rank path on a single GPU)")
     ap.add_argument("--exchange", default="sparse", choices=["sparse", "dense"],
                     help="--gpus > 1: all-gather the gradient contribution entries (sparse) or all-reduce the dense arena")
+    ap.add_argument("--lazy-adam", action="store_true", help="run the MAIN measurement in lazy-Adam mode (non-default; the config "
+                    "then says so).  Works with --gpus N and the sparse exchange.")
     ap.add_argument("--no-lazy", action="store_true", help="skip the secondary measurement of the lazy (deferred, bit-exact) Adam mode")
     ap.add_argument("--check-replicas", action="store_true", help="after the run, verify that all ranks hold identical parameters")
     args = ap.parse_args()
@@ -222,7 +224,7 @@ def main():
     qpi = B * len(mix)                                             # queries per iteration per GPU
     sparse = world > 1 and args.exchange == "sparse"
     eng = Engine(d, args.decoder, args.inter_decoder, layout, max_queries=qpi, max_batches=len(mix),
-                 rank=rank if sparse else 0, world=world if sparse else 1)
+                 rank=rank if sparse else 0, world=world if sparse else 1, lazy_adam=args.lazy_adam)
     init_params(eng, d, seed=0)                                    # same seed on every rank: replicas start equal
     pools = synth.make_pools(g, sorted(set(m[0] for m in mix)), formulas_per_type=6, pool_size=max(16 * B, 8192), seed=0)
 
@@ -279,6 +281,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    eng.sync()                                                     # lazy Adam: deferred steps are settled inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -297,6 +300,10 @@ def main():
     value = args.steps * qpi * world / elapsed
     used = [prepared[(args.warmup + i) % n_distinct] for i in range(min(args.steps, n_distinct))]
     a_step = 32.0 * np.mean([p["p_touched"] for p in used])        # bytes per optimiser launch
+    opt_kernel = "gqe_opt_kernel<ADAM> (fused Adam + grad re-zero)"
+    if args.lazy_adam:                                             # the row launch: 32 B per parameter of the rows it names
+        a_step = 32.0 * d * world * np.mean([p["n_entries"] for p in used])
+        opt_kernel = "gqe_rows_kernel (lazy Adam: rows of the step; duplicates counted once per entry)"
     a_q = float(np.mean([p["aq_bytes"] for p in used]))            # bytes per fused fwd/bwd launch
     achieved = a_step / (ms_opt * 1e-3) / 1e9 if ms_opt > 0 else 0.0
     out = {
@@ -309,14 +316,15 @@ def main():
                                % (len(mix), B, d, args.decoder, args.inter_decoder, layout.total),
                    "graph": "5 modes, 97000 nodes, 14 directed relations, 60000 edges/kind, seed 0",
                    "queries_per_step_per_gpu": qpi, "parallelism": "dp%d" % world,
+                   "optimizer": "lazy (deferred, bit-exact) Adam — NON-DEFAULT mode" if args.lazy_adam else "eager dense Adam",
                    "gradient_exchange": "none" if world == 1 else
                    ("one all-gather per step of per-rank slabs: %d contribution entries x (%d floats + row id) + the dense "
                     "relation/Pre/Post gradients" % (prepared[0]["n_entries"], d)) if mode["sparse"] else
                    "all-reduce of the %d-float gradient arena" % layout.total},
-        "roofline": {"bound": "hbm", "kernel": "gqe_opt_kernel<ADAM> (fused Adam + grad re-zero)",
+        "roofline": {"bound": "hbm", "kernel": opt_kernel,
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": pmc_traffic("gqe_opt_kernel") if (d, B, args.decoder, args.inter_decoder) == (128, 512, "bilinear-diag", "min") else None,
+                     "traffic": pmc_traffic("gqe_opt_kernel") if (d, B, args.decoder, args.inter_decoder, args.lazy_adam) == (128, 512, "bilinear-diag", "min", False) else None,
                      "algorithmic_bytes_per_launch": a_step, "avg_launch_ms": round(ms_opt, 5), "launches": n_opt},
         "kernels": {"fused_fwd_bwd": {"avg_launch_ms": round(ms_fused, 5), "launches": n_fused,
                                       "algorithmic_bytes_per_launch": a_q,
@@ -327,7 +335,7 @@ def main():
                           "frac": round((a_step + a_q) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "final_loss": round(loss, 6),
     }
-    if world == 1 and not args.no_lazy:
+    if world == 1 and not args.no_lazy and not args.lazy_adam:
         out["lazy_exact_adam"] = lazy_measurement(args, layout, d, qpi, item_sets, plans, n_distinct)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(eng, args.decoder, args.inter_decoder, item_sets[:8], args.cpu_seconds, qpi)

@@ -105,6 +105,7 @@ struct GqeStepCoef {
 #define GQE_LAZY_TABLES 8
 #define GQE_LAZY_SEGS 96        // index-feed segments one rows launch can cover
 struct GqeLazyTabs {
+  int n;  // tables in gqe_set_tables order (head_base ascending)
   long long offset[GQE_LAZY_TABLES], head_base[GQE_LAZY_TABLES];
   int target[GQE_LAZY_TABLES];     // bring rows to this Adam step count of their table
   int grad_step[GQE_LAZY_TABLES];  // the step that consumes the row's gradient list (== target), or -1: replay only
@@ -117,6 +118,7 @@ struct GqeLazyArgs {      // rides along with the optimiser launch
   int8_t table_of_seg[GQE_MAX_SEGS];  // universe entry -> slot in t (tables only)
 };
 struct GqeRowSegs {       // the table rows named by an index feed: segment k = idx[idx_begin[k] .. +count) of table tid[k]
+                          // (tid -1: skip; -2: the values are list heads of any table — exchanged slabs)
   int n, total;
   int begin[GQE_LAZY_SEGS + 1];  // prefix sums of the counts
   int idx_begin[GQE_LAZY_SEGS];

@@ -96,6 +96,8 @@ struct gqe_ctx {
   int64_t step_entries = 0;    // world > 1: contribution entries per rank slab of the pending margin call (n)
   int64_t step_slab = 0;       // ... and the slab size in entries: n + row-id tail + dense-gradient tail (S)
   bool step_exported = false;
+  bool imported = false;       // the pending lists include every rank's entries (gqe_import_entries ran)
+  int64_t imported_n = 0, imported_slab = 0;
   int64_t slab_hint = 0;       // gqe_exchange_reserve: slab size for the next margin call (0 = its own entry count)
   bool dense_dirty = false;  // the dense gradient of some table may be non-zero (after materialize)
   RingSlot ring[kRing];
@@ -485,6 +487,7 @@ void build_feed(const gqe_ctx* ctx, const gqe_batch* batches, int n_batches, boo
 void lazy_rows_args(const gqe_ctx* ctx, GqeRowsArgs& ra, hipStream_t st) {
   const Layout& L = ctx->lay;
   memset(&ra.t, 0, sizeof ra.t);
+  ra.t.n = (int)std::min<size_t>(ctx->tables.size(), GQE_LAZY_TABLES);
   for (size_t t = 0; t < ctx->tables.size() && t < GQE_LAZY_TABLES; ++t) {
     ra.t.offset[t] = ctx->tables[t].offset;
     ra.t.head_base[t] = ctx->tables[t].head_base;
@@ -677,6 +680,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     ctx->step_entries = slab;
     ctx->step_slab = slab_entries(ctx, slab, dense_spans(ctx).total);
     ctx->step_exported = false;
+    ctx->imported = false;
     entry = (int64_t)ctx->rank * ctx->step_slab;
     HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.rows_off + sizeof(int32_t) * (size_t)entry, 0xff, sizeof(int32_t) * (size_t)slab, st));
   }
@@ -934,7 +938,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       ctx->lz_b2 = b2;
       ctx->lz_eps = eps;
       ctx->lz_hyper = true;
-      sparse = lists && ctx->feed_valid && !ctx->dense_dirty && ctx->world == 1 && ctx->bags.empty() &&
+      sparse = lists && ctx->feed_valid && !ctx->dense_dirty && (ctx->world == 1 || ctx->imported) && ctx->bags.empty() &&
                (int)ctx->tables.size() <= GQE_LAZY_TABLES && (64 % (d / 4)) == 0;
       for (size_t t = 0; t < ctx->tables.size() && sparse; ++t)
         if (seen[t] && ctx->tables[t].since_full >= GQE_LAZY_PERIOD) sparse = false;  // bound the replay depth of any row
@@ -953,6 +957,28 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       ra.with_grad = true;
       ra.sorted = oa.sorted;
       ra.idx = ctx->feed_idx;
+      std::vector<SavedFeed> gathered;
+      if (ctx->world > 1) {
+        // the lists now hold every rank's entries: walk the gathered slabs' list-head tails instead of the local feed
+        const int64_t n = ctx->imported_n, S = ctx->imported_slab;
+        SavedFeed cur;
+        memset(&cur, 0, sizeof cur);
+        for (int k = 0; k < ctx->world; ++k) {
+          if (cur.segs.n == GQE_LAZY_SEGS) {
+            gathered.push_back(cur);
+            memset(&cur, 0, sizeof cur);
+          }
+          GqeRowSegs& g = cur.segs;
+          g.idx_begin[g.n] = (int)((k * S + n) * d);   // int32 view of the contribution array: the slab's head tail
+          g.tid[g.n] = -2;
+          g.begin[g.n] = g.total;
+          g.total += (int)n;
+          g.begin[++g.n] = g.total;
+        }
+        gathered.push_back(cur);
+        ra.idx = reinterpret_cast<const int32_t*>(ctx->ws + L.contrib_off);
+      }
+      const std::vector<SavedFeed>& feeds = ctx->world > 1 ? gathered : ctx->feed;
       for (size_t t = 0; t < ctx->tables.size(); ++t)
         if (seen[t]) {
           ra.t.target[t] = ra.t.grad_step[t] = ctx->tables[t].lstep + 1;
@@ -972,7 +998,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       ra.dactive = oa.active;
       rc = timing_begin(ctx, 2, st);
       if (rc != GQE_OK) return rc;
-      for (const SavedFeed& sf : ctx->feed) {
+      for (const SavedFeed& sf : feeds) {
         ra.segs = sf.segs;
         HIP_TRY(ctx, gqe_launch_rows(ra));
         ra.dense_chunks = 0;
@@ -1205,7 +1231,6 @@ int gqe_set_lazy_adam(gqe_ctx* ctx, int32_t enable) {
   if (!ctx) return GQE_ERR_ARG;
   if (enable) {
     if ((int)ctx->tables.size() > GQE_LAZY_TABLES) return fail(ctx, GQE_ERR_ARG, "lazy Adam supports at most %d tables", GQE_LAZY_TABLES);
-    if (ctx->world > 1) return fail(ctx, GQE_ERR_STATE, "lazy Adam is not available together with gqe_set_exchange");
     if (ctx->dense_dirty || ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "gradients pending: step first");
   } else if (lazy_any_dirty(ctx)) {
     return fail(ctx, GQE_ERR_STATE, "rows still owe Adam steps: call gqe_optimizer_sync before leaving lazy mode");
@@ -1222,7 +1247,6 @@ int gqe_optimizer_sync(gqe_ctx* ctx, void* stream) {
 
 int gqe_set_exchange(gqe_ctx* ctx, int32_t rank, int32_t world) {
   if (!ctx) return GQE_ERR_ARG;
-  if (ctx->lazy && world > 1) return fail(ctx, GQE_ERR_STATE, "gqe_set_exchange is not available in lazy Adam mode");
   if (world < 1 || world > 1024 || rank < 0 || rank >= world) return fail(ctx, GQE_ERR_ARG, "need 0 <= rank < world <= 1024, got rank %d world %d", rank, world);
   if (ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_set_exchange must precede gqe_workspace_bytes / gqe_bind_workspace");
   ctx->rank = rank;
@@ -1266,6 +1290,9 @@ int gqe_import_entries(gqe_ctx* ctx, int64_t slab, void* stream) {
   HIP_TRY(ctx, gqe_launch_import(reinterpret_cast<int32_t*>(ctx->ws + L.head_off), reinterpret_cast<int32_t*>(ctx->ws + L.next_off),
                                  reinterpret_cast<const float*>(ctx->ws + L.contrib_off), ctx->grads, ctx->cfg.dim, (long long)slab,
                                  (int32_t)ctx->step_entries, ctx->rank, ctx->world, dense_spans(ctx), reinterpret_cast<hipStream_t>(stream)));
+  ctx->imported = true;
+  ctx->imported_n = ctx->step_entries;
+  ctx->imported_slab = slab;
   ctx->step_exported = false;  // imported: a second import of the same step is refused
   ctx->step_slab = 0;
   return GQE_OK;

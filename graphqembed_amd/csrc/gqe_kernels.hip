@@ -432,8 +432,10 @@ static void launch_opt_mode(const GqeOptArgs& a, unsigned blocks) {
   hipLaunchKernelGGL((gqe_opt_kernel<MODE, L, D, S, Z>), dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.n_segs,    \
                      a.total_chunks, a.p, a.g, a.m, a.v, a.head, a.next, a.contrib, a.link_contrib, a.max_entries, a.d, a.lr, a.b1,  \
                      a.b2, a.eps, a.coef, a.active, a.lz)
-  if (a.lazy && MODE == GQE_OPT_ADAM) {  // lazy full pass: lists are summed order-independently only when asked to
-    if (a.lists) {
+  if (a.lazy && MODE == GQE_OPT_ADAM) {  // lazy full pass
+    if (a.lists && a.sorted) {
+      if (a.dense_tables) GO(true, true, true, true); else GO(true, false, true, true);
+    } else if (a.lists) {
       if (a.dense_tables) GO(true, true, false, true); else GO(true, false, false, true);
     } else {
       if (a.dense_tables) GO(false, true, false, true); else GO(false, false, false, true);
@@ -490,10 +492,16 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_rows_kernel(const GqeRowSegs 
   const int c4 = (threadIdx.x % tpr) * 4;
   int k = 0;  // segment of entry e: begin[k] <= e < begin[k+1]; a scan with uniform (scalar) loads of the kernel
   for (int i = 1; i < segs.n; ++i) k += (e >= segs.begin[i]) ? 1 : 0;  // arguments, not a per-lane search through memory
-  const int lt = segs.tid[k];
-  if (lt < 0) return;
-  const int row = idx[segs.idx_begin[k] + (e - segs.begin[k])];
-  if (row < 0) return;  // padding query
+  int lt = segs.tid[k];
+  if (lt == -1) return;  // rows of a table that is not tracked per row (bag mode)
+  int row = idx[segs.idx_begin[k] + (e - segs.begin[k])];
+  if (row < 0) return;  // padding query / contribution that was never pushed
+  if (lt == -2) {       // exchanged slabs name list heads (head_base + row): recover the table
+    lt = 0;
+#pragma unroll
+    for (int i = 1; i < GQE_LAZY_TABLES; ++i) lt += (i < t.n && row >= t.head_base[i]) ? 1 : 0;
+    row -= (int)t.head_base[lt];
+  }
   const int target = t.target[lt];
   const long long hrow = t.head_base[lt] + row;
   const long long off = t.offset[lt] + (long long)row * d + c4;

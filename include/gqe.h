@@ -176,7 +176,8 @@ int gqe_materialize_grads(gqe_ctx* ctx, void* stream);
  * the missing steps of the rows they are about to read (and only those), and a full pass runs whenever the
  * 64-step coefficient ring of a table is about to wrap.  The parameters every kernel reads, and the arena after
  * gqe_optimizer_sync, are bit-identical to the eager schedule (tests/test_gpu_parity.py::test_lazy_adam_*).
- * Not available together with gqe_set_exchange; tables of bag modes always take the full pass.
+ * Works with gqe_set_exchange (the row launch then walks the gathered slabs; replicas stay bit-identical); tables of
+ * bag modes always take the full pass.
  *
  * gqe_set_lazy_adam(ctx, 1)     switch on (any time no gradients are pending); 0 switches off (sync first)
  * gqe_optimizer_sync(ctx, st)   bring every row up to date — before the caller reads or writes the parameter /

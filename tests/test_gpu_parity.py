@@ -597,7 +597,7 @@ def test_lazy_adam_state_machine():
         e.margin_fwd_bwd(descs, idx, n)
         e.sgd_step(pl.touched, 0.05)
     assert torch.equal(eng.params, ref.params) and torch.equal(eng.exp_avg_sq, ref.exp_avg_sq)
-    # leaving lazy mode needs a sync; the exchange mode refuses lazy engines
+    # leaving lazy mode needs a sync
     t, g, a = _disjoint_batch(rng, "2-inter", 8, 0.0, 0.5)
     descs, idx, n = pack_margin_batches([(plan_l, t, g, a, 1.0, 1.0)])
     eng.margin_fwd_bwd(descs, idx, n)
@@ -605,8 +605,6 @@ def test_lazy_adam_state_machine():
     assert eng.lib.gqe_set_lazy_adam(eng.ctx, 0) != 0
     eng.sync()
     assert eng.lib.gqe_set_lazy_adam(eng.ctx, 0) == 0
-    with pytest.raises(GqeError):
-        engine_from_params(params, d, "bilinear-diag", "min-simple", lazy_adam=True, rank=0, world=2)
     eng.close()
     ref.close()
 
