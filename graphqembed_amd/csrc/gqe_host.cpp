@@ -930,9 +930,18 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     // the full pass (which also replays whatever any row is behind).
     if (!flush) {
       for (size_t t = 0; t < ctx->tables.size(); ++t)
-        if (seen[t] && ctx->adam_steps[ctx->tables[t].offset] != ctx->tables[t].lstep + 1)
-          return fail(ctx, GQE_ERR_ARG, "lazy Adam: table at offset %lld is at step %d, cannot apply step %d",
-                      (long long)ctx->tables[t].offset, ctx->tables[t].lstep, ctx->adam_steps[ctx->tables[t].offset]);
+        if (seen[t] && ctx->adam_steps[ctx->tables[t].offset] != ctx->tables[t].lstep + 1) {
+          Table& tb = ctx->tables[t];
+          const int want = ctx->adam_steps[tb.offset];
+          if (tb.dirty)
+            return fail(ctx, GQE_ERR_ARG, "lazy Adam: table at offset %lld is at step %d with rows still lagging, cannot jump to step %d",
+                        (long long)tb.offset, tb.lstep, want);
+          // a caller-supplied step count (resumed checkpoint): every row is current, so re-base the row counters
+          tb.lstep = want - 1;
+          tb.since_full = 0;
+          HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->ws + L.last_off + sizeof(int32_t) * (size_t)tb.head_base),
+                                         tb.lstep, (size_t)tb.rows, st));
+        }
       ctx->lz_lr = lr;
       ctx->lz_b1 = b1;
       ctx->lz_b2 = b2;

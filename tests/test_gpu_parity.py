@@ -597,6 +597,16 @@ def test_lazy_adam_state_machine():
         e.margin_fwd_bwd(descs, idx, n)
         e.sgd_step(pl.touched, 0.05)
     assert torch.equal(eng.params, ref.params) and torch.equal(eng.exp_avg_sq, ref.exp_avg_sq)
+    # a resumed run hands in its own step counts: accepted when every row is current (the row counters are re-based)
+    eng.sync()
+    eng.steps = {k: v + 1000 for k, v in eng.steps.items()}
+    ref.steps = dict(eng.steps)
+    t, g, a = _disjoint_batch(rng, "2-inter", 8, 0.0, 1.0)
+    for e, pl in ((eng, plan_l), (ref, plan_r)):
+        descs, idx, n = pack_margin_batches([(pl, t, g, a, 1.0, 1.0)])
+        e.margin_fwd_bwd(descs, idx, n)
+        e.adam_step(pl.touched, 0.003)
+    assert torch.equal(eng.params, ref.params) and torch.equal(eng.exp_avg, ref.exp_avg)
     # leaving lazy mode needs a sync
     t, g, a = _disjoint_batch(rng, "2-inter", 8, 0.0, 0.5)
     descs, idx, n = pack_margin_batches([(plan_l, t, g, a, 1.0, 1.0)])
