@@ -198,3 +198,32 @@ def test_online_pools_refresh_in_the_background(world):
     with pytest.raises(ValueError):
         bad.current()
     bad.close()
+
+
+def test_reference_sampled_queries_agree_with_both_samplers(world):
+    """tests/golden/queries_tiny.pkl was drawn by the REFERENCE's own sampler (oracle/make_golden.py imports
+    netquery.graph.Graph) on this very graph.  Every such query must be a subgraph here, its stored negatives /
+    hard negatives must lie inside the sets our restatement and the native sampler compute, and its target must
+    answer it — for both implementations."""
+    import os
+    import pickle
+    g, s, _ = world
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "queries_tiny.pkl"), "rb") as f:
+        data = pickle.load(f)
+    checked = 0
+    for split in ("train",):
+        for qtype, infos in data[split].items():
+            if qtype == "1-chain":
+                continue
+            for qg, negs, hard in infos[:120]:
+                assert g._is_subgraph(qg) and s.check(qg, qg[1][0]) == 1      # bit 0 only: the target is no negative
+                my_negs, my_hard = g.get_negative_samples(qg)
+                assert my_negs is not None and set(negs) <= set(my_negs)
+                for n in list(negs)[:6]:
+                    assert s.check(qg, n) & 2
+                if hard is not None:
+                    assert set(hard) <= set(my_hard)
+                    for n in list(hard)[:6]:
+                        assert s.check(qg, n) & 4
+                checked += 1
+    assert checked > 300
