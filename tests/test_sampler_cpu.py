@@ -227,3 +227,43 @@ def test_reference_sampled_queries_agree_with_both_samplers(world):
                         assert s.check(qg, n) & 4
                 checked += 1
     assert checked > 300
+
+
+def _tuplify(x):
+    return tuple(_tuplify(y) for y in x) if isinstance(x, list) else x
+
+
+def test_samplers_against_the_reference_samplers_own_outputs(world):
+    """tests/golden/sampler_ref.json (oracle/make_sampler_golden.py: the reference's netquery.graph.Graph run in the
+    build container): the FULL negative / hard-negative sets of 240 reference-sampled queries must be reproduced
+    exactly by the Python restatement and, node by node, by the native checker; the accepted query-type mix of the
+    reference's sample_queries must be the native sampler's mix."""
+    import json
+    import os
+    g, s, ids = world
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sampler_ref.json")) as f:
+        ref = json.load(f)
+    assert len(ref["queries"]) == 240
+    for rec in ref["queries"]:
+        qg = _tuplify(rec["graph"])
+        negs, hard = g.get_negative_samples(qg)
+        assert sorted(negs) == rec["negs"]
+        assert (None if hard is None else sorted(hard)) == rec["hard"]
+        tm = qg[1][1][0]
+        universe = sorted(g.full_sets[tm])
+        flags = [s.check(qg, n) for n in universe]
+        assert all(f & 1 for f in flags)
+        assert [n for n, f in zip(universe, flags) if f & 2] == rec["negs"]
+        if rec["hard"] is not None:
+            assert [n for n, f in zip(universe, flags) if f & 4] == rec["hard"]
+    names = {1: "2-chain", 2: "3-chain", 3: "2-inter", 4: "3-inter", 5: "3-inter_chain", 6: "3-chain_inter"}
+    for arity in (2, 3):
+        want = ref["type_counts"][str(arity)]
+        n_ref = float(sum(want.values()))
+        res = s.sample(40000, arity=arity, neg_sample_max=1, seed=21 + arity, threads=2)
+        got = collections.Counter(names[int(t)] for t in res.qtype)
+        assert set(got) == set(want)
+        for t, c in want.items():
+            p_ref, p_nat = c / n_ref, got[t] / 40000.0
+            sigma = np.sqrt(p_ref * (1 - p_ref) / n_ref)
+            assert abs(p_ref - p_nat) < 4 * sigma + 0.004, (arity, t, p_ref, p_nat)
