@@ -2,7 +2,7 @@
 //
 // What is computed follows netquery/model.py:70-127, encoders.py:40-43, decoders.py:142-150,
 // 200-208, 228-236, 288-319 (maths: SURVEY.md Appendix B / oracle/netquery_numpy.py).  How:
-//   * one workgroup = 8 wave64 owns a TILE of 16 queries of ONE batch (= one Formula), so every
+//   * one workgroup = 16 wave64 (GQE_FWAVES) owns a TILE of 16 queries of ONE batch (= one Formula), so every
 //     relation parameter is workgroup-uniform; one grouped launch covers all batches of an iteration;
 //   * the tile's table rows are fetched with one coalesced index read, then EVERY embedding row the
 //     tile needs (target, negative, up to 3 anchors per query) is requested at once — one wave per row,
@@ -418,7 +418,7 @@ __device__ __forceinline__ void push_links(const TileEnv& e, const int (&olds)[R
 
 // Relation-vector gradients (bilinear-diag / TransE): every wave keeps its partial sums in registers
 // (slot k = 2*branch + hop, 6 = final projection; chains use slot = hop) until the end of the kernel, when
-// one LDS round (the tiles are dead by then) reduces the 8 waves and wave k flushes vector k with one
+// one LDS round (the tiles are dead by then) reduces the waves and wave k flushes vector k with one
 // atomic row: two barriers per tile instead of two per vector.
 #define GQE_VG_SLOTS 7
 
@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
   if (BWD && DEC != DEC_BILINEAR) vecgrads_commit<NC>(e, smem, reinterpret_cast<long long*>(s_idx), vg);
   if (BWD) push_links(e, olds);
   if (BWD) {
-    // mean hinge loss of the batch (model.py:124-126) and the weighted iteration loss: reduce the 8 waves in
+    // mean hinge loss of the batch (model.py:124-126) and the weighted iteration loss: reduce the waves in
     // LDS (thousands of same-address device atomics serialise at ~12 ns each) and park one partial per tile.
     __syncthreads();
     if (lane == 0) red[wave] = loss_part;
