@@ -67,6 +67,9 @@ struct GqeDynBatch {
 
 // Bag modes (Reddit posts: nn.EmbeddingBag mean over word rows, reddit/data_utils_new.py:155,162-169):
 // CSR of row ids per bag, borrowed device pointers, passed by value with the launch.
+// entry -> list head map (exchange): >= 0 a list head, -1 not pushed, <= -2 a bag: -(2 + (slot << 27 | bag index))
+#define GQE_BAG_CODE(slot, bag) (-(2 + (((slot) << 27) | (bag))))
+
 struct GqeBagTable {
   const int32_t* ptr[GQE_MAX_BAGS];
   const int32_t* ids[GQE_MAX_BAGS];
@@ -209,7 +212,14 @@ struct GqeSpans {
 };
 hipError_t gqe_launch_export(float* contrib, const int32_t* rows, const float* grads, int d, long long slab_base, int32_t n,
                              const GqeSpans& sp, hipStream_t stream);
+struct GqeImportBags {  // bag tables on the importing side: CSR + where the word table's list heads start
+  GqeBagTable csr;
+  long long head_base[GQE_MAX_BAGS];
+  int32_t* link_contrib;
+  int32_t* link_counter;
+  int32_t max_entries;
+};
 hipError_t gqe_launch_import(int32_t* head, int32_t* next, const float* contrib, float* grads, int d, long long slab, int32_t n,
-                             int rank, int world, const GqeSpans& sp, hipStream_t stream);
+                             int rank, int world, const GqeSpans& sp, const GqeImportBags& bags, hipStream_t stream);
 
 #endif

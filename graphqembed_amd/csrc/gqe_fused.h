@@ -374,7 +374,7 @@ __device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_
 template <int NC>
 __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t head_base, int role, int r, int p0, int len,
                                                      const int32_t* __restrict__ ids, const Vec<NC>& xhat, float nrm,
-                                                     const Vec<NC>& g) {
+                                                     const Vec<NC>& g, int bag_slot, int bag_index) {
   const float pg = vdot<NC>(xhat, g);
   const float inv = 1.f / (nrm * (float)len);
   Vec<NC> gx;
@@ -382,7 +382,11 @@ __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t h
   const int64_t entry = e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
   vstore<NC>(e.contrib + entry * e.d, gx, e.d, e.lane);
   int base = 0;
-  if (e.lane == 0) base = __hip_atomic_fetch_add(e.link_counter, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (e.lane == 0) {
+    base = __hip_atomic_fetch_add(e.link_counter, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // entry -> "bag b of bag table s", for the data-parallel exchange: the importer re-expands the bag itself
+    e.next[entry - e.max_entries] = GQE_BAG_CODE(bag_slot, bag_index);
+  }
   base = __builtin_amdgcn_readfirstlane(base);
   for (int c0 = 0; c0 < len; c0 += 64) {
     const int k = c0 + e.lane;
@@ -402,7 +406,8 @@ __device__ __forceinline__ void scatter_row(const TileEnv& e, const GqeBagTable&
   if (bag < 0)
     scatter_norm_bwd<NC>(e, head_base, role, r, rs.row[rr], rs.x[rr], rs.nrm[rr], g, old_head);
   else
-    scatter_norm_bwd_bag<NC>(e, head_base, role, r, rs.bag_p0[rr], rs.bag_len[rr], bags.ids[bag], rs.x[rr], rs.nrm[rr], g);
+    scatter_norm_bwd_bag<NC>(e, head_base, role, r, rs.bag_p0[rr], rs.bag_len[rr], bags.ids[bag], rs.x[rr], rs.nrm[rr], g, bag,
+                             rs.row[rr]);
 }
 
 // next[entry] = previous head, for every contribution this wave pushed

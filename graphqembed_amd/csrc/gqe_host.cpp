@@ -566,7 +566,6 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   if (idx_bytes > L.idx_cap) return fail(ctx, GQE_ERR_WORKSPACE, "index feed of %lld entries exceeds the bound workspace (%lld queries)", (long long)n_idx, (long long)ctx->cap_queries);
   if (bwd && ctx->world > 1) {
     if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "exchange mode: one gqe_margin_fwd_bwd per optimiser step (gradients of the previous call are still pending)");
-    if (!ctx->bags.empty()) return fail(ctx, GQE_ERR_STATE, "exchange mode is not available with bag modes: use gqe_materialize_grads + a dense all-reduce");
     const int64_t slab = ctx->slab_hint ? ctx->slab_hint : entries;
     if (entries > slab) return fail(ctx, GQE_ERR_ARG, "this call produces %lld gradient entries, more than the reserved slab of %lld", (long long)entries, (long long)slab);
     const GqeSpans sp = dense_spans(ctx);
@@ -1296,9 +1295,20 @@ int gqe_import_entries(gqe_ctx* ctx, int64_t slab, void* stream) {
     return fail(ctx, GQE_ERR_ARG, "import of %lld-entry slabs, but the exported slab of the pending margin call has %lld (0: none exported)",
                 (long long)slab, (long long)(ctx->step_exported ? ctx->step_slab : 0));
   const Layout& L = ctx->lay;
+  GqeImportBags ib;
+  memset(&ib, 0, sizeof ib);
+  for (size_t k = 0; k < ctx->bags.size(); ++k) {
+    ib.csr.ptr[k] = ctx->bags[k].ptr;
+    ib.csr.ids[k] = ctx->bags[k].ids;
+    ib.head_base[k] = ctx->tables[ctx->bags[k].table].head_base;
+  }
+  ib.link_contrib = reinterpret_cast<int32_t*>(ctx->ws + L.linkc_off);
+  ib.link_counter = reinterpret_cast<int32_t*>(ctx->ws + L.counter_off);
+  ib.max_entries = (int32_t)L.max_entries;
+  if (!ctx->bags.empty()) ctx->links_used = true;
   HIP_TRY(ctx, gqe_launch_import(reinterpret_cast<int32_t*>(ctx->ws + L.head_off), reinterpret_cast<int32_t*>(ctx->ws + L.next_off),
                                  reinterpret_cast<const float*>(ctx->ws + L.contrib_off), ctx->grads, ctx->cfg.dim, (long long)slab,
-                                 (int32_t)ctx->step_entries, ctx->rank, ctx->world, dense_spans(ctx), reinterpret_cast<hipStream_t>(stream)));
+                                 (int32_t)ctx->step_entries, ctx->rank, ctx->world, dense_spans(ctx), ib, reinterpret_cast<hipStream_t>(stream)));
   ctx->imported = true;
   ctx->imported_n = ctx->step_entries;
   ctx->imported_slab = slab;

@@ -579,7 +579,8 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_export_kernel(float* __restri
 
 __global__ __launch_bounds__(GQE_THREADS) void gqe_import_kernel(int32_t* __restrict__ head, int32_t* __restrict__ next,
                                                                 const float* __restrict__ contrib, float* __restrict__ grads, int d,
-                                                                long long slab, int32_t n, int rank, int world, const GqeSpans sp) {
+                                                                long long slab, int32_t n, int rank, int world, const GqeSpans sp,
+                                                                const GqeImportBags bags) {
   const long long t = (long long)blockIdx.x * GQE_THREADS + threadIdx.x;
   const long long links = (long long)n * (world - 1);
   const long long R = (n + d - 1) / d;
@@ -588,9 +589,23 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_import_kernel(int32_t* __rest
     const int i = (int)(t - (long long)k * n);
     if (k >= rank) ++k;
     const int h = reinterpret_cast<const int32_t*>(contrib + (k * slab + n) * d)[i];
-    if (h < 0) return;
+    if (h == -1) return;  // never pushed (inactive hinge / padding)
     const int e = (int)(k * slab + i);
-    next[e] = __hip_atomic_exchange(head + h, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (h >= 0) {
+      next[e] = __hip_atomic_exchange(head + h, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      // a bag contribution: one link node per word row of the bag, exactly what the producer's fused kernel did
+      const int code = -h - 2, slot = code >> 27, bag = code & ((1 << 27) - 1);
+      const int p0 = bags.csr.ptr[slot][bag], len = bags.csr.ptr[slot][bag + 1] - p0;
+      const int base = __hip_atomic_fetch_add(bags.link_counter, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int j = 0; j < len; ++j) {
+        const int node = base + j;
+        const int w = bags.csr.ids[slot][p0 + j];
+        next[bags.max_entries + node] =
+            __hip_atomic_exchange(head + bags.head_base[slot] + w, bags.max_entries + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bags.link_contrib[node] = e;
+      }
+    }
   } else if (t - links < sp.total) {
     const long long j = t - links;
     float sum = 0.f;
@@ -609,11 +624,11 @@ hipError_t gqe_launch_export(float* contrib, const int32_t* rows, const float* g
 }
 
 hipError_t gqe_launch_import(int32_t* head, int32_t* next, const float* contrib, float* grads, int d, long long slab, int32_t n,
-                             int rank, int world, const GqeSpans& sp, hipStream_t stream) {
+                             int rank, int world, const GqeSpans& sp, const GqeImportBags& bags, hipStream_t stream) {
   const long long total = (long long)n * (world - 1) + sp.total;
   if (total < 1) return hipSuccess;
   hipLaunchKernelGGL(gqe_import_kernel, dim3((unsigned)((total + GQE_THREADS - 1) / GQE_THREADS)), dim3(GQE_THREADS), 0, stream,
-                     head, next, contrib, grads, d, slab, n, rank, world, sp);
+                     head, next, contrib, grads, d, slab, n, rank, world, sp, bags);
   return hipGetLastError();
 }
 

@@ -200,7 +200,7 @@ class Engine(object):
             self._check(self.lib.gqe_set_bag(self.ctx, layout.offset(key), dp.data_ptr(), di.data_ptr(), len(ptr) - 1,
                                              int(np.diff(ptr).max())))
         self.rank, self.world = int(rank), int(world)
-        self.sparse_exchange = self.world > 1 and not self._bags
+        self.sparse_exchange = self.world > 1
         if self.sparse_exchange:
             self._check(self.lib.gqe_set_exchange(self.ctx, self.rank, self.world))
         if lazy_adam:

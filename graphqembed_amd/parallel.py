@@ -10,7 +10,7 @@ concatenated queries (tests/test_parallel_gloo.py, 2 gloo ranks on CPU).
 
 Two exchange forms (both leave bit-identical replicas):
   dense  : fold the per-row gradient lists into the dense arena, all-reduce all P floats
-           (what the north star names; the only form for bag modes).
+           (what the north star names).
   sparse : ONE all-gather of per-rank slabs = the contribution entries the fused kernel wrote
            (d floats + a row id per (query, role)) followed by the small dense relation / Pre /
            Post gradients; the other ranks' entries are linked into the local lists and the dense

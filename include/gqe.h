@@ -197,7 +197,7 @@ int gqe_optimizer_sync(gqe_ctx* ctx, void* stream);
  *
  *   gqe_set_exchange(ctx, rank, world)      once, before gqe_workspace_bytes (sizes the entry space x world)
  *   [gqe_exchange_reserve(ctx, n)]          contributions per slab when ranks may produce different counts
- *   gqe_margin_fwd_bwd(...)                 exactly one per optimiser step in this mode; no bag modes
+ *   gqe_margin_fwd_bwd(...)                 exactly one per optimiser step in this mode
  *   gqe_export_entries(ctx, &S, &off, st)   all-gather float[world][S][dim] at workspace + off,
  *                                           this rank's part being [rank*S, (rank+1)*S)
  *   gqe_import_entries(ctx, S, stream)
