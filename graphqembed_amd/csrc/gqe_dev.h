@@ -113,6 +113,7 @@ struct GqeLazyTabs {
   int target[GQE_LAZY_TABLES];     // bring rows to this Adam step count of their table
   int grad_step[GQE_LAZY_TABLES];  // the step that consumes the row's gradient list (== target), or -1: replay only
   float step_size[GQE_LAZY_TABLES], bc2_sqrt[GQE_LAZY_TABLES];  // coefficients of grad_step
+  unsigned char eager[GQE_LAZY_TABLES];  // bag-mode tables: always stepped in full, no per-row counts (every row is current)
 };
 struct GqeLazyArgs {      // rides along with the optimiser launch
   int32_t* last;          // [total rows] step count each row is current for

@@ -946,10 +946,11 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       ctx->lz_b2 = b2;
       ctx->lz_eps = eps;
       ctx->lz_hyper = true;
-      sparse = lists && ctx->feed_valid && !ctx->dense_dirty && (ctx->world == 1 || ctx->imported) && ctx->bags.empty() &&
+      sparse = lists && ctx->feed_valid && !ctx->dense_dirty && (ctx->world == 1 || ctx->imported) &&
                (int)ctx->tables.size() <= GQE_LAZY_TABLES && (64 % (d / 4)) == 0;
       for (size_t t = 0; t < ctx->tables.size() && sparse; ++t)
-        if (seen[t] && ctx->tables[t].since_full >= GQE_LAZY_PERIOD) sparse = false;  // bound the replay depth of any row
+        if (seen[t] && lazy_table_ok(ctx, (int)t) && ctx->tables[t].since_full >= GQE_LAZY_PERIOD)
+          sparse = false;  // bound the replay depth of any row
     }
     auto coef_of = [&](size_t t, float* ss, float* bc) {
       for (size_t ui = 0; ui < ctx->universe.size(); ++ui)
@@ -988,10 +989,20 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       }
       const std::vector<SavedFeed>& feeds = ctx->world > 1 ? gathered : ctx->feed;
       for (size_t t = 0; t < ctx->tables.size(); ++t)
-        if (seen[t]) {
+        if (seen[t] && lazy_table_ok(ctx, (int)t)) {
           ra.t.target[t] = ra.t.grad_step[t] = ctx->tables[t].lstep + 1;
           coef_of(t, &ra.t.step_size[t], &ra.t.bc2_sqrt[t]);
         }
+      // bag-mode tables (their gradient lists hang on word rows no index feed names) are stepped in full by the
+      // ordinary pass: every row of such a table is always current
+      GqeOptArgs ob = oa;
+      long long bag_chunks = 0;
+      for (size_t ui = 0; ui < ctx->universe.size(); ++ui) {
+        const bool bag_table = oa.active.group[ui] != 0xFF && ctx->universe[ui].is_table &&
+                               !lazy_table_ok(ctx, table_of(ctx, ctx->universe[ui].offset));
+        if (bag_table) bag_chunks += ctx->universe[ui].n_chunks;
+        else ob.active.group[ui] = 0xFF;
+      }
       // the small dense tensors ride in extra workgroups of the (first) row launch: the ordinary pass, tables masked out
       long long dense_chunks = 0;
       for (size_t ui = 0; ui < ctx->universe.size(); ++ui) {
@@ -1014,11 +1025,22 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       rc = timing_end(ctx, 2, st);
       if (rc != GQE_OK) return rc;
       if (ctx->feed_buf >= 0) HIP_TRY(ctx, hipEventRecord(ctx->plan_free[ctx->feed_buf], st));  // the staged feed may go now
+      if (bag_chunks > 0) {
+        ob.total_chunks = bag_chunks;
+        ob.lazy = false;
+        rc = timing_begin(ctx, 3, st);
+        if (rc != GQE_OK) return rc;
+        HIP_TRY(ctx, gqe_launch_opt(ob));
+        rc = timing_end(ctx, 3, st);
+        if (rc != GQE_OK) return rc;
+      }
       for (size_t t = 0; t < ctx->tables.size(); ++t)
         if (seen[t]) {
           ++ctx->tables[t].lstep;
-          ++ctx->tables[t].since_full;
-          ctx->tables[t].dirty = true;
+          if (lazy_table_ok(ctx, (int)t)) {
+            ++ctx->tables[t].since_full;
+            ctx->tables[t].dirty = true;
+          }
         }
     } else {
       oa.lazy = true;
@@ -1029,6 +1051,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       for (size_t t = 0; t < ctx->tables.size(); ++t) {
         oa.lz.t.target[t] = ctx->tables[t].lstep + ((seen[t] && !flush) ? 1 : 0);
         oa.lz.t.grad_step[t] = (seen[t] && !flush) ? ctx->tables[t].lstep + 1 : -1;
+        oa.lz.t.eager[t] = lazy_table_ok(ctx, (int)t) ? 0 : 1;
       }
       for (size_t ui = 0; ui < ctx->universe.size(); ++ui)
         if (ctx->universe[ui].is_table) oa.lz.table_of_seg[ui] = (int8_t)table_of(ctx, ctx->universe[ui].offset);

@@ -324,8 +324,8 @@ __device__ __forceinline__ void opt_body(const long long first_chunk, const long
       if (LAZY && MODE == GQE_OPT_ADAM) {
         // full pass in lazy mode: replay what the row is behind, then (grad_step == target) the step with gradient
         const int lt = lazy.table_of_seg[si];
-        const int from = lazy.last[sg.head_base + row];
         const int target = lazy.t.target[lt];
+        const int from = lazy.t.eager[lt] ? target - 1 : lazy.last[sg.head_base + row];
         if (from < target) {
           lazy_advance(pp, mm, vv, gg, from, target, lazy.t.grad_step[lt], lazy.ring + lt * GQE_LAZY_RING, step_size, bc2_sqrt,
                        lazy.t.grad_step[lt], b1, b2, eps);

@@ -177,7 +177,7 @@ int gqe_materialize_grads(gqe_ctx* ctx, void* stream);
  * 64-step coefficient ring of a table is about to wrap.  The parameters every kernel reads, and the arena after
  * gqe_optimizer_sync, are bit-identical to the eager schedule (tests/test_gpu_parity.py::test_lazy_adam_*).
  * Works with gqe_set_exchange (the row launch then walks the gathered slabs; replicas stay bit-identical); tables of
- * bag modes always take the full pass.
+ * bag modes are stepped in full every iteration, next to the sparse launch for the other tables.
  *
  * gqe_set_lazy_adam(ctx, 1)     switch on (any time no gradients are pending); 0 switches off (sync first)
  * gqe_optimizer_sync(ctx, st)   bring every row up to date — before the caller reads or writes the parameter /

@@ -677,3 +677,43 @@ def test_full_size_properties(dec, inter):
     descs, idx, n = pack_forward_batches([(pl, t, a) for (pl, t, g, a, w, m) in base])
     np.testing.assert_allclose(eng.forward(descs, idx, n).cpu().numpy(), p1, rtol=0, atol=1e-6)   # (the training variant
     eng.close()                                                             # of the Bilinear chain contracts in another order)
+
+
+def test_lazy_adam_with_a_bag_mode():
+    """An EmbeddingBag mode next to ordinary tables (the Reddit shape): the bag table is stepped in full every
+    iteration (its gradient lists hang on word rows no index feed names), the other tables lazily, in the same
+    step.  With bags no run is reproducible bit for bit (word rows sum many contributions in atomic order and Adam
+    turns that noise into lr-sized steps — two EAGER engines drift apart by ~0.2 over these 60 steps), so the yardstick
+    is a second eager engine: the lazy engine must stay as close to eager #1 as eager #2 does."""
+    import torch
+    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, toy_batch
+    from graphqembed_amd.tensorize import pack_margin_batches
+    rng = np.random.RandomState(8)
+    d, dec, inter = 64, "bilinear-diag", "min"
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS, bag_modes=("b",))
+    eager = engine_from_params(params, d, dec, inter)
+    eager2 = engine_from_params(params, d, dec, inter)
+    lazy = engine_from_params(params, d, dec, inter, lazy_adam=True)
+    types = ["1-chain", "2-inter", "2-chain", "3-inter_chain", "3-chain_inter"]
+    for step in range(60):
+        qt = types[step % len(types)]
+        t, g, a = toy_batch(rng, qt, 12)
+        t[:], g[:] = np.minimum(t, 30), np.minimum(g, 30)      # keep most rows of the big tables untouched: they must lag
+        outs = []
+        for eng in (eager, eager2, lazy):
+            plan = plan_for(eng, qt, TOY_FORMULAS[qt])
+            descs, idx, n = pack_margin_batches([(plan, t, g, a, 1.0, 1.0)])
+            losses, _, _ = eng.margin_fwd_bwd(descs, idx, n)
+            eng.adam_step(plan.touched, 0.01)
+            outs.append(float(losses[-1].item()))
+        if step == 1:      # before the noise has had time to grow, everything still agrees tightly
+            assert float((lazy.params - eager.params).abs().max()) < 1e-5
+        assert abs(outs[2] - outs[0]) <= 0.25 * abs(outs[0]) + 1e-3, (step, outs)      # same loss curve, loosely
+    torch.cuda.synchronize()
+    assert not torch.equal(lazy._params, eager._params)            # rows of the ordinary tables do lag
+    noise = (eager2.params - eager.params).abs()
+    diff = (lazy.params - eager.params).abs()
+    assert float(diff.max()) <= 3.0 * float(noise.max()) + 0.02, (float(diff.max()), float(noise.max()))
+    assert float(diff.mean()) <= 3.0 * float(noise.mean()) + 1e-4, (float(diff.mean()), float(noise.mean()))
+    for e in (eager, eager2, lazy):
+        e.close()
