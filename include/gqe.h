@@ -173,8 +173,8 @@ int gqe_materialize_grads(gqe_ctx* ctx, void* stream);
  * zero-gradient steps depend only on the row's own (p, m, v) and the step number, so they can be replayed later
  * with exactly the same arithmetic: in lazy mode gqe_adam_step updates only the rows the pending margin call
  * touched and records, per row, the step count it is current for; gqe_forward / gqe_margin_fwd_bwd first replay
- * the missing steps of the rows they are about to read (and only those), and a full pass runs whenever the
- * 64-step coefficient ring of a table is about to wrap.  The parameters every kernel reads, and the arena after
+ * the missing steps of the rows they are about to read (and only those), and a full pass runs per table at least
+ * every 32 steps (the bound on a row's debt; the per-table ring of bias corrections holds the last 64 steps).  The parameters every kernel reads, and the arena after
  * gqe_optimizer_sync, are bit-identical to the eager schedule (tests/test_gpu_parity.py::test_lazy_adam_*).
  * Works with gqe_set_exchange (the row launch then walks the gathered slabs; replicas stay bit-identical); tables of
  * bag modes are stepped in full every iteration, next to the sparse launch for the other tables.
