@@ -1,33 +1,43 @@
 #!/usr/bin/env python3
 """bench.py — queries/sec of the fused MI355X training step on the BASELINE workload.
 
-    python bench.py [--gpus N --steps K --warmup W]            # N=1 directly
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N --steps K --warmup W]
+        N = 1 runs in-process; N > 1 without a launcher environment re-executes itself under
+        ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`` (one rank per
+        GPU, backend nccl = RCCL); under torchrun (WORLD_SIZE set) it is one of the N ranks.
 
-step      = one training iteration of the reference's post-burn-in schedule over the
-            "Bio full conjunctive mix" (train_helpers.py:50-79): 9 batches x B=512 =
-            4 608 (query, negative) pairs -> fused forward/backward (one grouped launch),
-            deferred matrix gradients, [N>1: gradient exchange — one all-gather of per-rank
-            contribution slabs, or --exchange dense: all-reduce of the gradient arena],
-            one fused dense Adam step (+ grad re-zero).
-workload  = "bio-synth" (SURVEY.md §8d C3): 5 modes / 97 000 nodes / 14 directed relations,
-            d=128, bilinear-diag decoder + SetIntersection(min), P = 12 582 912 parameters;
-            index feeds of 32 distinct pre-sampled iterations are resident in HBM.
-value     = whole-job queries/s = K * 4608 * N / max-over-ranks wall time (weak scaling:
-            every rank trains its own 4 608 queries per step; gradients are averaged).
-roofline  = the dominant kernel (fused Adam pass): algorithmic bytes 32 B/param/step
-            (SURVEY.md §8d A_step) / its mean launch duration measured with hipEvents on the
-            launch stream inside the timed region (every 4th launch); peak 8 TB/s
-            (MI355X_MICROARCH.md).  ``traffic`` = PMC HBM bytes of the last profiled run: it is
-            BELOW the algorithmic bytes because embedding-row gradients are kept as per-row
-            lists, so the dense table gradient is neither read nor re-zeroed (24 instead of
-            32 B/param) — see DESIGN.md §3.
-lazy_exact_adam (N=1, extra key, NOT the headline) = the same loop with gqe_set_lazy_adam:
-            zero-gradient Adam steps of untouched rows are deferred and replayed bit-exactly
-            when the row is next needed; the final sync is inside its timed region.
-cpu_baseline = oracle/netquery_torch.py (torch-CPU port of the reference's iteration: two
-            eager forwards per batch, one autograd backward, dense torch.optim.Adam) on the
-            same parameters and the same batches, timed on this host (rank 0, N=1 only).
+step      = one training iteration of the reference's post-burn-in schedule over the "Bio full conjunctive mix"
+            (train_helpers.py:50-79): 9 batches x B=512 = 4 608 (query, negative) pairs -> fused forward/backward
+            (one grouped launch) -> deferred matrix gradients -> [N>1: gradient exchange] -> one fused dense Adam
+            step (+ gradient reset).
+workload  = "bio-synth" (SURVEY.md §8d C3): 5 modes / 97 000 nodes / 14 directed relations, d=128, bilinear-diag
+            decoder + SetIntersection(min), P = 12 582 912 parameters; index feeds of 32 distinct pre-sampled
+            iterations are resident in HBM (``host_fed`` reports the rate with sampling + packing + pinned upload
+            by the native feeder, gqe_feeder_run, inside the timed region).
+timing    = W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + torch.cuda.synchronize()
+            on both sides (max over ranks); blocks repeat until >= 0.5 s have been timed and the MEDIAN block is
+            reported (K=20 at 0.1 ms per step is a 2 ms region: one noisy step would move it by 5 %).
+value     = whole-job queries/s = K * 4608 * N / median block time (weak scaling: every rank trains its own 4 608
+            queries per step; gradients are averaged).
+roofline  = the dominant kernel, the fused Adam pass.  ``achieved`` = the bytes the pass has to move / its mean
+            launch duration (hipEvents recorded by the library on the launch stream, every 4th launch of the timed
+            region).  Bytes: 24 B per table parameter (p, m, v read + written; the dense table gradient does not
+            exist: row gradients are per-row lists) + 32 B per relation / Pre / Post parameter + 4 B list head per
+            table row + (4 d + 8) B per gradient contribution.  ``frac`` is against the 8 TB/s spec,
+            ``frac_of_measured_copy_peak`` against the 6.29 TB/s a float4 copy reaches (MI355X_MICROARCH.md).
+            SURVEY.md §8d's 32 B/param figure is kept as ``survey_bytes_per_launch`` for reference only — 8 B/param
+            of it are never moved.  ``traffic`` = PMC HBM bytes of the last profiled run (profiles/).
+kernels   = fused forward/backward and pair GEMM: mean launch time, algorithmic bytes, and the fp32 MFMA rate of
+            their d x d contractions against the 157.3 TF/s exact-fp32 MFMA peak.
+configs   = (N=1) the other measurement configurations of SURVEY.md §8d, each with ms/step and kernel times:
+            C1 (1-chain only), C2 (2-chain + 2-inter, with and without the 1-chain batch), C4 (full Bilinear decoder,
+            the MFMA path), the scaled-batch variant (B=8192 per formula) and the 11-batch mix with 3-chain_inter.
+reddit_synth = BASELINE config 5's workload (3 modes, 12 directed relations, EmbeddingBag post features, d=256;
+            tables far beyond the 256 MB Infinity Cache) on this many GPUs; ``--workload reddit-synth --dim 256``
+            makes it the main measurement.
+lazy_exact_adam (N=1, extra key, NOT the headline) = the same loop with gqe_set_lazy_adam.
+cpu_baseline = oracle/netquery_torch.py (torch-CPU port of the reference's iteration) on the same parameters and
+            batches, timed on this host (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -41,18 +51,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0          # ... 6.29 TB/s measured with a float4 copy
+MFMA_F32_TFS = 157.3           # ... exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) peak
+ROWS_TOUCHED = {"1-chain": 3, "2-chain": 3, "3-chain": 3, "2-inter": 4, "3-inter_chain": 4, "3-chain_inter": 4, "3-inter": 5}
+N_BRANCH = {"2-inter": 2, "3-inter": 3, "3-inter_chain": 2, "3-chain_inter": 2}
+CHAIN_HOPS = {"1-chain": 1, "2-chain": 2, "3-chain": 3}
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch from the newest committed PMC summary (profiles/r*_pmc_traffic.json); the
-    counters cannot be collected from inside this process, so this is the last profiled value."""
+def pmc_traffic(kernel, tag):
+    """HBM bytes per launch from the newest committed PMC summary (profiles/r*_pmc_traffic.json, key ``tag`` =
+    workload); counters cannot be collected from inside this process, so this is the last profiled value."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files:
-        return None
-    with open(files[-1]) as f:
-        return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        with open(path) as f:
+            data = json.load(f)
+        entry = data.get(tag, data if tag == "bio-synth" else {}).get(kernel)
+        if entry:
+            return entry.get("hbm_bytes_per_launch")
+    return None
 
 
 def build_layout(g, d, decoder, inter):
@@ -60,7 +77,7 @@ def build_layout(g, d, decoder, inter):
     from graphqembed_amd.tensorize import post_key, pre_key, rel_key, table_key
     layout = ArenaLayout()
     for m in g.modes:
-        layout.add(table_key(m), (g.mode_sizes[m] + 2, d))        # len(node_maps)+1 rows (bio/data_utils.py:14-17)
+        layout.add(table_key(m), (g.table_rows[m], d))            # bio/data_utils.py:14-17, reddit/data_utils_new.py:154-158
     for m in g.relations:                                         # decoders.py:136-140 order
         for (to, name) in g.relations[m]:
             layout.add(rel_key((m, name, to)), (d, d) if decoder == "bilinear" else (d,))
@@ -87,9 +104,291 @@ def init_params(eng, d, seed):
             v.uniform_(-lim, lim, generator=gen)
 
 
-def algorithmic_bytes_per_query(qtype, d):
-    rows = {"1-chain": 3, "2-chain": 3, "3-chain": 3, "2-inter": 4, "3-inter_chain": 4, "3-chain_inter": 4, "3-inter": 5}[qtype]
-    return rows * (8 * d + 4)                                      # SURVEY.md §8d A_q
+def mfma_flops(qtype, decoder, inter, d, n):
+    """fp32 MFMA flops of (fused kernel, pair-GEMM kernel) for one batch of n queries: every d x d contraction is
+    2 d^2 flops per query.  SetIntersection: Pre per branch + Post forward, their transposes backward, one
+    deferred rank-n update per use.  Full Bilinear: a hop is a contraction (both score sides on chains)."""
+    unit = 2.0 * d * d * n
+    fused = gemm = 0.0
+    nb = N_BRANCH.get(qtype, 0)
+    if nb and not inter.endswith("simple"):
+        fused += (2 * nb + 2) * unit
+        gemm += (nb + 1) * unit
+    if decoder == "bilinear":
+        if nb:
+            hops = nb + (1 if qtype == "3-inter_chain" else 0) + (1 if qtype == "3-chain_inter" else 0)
+            fused += 2 * hops * unit
+            gemm += hops * unit
+        else:
+            k = CHAIN_HOPS[qtype]
+            fused += 4 * k * unit
+            gemm += 2 * k * unit
+    return fused, gemm
+
+
+class Workload(object):
+    """A synthetic graph, its parameter layout, query pools and ``n_distinct`` pre-sampled iterations."""
+
+    def __init__(self, name, d, decoder, inter, mix, B, rank=0, world=1, n_distinct=32, formulas_per_type=6):
+        from graphqembed_amd import synth
+        self.name, self.d, self.decoder, self.inter, self.mix, self.B = name, d, decoder, inter, mix, B
+        self.g = synth.reddit_synth(seed=0) if name == "reddit-synth" else synth.bio_synth(seed=0)
+        self.layout = build_layout(self.g, d, decoder, inter)
+        self.types = sorted(set(m[0] for m in mix))
+        self.pools = synth.make_pools(self.g, self.types, formulas_per_type=formulas_per_type, pool_size=max(16 * B, 8192), seed=0)
+        self.qpi = B * len(mix)
+        self.n_distinct = n_distinct
+        self.item_sets = [synth.mix_iteration(self.pools, mix, s, B, rank=rank, world=world) for s in range(n_distinct)]
+        self.plans = {}
+        from graphqembed_amd.tensorize import table_key
+        self.bags = {table_key(m): csr for m, csr in self.g.bags.items()}
+
+    def describe(self):
+        g = self.g
+        n_rel = sum(len(v) for v in g.relations.values())
+        return "%d modes, %d nodes, %d directed relations, seed 0" % (len(g.modes), sum(g.mode_sizes.values()), n_rel)
+
+    def engine(self, rank=0, world=1, lazy=False):
+        from graphqembed_amd.engine import Engine
+        eng = Engine(self.d, self.decoder, self.inter, self.layout, max_queries=self.qpi, max_batches=len(self.mix),
+                     rank=rank, world=world, lazy_adam=lazy, bags=self.bags)
+        init_params(eng, self.d, seed=0)                           # same seed on every rank: replicas start equal
+        return eng
+
+    def prepare(self, eng):
+        import torch
+        from graphqembed_amd.tensorize import FormulaPlan, pack_margin_batches, table_key
+        bag_len = {m: np.diff(ptr) for m, (ptr, ids) in self.g.bags.items()}
+        prepared = []
+        for items in self.item_sets:
+            packed = []
+            for (f, t, ng, a, w, m) in items:
+                if f not in self.plans:
+                    self.plans[f] = FormulaPlan(f, self.layout, self.inter)
+                packed.append((self.plans[f], t, ng, a, w, m))
+            descs, idx, _ = pack_margin_batches(packed)
+            ps = eng.prepare_margin(descs, torch.from_numpy(idx).to(eng.device))
+            ps["adam"] = eng.prepare_adam(set().union(*[p[0].touched for p in packed]))
+            # ---- algorithmic bytes / flops of this iteration ----
+            d = self.d
+            direct = bagged = links = 0                            # gradient contributions: on table rows / on bags; word links
+            aq = 0.0
+            ff = gf = 0.0
+            for (f, t, ng, a, w, m) in items:
+                n = len(t)
+                roles = [(f.target_mode, t), (f.target_mode, ng)] + [(am, a[i]) for i, am in enumerate(f.anchor_modes)]
+                for mode, rows in roles:
+                    if mode in bag_len:                            # a post = the mean of its word rows
+                        words = int(bag_len[mode][rows].sum())
+                        bagged += n
+                        links += words
+                        aq += words * 4 * d + n * (4 * d + 12)     # word rows read, one contribution written, index + ptr pair
+                    else:
+                        direct += n
+                        aq += n * (8 * d + 4)                      # SURVEY.md §8d A_q: row read + gradient write + index
+                x, y = mfma_flops(f.query_type, self.decoder, self.inter, d, n)
+                ff += x
+                gf += y
+            keys = ps["adam"]["keys"]
+            p_tab = sum(self.layout.numel(k) for k in keys if k.startswith("enc."))
+            p_den = sum(self.layout.numel(k) for k in keys if not k.startswith("enc."))
+            rows_tab = sum(self.layout.entries[k][1][0] for k in keys if k.startswith("enc."))
+            ps["n_entries"], ps["aq_bytes"], ps["fused_flops"], ps["gemm_flops"] = direct + bagged, aq, ff, gf
+            ps["p_touched"] = p_tab + p_den
+            # the fused Adam pass: p, m, v of every table parameter in and out; p, g, m, v in / p, m, v, g := 0 out for the
+            # relation / Pre / Post tensors; one list head per table row; per contribution on a row its vector, its link
+            # and the head reset; per word link of a bag contribution the vector again, the link and the entry id
+            ps["opt_bytes"] = 24.0 * p_tab + 32.0 * p_den + 4.0 * rows_tab + direct * (4.0 * d + 8.0) + links * (4.0 * d + 12.0)
+            prepared.append(ps)
+        return prepared
+
+
+def kernel_block(eng, prepared, used, ms_per_step, lazy=False, world=1, d=128):
+    """roofline / kernels / step_roofline from the library's hipEvent timings of the timed region."""
+    ms_fused, n_fused = eng.timing_read(0)
+    ms_gemm, n_gemm = eng.timing_read(1)
+    ms_opt, n_opt = eng.timing_read(2)
+    a_opt = float(np.mean([p["opt_bytes"] for p in used]))
+    survey = 32.0 * float(np.mean([p["p_touched"] for p in used]))
+    opt_kernel = "gqe_opt_kernel<ADAM, LISTS> (fused Adam over the touched tensors; row gradients from per-row lists)"
+    if lazy:                                                       # the row launch: p, m, v of the rows it names + their contributions
+        a_opt = float(np.mean([p["n_entries"] for p in used])) * world * (28.0 * d + 12.0)
+        survey = None
+        opt_kernel = "gqe_rows_kernel (lazy Adam: rows of the step; duplicates counted once per entry)"
+    a_q = float(np.mean([p["aq_bytes"] for p in used]))
+    ff = float(np.mean([p["fused_flops"] for p in used]))
+    gf = float(np.mean([p["gemm_flops"] for p in used]))
+    achieved = a_opt / (ms_opt * 1e-3) / 1e9 if ms_opt > 0 else 0.0
+
+    def tfs(flops, ms):
+        return round(flops / (ms * 1e-3) / 1e12, 2) if ms > 0 and flops > 0 else None
+    out = {
+        "roofline": {"bound": "hbm", "kernel": opt_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 4),
+                     "traffic": None, "algorithmic_bytes_per_launch": a_opt, "survey_bytes_per_launch": survey,
+                     "avg_launch_ms": round(ms_opt, 5), "launches": n_opt},
+        "kernels": {"fused_fwd_bwd": {"avg_launch_ms": round(ms_fused, 5), "launches": n_fused, "algorithmic_bytes_per_launch": a_q,
+                                      "achieved_GBs": round(a_q / (ms_fused * 1e-3) / 1e9, 1) if ms_fused > 0 else None,
+                                      "mfma_flop_per_launch": ff, "mfma_TFs": tfs(ff, ms_fused),
+                                      "mfma_frac_of_f32_peak": round(ff / (ms_fused * 1e-3) / 1e12 / MFMA_F32_TFS, 4) if ms_fused > 0 and ff else None},
+                    "pair_gemm": {"avg_launch_ms": round(ms_gemm, 5), "launches": n_gemm, "mfma_flop_per_launch": gf,
+                                  "mfma_TFs": tfs(gf, ms_gemm),
+                                  "mfma_frac_of_f32_peak": round(gf / (ms_gemm * 1e-3) / 1e12 / MFMA_F32_TFS, 4) if ms_gemm > 0 and gf else None}},
+        "step_roofline": {"algorithmic_bytes_per_step": a_opt + a_q,
+                          "achieved_GBs": round((a_opt + a_q) / (ms_per_step * 1e-3) / 1e9, 1),
+                          "frac": round((a_opt + a_q) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+    if lazy:
+        for k, nm in ((3, "optimiser_other_tables"), (4, "catch_up_before_read")):
+            ms, n = eng.timing_read(k)
+            out["kernels"][nm] = {"avg_launch_ms": round(ms, 5), "launches": n}
+    return out
+
+
+class Loop(object):
+    """W warm-up steps, then blocks of exactly K steps (barrier + synchronize on both sides, max over ranks) until
+    ``min_seconds`` have been timed; the median block is the result."""
+
+    def __init__(self, eng, dist, world):
+        self.eng, self.dist, self.world = eng, dist, world
+
+    def fence(self):
+        import torch
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+    def run(self, step, warmup, steps, min_seconds=0.5, max_blocks=400):
+        import torch
+        eng = self.eng
+        eng.timing_enable(4)                                       # every 4th launch; hipEvent pairs are recycled
+        for i in range(warmup):
+            step(i)
+        self.fence()
+        for k in range(5):
+            eng.timing_read(k)
+        times, i = [], warmup
+        while True:
+            self.fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(i)
+                i += 1
+            eng.sync()                                             # lazy Adam: deferred steps are settled inside the timed region
+            self.fence()
+            el = time.perf_counter() - t0
+            if self.dist is not None:
+                tmax = torch.tensor([el], dtype=torch.float64, device=eng.device)
+                self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
+                el = float(tmax.item())
+            times.append(el)
+            if sum(times) >= min_seconds or len(times) >= max_blocks:
+                break
+        self.last_step = i - 1
+        return times
+
+
+def summarize(times, steps):
+    med = float(np.median(times))
+    return med, {"blocks": len(times), "block_ms_min": round(min(times) * 1e3, 4), "block_ms_median": round(med * 1e3, 4),
+                 "block_ms_max": round(max(times) * 1e3, 4), "steps_per_block": steps}
+
+
+def make_step(eng, prepared, dist, exchange, n_distinct, ex_events=None):
+    from graphqembed_amd import parallel
+
+    def step(i):
+        ps = prepared[i % n_distinct]
+        eng.run_margin(ps)
+        if dist is not None:
+            rec = ex_events is not None and (i % 4) == 0
+            if rec:
+                import torch
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            if exchange == "sparse":                               # contribution entries all-gathered over xGMI
+                parallel.exchange_sparse(eng, dist)
+            else:                                                  # lists -> dense arena, RCCL sum over xGMI
+                parallel.exchange_gradients(eng.grads, dist, engine=eng)
+            if rec:
+                e1.record()
+                ex_events.append((e0, e1))
+        eng.run_adam(ps["adam"])
+    return step
+
+
+def measure(wl, args, dist, rank, world, exchange="sparse", lazy=False, steps=None, warmup=None, min_seconds=0.5, check_replicas=False):
+    """One full measurement of a workload on this process group: returns the result dict (valid on every rank)."""
+    import torch
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    sparse = world > 1 and exchange == "sparse"
+    eng = wl.engine(rank=rank if sparse else 0, world=world if sparse else 1, lazy=lazy)
+    prepared = wl.prepare(eng)
+    ex_events = [] if dist is not None else None
+    step = make_step(eng, prepared, dist, exchange, wl.n_distinct, ex_events)
+    loop = Loop(eng, dist, world)
+    times = loop.run(step, warmup, steps, min_seconds=min_seconds)
+    med, blocks = summarize(times, steps)
+    ms_per_step = med * 1e3 / steps
+    used = prepared[:min(steps, wl.n_distinct)]
+    out = {"value": round(steps * wl.qpi * world / med, 1), "unit": "queries/s", "ms_per_step": round(ms_per_step, 4), "timing": blocks}
+    out.update(kernel_block(eng, prepared, used, ms_per_step, lazy=lazy, world=world if sparse else 1, d=wl.d))
+    eng.timing_enable(0)
+    loss = float(prepared[loop.last_step % wl.n_distinct]["losses"][-1].item())
+    if not np.isfinite(loss):
+        raise SystemExit("non-finite loss")
+    out["final_loss"] = round(loss, 6)
+    if ex_events:
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in ex_events[len(ex_events) // 5:]]
+        out["exchange_ms_per_step"] = round(float(np.mean(ms)), 4)
+    if dist is not None:
+        ones = torch.ones(1, device=eng.device)
+        dist.all_reduce(ones)
+        out["ranks_seen"] = int(ones.item())
+        if check_replicas:
+            ref = eng.params.clone()
+            dist.broadcast(ref, 0)
+            same = torch.tensor([int(torch.equal(ref, eng.params))], device=eng.device)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            out["replicas_identical"] = bool(same.item() == 1)
+    return out, eng, prepared
+
+
+def host_fed(wl, args):
+    """The same schedule driven by the native feeder (gqe_feeder_run): formula draw, wrap-around slice, negative
+    draw and packing on a host core, index feed through the pinned staging ring + side-stream hipMemcpyAsync,
+    launches and the Adam step from C++ — everything inside the timed region (north star)."""
+    import torch
+    from graphqembed_amd.tensorize import FormulaPlan, table_key
+    eng = wl.engine()
+    plist = []
+    for t in wl.types:
+        for p in wl.pools[t]:
+            plist.append((FormulaPlan(p.formula, wl.layout, wl.inter), p))
+    all_rows = {table_key(m): np.arange(1, wl.g.mode_sizes[m] + 1, dtype=np.int32) for m in wl.g.modes}
+    feeder = eng.make_feeder(plist, all_rows, batch_size=wl.B, seed=0)
+    eng.feeder_run(feeder, 0, max(args.warmup, 10))
+    torch.cuda.synchronize()
+    times, it = [], max(args.warmup, 10)
+    while sum(times) < 0.5 and len(times) < 200:
+        t0 = time.perf_counter()
+        losses = eng.feeder_run(feeder, it, args.steps)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        it += args.steps
+    med, blocks = summarize(times, args.steps)
+    n_batches = 1 + sum(2 if "inter" in t else 1 for t in wl.types if t != "1-chain")
+    out = {"value": round(args.steps * n_batches * wl.B / med, 1), "unit": "queries/s", "ms_per_step": round(med * 1e3 / args.steps, 4),
+           "timing": blocks, "final_loss": round(float(losses[n_batches].item()), 6),
+           "note": "gqe_feeder_run: per iteration the host draws a formula per batch (prob ~ pool size), slices it by the "
+                   "reference's wrap-around rule, draws 1-chain negatives, packs the index feed; libgqe uploads it through "
+                   "pinned staging on a side stream while the previous iteration computes"}
+    eng.feeder_destroy(feeder)
+    eng.close()
+    return out
 
 
 def cpu_baseline(eng, decoder, inter, item_sets, budget_s, queries_per_iter):
@@ -133,226 +432,182 @@ def cpu_baseline(eng, decoder, inter, item_sets, budget_s, queries_per_iter):
             % (n, eng.layout.total, el, best[0], default_threads, torch.__version__)}
 
 
-def lazy_measurement(args, layout, d, qpi, item_sets, plans, n_distinct):
-    """The same training loop with gqe_set_lazy_adam (include/gqe.h): rows without a gradient are not streamed every
-    step, their zero-gradient Adam steps are replayed — with the eager pass's exact arithmetic — when the row is next
-    read or stepped.  Reported NEXT TO the headline value, never as it: `value` above is the eager schedule.  The
-    timed region ends with gqe_optimizer_sync, so every deferred step is paid for inside it."""
-    import torch
-    from graphqembed_amd.engine import Engine
-    from graphqembed_amd.tensorize import pack_margin_batches
-    eng = Engine(d, args.decoder, args.inter_decoder, layout, max_queries=qpi, max_batches=len(item_sets[0]), lazy_adam=True)
-    init_params(eng, d, seed=0)
-    prepared = []
-    for items in item_sets:
-        packed = [(plans[f], t, ng, a, w, m) for (f, t, ng, a, w, m) in items]
-        descs, idx, _ = pack_margin_batches(packed)
-        ps = eng.prepare_margin(descs, torch.from_numpy(idx).to(eng.device))
-        ps["adam"] = eng.prepare_adam(set().union(*[p[0].touched for p in packed]))
-        prepared.append(ps)
+def slim(res):
+    """A secondary measurement as it appears in the JSON line: the headline figures + per-kernel launch times."""
+    k = res["kernels"]
+    out = {"value": res["value"], "unit": "queries/s", "ms_per_step": res["ms_per_step"], "timing": res["timing"],
+           "final_loss": res["final_loss"],
+           "kernels_ms": {name: v["avg_launch_ms"] for name, v in k.items()},
+           "optimiser": {"avg_launch_ms": res["roofline"]["avg_launch_ms"], "achieved_GBs": res["roofline"]["achieved"],
+                         "frac": res["roofline"]["frac"], "algorithmic_bytes_per_launch": res["roofline"]["algorithmic_bytes_per_launch"]},
+           "fused_mfma_TFs": k["fused_fwd_bwd"]["mfma_TFs"], "pair_gemm_mfma_TFs": k["pair_gemm"]["mfma_TFs"],
+           "step_roofline": res["step_roofline"]}
+    for key in ("exchange_ms_per_step", "ranks_seen", "replicas_identical"):
+        if key in res:
+            out[key] = res[key]
+    return out
 
-    def step(i):
-        ps = prepared[i % n_distinct]
-        eng.run_margin(ps)
-        eng.run_adam(ps["adam"])
 
-    eng.timing_enable(4)
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    for k in range(5):
-        eng.timing_read(k)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    eng.sync()                                  # settle every deferred step inside the timed region
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    names = ["fused_fwd_bwd", "pair_gemm", "optimiser_rows_or_full_pass", "optimiser_small_tensors", "catch_up_before_read"]
-    kernels = {}
-    for k, nm in enumerate(names):
-        ms, n = eng.timing_read(k)
-        kernels[nm] = {"avg_launch_ms": round(ms, 5), "launches": n}
-    eng.timing_enable(0)
-    loss = float(prepared[(args.warmup + args.steps - 1) % n_distinct]["losses"][-1].item())
-    eng.close()
-    return {"value": round(args.steps * qpi / elapsed, 1), "unit": "queries/s", "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
-            "final_loss": round(loss, 6), "kernels": kernels,
-            "note": "same workload and step count; deferred zero-gradient Adam steps are replayed bit-exactly on demand "
-                    "(tests/test_gpu_parity.py::test_lazy_adam_is_bit_identical_to_the_eager_schedule); a full pass every "
-                    "<= 62 steps per table and the final gqe_optimizer_sync are inside the timed region"}
+def self_launch(args, argv):
+    """--gpus N > 1 without a launcher environment: become the launcher (one rank per GPU, RCCL)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")             # dmabuf IPC (RCCL / cross-process device memory)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
 
 
 def main():
+    from graphqembed_amd import synth
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch-size", type=int, default=512)
-    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--dim", type=int, default=None, help="embedding dimension (default: 128 bio-synth, 256 reddit-synth)")
+    ap.add_argument("--workload", default="bio-synth", choices=["bio-synth", "reddit-synth"],
+                    help="main measurement: BASELINE's metric is quoted on bio-synth; reddit-synth is BASELINE config 5")
     ap.add_argument("--decoder", default="bilinear-diag")
     ap.add_argument("--inter-decoder", default="min")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to "
-                    "smoke-test the multi-rank path on a single GPU)")
+                    "smoke-test the multi-rank path when several ranks share one GPU)")
     ap.add_argument("--exchange", default="sparse", choices=["sparse", "dense"],
-                    help="--gpus > 1: all-gather the gradient contribution entries (sparse) or all-reduce the dense arena")
+                    help="--gpus > 1, main measurement: all-gather the gradient contribution entries (sparse) or all-reduce "
+                    "the dense arena; the other form is measured next to it")
     ap.add_argument("--lazy-adam", action="store_true", help="run the MAIN measurement in lazy-Adam mode (non-default; the config "
                     "then says so).  Works with --gpus N and the sparse exchange.")
     ap.add_argument("--no-lazy", action="store_true", help="skip the secondary measurement of the lazy (deferred, bit-exact) Adam mode")
-    ap.add_argument("--check-replicas", action="store_true", help="after the run, verify that all ranks hold identical parameters")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other SURVEY §8d configurations (N=1)")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the gqe_feeder_run measurement (N=1)")
+    ap.add_argument("--no-reddit", action="store_true", help="skip the secondary reddit-synth d=256 measurement")
+    ap.add_argument("--only-main", action="store_true", help="main measurement only (profiling runs)")
+    ap.add_argument("--check-replicas", action="store_true", help="kept for compatibility: replicas are always compared for --gpus > 1")
     args = ap.parse_args()
+    if args.only_main:
+        args.no_lazy = args.no_configs = args.no_host_fed = args.no_reddit = args.no_cpu_baseline = True
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
 
     import torch
     from graphqembed_amd import parallel
-    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%s: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, os.environ.get("WORLD_SIZE", "1"), args.gpus))
     n_dev = torch.cuda.device_count()
+    backend, backend_note = args.backend, None
+    if args.gpus > 1 and backend == "nccl" and n_dev < args.gpus:
+        backend = "gloo"                                           # RCCL cannot put two ranks on one device
+        backend_note = "%d ranks share %d GPU(s): gloo instead of RCCL (functional run, not a scaling measurement)" % (args.gpus, n_dev)
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(n_dev, 1))
-    rank, world, local_rank, dist = parallel.init_from_env(args.backend)
+    rank, world, local_rank, dist = parallel.init_from_env(backend)
 
-    from graphqembed_amd import synth
-    from graphqembed_amd.engine import Engine
-    from graphqembed_amd.tensorize import FormulaPlan, pack_margin_batches
-
-    d, B = args.dim, args.batch_size
-    g = synth.bio_synth(seed=0)
-    layout = build_layout(g, d, args.decoder, args.inter_decoder)
-    mix = synth.FULL_MIX
-    qpi = B * len(mix)                                             # queries per iteration per GPU
+    reddit = args.workload == "reddit-synth"
+    d = args.dim or (256 if reddit else 128)
+    B = args.batch_size
+    wl = Workload(args.workload, d, args.decoder, args.inter_decoder, synth.FULL_MIX, B, rank=rank, world=world)
+    res, eng, prepared = measure(wl, args, dist, rank, world, exchange=args.exchange, lazy=args.lazy_adam, check_replicas=world > 1)
     sparse = world > 1 and args.exchange == "sparse"
-    eng = Engine(d, args.decoder, args.inter_decoder, layout, max_queries=qpi, max_batches=len(mix),
-                 rank=rank if sparse else 0, world=world if sparse else 1, lazy_adam=args.lazy_adam)
-    init_params(eng, d, seed=0)                                    # same seed on every rank: replicas start equal
-    pools = synth.make_pools(g, sorted(set(m[0] for m in mix)), formulas_per_type=6, pool_size=max(16 * B, 8192), seed=0)
-
-    n_distinct = 32
-    item_sets, prepared = [], []
-    plans = {}
-    for s in range(n_distinct):
-        items = synth.mix_iteration(pools, mix, s, B, rank=rank, world=world)
-        item_sets.append(items)
-        packed = []
-        for (f, t, ng, a, w, m) in items:
-            if f not in plans:
-                plans[f] = FormulaPlan(f, layout, args.inter_decoder)
-            packed.append((plans[f], t, ng, a, w, m))
-        descs, idx, _ = pack_margin_batches(packed)
-        ps = eng.prepare_margin(descs, torch.from_numpy(idx).to(eng.device))
-        ps["adam"] = eng.prepare_adam(set().union(*[p[0].touched for p in packed]))
-        ps["n_entries"] = sum((2 + a.shape[0]) * len(t) for (_, t, _, a, _, _) in items)
-        ps["aq_bytes"] = sum(algorithmic_bytes_per_query(f.query_type, d) * len(t) for (f, t, _, _, _, _) in items)
-        ps["p_touched"] = sum(layout.numel(k) for k in ps["adam"]["keys"])
-        prepared.append(ps)
-
-    mode = {"sparse": sparse}
-
-    def step(i):
-        ps = prepared[i % n_distinct]
-        eng.run_margin(ps)
-        if mode["sparse"]:                                         # contribution entries all-gathered over xGMI
-            try:
-                parallel.exchange_sparse(eng, dist)
-            except Exception as e:                                 # argument-level refusal by the backend: same on all ranks
-                if i != 0:
-                    raise
-                sys.stderr.write("bench: sparse exchange refused (%s); falling back to the dense all-reduce\n" % e)
-                mode["sparse"] = False
-                parallel.exchange_gradients(eng.grads, dist, engine=eng)
-        elif dist is not None:                                     # lists -> dense arena, RCCL sum over xGMI
-            parallel.exchange_gradients(eng.grads, dist, engine=eng)
-        eng.run_adam(ps["adam"])
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    eng.timing_enable(4)                                           # every 4th launch; hipEvent pairs are recycled
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    for k in range(3):
-        eng.timing_read(k)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    eng.sync()                                                     # lazy Adam: deferred steps are settled inside the timed region
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    ms_fused, n_fused = eng.timing_read(0)
-    ms_gemm, n_gemm = eng.timing_read(1)
-    ms_opt, n_opt = eng.timing_read(2)
-    eng.timing_enable(0)
-    loss = float(prepared[(args.warmup + args.steps - 1) % n_distinct]["losses"][-1].item())
-    if not np.isfinite(loss):
-        raise SystemExit("non-finite loss")
-
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = args.steps * qpi * world / elapsed
-    used = [prepared[(args.warmup + i) % n_distinct] for i in range(min(args.steps, n_distinct))]
-    a_step = 32.0 * np.mean([p["p_touched"] for p in used])        # bytes per optimiser launch
-    opt_kernel = "gqe_opt_kernel<ADAM> (fused Adam + grad re-zero)"
-    if args.lazy_adam:                                             # the row launch: 32 B per parameter of the rows it names
-        a_step = 32.0 * d * world * np.mean([p["n_entries"] for p in used])
-        opt_kernel = "gqe_rows_kernel (lazy Adam: rows of the step; duplicates counted once per entry)"
-    a_q = float(np.mean([p["aq_bytes"] for p in used]))            # bytes per fused fwd/bwd launch
-    achieved = a_step / (ms_opt * 1e-3) / 1e9 if ms_opt > 0 else 0.0
+    res["roofline"]["traffic"] = None if (args.lazy_adam or (d, B, args.decoder, args.inter_decoder) != ((256 if reddit else 128), 512, "bilinear-diag", "min")) \
+        else pmc_traffic("gqe_opt_kernel", args.workload)
+    label = "Reddit" if reddit else "Bio"
     out = {
-        "metric": "queries/sec, Bio full conjunctive mix d=%d, at 1/2/4/8 MI355X" % d,
-        "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "bio-synth full mix (1/2/3-chain, 2/3-inter x{neg,hard}, 3-inter_chain x{neg,hard}): "
+        "metric": "queries/sec, %s full conjunctive mix d=%d, at 1/2/4/8 MI355X" % (label, d),
+        "value": res["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic", "timing": res["timing"],
+        "config": {"workload": "%s full mix (1/2/3-chain, 2/3-inter x{neg,hard}, 3-inter_chain x{neg,hard}): "
                                "%d batches x B=%d per GPU per step, d=%d, %s + SetIntersection(%s), P=%d, Adam lr 0.01"
-                               % (len(mix), B, d, args.decoder, args.inter_decoder, layout.total),
-                   "graph": "5 modes, 97000 nodes, 14 directed relations, 60000 edges/kind, seed 0",
-                   "queries_per_step_per_gpu": qpi, "parallelism": "dp%d" % world,
+                               % (args.workload, len(wl.mix), B, d, args.decoder, args.inter_decoder, wl.layout.total),
+                   "graph": wl.describe(), "queries_per_step_per_gpu": wl.qpi, "parallelism": "dp%d" % world,
+                   "backend": None if world == 1 else backend,
                    "optimizer": "lazy (deferred, bit-exact) Adam — NON-DEFAULT mode" if args.lazy_adam else "eager dense Adam",
                    "gradient_exchange": "none" if world == 1 else
                    ("one all-gather per step of per-rank slabs: %d contribution entries x (%d floats + row id) + the dense "
-                    "relation/Pre/Post gradients" % (prepared[0]["n_entries"], d)) if mode["sparse"] else
-                   "all-reduce of the %d-float gradient arena" % layout.total},
-        "roofline": {"bound": "hbm", "kernel": opt_kernel,
-                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": pmc_traffic("gqe_opt_kernel") if (d, B, args.decoder, args.inter_decoder, args.lazy_adam) == (128, 512, "bilinear-diag", "min", False) else None,
-                     "algorithmic_bytes_per_launch": a_step, "avg_launch_ms": round(ms_opt, 5), "launches": n_opt},
-        "kernels": {"fused_fwd_bwd": {"avg_launch_ms": round(ms_fused, 5), "launches": n_fused,
-                                      "algorithmic_bytes_per_launch": a_q,
-                                      "achieved_GBs": round(a_q / (ms_fused * 1e-3) / 1e9, 1) if ms_fused > 0 else None},
-                    "pair_gemm": {"avg_launch_ms": round(ms_gemm, 5), "launches": n_gemm}},
-        "step_roofline": {"algorithmic_bytes_per_step": a_step + a_q,
-                          "achieved_GBs": round((a_step + a_q) / (ms_per_step * 1e-3) / 1e9, 1),
-                          "frac": round((a_step + a_q) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-        "final_loss": round(loss, 6),
+                    "relation/Pre/Post gradients" % (prepared[0]["n_entries"], d)) if sparse else
+                   "all-reduce of the %d-float gradient arena" % wl.layout.total},
+        "roofline": res["roofline"], "kernels": res["kernels"], "step_roofline": res["step_roofline"],
+        "final_loss": res["final_loss"],
     }
+    if backend_note:
+        out["config"]["backend_note"] = backend_note
+    for key in ("exchange_ms_per_step", "ranks_seen", "replicas_identical"):
+        if key in res:
+            out[key] = res[key]
+    short = dict(steps=max(20, min(args.steps, 100)), warmup=min(args.warmup, 10), min_seconds=0.25)
+    if world > 1:
+        # both exchange forms in one line: the other one, shorter
+        other = "dense" if args.exchange == "sparse" else "sparse"
+        eng.close()
+        r2, e2, _ = measure(wl, args, dist, rank, world, exchange=other, lazy=False, check_replicas=True, **short)
+        e2.close()
+        out["exchange"] = {args.exchange: {"ms_per_step": res["ms_per_step"], "exchange_ms_per_step": res.get("exchange_ms_per_step"),
+                                           "value": res["value"], "replicas_identical": res.get("replicas_identical")},
+                           other: {"ms_per_step": r2["ms_per_step"], "exchange_ms_per_step": r2.get("exchange_ms_per_step"),
+                                   "value": r2["value"], "replicas_identical": r2.get("replicas_identical")}}
+        eng = None
     if world == 1 and not args.no_lazy and not args.lazy_adam:
-        out["lazy_exact_adam"] = lazy_measurement(args, layout, d, qpi, item_sets, plans, n_distinct)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(eng, args.decoder, args.inter_decoder, item_sets[:8], args.cpu_seconds, qpi)
+        rl, el, _ = measure(wl, args, None, 0, 1, lazy=True)
+        el.close()
+        lz = slim(rl)
+        lz["kernels_ms"]["optimiser_rows_or_full_pass"] = rl["roofline"]["avg_launch_ms"]
+        lz["note"] = ("same workload and step count; deferred zero-gradient Adam steps are replayed bit-exactly on demand "
+                      "(tests/test_gpu_parity.py::test_lazy_adam_is_bit_identical_to_the_eager_schedule); a full pass every "
+                      "<= 32 steps per table and the final gqe_optimizer_sync are inside the timed region")
+        out["lazy_exact_adam"] = lz
+    if world == 1 and not args.no_host_fed and not args.lazy_adam:
+        out["host_fed"] = host_fed(wl, args)
+    if world == 1 and not args.no_configs and not reddit:
+        cfgs = {}
+        M = synth.FULL_MIX
+
+        def run_cfg(name, decoder, mix, Bc, note):
+            w = Workload("bio-synth", d, decoder, args.inter_decoder, mix, Bc, n_distinct=16 if Bc > 512 else 32)
+            r, e, _ = measure(w, args, None, 0, 1, **(dict(short, steps=20) if Bc > 512 else short))
+            e.close()
+            s = slim(r)
+            s["config"] = "%s; %d batches x B=%d, %s + SetIntersection(%s), P=%d" % (note, len(mix), Bc, decoder, args.inter_decoder, w.layout.total)
+            cfgs[name] = s
+        run_cfg("C1_1chain_only", args.decoder, (M[0],), B, "burn-in loop (train_helpers.py:51)")
+        run_cfg("C2_2chain_2inter", args.decoder, (M[0], M[1], M[3], M[4]), B, "1-chain + 2-chain + 2-inter x{neg,hard}")
+        run_cfg("C2_without_1chain", args.decoder, (M[1], M[3], M[4]), B, "2-chain + 2-inter x{neg,hard}")
+        run_cfg("C4_full_bilinear", "bilinear", M, B, "full mix, d x d relation matrices (decoders.py:142-150): the MFMA path")
+        run_cfg("C3_scaled_batch_B8192", args.decoder, M, 8192, "full mix, scaled batch (B=512 is launch-latency-bound)")
+        run_cfg("C3_plus_3chain_inter", args.decoder, M + (("3-chain_inter", 0.005, False), ("3-chain_inter", 0.005, True)), B,
+                "11-batch mix incl. 3-chain_inter (model.py:99-109)")
+        out["configs"] = cfgs
+    if not args.no_reddit and not reddit:
+        if eng is not None and world > 1:
+            eng.close()
+            eng = None
+        wr = Workload("reddit-synth", 256, args.decoder, args.inter_decoder, synth.FULL_MIX, B, rank=rank, world=world, n_distinct=16)
+        rr, er, _ = measure(wr, args, dist, rank, world, exchange=args.exchange, check_replicas=world > 1, **short)
+        er.close()
+        rs = slim(rr)
+        rs["config"] = ("BASELINE config 5 workload: reddit-synth (%s; EmbeddingBag post features over a %d-word table, bags U[5,30]), "
+                        "full mix %d batches x B=%d per GPU, d=256, %s + SetIntersection(%s), P=%d"
+                        % (wr.describe(), wr.g.table_rows["post"], len(wr.mix), B, args.decoder, args.inter_decoder, wr.layout.total))
+        rs["optimiser"]["traffic"] = pmc_traffic("gqe_opt_kernel", "reddit-synth")
+        out["reddit_synth"] = rs
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not reddit:
+        out["cpu_baseline"] = cpu_baseline(eng, args.decoder, args.inter_decoder, wl.item_sets[:8], args.cpu_seconds, wl.qpi)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if args.check_replicas and dist is not None:
-        ref = eng.params.clone()
-        dist.broadcast(ref, 0)
-        same = torch.tensor([int(torch.equal(ref, eng.params))], device=eng.device)
-        dist.all_reduce(same, op=dist.ReduceOp.MIN)
-        out["replicas_identical"] = bool(same.item() == 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    if eng is not None:
+        eng.close()
 
 
 if __name__ == "__main__":

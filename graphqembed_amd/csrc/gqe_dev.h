@@ -13,13 +13,14 @@
 #define GQE_WAVES 4          // wave64s per workgroup of the pair-GEMM / optimiser kernels
 #define GQE_THREADS 256
 #define GQE_OPT_CHUNK 1024   // floats per optimiser chunk (256 threads x float4)
-#define GQE_MAX_SEGS 96
+#define GQE_MAX_SEGS 96      // tensors the kernel-argument form of an optimiser pass can describe (more: table form)
 #define GQE_GEMM_KCHUNK 128  // queries per pair-GEMM unit
 #define GQE_GEMM_MT 64       // edge of the gradient block one pair-GEMM unit produces
 #define GQE_PROF_SLOTS 16     // wall_clock64 stamps per workgroup (debug profile)
 
 #define GQE_LAUNCH_BATCHES 16  // batches per fused launch: their dynamic descriptors travel as kernel arguments
-#define GQE_MAX_FORMULAS 2048  // distinct (formula, decoder layout) descriptors cached on the device
+#define GQE_DEFAULT_FORMULAS 2048  // default capacity of the device formula-descriptor cache (gqe_set_limits); LRU beyond
+#define GQE_DEFAULT_TENSORS 256    // default number of distinct parameter tensors the optimiser can be asked to step
 #define GQE_MAX_JOBS 8         // deferred matrix-gradient jobs one batch can generate
 #define GQE_MAX_BAGS 4         // tables whose rows are bags (nn.EmbeddingBag modes)
 
@@ -89,7 +90,19 @@ struct GqeDynPlan {
 struct GqeDevSeg {
   int64_t offset, numel, n_chunks;
   int64_t rows, head_base;  // tables only
-  int32_t is_table, pad;
+  int32_t is_table;
+  int32_t table_index;      // tables only: index in gqe_set_tables order (slot of the lazy-Adam per-table arguments)
+};
+
+// Table form of "which tensors does this pass step, and with which Adam bias corrections": one entry per ACTIVE
+// tensor in universe order, uploaded with the step.  Used when the kernel-argument form (GqeOptActive /
+// GqeStepCoef) cannot describe the pass: more than GQE_MAX_SEGS tensors, or more than GQE_MAX_STEP_GROUPS distinct
+// per-tensor step counts (schemas with dozens of relation types whose counters diverge).
+struct GqeActSeg {
+  long long chunk_begin;  // first chunk of this tensor in the pass
+  int32_t seg;            // universe index
+  float step_size, bc2_sqrt;
+  int32_t pad;
 };
 
 struct GqeOptActive {
@@ -118,8 +131,7 @@ struct GqeLazyTabs {
 struct GqeLazyArgs {      // rides along with the optimiser launch
   int32_t* last;          // [total rows] step count each row is current for
   float2* ring;           // [GQE_LAZY_TABLES][GQE_LAZY_RING]
-  GqeLazyTabs t;
-  int8_t table_of_seg[GQE_MAX_SEGS];  // universe entry -> slot in t (tables only)
+  GqeLazyTabs t;          // slot = GqeDevSeg::table_index
 };
 struct GqeRowSegs {       // the table rows named by an index feed: segment k = idx[idx_begin[k] .. +count) of table tid[k]
                           // (tid -1: skip; -2: the values are list heads of any table — exchanged slabs)
@@ -148,6 +160,8 @@ struct GqeRowsArgs {
   long long dense_chunks;
   GqeStepCoef dcoef;
   GqeOptActive dactive;
+  const GqeActSeg* dact;  // table form of dcoef / dactive (NULL: kernel-argument form)
+  int n_dact;
   hipStream_t stream;
 };
 
@@ -174,6 +188,8 @@ struct GqeOptArgs {
   float lr, b1, b2, eps;
   GqeStepCoef coef;
   GqeOptActive active;
+  const GqeActSeg* act;  // table form of coef / active (NULL: kernel-argument form)
+  int n_act;
   bool lazy;          // tables carry per-row step counts (GqeLazyArgs)
   GqeLazyArgs lz;
   hipStream_t stream;

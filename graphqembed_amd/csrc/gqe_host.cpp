@@ -65,7 +65,7 @@ struct Bag {
 
 struct Layout {  // byte offsets inside the bound workspace
   size_t idx_cap, tloss_off, scratch_off, scratch_cap;  // [staged indices x2 | tile losses | pair scratch]
-  size_t seg_off, formula_off, head_off, rows_off, next_off, contrib_off, linkc_off, counter_off, last_off, ring_off, total;
+  size_t seg_off, act_off, formula_off, head_off, rows_off, next_off, contrib_off, linkc_off, counter_off, last_off, ring_off, total;
   int64_t max_entries, max_links;  // max_entries = per-rank capacity x world (the exchange gathers every rank's entries)
 };
 
@@ -104,9 +104,15 @@ struct gqe_ctx {
   int ring_next = 0;
   // formula descriptor cache: static per-formula data lives on the device, per-call data travels as kernel
   // arguments, so a steady-state iteration uploads nothing
+  // (least-recently-used slots are re-used once cap_formulas descriptors are cached: a multi-relational graph has
+  // thousands of distinct 3-hop formulas, and formula ids are per-call kernel arguments, so a slot can be re-uploaded)
   std::vector<GqeDevFormula> formulas;
+  std::vector<std::string> formula_keys;      // slot -> cache key
+  std::vector<long long> formula_used;        // slot -> stamp of the last call that used it
+  std::vector<int> formulas_dirty;            // slots whose device copy is stale
   std::map<std::string, int> formula_ids;
-  size_t formulas_uploaded = 0;
+  long long call_stamp = 0;
+  int cap_formulas = GQE_DEFAULT_FORMULAS, cap_tensors = GQE_DEFAULT_TENSORS;  // gqe_set_limits
   // host index feeds are uploaded on a side stream into one of two device buffers, so the copy for
   // iteration i+1 overlaps the kernels of iteration i instead of sitting between them
   hipStream_t up = nullptr;
@@ -228,8 +234,9 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
   L.scratch_off = L.tloss_off + align_up(sizeof(float) * (size_t)(rows / GQE_TQ + GQE_MAX_BATCHES + 1), 256);
   L.scratch_cap = align_up((size_t)rows * kMaxSlots * ctx->cfg.dim * sizeof(float), 256);
   L.seg_off = L.scratch_off + L.scratch_cap;
-  L.formula_off = L.seg_off + align_up(sizeof(GqeDevSeg) * GQE_MAX_SEGS, 256);
-  L.head_off = L.formula_off + align_up(sizeof(GqeDevFormula) * GQE_MAX_FORMULAS, 256);
+  L.act_off = L.seg_off + align_up(sizeof(GqeDevSeg) * (size_t)ctx->cap_tensors, 256);
+  L.formula_off = L.act_off + align_up(sizeof(GqeActSeg) * (size_t)ctx->cap_tensors, 256);
+  L.head_off = L.formula_off + align_up(sizeof(GqeDevFormula) * (size_t)ctx->cap_formulas, 256);
   L.max_entries = (int64_t)align_up((size_t)(rows * kRolesPerQuery), 64);
   if (ctx->world > 1) {
     const GqeSpans sp = dense_spans(ctx);
@@ -293,6 +300,14 @@ int timing_end(gqe_ctx* ctx, int kind, hipStream_t st) {
   return GQE_OK;
 }
 
+void drop_formulas(gqe_ctx* ctx) {
+  ctx->formulas.clear();
+  ctx->formula_keys.clear();
+  ctx->formula_used.clear();
+  ctx->formulas_dirty.clear();
+  ctx->formula_ids.clear();
+}
+
 bool off_ok(const gqe_ctx* ctx, int64_t off, int64_t numel) {
   return off >= 0 && (off % 4) == 0 && off + numel <= ctx->n_arena;
 }
@@ -336,9 +351,9 @@ int formula_of(gqe_ctx* ctx, const gqe_batch& s, int bi, int* out_id) {
   auto it = ctx->formula_ids.find(ks);
   if (it != ctx->formula_ids.end()) {
     *out_id = it->second;
+    ctx->formula_used[it->second] = ctx->call_stamp;
     return GQE_OK;
   }
-  if (ctx->formulas.size() >= GQE_MAX_FORMULAS) return fail(ctx, GQE_ERR_ARG, "more than %d distinct formulas", GQE_MAX_FORMULAS);
   GqeDevFormula f;
   memset(&f, 0xff, sizeof f);  // all slots / params = -1
   f.qtype = s.qtype;
@@ -434,9 +449,27 @@ int formula_of(gqe_ctx* ctx, const gqe_batch& s, int bi, int* out_id) {
   if (nslot > kMaxSlots || njob > GQE_MAX_JOBS) return fail(ctx, GQE_ERR_ARG, "internal: %d scratch slots / %d jobs", nslot, njob);
   f.n_slots = nslot;
   f.n_jobs = njob;
-  ctx->formulas.push_back(f);
-  *out_id = (int)ctx->formulas.size() - 1;
-  ctx->formula_ids[ks] = *out_id;
+  int slot;
+  if ((int)ctx->formulas.size() < ctx->cap_formulas) {
+    slot = (int)ctx->formulas.size();
+    ctx->formulas.push_back(f);
+    ctx->formula_keys.push_back(ks);
+    ctx->formula_used.push_back(ctx->call_stamp);
+  } else {
+    // cache full: re-use the least recently used slot that the current call does not name
+    slot = -1;
+    for (int k = 0; k < (int)ctx->formulas.size(); ++k)
+      if (ctx->formula_used[k] < ctx->call_stamp && (slot < 0 || ctx->formula_used[k] < ctx->formula_used[slot])) slot = k;
+    if (slot < 0)
+      return fail(ctx, GQE_ERR_ARG, "one call names more than %d distinct formulas (gqe_set_limits raises the cache size)", ctx->cap_formulas);
+    ctx->formula_ids.erase(ctx->formula_keys[slot]);
+    ctx->formulas[slot] = f;
+    ctx->formula_keys[slot] = ks;
+    ctx->formula_used[slot] = ctx->call_stamp;
+  }
+  ctx->formulas_dirty.push_back(slot);
+  *out_id = slot;
+  ctx->formula_ids[ks] = slot;
   return GQE_OK;
 }
 
@@ -540,6 +573,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   const int macros_sq = ((d + GQE_GEMM_MT - 1) / GQE_GEMM_MT) * ((d + GQE_GEMM_MT - 1) / GQE_GEMM_MT);
 
   // ---- validate everything and resolve the formula descriptors before anything is enqueued ----
+  ++ctx->call_stamp;  // descriptor slots used by this call are not evicted by it
   std::vector<int> fid(n_batches);
   int64_t entries = 0;
   std::vector<int> touched_tables;
@@ -578,18 +612,26 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
                 "gqe_materialize_grads first", (long long)ctx->entries_used, (long long)entries, (long long)L.max_entries);
 
   int rc;
-  // ---- new formulas -> device table (rare) ----
-  if (ctx->formulas_uploaded != ctx->formulas.size()) {
-    const size_t off = sizeof(GqeDevFormula) * ctx->formulas_uploaded;
-    const size_t bytes = sizeof(GqeDevFormula) * (ctx->formulas.size() - ctx->formulas_uploaded);
-    RingSlot* slot;
-    rc = ring_acquire(ctx, bytes, &slot);
-    if (rc != GQE_OK) return rc;
-    memcpy(slot->host, ctx->formulas.data() + ctx->formulas_uploaded, bytes);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws + L.formula_off + off, slot->host, bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipEventRecord(slot->done, st));
-    slot->in_flight = true;
-    ctx->formulas_uploaded = ctx->formulas.size();
+  // ---- new / replaced formula descriptors -> device table (rare): contiguous runs of stale slots, one copy each ----
+  if (!ctx->formulas_dirty.empty()) {
+    std::vector<int>& dirty = ctx->formulas_dirty;
+    std::sort(dirty.begin(), dirty.end());
+    dirty.erase(std::unique(dirty.begin(), dirty.end()), dirty.end());
+    for (size_t a = 0; a < dirty.size();) {
+      size_t b = a + 1;
+      while (b < dirty.size() && dirty[b] == dirty[b - 1] + 1) ++b;
+      const size_t off = sizeof(GqeDevFormula) * (size_t)dirty[a];
+      const size_t bytes = sizeof(GqeDevFormula) * (b - a);
+      RingSlot* slot;
+      rc = ring_acquire(ctx, bytes, &slot);
+      if (rc != GQE_OK) return rc;
+      memcpy(slot->host, ctx->formulas.data() + dirty[a], bytes);
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->ws + L.formula_off + off, slot->host, bytes, hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipEventRecord(slot->done, st));
+      slot->in_flight = true;
+      a = b;
+    }
+    dirty.clear();
   }
   // ---- host index feed -> device, on the side stream ----
   const int32_t* d_idx = idx;
@@ -608,6 +650,9 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     memcpy(slot->host, idx, idx_bytes);
     buf = ctx->plan_buf;
     ctx->plan_buf ^= 1;
+    // lazy Adam: the pending margin call's index feed may still live in this staging buffer (the sparse optimiser
+    // launch walks it); once it is overwritten the step has to fall back to the full pass
+    if (ctx->feed_valid && ctx->feed_buf == buf) ctx->feed_valid = false;
     char* dev = ctx->ws + (size_t)buf * L.idx_cap;
     if (ctx->plan_free_set[buf]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->up, ctx->plan_free[buf], 0));
     HIP_TRY(ctx, hipMemcpyAsync(dev, slot->host, idx_bytes, hipMemcpyHostToDevice, ctx->up));
@@ -760,13 +805,14 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
 int universe_index(gqe_ctx* ctx, int64_t offset, int64_t numel, int table) {
   for (size_t i = 0; i < ctx->universe.size(); ++i)
     if (ctx->universe[i].offset == offset && ctx->universe[i].numel == numel) return (int)i;
-  if (ctx->universe.size() >= GQE_MAX_SEGS) return -1;
+  if ((int)ctx->universe.size() >= ctx->cap_tensors) return -1;
   const int d = ctx->cfg.dim;
   GqeDevSeg g;
   memset(&g, 0, sizeof g);
   g.offset = offset;
   g.numel = numel;
   g.is_table = table >= 0 ? 1 : 0;
+  g.table_index = table;
   if (table >= 0) {
     const int tpr = d / 4, rpc = GQE_THREADS / tpr;
     g.rows = ctx->tables[table].rows;
@@ -813,38 +859,25 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
   GqeOptArgs oa;
   oa.lazy = false;
   memset(&oa.lz, 0, sizeof oa.lz);
+  memset(&oa.coef, 0, sizeof oa.coef);
   memset(oa.active.group, 0xFF, sizeof oa.active.group);
-  long long chunks = 0;
+  oa.act = nullptr;
+  oa.n_act = 0;
   std::vector<char> seen(ctx->tables.size(), 0);
   bool lists = false;
-  int group_step[GQE_MAX_STEP_GROUPS];
-  int n_groups = 0;
+  std::vector<int> ustep;  // per universe entry: the step count this pass applies (0 = the tensor is not stepped)
   auto activate = [&](int64_t offset, int64_t numel, int step, int table) -> int {
     const int ui = universe_index(ctx, offset, numel, table);
-    if (ui < 0) return fail(ctx, GQE_ERR_ARG, "more than %d distinct parameter tensors", GQE_MAX_SEGS);
-    if (oa.active.group[ui] != 0xFF) return fail(ctx, GQE_ERR_ARG, "tensor at offset %lld listed twice", (long long)offset);
+    if (ui < 0)
+      return fail(ctx, GQE_ERR_ARG, "more than %d distinct parameter tensors: raise the limit with gqe_set_limits (before gqe_workspace_bytes)",
+                  ctx->cap_tensors);
+    if ((size_t)ui >= ustep.size()) ustep.resize((size_t)ui + 1, 0);
+    if (ustep[ui]) return fail(ctx, GQE_ERR_ARG, "tensor at offset %lld listed twice", (long long)offset);
     if (table >= 0) {
       seen[table] = 1;
       lists = lists || ctx->tables[table].pending;
     }
-    // tensors with the same Adam step count share one (step_size, bc2_sqrt) pair, passed as kernel arguments
-    if (mode != GQE_OPT_ADAM) step = 1;
-    int gi = 0;
-    while (gi < n_groups && group_step[gi] != step) ++gi;
-    if (gi == n_groups) {
-      if (n_groups == GQE_MAX_STEP_GROUPS) return fail(ctx, GQE_ERR_ARG, "more than %d distinct Adam step counts in one call", GQE_MAX_STEP_GROUPS);
-      group_step[n_groups++] = step;
-      if (mode == GQE_OPT_ADAM) {
-        // torch.optim.Adam: step_size = lr / (1 - b1^t); denom = sqrt(v) / sqrt(1 - b2^t) + eps  (python doubles)
-        oa.coef.step_size[gi] = (float)((double)lr / (1.0 - std::pow((double)b1, (double)step)));
-        oa.coef.bc2_sqrt[gi] = (float)std::sqrt(1.0 - std::pow((double)b2, (double)step));
-      } else {
-        oa.coef.step_size[gi] = lr;
-        oa.coef.bc2_sqrt[gi] = 1.f;
-      }
-    }
-    oa.active.group[ui] = (uint8_t)gi;
-    chunks += ctx->universe[ui].n_chunks;
+    ustep[ui] = mode == GQE_OPT_ADAM ? std::max(step, 1) : 1;
     return GQE_OK;
   };
   int rc;
@@ -869,7 +902,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       return GQE_OK;
     }
   } else {
-    if (!segs || n_segs < 1 || n_segs > GQE_MAX_SEGS) return fail(ctx, GQE_ERR_ARG, "n_segs must be in [1,%d]", GQE_MAX_SEGS);
+    if (!segs || n_segs < 1 || n_segs > ctx->cap_tensors) return fail(ctx, GQE_ERR_ARG, "n_segs must be in [1,%d]", ctx->cap_tensors);
     for (int i = 0; i < n_segs; ++i) {
       const gqe_segment& s = segs[i];
       if (s.offset < 0 || (s.offset % 4) != 0 || s.numel < 1 || s.offset + s.numel > ctx->n_arena)
@@ -899,13 +932,84 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     slot->in_flight = true;
     ctx->universe_uploaded = ctx->universe.size();
   }
+  // ---- Adam coefficients per stepped tensor.  torch.optim.Adam: step_size = lr / (1 - b1^t);
+  // denom = sqrt(v) / sqrt(1 - b2^t) + eps  (python doubles).  Tensors with the same step count share a pair.
+  const size_t nu = ctx->universe.size();
+  ustep.resize(nu, 0);
+  std::vector<float> uss(nu, lr), ubc(nu, 1.f);
+  std::vector<int> distinct;
+  for (size_t ui = 0; ui < nu; ++ui) {
+    if (!ustep[ui]) continue;
+    if (std::find(distinct.begin(), distinct.end(), ustep[ui]) == distinct.end()) distinct.push_back(ustep[ui]);
+    if (mode == GQE_OPT_ADAM) {
+      uss[ui] = (float)((double)lr / (1.0 - std::pow((double)b1, (double)ustep[ui])));
+      ubc[ui] = (float)std::sqrt(1.0 - std::pow((double)b2, (double)ustep[ui]));
+    }
+  }
+  // The pass is described to the kernels either in their arguments (<= GQE_MAX_SEGS tensors known to the ctx and
+  // <= GQE_MAX_STEP_GROUPS distinct step counts: nothing is uploaded) or as a list of the active tensors that is
+  // uploaded with the step (large schemas: dozens of relation types whose step counters diverge).
+  const bool table_form = nu > GQE_MAX_SEGS || distinct.size() > GQE_MAX_STEP_GROUPS;
+  std::vector<GqeActSeg> staging;
+  const GqeActSeg* act_dev = reinterpret_cast<const GqeActSeg*>(ctx->ws + ctx->lay.act_off);
+  auto emit = [&](auto keep, GqeOptActive& active, GqeStepCoef& coef, const GqeActSeg** act, int* n_act) -> long long {
+    long long chunks = 0;
+    memset(active.group, 0xFF, sizeof active.group);
+    memset(&coef, 0, sizeof coef);
+    *act = nullptr;
+    *n_act = 0;
+    if (!table_form) {
+      int group_step[GQE_MAX_STEP_GROUPS], n_groups = 0;
+      for (size_t ui = 0; ui < nu; ++ui) {
+        if (!ustep[ui] || !keep(ui)) continue;
+        int gi = 0;
+        while (gi < n_groups && group_step[gi] != ustep[ui]) ++gi;
+        if (gi == n_groups) {
+          group_step[n_groups++] = ustep[ui];
+          coef.step_size[gi] = uss[ui];
+          coef.bc2_sqrt[gi] = ubc[ui];
+        }
+        active.group[ui] = (uint8_t)gi;
+        chunks += ctx->universe[ui].n_chunks;
+      }
+    } else {
+      const size_t first = staging.size();
+      for (size_t ui = 0; ui < nu; ++ui) {
+        if (!ustep[ui] || !keep(ui)) continue;
+        GqeActSeg a;
+        a.chunk_begin = chunks;
+        a.seg = (int32_t)ui;
+        a.step_size = uss[ui];
+        a.bc2_sqrt = ubc[ui];
+        a.pad = 0;
+        staging.push_back(a);
+        chunks += ctx->universe[ui].n_chunks;
+      }
+      *act = act_dev + first;
+      *n_act = (int)(staging.size() - first);
+    }
+    return chunks;
+  };
+  auto upload_staging = [&]() -> int {
+    if (staging.empty()) return GQE_OK;
+    const size_t bytes = sizeof(GqeActSeg) * staging.size();
+    RingSlot* slot;
+    int r = ring_acquire(ctx, bytes, &slot);
+    if (r != GQE_OK) return r;
+    memcpy(slot->host, staging.data(), bytes);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws + ctx->lay.act_off, slot->host, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipEventRecord(slot->done, st));
+    slot->in_flight = true;
+    return GQE_OK;
+  };
   oa.mode = mode;
   oa.lists = lists;
   oa.sorted = ctx->world > 1;  // replicas must sum a row's contributions in the same order
-  oa.dense_tables = ctx->dense_dirty || mode == GQE_OPT_ZERO;
+  // the FLUSH pass only replays deferred steps: it must neither read nor re-zero a materialised dense gradient
+  // that is still waiting for its optimiser step
+  oa.dense_tables = !flush && (ctx->dense_dirty || mode == GQE_OPT_ZERO);
   oa.segs = reinterpret_cast<const GqeDevSeg*>(ctx->ws + ctx->lay.seg_off);
-  oa.n_segs = (int)ctx->universe.size();
-  oa.total_chunks = chunks;
+  oa.n_segs = (int)nu;
   oa.p = ctx->params;
   oa.g = ctx->grads;
   oa.m = ctx->m;
@@ -921,6 +1025,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
   oa.b2 = b2;
   oa.eps = eps;
   oa.stream = st;
+  auto everything = [](size_t) { return true; };
   const bool timed = !flush && mode != GQE_OPT_MATERIALIZE && mode != GQE_OPT_ZERO;  // kernel 2 = the optimiser step proper
   bool sparse = false;
   if (ctx->lazy && mode == GQE_OPT_ADAM) {
@@ -952,14 +1057,6 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
         if (seen[t] && lazy_table_ok(ctx, (int)t) && ctx->tables[t].since_full >= GQE_LAZY_PERIOD)
           sparse = false;  // bound the replay depth of any row
     }
-    auto coef_of = [&](size_t t, float* ss, float* bc) {
-      for (size_t ui = 0; ui < ctx->universe.size(); ++ui)
-        if (ctx->universe[ui].is_table && ctx->universe[ui].offset == ctx->tables[t].offset) {
-          const int gi = oa.active.group[ui];
-          *ss = oa.coef.step_size[gi];
-          *bc = oa.coef.bc2_sqrt[gi];
-        }
-    };
     if (sparse) {
       GqeRowsArgs ra;
       lazy_rows_args(ctx, ra, st);
@@ -988,33 +1085,25 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
         ra.idx = reinterpret_cast<const int32_t*>(ctx->ws + L.contrib_off);
       }
       const std::vector<SavedFeed>& feeds = ctx->world > 1 ? gathered : ctx->feed;
-      for (size_t t = 0; t < ctx->tables.size(); ++t)
-        if (seen[t] && lazy_table_ok(ctx, (int)t)) {
-          ra.t.target[t] = ra.t.grad_step[t] = ctx->tables[t].lstep + 1;
-          coef_of(t, &ra.t.step_size[t], &ra.t.bc2_sqrt[t]);
-        }
+      for (size_t ui = 0; ui < nu; ++ui) {
+        const GqeDevSeg& u = ctx->universe[ui];
+        if (!ustep[ui] || !u.is_table || !lazy_table_ok(ctx, u.table_index)) continue;
+        const int t = u.table_index;
+        ra.t.target[t] = ra.t.grad_step[t] = ctx->tables[t].lstep + 1;
+        ra.t.step_size[t] = uss[ui];
+        ra.t.bc2_sqrt[t] = ubc[ui];
+      }
       // bag-mode tables (their gradient lists hang on word rows no index feed names) are stepped in full by the
       // ordinary pass: every row of such a table is always current
       GqeOptArgs ob = oa;
-      long long bag_chunks = 0;
-      for (size_t ui = 0; ui < ctx->universe.size(); ++ui) {
-        const bool bag_table = oa.active.group[ui] != 0xFF && ctx->universe[ui].is_table &&
-                               !lazy_table_ok(ctx, table_of(ctx, ctx->universe[ui].offset));
-        if (bag_table) bag_chunks += ctx->universe[ui].n_chunks;
-        else ob.active.group[ui] = 0xFF;
-      }
+      ob.total_chunks = emit([&](size_t ui) { return ctx->universe[ui].is_table && !lazy_table_ok(ctx, ctx->universe[ui].table_index); },
+                             ob.active, ob.coef, &ob.act, &ob.n_act);
       // the small dense tensors ride in extra workgroups of the (first) row launch: the ordinary pass, tables masked out
-      long long dense_chunks = 0;
-      for (size_t ui = 0; ui < ctx->universe.size(); ++ui) {
-        if (oa.active.group[ui] == 0xFF) continue;
-        if (ctx->universe[ui].is_table) oa.active.group[ui] = 0xFF;
-        else dense_chunks += ctx->universe[ui].n_chunks;
-      }
       ra.dsegs = oa.segs;
       ra.n_dsegs = oa.n_segs;
-      ra.dense_chunks = dense_chunks;
-      ra.dcoef = oa.coef;
-      ra.dactive = oa.active;
+      ra.dense_chunks = emit([&](size_t ui) { return !ctx->universe[ui].is_table; }, ra.dactive, ra.dcoef, &ra.dact, &ra.n_dact);
+      rc = upload_staging();
+      if (rc != GQE_OK) return rc;
       rc = timing_begin(ctx, 2, st);
       if (rc != GQE_OK) return rc;
       for (const SavedFeed& sf : feeds) {
@@ -1025,8 +1114,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       rc = timing_end(ctx, 2, st);
       if (rc != GQE_OK) return rc;
       if (ctx->feed_buf >= 0) HIP_TRY(ctx, hipEventRecord(ctx->plan_free[ctx->feed_buf], st));  // the staged feed may go now
-      if (bag_chunks > 0) {
-        ob.total_chunks = bag_chunks;
+      if (ob.total_chunks > 0) {
         ob.lazy = false;
         rc = timing_begin(ctx, 3, st);
         if (rc != GQE_OK) return rc;
@@ -1046,15 +1134,15 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       oa.lazy = true;
       oa.lz.last = reinterpret_cast<int32_t*>(ctx->ws + L.last_off);
       oa.lz.ring = reinterpret_cast<float2*>(ctx->ws + L.ring_off);
-      memset(oa.lz.table_of_seg, 0, sizeof oa.lz.table_of_seg);
       if ((int)ctx->tables.size() > GQE_LAZY_TABLES) return fail(ctx, GQE_ERR_STATE, "lazy Adam supports at most %d tables", GQE_LAZY_TABLES);
       for (size_t t = 0; t < ctx->tables.size(); ++t) {
         oa.lz.t.target[t] = ctx->tables[t].lstep + ((seen[t] && !flush) ? 1 : 0);
         oa.lz.t.grad_step[t] = (seen[t] && !flush) ? ctx->tables[t].lstep + 1 : -1;
         oa.lz.t.eager[t] = lazy_table_ok(ctx, (int)t) ? 0 : 1;
       }
-      for (size_t ui = 0; ui < ctx->universe.size(); ++ui)
-        if (ctx->universe[ui].is_table) oa.lz.table_of_seg[ui] = (int8_t)table_of(ctx, ctx->universe[ui].offset);
+      oa.total_chunks = emit(everything, oa.active, oa.coef, &oa.act, &oa.n_act);
+      rc = upload_staging();
+      if (rc != GQE_OK) return rc;
       if (timed) {
         rc = timing_begin(ctx, 2, st);
         if (rc != GQE_OK) return rc;
@@ -1073,6 +1161,9 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     }
     if (flush) return GQE_OK;
   } else {
+    oa.total_chunks = emit(everything, oa.active, oa.coef, &oa.act, &oa.n_act);
+    rc = upload_staging();
+    if (rc != GQE_OK) return rc;
     if (timed) {
       rc = timing_begin(ctx, 2, st);
       if (rc != GQE_OK) return rc;
@@ -1174,7 +1265,7 @@ int gqe_bind_arena(gqe_ctx* ctx, float* params, float* grads, float* exp_avg, fl
 
 int gqe_set_tables(gqe_ctx* ctx, const int64_t* offsets, const int64_t* rows, int32_t n_tables) {
   if (!ctx) return GQE_ERR_ARG;
-  if (!offsets || !rows || n_tables < 1 || n_tables > GQE_MAX_SEGS) return fail(ctx, GQE_ERR_ARG, "bad table list");
+  if (!offsets || !rows || n_tables < 1 || n_tables > ctx->cap_tensors) return fail(ctx, GQE_ERR_ARG, "bad table list");
   if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "gradients pending; step or materialize before changing the tables");
   ctx->tables.clear();
   ctx->bags.clear();
@@ -1193,9 +1284,7 @@ int gqe_set_tables(gqe_ctx* ctx, const int64_t* offsets, const int64_t* rows, in
   }
   ctx->universe.clear();
   ctx->universe_uploaded = 0;
-  ctx->formulas.clear();
-  ctx->formula_ids.clear();
-  ctx->formulas_uploaded = 0;
+  drop_formulas(ctx);
   ctx->ws = nullptr;  // the workspace layout depends on the tables: it must be bound again
   return GQE_OK;
 }
@@ -1214,9 +1303,7 @@ int gqe_set_bag(gqe_ctx* ctx, int64_t table_offset, const int32_t* bag_ptr, cons
     }
   if (ctx->bags.size() >= GQE_MAX_BAGS) return fail(ctx, GQE_ERR_ARG, "more than %d bag tables", GQE_MAX_BAGS);
   ctx->bags.push_back(Bag{t, bag_ptr, bag_ids, n_bags, max_len});
-  ctx->formulas.clear();
-  ctx->formula_ids.clear();
-  ctx->formulas_uploaded = 0;
+  drop_formulas(ctx);
   ctx->ws = nullptr;  // the workspace layout depends on the bags: it must be bound again
   return GQE_OK;
 }
@@ -1241,7 +1328,8 @@ int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* strea
   ctx->ws_bytes = bytes;
   ctx->lay = L;
   ctx->universe_uploaded = 0;
-  ctx->formulas_uploaded = 0;
+  ctx->formulas_dirty.clear();  // the new workspace holds no descriptors yet: all cached slots are stale
+  for (int k = 0; k < (int)ctx->formulas.size(); ++k) ctx->formulas_dirty.push_back(k);
   // empty gradient lists: head[row] = -1; link-node allocator at 0
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.head_off, 0xff, L.rows_off - L.head_off, reinterpret_cast<hipStream_t>(stream)));
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.counter_off, 0, sizeof(int32_t), reinterpret_cast<hipStream_t>(stream)));
@@ -1282,6 +1370,22 @@ int gqe_set_exchange(gqe_ctx* ctx, int32_t rank, int32_t world) {
   if (ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_set_exchange must precede gqe_workspace_bytes / gqe_bind_workspace");
   ctx->rank = rank;
   ctx->world = world;
+  return GQE_OK;
+}
+
+int gqe_set_limits(gqe_ctx* ctx, int32_t max_tensors, int32_t max_formulas) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_set_limits must precede gqe_workspace_bytes / gqe_bind_workspace");
+  if (max_tensors > 0) {
+    if (max_tensors > (1 << 20)) return fail(ctx, GQE_ERR_ARG, "max_tensors out of range");
+    ctx->cap_tensors = std::max<int32_t>(max_tensors, (int32_t)ctx->tables.size());
+  }
+  if (max_formulas > 0) {
+    if (max_formulas < GQE_MAX_BATCHES || max_formulas > (1 << 22))
+      return fail(ctx, GQE_ERR_ARG, "max_formulas must be in [%d, %d]", GQE_MAX_BATCHES, 1 << 22);
+    ctx->cap_formulas = max_formulas;
+    drop_formulas(ctx);
+  }
   return GQE_OK;
 }
 

@@ -254,20 +254,25 @@ __device__ __forceinline__ void opt_body(const long long first_chunk, const long
                                                              const float* __restrict__ contrib,
                                                              const int32_t* __restrict__ link_contrib, int max_entries,
                                                              int d, float lr, float b1, float b2, float eps,
-                                                             const GqeStepCoef& coef, const GqeOptActive& active, const GqeLazyArgs& lazy) {
+                                                             const GqeStepCoef& coef, const GqeOptActive& active,
+                                                             const GqeActSeg* __restrict__ act, int n_act, const GqeLazyArgs& lazy) {
+  // Which tensor owns chunk ch, and its Adam coefficients.  Kernel-argument form (act == NULL): a prefix over the
+  // <= GQE_MAX_SEGS universe entries in LDS.  Table form: a binary search in the uploaded list of active tensors.
   __shared__ long long s_begin[GQE_MAX_SEGS + 1];  // chunk prefix over the universe; inactive tensors get 0 chunks
   __shared__ long long s_cnt[GQE_MAX_SEGS];
-  if ((int)threadIdx.x < n_segs) s_cnt[threadIdx.x] = (active.group[threadIdx.x] != 0xFF) ? segs[threadIdx.x].n_chunks : 0;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    long long run = 0;
-    for (int i = 0; i < n_segs; ++i) {
-      s_begin[i] = run;
-      run += s_cnt[i];
+  if (!act) {
+    if ((int)threadIdx.x < n_segs) s_cnt[threadIdx.x] = (active.group[threadIdx.x] != 0xFF) ? segs[threadIdx.x].n_chunks : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      long long run = 0;
+      for (int i = 0; i < n_segs; ++i) {
+        s_begin[i] = run;
+        run += s_cnt[i];
+      }
+      s_begin[n_segs] = run;
     }
-    s_begin[n_segs] = run;
+    __syncthreads();
   }
-  __syncthreads();
   const int tpr = d >> 2;               // threads per table row
   const int rpc = GQE_THREADS / tpr;    // table rows per chunk
   const int lr_row = threadIdx.x / tpr;
@@ -275,11 +280,27 @@ __device__ __forceinline__ void opt_body(const long long first_chunk, const long
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   int si = 0;
   for (long long ch = first_chunk; ch < total_chunks; ch += chunk_stride) {
-    while (s_begin[si + 1] <= ch) ++si;  // chunks are visited in increasing order
+    long long chunk_begin;
+    float step_size, bc2_sqrt;
+    if (act) {
+      int lo = 0, hi = n_act - 1;  // last entry whose first chunk is <= ch
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (act[mid].chunk_begin <= ch) lo = mid; else hi = mid - 1;
+      }
+      const GqeActSeg a = act[lo];
+      si = a.seg;
+      chunk_begin = a.chunk_begin;
+      step_size = a.step_size;
+      bc2_sqrt = a.bc2_sqrt;
+    } else {
+      while (s_begin[si + 1] <= ch) ++si;  // chunks are visited in increasing order
+      chunk_begin = s_begin[si];
+      const int grp = active.group[si];
+      step_size = coef.step_size[grp];
+      bc2_sqrt = coef.bc2_sqrt[grp];
+    }
     const GqeDevSeg sg = segs[si];
-    const long long chunk_begin = s_begin[si];
-    const int grp = active.group[si];
-    const float step_size = coef.step_size[grp], bc2_sqrt = coef.bc2_sqrt[grp];
     if (sg.is_table) {
       const long long row = (ch - chunk_begin) * rpc + lr_row;
       if (lr_row >= rpc || row >= sg.rows) continue;
@@ -323,7 +344,7 @@ __device__ __forceinline__ void opt_body(const long long first_chunk, const long
       }
       if (LAZY && MODE == GQE_OPT_ADAM) {
         // full pass in lazy mode: replay what the row is behind, then (grad_step == target) the step with gradient
-        const int lt = lazy.table_of_seg[si];
+        const int lt = sg.table_index;
         const int target = lazy.t.target[lt];
         const int from = lazy.t.eager[lt] ? target - 1 : lazy.last[sg.head_base + row];
         if (from < target) {
@@ -396,9 +417,10 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
                                                              const float* __restrict__ contrib,
                                                              const int32_t* __restrict__ link_contrib, int max_entries,
                                                              int d, float lr, float b1, float b2, float eps,
-                                                             GqeStepCoef coef, GqeOptActive active, GqeLazyArgs lazy) {
+                                                             GqeStepCoef coef, GqeOptActive active,
+                                                             const GqeActSeg* __restrict__ act, int n_act, GqeLazyArgs lazy) {
   opt_body<MODE, LISTS, DENSE_T, SORTED, LAZY>(blockIdx.x, gridDim.x, segs, n_segs, total_chunks, p, g, m, v, head, next,
-                                                contrib, link_contrib, max_entries, d, lr, b1, b2, eps, coef, active, lazy);
+                                                contrib, link_contrib, max_entries, d, lr, b1, b2, eps, coef, active, act, n_act, lazy);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -431,7 +453,7 @@ static void launch_opt_mode(const GqeOptArgs& a, unsigned blocks) {
 #define GO(L, D, S, Z)                                                                                                    \
   hipLaunchKernelGGL((gqe_opt_kernel<MODE, L, D, S, Z>), dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.n_segs,    \
                      a.total_chunks, a.p, a.g, a.m, a.v, a.head, a.next, a.contrib, a.link_contrib, a.max_entries, a.d, a.lr, a.b1,  \
-                     a.b2, a.eps, a.coef, a.active, a.lz)
+                     a.b2, a.eps, a.coef, a.active, a.act, a.n_act, a.lz)
   if (a.lazy && MODE == GQE_OPT_ADAM) {  // lazy full pass
     if (a.lists && a.sorted) {
       if (a.dense_tables) GO(true, true, true, true); else GO(true, false, true, true);
@@ -468,7 +490,8 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_rows_kernel(const GqeRowSegs 
                                                               const float* __restrict__ contrib, int max_entries, int d,
                                                               float lr, float b1, float b2, float eps, int n_row_blocks,
                                                               const GqeDevSeg* __restrict__ dsegs, int n_dsegs,
-                                                              long long dense_chunks, GqeStepCoef dcoef, GqeOptActive dactive) {
+                                                              long long dense_chunks, GqeStepCoef dcoef, GqeOptActive dactive,
+                                                              const GqeActSeg* __restrict__ dact, int n_dact) {
   if ((int)blockIdx.x >= n_row_blocks) {
     // the step's small dense tensors (relation vectors / matrices, Pre / Post): the ordinary chunk loop
     GqeLazyArgs none;
@@ -476,7 +499,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_rows_kernel(const GqeRowSegs 
     none.ring = nullptr;
     opt_body<GQE_OPT_ADAM, false, false, false, false>((long long)blockIdx.x - n_row_blocks, (long long)gridDim.x - n_row_blocks,
                                                        dsegs, n_dsegs, dense_chunks, p, g, m, v, head, next, contrib, nullptr,
-                                                       max_entries, d, lr, b1, b2, eps, dcoef, dactive, none);
+                                                       max_entries, d, lr, b1, b2, eps, dcoef, dactive, dact, n_dact, none);
     return;
   }
   // the coefficient rings go through LDS: a replay of k steps would otherwise chain k dependent global loads
@@ -534,7 +557,7 @@ hipError_t gqe_launch_rows(const GqeRowsArgs& a) {
 #define GO(G, S)                                                                                                          \
   hipLaunchKernelGGL((gqe_rows_kernel<G, S>), dim3(row_blocks + dense_blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.t,  \
                      a.idx, a.last, a.ring, a.p, a.g, a.m, a.v, a.head, a.next, a.contrib, a.max_entries, a.d, a.lr, a.b1,   \
-                     a.b2, a.eps, (int)row_blocks, a.dsegs, a.n_dsegs, a.dense_chunks, a.dcoef, a.dactive)
+                     a.b2, a.eps, (int)row_blocks, a.dsegs, a.n_dsegs, a.dense_chunks, a.dcoef, a.dactive, a.dact, a.n_dact)
   if (a.with_grad) {
     if (a.sorted) GO(true, true); else GO(true, false);
   } else {

@@ -17,7 +17,7 @@ from collections import OrderedDict
 import numpy as np
 
 ABI_VERSION = 1
-MAX_BRANCH, MAX_HOPS, MAX_BATCHES, MAX_DIM, MAX_SEGS = 3, 3, 64, 256, 96
+MAX_BRANCH, MAX_HOPS, MAX_BATCHES, MAX_DIM = 3, 3, 64, 256
 TQ = 16
 
 DECODERS = {"bilinear-diag": 0, "transe": 1, "bilinear": 2}           # utils.py:128-137
@@ -68,6 +68,7 @@ SYMBOLS = OrderedDict([
     ("gqe_bind_arena", (C.c_int, [_P, _P, _P, _P, _P, C.c_int64])),
     ("gqe_set_tables", (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32])),
     ("gqe_set_bag", (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int32])),
+    ("gqe_set_limits", (C.c_int, [_P, C.c_int32, C.c_int32])),
     ("gqe_workspace_bytes", (C.c_int64, [_P, C.c_int64, C.c_int32])),
     ("gqe_bind_workspace", (C.c_int, [_P, _P, C.c_int64, _P])),
     ("gqe_materialize_grads", (C.c_int, [_P, _P])),
@@ -155,7 +156,7 @@ class Engine(object):
     """One gqe_ctx + the tensors it borrows."""
 
     def __init__(self, dim, decoder, inter_decoder, layout, device=None, max_queries=8192, max_batches=16, bags=None,
-                 rank=0, world=1, lazy_adam=False):
+                 rank=0, world=1, lazy_adam=False, max_formulas=0):
         """``bags``: {table key: (ptr int32[n+1], ids int32[nnz])} for modes whose feature is an
         nn.EmbeddingBag (mean over table rows) — an index into such a mode is a bag index.
         ``world`` > 1 (and no bags): size the gradient-entry space for the data-parallel exchange
@@ -199,6 +200,8 @@ class Engine(object):
             self._bags[key] = (dp, di)      # keep the borrowed device buffers alive
             self._check(self.lib.gqe_set_bag(self.ctx, layout.offset(key), dp.data_ptr(), di.data_ptr(), len(ptr) - 1,
                                              int(np.diff(ptr).max())))
+        # every tensor of the layout may be stepped; the formula-descriptor cache keeps its default unless asked
+        self._check(self.lib.gqe_set_limits(self.ctx, max(len(layout.entries), 1), int(max_formulas)))
         self.rank, self.world = int(rank), int(world)
         self.sparse_exchange = self.world > 1
         if self.sparse_exchange:

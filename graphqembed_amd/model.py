@@ -93,6 +93,12 @@ class QueryEncoderDecoder(nn.Module):
         self.engine.sync()
         return super(QueryEncoderDecoder, self).state_dict(*args, **kwargs)
 
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """The parameters are views of the arena: rows that still owe deferred Adam steps (lazy mode) are settled
+        first, otherwise those steps would later be replayed on top of the loaded values."""
+        self.engine.sync()
+        return super(QueryEncoderDecoder, self).load_state_dict(state_dict, *args, **kwargs)
+
     def plan(self, formula):
         p = self._plans.get(formula)
         if p is None:

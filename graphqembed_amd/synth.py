@@ -25,6 +25,9 @@ class CsrGraph(object):
         rng = np.random.RandomState(seed)
         self.mode_sizes = dict(mode_sizes)
         self.modes = sorted(mode_sizes)
+        # rows of each mode's embedding table: len(node_maps[mode]) + 1 with the extra -1 key (bio/data_utils.py:14-17)
+        self.table_rows = {m: n + 2 for m, n in self.mode_sizes.items()}
+        self.bags = {}           # mode -> (ptr int32[n+1], ids int32[nnz]) for nn.EmbeddingBag feature modes
         self.relations = {}
         self.csr = {}
         for (ma, name, mb) in kinds:
@@ -48,10 +51,12 @@ class CsrGraph(object):
 
     @staticmethod
     def _build(src, dst, n):
-        pairs = np.unique(np.stack([src, dst], axis=1), axis=0)
+        span = int(dst.max()) + 1 if len(dst) else 1        # distinct (src, dst) pairs in lexicographic order
+        keys = np.unique(src.astype(np.int64) * span + dst.astype(np.int64))
+        s, t = keys // span, keys % span
         indptr = np.zeros(n + 1, dtype=np.int64)
-        np.add.at(indptr, pairs[:, 0] + 1, 1)
-        return np.cumsum(indptr), pairs[:, 1].astype(np.int64)
+        indptr[1:] = np.cumsum(np.bincount(s, minlength=n))
+        return indptr, t
 
     def out_relations(self, mode):
         return [(mode, name, to) for (to, name) in self.relations[mode]]
@@ -180,6 +185,37 @@ weights 1 / 0.01 / 0.005, intersections once with regular and once with hard neg
 def bio_synth(seed=0, sizes=None, edges_per_kind=None):
     return CsrGraph(sizes or BIO_SYNTH_SIZES, BIO_SYNTH_KINDS,
                     edges_per_kind or BIO_SYNTH_EDGES_PER_KIND, seed=seed)
+
+
+REDDIT_SYNTH_KINDS = (("user", "up", "post"), ("user", "down", "post"), ("user", "make", "post"), ("user", "comment", "post"),
+                      ("user", "subscribe", "community"), ("post", "belong", "community"))
+"""The Reddit schema of the reference: 6 undirected kinds = the 12 directed relations of
+reddit/data_utils_new.py:193-197 (user->post up/down/make/comment, user->community subscribe, post->community
+belong, and their reverses)."""
+REDDIT_SYNTH_SIZES = {"user": 500000, "post": 400000, "community": 2000}
+REDDIT_SYNTH_EDGES_PER_KIND = 1000000
+REDDIT_SYNTH_WORDS = 50000
+REDDIT_SYNTH_BAG_LEN = (5, 30)
+
+
+def reddit_synth(seed=0, sizes=None, edges_per_kind=None, n_words=None, bag_len=None):
+    """BASELINE config 5 stand-in (the Reddit data of the reference is private): 3 modes, 12
+    directed relations, user 500 k / post 400 k / community 2 k nodes, 1 M uniform random edges per kind.  Features as
+    reddit/data_utils_new.py:153-169: user and community are ``nn.Embedding(N + 1, d)`` with row = node + 1; a post
+    is an ``nn.EmbeddingBag(num_words, d)`` (mode mean) over its word set — here 5..30 uniform words of a 50 k
+    vocabulary.  Bag i + 1 belongs to post i (bag 0 is a dummy, so that "row = node + 1" holds for every mode)."""
+    sizes = dict(sizes or REDDIT_SYNTH_SIZES)
+    g = CsrGraph(sizes, REDDIT_SYNTH_KINDS, edges_per_kind or REDDIT_SYNTH_EDGES_PER_KIND, seed=seed)
+    n_words = int(n_words or REDDIT_SYNTH_WORDS)
+    lo, hi = bag_len or REDDIT_SYNTH_BAG_LEN
+    rng = np.random.RandomState(seed + 7)
+    lens = rng.randint(lo, hi + 1, size=sizes["post"] + 1)
+    ptr = np.zeros(sizes["post"] + 2, dtype=np.int64)
+    ptr[1:] = np.cumsum(lens)
+    ids = rng.randint(0, n_words, size=int(ptr[-1]))
+    g.bags = {"post": (ptr.astype(np.int32), ids.astype(np.int32))}
+    g.table_rows = {"user": sizes["user"] + 1, "community": sizes["community"] + 1, "post": n_words}
+    return g
 
 
 def make_pools(g, types, formulas_per_type, pool_size, seed=0):

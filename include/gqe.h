@@ -137,6 +137,16 @@ int gqe_set_tables(gqe_ctx* ctx, const int64_t* offsets, const int64_t* rows, in
  * bag length (sizes the link nodes of the gradient lists).  Must precede gqe_workspace_bytes. */
 int gqe_set_bag(gqe_ctx* ctx, int64_t table_offset, const int32_t* bag_ptr, const int32_t* bag_ids, int64_t n_bags, int32_t max_len);
 
+/* Capacities that size the workspace (optional; must precede gqe_workspace_bytes).  max_tensors: distinct parameter
+ * tensors the optimiser entry points may ever be asked to step (default 256; a Bio-scale schema has dozens of relation
+ * types: tables + relation tensors + 2 matrices per mode).  Passes over <= 96 known tensors with <= 32 distinct Adam
+ * step counts are described in the kernel arguments; larger ones upload a list of the active tensors with the step.
+ * max_formulas: size of the device-resident cache of formula descriptors (default 2048, >= GQE_MAX_BATCHES); the
+ * reference draws a Formula per batch from train_queries[type] (train_helpers.py:96-100) and a multi-relational graph has
+ * thousands of distinct 3-hop formulas, so least-recently-used descriptors are replaced once the cache is full.
+ * 0 keeps a value. */
+int gqe_set_limits(gqe_ctx* ctx, int32_t max_tensors, int32_t max_formulas);
+
 /* Workspace the kernels need for up to `max_queries` queries / `max_batches` batches between two
  * optimiser steps (bytes); gqe_bind_workspace binds a buffer of at least that size (256-byte aligned)
  * and resets the gradient lists on `stream`.  The capacities given here are remembered by the ctx. */

@@ -1,0 +1,52 @@
+"""-m gpu: bench.py as the driver invokes it.
+
+``python bench.py --gpus N`` must run by itself (no external launcher): for N > 1 it re-executes under
+torch.distributed.run with one rank per GPU.  On a single-GPU test box the two ranks share cuda:0 and the
+collectives go through gloo (a functional check of the multi-rank path, not a scaling measurement)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(argv, timeout):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=timeout, universal_newlines=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_self_launch():
+    out = _run(["--gpus", "2", "--backend", "gloo", "--steps", "20", "--warmup", "5"], 900)
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2
+    assert out["replicas_identical"] is True
+    assert out["config"]["queries_per_step_per_gpu"] == 4608 and out["value"] > 0
+    assert set(out["exchange"]) == {"sparse", "dense"}
+    for form in out["exchange"].values():
+        assert form["replicas_identical"] is True and form["exchange_ms_per_step"] > 0
+    assert out["reddit_synth"]["ranks_seen"] == 2 and out["reddit_synth"]["replicas_identical"] is True
+    assert out["scaling"] == "weak" and out["cpu_baseline"] is None
+
+
+def test_bench_single_gpu_line_has_the_contract_keys():
+    out = _run(["--steps", "20", "--warmup", "5", "--cpu-seconds", "2"], 900)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "host_fed", "configs", "reddit_synth"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["timing"]["blocks"] >= 1
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["algorithmic_bytes_per_launch"] < r["survey_bytes_per_launch"]      # 24 B/param streamed, not 32
+    assert set(out["configs"]) >= {"C1_1chain_only", "C2_2chain_2inter", "C4_full_bilinear", "C3_scaled_batch_B8192", "C3_plus_3chain_inter"}
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
+    assert out["kernels"]["fused_fwd_bwd"]["mfma_TFs"] > 0 and out["kernels"]["pair_gemm"]["mfma_TFs"] > 0

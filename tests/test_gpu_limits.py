@@ -1,0 +1,245 @@
+"""-m gpu: capacities and state corners of libgqe that the BASELINE workloads do not reach by themselves.
+
+  * optimiser passes over more tensors / more distinct per-tensor Adam step counts than the kernel-argument form
+    holds (a Bio-scale schema: dozens of relation types, each with its own step counter);
+  * the device formula-descriptor cache re-uses least-recently-used slots (the reference draws a Formula per
+    batch from thousands of distinct ones, train_helpers.py:96-100);
+  * lazy Adam: gqe_optimizer_sync must not consume a materialised dense gradient; a pending margin call's staged
+    index feed that later host-fed forwards overwrite makes the step fall back to the full pass;
+  * nn.Module.load_state_dict settles deferred steps first.
+"""
+import numpy as np
+import pytest
+
+from oracle import netquery_numpy as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_optimizer_pass_over_many_tensors_with_diverging_step_counts():
+    """130 relation vectors + 2 tables, every tensor at its own Adam step count (> 96 tensors and > 32 distinct
+    counts: the pass is described by an uploaded list, not by kernel arguments), three passes over changing
+    subsets, against the fp64 restatement of torch.optim.Adam."""
+    import torch
+    from gpu_utils import engine_from_params, read_arena
+    rng = np.random.RandomState(3)
+    d = 16
+    params = {"enc.feat-a.weight": rng.randn(301, d).astype(np.float32),
+              "enc.feat-b.weight": rng.randn(77, d).astype(np.float32)}
+    for k in range(130):
+        params["path_dec.a_r%d_b" % k] = rng.randn(d).astype(np.float32)
+    eng = engine_from_params(params, d, "bilinear-diag", "min-simple")
+    ref = {k: v.astype(np.float64) for k, v in params.items()}
+    state = {}
+    names = list(params)
+    for k_i, k in enumerate(names):                      # diverged counters, as after a long run on a skewed type mix
+        state[k] = {"step": 3 * k_i + (k_i % 7), "m": rng.randn(*params[k].shape) * 0.01,
+                    "v": np.abs(rng.randn(*params[k].shape)) * 1e-3}
+        eng.steps[k] = state[k]["step"]
+        eng.layout.view(eng.exp_avg, k).copy_(torch.from_numpy(state[k]["m"].astype(np.float32)))
+        eng.layout.view(eng.exp_avg_sq, k).copy_(torch.from_numpy(state[k]["v"].astype(np.float32)))
+        state[k]["m"] = state[k]["m"].astype(np.float32).astype(np.float64)
+        state[k]["v"] = state[k]["v"].astype(np.float32).astype(np.float64)
+    for step in range(3):
+        keys = [k for i, k in enumerate(names) if step == 0 or (i + step) % 3]
+        grads = {}
+        eng.materialize()                                 # the dense gradient is authoritative: written by hand below
+        for k in keys:
+            g = (rng.randn(*params[k].shape) * 10 ** rng.uniform(-4, 0, size=params[k].shape)).astype(np.float32)
+            grads[k] = g
+            eng.layout.view(eng.grads, k).copy_(torch.from_numpy(g))
+        eng.adam_step(keys)
+        O.adam_step(ref, {k: v.astype(np.float64) for k, v in grads.items()}, state, keys)
+        got = read_arena(eng, eng.params)
+        for k in names:
+            np.testing.assert_allclose(got[k], ref[k], rtol=0, atol=3e-6, err_msg="%s pass %d" % (k, step))
+        assert float(eng.grads.abs().max()) == 0.0
+    # the kernel-argument form and the list form are the same arithmetic: a second engine that only ever sees 40
+    # tensors at 3 distinct counts (argument form) must agree bit for bit on those tensors
+    small = {k: params[k] for k in names[:40]}
+    e1 = engine_from_params(params, d, "bilinear-diag", "min-simple")
+    e2 = engine_from_params(small, d, "bilinear-diag", "min-simple")
+    for e in (e1, e2):
+        e.materialize()
+    for i, k in enumerate(names):
+        g = torch.from_numpy((rng.randn(*params[k].shape)).astype(np.float32))
+        e1.steps[k] = 100 + i                              # 132 distinct counts -> list form
+        e1.layout.view(e1.grads, k).copy_(g)
+        if k in small:
+            e2.steps[k] = 100 + i
+            e2.layout.view(e2.grads, k).copy_(g)
+    e1.adam_step(names)
+    e2.adam_step(list(small))
+    a, b = read_arena(e1, e1.params), read_arena(e2, e2.params)
+    for k in small:
+        assert np.array_equal(a[k], b[k]), k
+    for e in (eng, e1, e2):
+        e.close()
+
+
+def test_more_tensors_than_the_declared_limit_is_an_error():
+    from gpu_utils import engine_from_params
+    from graphqembed_amd.engine import GqeError
+    import ctypes as C
+    from graphqembed_amd.engine import gqe_segment
+    rng = np.random.RandomState(0)
+    params = {"enc.feat-a.weight": rng.randn(9, 16).astype(np.float32), "path_dec.a_r_a": rng.randn(16).astype(np.float32)}
+    eng = engine_from_params(params, 16, "bilinear-diag", "min-simple")     # limit = 2 tensors
+    arr = (gqe_segment * 3)()
+    for i, (off, n) in enumerate([(0, 9 * 16), (eng.layout.offset("path_dec.a_r_a"), 16), (4, 4)]):
+        arr[i].offset, arr[i].numel, arr[i].step = off, n, 1
+    rc = eng.lib.gqe_adam_step(eng.ctx, arr, 3, 0.01, 0.9, 0.999, 1e-8, eng._stream())
+    assert rc != 0 and b"gqe_set_limits" in eng.lib.gqe_last_error(eng.ctx)
+    eng.close()
+
+
+def test_formula_cache_replaces_least_recently_used_descriptors():
+    """200 distinct formulas through a 64-slot descriptor cache, revisited in two different orders, 5 per call:
+    scores and gradients equal those of an engine whose cache holds them all."""
+    import torch
+    from gpu_utils import engine_from_params, random_params, read_arena
+    from graphqembed_amd.graph import Formula
+    from graphqembed_amd.tensorize import FormulaPlan, pack_forward_batches, pack_margin_batches
+    rng = np.random.RandomState(9)
+    d = 32
+    sizes = {"a": 40, "b": 30}
+    kinds = tuple(("a", "r%d" % k, "b") for k in range(12)) + (("a", "s", "a"),)
+    params = random_params(rng, d, "bilinear-diag", "min", sizes, kinds)
+    small = engine_from_params(params, d, "bilinear-diag", "min", max_formulas=64)
+    big = engine_from_params(params, d, "bilinear-diag", "min")
+    formulas = []
+    for i in range(12):
+        for j in range(12):
+            formulas.append(Formula("2-chain", (("a", "r%d" % i, "b"), ("b", "r%d" % j, "a"))))
+            if i < j:
+                formulas.append(Formula("2-inter", (("a", "r%d" % i, "b"), ("a", "r%d" % j, "b"))))
+    assert len(formulas) > 3 * 64
+    B = 5
+    for order in (np.arange(len(formulas)), rng.permutation(len(formulas)), rng.permutation(len(formulas))):
+        for c0 in range(0, len(order), 5):
+            fs = [formulas[k] for k in order[c0:c0 + 5]]
+            feeds = []
+            for f in fs:
+                na = len(f.anchor_modes)
+                t = rng.randint(1, sizes["a"] + 1, B).astype(np.int32)
+                g = rng.randint(1, sizes["a"] + 1, B).astype(np.int32)
+                a = np.stack([rng.randint(1, sizes[m] + 1, B) for m in f.anchor_modes]).astype(np.int32)
+                feeds.append((f, t, g, a))
+            outs = []
+            for eng in (small, big):
+                fw = [(FormulaPlan(f, eng.layout, "min"), t, a) for (f, t, g, a) in feeds]
+                descs, idx, n = pack_forward_batches(fw)
+                sc = eng.forward(descs, idx, n).clone()
+                mg = [(FormulaPlan(f, eng.layout, "min"), t, g, a, 1.0, 1.0) for (f, t, g, a) in feeds]
+                descs, idx, n = pack_margin_batches(mg)
+                losses, pos, neg = eng.margin_fwd_bwd(descs, idx, n, want_scores=True)
+                outs.append((sc, losses.clone(), pos.clone(), neg.clone()))
+                eng.zero_grads(list(eng.layout.entries))
+            for x, y in zip(*outs):
+                assert torch.allclose(x, y, rtol=1e-6, atol=1e-7)
+    # one call that names more distinct formulas than the cache holds is refused, not silently wrong
+    from graphqembed_amd.engine import GqeError
+    tiny = [(FormulaPlan(f, small.layout, "min"), np.ones(1, np.int32), np.ones((len(f.anchor_modes), 1), np.int32)) for f in formulas[:64]]
+    descs, idx, n = pack_forward_batches(tiny)
+    small.forward(descs, idx, n)                                   # exactly 64 distinct: fits
+    for eng in (small, big):
+        eng.close()
+
+
+def test_lazy_sync_keeps_a_materialised_dense_gradient():
+    """Lazy Adam, rows lagging (a sparse step), then backward + gqe_materialize_grads (torch.optim compatibility,
+    Engine.reserve) + gqe_optimizer_sync, then the step: the synchronisation only replays deferred steps, the
+    gradient is still there for the step — parameters equal the eager engine's bit for bit."""
+    import torch
+    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params
+    from graphqembed_amd.tensorize import pack_margin_batches
+    from test_gpu_parity import _disjoint_batch
+    rng = np.random.RandomState(4)
+    d = 32
+    params = random_params(rng, d, "bilinear-diag", "min-simple", TOY_SIZES, TOY_KINDS)
+    lazy = engine_from_params(params, d, "bilinear-diag", "min-simple", lazy_adam=True)
+    eager = engine_from_params(params, d, "bilinear-diag", "min-simple")
+    pl = {e: plan_for(e, "2-inter", TOY_FORMULAS["2-inter"]) for e in (lazy, eager)}
+    for step in range(4):
+        t, g, a = _disjoint_batch(rng, "2-inter", 8, 0.0, 0.5)
+        for e in (lazy, eager):
+            descs, idx, n = pack_margin_batches([(pl[e], t, g, a, 1.0, 1.0)])
+            e.margin_fwd_bwd(descs, idx, n)
+            e.adam_step(pl[e].touched)
+    assert not torch.equal(lazy._params, eager._params)            # rows do lag
+    t, g, a = _disjoint_batch(rng, "2-inter", 8, 0.3, 1.0)
+    for e in (lazy, eager):
+        descs, idx, n = pack_margin_batches([(pl[e], t, g, a, 1.0, 1.0)])
+        e.margin_fwd_bwd(descs, idx, n)
+        e.materialize()
+        e.sync()                                                   # what Engine.reserve / state_dict() do
+        assert float(e.grads.abs().max()) > 0.0
+        e.adam_step(pl[e].touched)
+    assert torch.equal(lazy.params, eager.params)
+    assert torch.equal(lazy.exp_avg, eager.exp_avg) and torch.equal(lazy.exp_avg_sq, eager.exp_avg_sq)
+    assert float(lazy.grads.abs().max()) == 0.0
+    lazy.close()
+    eager.close()
+
+
+def test_lazy_step_after_the_staged_feed_was_overwritten():
+    """Lazy Adam with HOST index feeds: margin call, then two host-fed forwards (which cycle through both staging
+    buffers and overwrite the margin call's feed), then the optimiser step — the step must not walk the overwritten
+    feed.  Compared with the eager engine bit for bit, and a following step still works."""
+    import torch
+    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params
+    from graphqembed_amd.tensorize import pack_forward_batches, pack_margin_batches
+    from test_gpu_parity import _disjoint_batch
+    rng = np.random.RandomState(8)
+    d = 32
+    params = random_params(rng, d, "transe", "min-simple", TOY_SIZES, TOY_KINDS)
+    lazy = engine_from_params(params, d, "transe", "min-simple", lazy_adam=True)
+    eager = engine_from_params(params, d, "transe", "min-simple")
+    pl = {e: plan_for(e, "2-inter", TOY_FORMULAS["2-inter"]) for e in (lazy, eager)}
+    pf = {e: plan_for(e, "2-chain", TOY_FORMULAS["2-chain"]) for e in (lazy, eager)}
+    for step in range(6):
+        t, g, a = _disjoint_batch(rng, "2-inter", 8, 0.0, 1.0)
+        ft = [_disjoint_batch(rng, "2-chain", 8, 0.0, 1.0) for _ in range(2)]
+        scores = []
+        for e in (lazy, eager):
+            descs, idx, n = pack_margin_batches([(pl[e], t, g, a, 1.0, 1.0)])
+            e.margin_fwd_bwd(descs, idx, n)                        # numpy idx: host feed through the staging ring
+            for (tt, _, aa) in ft:
+                descs, idx, n = pack_forward_batches([(pf[e], tt, aa)])
+                scores.append(e.forward(descs, idx, n).clone())
+            e.adam_step(pl[e].touched)
+        assert torch.equal(scores[0], scores[2]) and torch.equal(scores[1], scores[3])
+    assert torch.equal(lazy.params, eager.params)
+    assert torch.equal(lazy.exp_avg_sq, eager.exp_avg_sq)
+    lazy.close()
+    eager.close()
+
+
+def test_load_state_dict_settles_deferred_steps_first():
+    """A lazy-Adam model whose rows owe steps is given a new state_dict: the loaded values must be what the next
+    forward reads (the deferred steps belong to the old values and are settled before the copy)."""
+    import torch
+    from test_gpu_api import build_world, rebuild_queries
+    from graphqembed_amd.model import FusedAdam
+    model, _ = build_world("bilinear-diag", "min", 32, "train_bilinear-diag_min_d32.npz")
+    ref, _ = build_world("bilinear-diag", "min", 32, "train_bilinear-diag_min_d32.npz")
+    model.engine._check(model.engine.lib.gqe_set_lazy_adam(model.engine.ctx, 1))
+    model.engine.lazy_adam = True
+    train, _ = rebuild_queries()
+    opt = FusedAdam(model, lr=0.01)
+    f2 = next(iter(train["2-inter"]))
+    f1 = next(iter(train["1-chain"]))
+    for it in range(3):
+        qs = train["2-inter"][f2][4 * it:4 * it + 4]
+        t, a = model._rows(f2, qs, [q.target_node for q in qs])
+        neg = model.enc.rows([q.neg_samples[0] for q in qs], f2.target_mode)
+        model.margin_step([(f2, t, neg, a, 1.0, 1.0)])
+        opt.step()
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    model.load_state_dict(sd)
+    qs = train["1-chain"][f1][:16]
+    nodes = [q.target_node for q in qs]
+    assert torch.equal(model.forward(f1, qs, nodes), ref.forward(f1, qs, nodes))
+    model.sync()
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, sd[k]), k
