@@ -119,6 +119,12 @@ struct gqe_ctx {
   hipEvent_t plan_ready[2] = {nullptr, nullptr}, plan_free[2] = {nullptr, nullptr};
   bool plan_free_set[2] = {false, false};
   int plan_buf = 0;
+  // overlap mode (gqe_set_overlap): the deferred matrix-gradient GEMM runs on a side stream, next to the table part
+  // of the following optimiser pass (which does not depend on it)
+  bool overlap = false;
+  hipStream_t side = nullptr;
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+  bool gemm_pending = false;  // work is in flight on `side` that the caller's stream has not been ordered after yet
   std::string err;
   long long* prof = nullptr;  // optional per-workgroup phase stamps (gqe_debug_profile)
   std::map<int64_t, int> adam_steps;          // per-tensor step counters for callers that pass step <= 0
@@ -273,6 +279,15 @@ int ring_acquire(gqe_ctx* ctx, size_t bytes, RingSlot** out) {
   }
   if (!s.done) HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   *out = &s;
+  return GQE_OK;
+}
+
+// order the caller's stream after everything the library put on its side stream (overlap mode)
+int join_side(gqe_ctx* ctx, hipStream_t st) {
+  if (!ctx->gemm_pending) return GQE_OK;
+  HIP_TRY(ctx, hipEventRecord(ctx->join_ev, ctx->side));
+  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->join_ev, 0));
+  ctx->gemm_pending = false;
   return GQE_OK;
 }
 
@@ -611,7 +626,8 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     return fail(ctx, GQE_ERR_WORKSPACE, "gradient contribution buffer full (%lld + %lld > %lld entries): step or "
                 "gqe_materialize_grads first", (long long)ctx->entries_used, (long long)entries, (long long)L.max_entries);
 
-  int rc;
+  int rc = join_side(ctx, st);  // a previous call's GEMM reads the pair scratch this call overwrites
+  if (rc != GQE_OK) return rc;
   // ---- new / replaced formula descriptors -> device table (rare): contiguous runs of stale slots, one copy each ----
   if (!ctx->formulas_dirty.empty()) {
     std::vector<int>& dirty = ctx->formulas_dirty;
@@ -737,18 +753,23 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     P.total_index = n_batches;
     for (int k = 0; k < GQE_LAUNCH_BATCHES; ++k) P.tile_begin[k] = P.unit_begin[k] = 0x7fffffff;
     int64_t scratch = (int64_t)(L.scratch_off / sizeof(float));
+    // Entries / scratch rows are assigned in the caller's batch order; the TILES are laid out longest batch first: the
+    // hardware starts workgroups in blockIdx order, and with more tiles than workgroup slots (one 1024-thread
+    // workgroup per CU at d >= 128) the tiles that start late should be the short chain tiles (~8 us), not the
+    // ~30 us three-branch intersection tiles.
+    GqeDynBatch tmp[GQE_LAUNCH_BATCHES];
+    int tiles_of[GQE_LAUNCH_BATCHES], units_of[GQE_LAUNCH_BATCHES], cost[GQE_LAUNCH_BATCHES], order[GQE_LAUNCH_BATCHES];
     for (int k = 0; k < nb; ++k) {
       const gqe_batch& s = batches[b0 + k];
       const GqeDevFormula& f = ctx->formulas[fid[b0 + k]];
-      GqeDynBatch& b = P.b[k];
+      GqeDynBatch& b = tmp[k];
+      memset(&b, 0, sizeof b);
       b.formula = fid[b0 + k];
       b.B = s.n_queries;
       b.Bpad = (int)align_up(s.n_queries, GQE_TQ);
       b.idx_offset = s.idx_offset;
       b.out_offset = s.out_offset;
-      b.tile_begin = P.tile_begin[k] = P.tiles;
       b.has_neg = bwd ? 1 : 0;
-      b.unit_begin = P.unit_begin[k] = P.units;
       b.entry_base = entry;
       b.scratch_base = scratch;
       b.margin = s.margin;
@@ -767,12 +788,30 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
         while (want > 1 && per_tile / want < 8 * GQE_FWAVES * 8) --want;   // keep >= 8 rounds of work per workgroup
         b.eval_splits = want;
       }
-      P.tiles += (b.Bpad / GQE_TQ) * b.eval_splits;
+      tiles_of[k] = (b.Bpad / GQE_TQ) * b.eval_splits;
+      units_of[k] = 0;
+      // relative length of one tile's dependent chain: contraction phases dominate (intersections: Pre / Post and
+      // their transposes; full Bilinear: one per hop and score side), then the rows gathered / scattered
+      const bool chain = f.qtype <= GQE_Q_3CHAIN;
+      const bool bil = ctx->cfg.decoder == GQE_DEC_BILINEAR;
+      int hops = 0;
+      for (int i = 0; i < GQE_MAX_BRANCH; ++i) hops += f.n_hops[i];
+      cost[k] = 2 + f.n_anchors + (chain ? (bil ? 4 * hops : 0) : (is_mlp(ctx) ? 6 + 2 * f.n_anchors : 2) + (bil ? 2 * (hops + f.n_final) : 0));
       if (bwd) {
         entry += (int64_t)(2 + f.n_anchors) * s.n_queries;
         scratch += (int64_t)f.n_slots * b.Bpad * d;
-        P.units += f.n_jobs * ((b.Bpad + GQE_GEMM_KCHUNK - 1) / GQE_GEMM_KCHUNK) * macros_sq;
+        units_of[k] = f.n_jobs * ((b.Bpad + GQE_GEMM_KCHUNK - 1) / GQE_GEMM_KCHUNK) * macros_sq;
       }
+      order[k] = k;
+    }
+    std::stable_sort(order, order + nb, [&](int a, int c) { return cost[a] > cost[c]; });
+    for (int pos = 0; pos < nb; ++pos) {
+      GqeDynBatch& b = P.b[pos];
+      b = tmp[order[pos]];
+      b.tile_begin = P.tile_begin[pos] = P.tiles;
+      b.unit_begin = P.unit_begin[pos] = P.units;
+      P.tiles += tiles_of[order[pos]];
+      P.units += units_of[order[pos]];
     }
     if ((size_t)(scratch * (int64_t)sizeof(float)) > L.scratch_off + L.scratch_cap)
       return fail(ctx, GQE_ERR_WORKSPACE, "workspace too small for this call (bound for %lld queries, %d batches)",
@@ -784,11 +823,27 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     if (rc != GQE_OK) return rc;
     if (bwd) {
       // deferred matrix gradients + the finalize block that turns per-tile hinge sums into losses[]
-      rc = timing_begin(ctx, 1, st);
+      hipStream_t gs = st;
+      if (ctx->overlap && n_batches <= GQE_LAUNCH_BATCHES) {
+        // overlap mode: on the side stream, so that the table part of the optimiser pass (which needs the row
+        // gradient lists, not the matrix gradients) can start right behind the fused kernel
+        if (!ctx->side) {
+          HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+          HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+          HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming));
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->fork_ev, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->fork_ev, 0));
+        gs = ctx->side;
+        ctx->gemm_pending = true;
+      }
+      fa.stream = gs;
+      rc = timing_begin(ctx, 1, gs);
       if (rc != GQE_OK) return rc;
       HIP_TRY(ctx, gqe_launch_pair_gemm(fa, losses));
-      rc = timing_end(ctx, 1, st);
+      rc = timing_end(ctx, 1, gs);
       if (rc != GQE_OK) return rc;
+      fa.stream = st;
     }
   }
   if (bwd) {
@@ -856,6 +911,13 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     b2 = ctx->lz_b2;
     eps = ctx->lz_eps;
   }
+  // overlap mode: an Adam / SGD step is split — tables on the caller's stream (next to the GEMM still running on the
+  // side stream), the relation / Pre / Post tensors on the side stream behind the GEMM that produces their gradients
+  bool split = ctx->gemm_pending && !flush && (mode == GQE_OPT_ADAM || mode == GQE_OPT_SGD);
+  if (!split) {
+    int rcj = join_side(ctx, st);
+    if (rcj != GQE_OK) return rcj;
+  }
   GqeOptArgs oa;
   oa.lazy = false;
   memset(&oa.lz, 0, sizeof oa.lz);
@@ -902,7 +964,10 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       return GQE_OK;
     }
   } else {
-    if (!segs || n_segs < 1 || n_segs > ctx->cap_tensors) return fail(ctx, GQE_ERR_ARG, "n_segs must be in [1,%d]", ctx->cap_tensors);
+    if (!segs || n_segs < 1) return fail(ctx, GQE_ERR_ARG, "no segments given");
+    if (n_segs > ctx->cap_tensors)
+      return fail(ctx, GQE_ERR_ARG, "%d segments, but the ctx was sized for %d parameter tensors: raise the limit with gqe_set_limits (before gqe_workspace_bytes)",
+                  n_segs, ctx->cap_tensors);
     for (int i = 0; i < n_segs; ++i) {
       const gqe_segment& s = segs[i];
       if (s.offset < 0 || (s.offset % 4) != 0 || s.numel < 1 || s.offset + s.numel > ctx->n_arena)
@@ -921,7 +986,9 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
           return fail(ctx, GQE_ERR_STATE, "table at offset %lld has pending gradients but is not among the stepped segments",
                       (long long)ctx->tables[t].offset);
   }
+  bool universe_sent = false;
   if (ctx->universe_uploaded != ctx->universe.size()) {
+    universe_sent = true;
     const size_t seg_bytes = sizeof(GqeDevSeg) * ctx->universe.size();
     RingSlot* slot;  // happens only when a tensor is stepped for the first time
     rc = ring_acquire(ctx, seg_bytes, &slot);
@@ -950,6 +1017,12 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
   // <= GQE_MAX_STEP_GROUPS distinct step counts: nothing is uploaded) or as a list of the active tensors that is
   // uploaded with the step (large schemas: dozens of relation types whose step counters diverge).
   const bool table_form = nu > GQE_MAX_SEGS || distinct.size() > GQE_MAX_STEP_GROUPS;
+  if (split && (table_form || universe_sent)) {
+    // the tensor table / the active list travel on the caller's stream: keep everything there
+    int rcj = join_side(ctx, st);
+    if (rcj != GQE_OK) return rcj;
+    split = false;
+  }
   std::vector<GqeActSeg> staging;
   const GqeActSeg* act_dev = reinterpret_cast<const GqeActSeg*>(ctx->ws + ctx->lay.act_off);
   auto emit = [&](auto keep, GqeOptActive& active, GqeStepCoef& coef, const GqeActSeg** act, int* n_act) -> long long {
@@ -1026,6 +1099,20 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
   oa.eps = eps;
   oa.stream = st;
   auto everything = [](size_t) { return true; };
+  auto tables_only = [&](size_t ui) { return ctx->universe[ui].is_table != 0; };
+  auto dense_only = [&](size_t ui) { return ctx->universe[ui].is_table == 0; };
+  // overlap mode: the relation / Pre / Post tensors are stepped on the side stream, behind the GEMM that is still
+  // producing their gradients; the caller's stream is ordered after both at the end of this call
+  auto dense_on_side = [&]() -> int {
+    GqeOptArgs od = oa;
+    od.lazy = false;
+    od.lists = false;
+    od.dense_tables = false;
+    od.stream = ctx->side;
+    od.total_chunks = emit(dense_only, od.active, od.coef, &od.act, &od.n_act);
+    if (od.total_chunks > 0) HIP_TRY(ctx, gqe_launch_opt(od));
+    return join_side(ctx, st);
+  };
   const bool timed = !flush && mode != GQE_OPT_MATERIALIZE && mode != GQE_OPT_ZERO;  // kernel 2 = the optimiser step proper
   bool sparse = false;
   if (ctx->lazy && mode == GQE_OPT_ADAM) {
@@ -1101,7 +1188,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       // the small dense tensors ride in extra workgroups of the (first) row launch: the ordinary pass, tables masked out
       ra.dsegs = oa.segs;
       ra.n_dsegs = oa.n_segs;
-      ra.dense_chunks = emit([&](size_t ui) { return !ctx->universe[ui].is_table; }, ra.dactive, ra.dcoef, &ra.dact, &ra.n_dact);
+      ra.dense_chunks = split ? 0 : emit(dense_only, ra.dactive, ra.dcoef, &ra.dact, &ra.n_dact);
       rc = upload_staging();
       if (rc != GQE_OK) return rc;
       rc = timing_begin(ctx, 2, st);
@@ -1114,6 +1201,10 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       rc = timing_end(ctx, 2, st);
       if (rc != GQE_OK) return rc;
       if (ctx->feed_buf >= 0) HIP_TRY(ctx, hipEventRecord(ctx->plan_free[ctx->feed_buf], st));  // the staged feed may go now
+      if (split) {
+        rc = dense_on_side();
+        if (rc != GQE_OK) return rc;
+      }
       if (ob.total_chunks > 0) {
         ob.lazy = false;
         rc = timing_begin(ctx, 3, st);
@@ -1140,16 +1231,21 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
         oa.lz.t.grad_step[t] = (seen[t] && !flush) ? ctx->tables[t].lstep + 1 : -1;
         oa.lz.t.eager[t] = lazy_table_ok(ctx, (int)t) ? 0 : 1;
       }
-      oa.total_chunks = emit(everything, oa.active, oa.coef, &oa.act, &oa.n_act);
+      if (split) oa.total_chunks = emit(tables_only, oa.active, oa.coef, &oa.act, &oa.n_act);
+      else oa.total_chunks = emit(everything, oa.active, oa.coef, &oa.act, &oa.n_act);
       rc = upload_staging();
       if (rc != GQE_OK) return rc;
       if (timed) {
         rc = timing_begin(ctx, 2, st);
         if (rc != GQE_OK) return rc;
       }
-      HIP_TRY(ctx, gqe_launch_opt(oa));
+      if (oa.total_chunks > 0) HIP_TRY(ctx, gqe_launch_opt(oa));
       if (timed) {
         rc = timing_end(ctx, 2, st);
+        if (rc != GQE_OK) return rc;
+      }
+      if (split) {
+        rc = dense_on_side();
         if (rc != GQE_OK) return rc;
       }
       for (size_t t = 0; t < ctx->tables.size(); ++t)
@@ -1161,16 +1257,21 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     }
     if (flush) return GQE_OK;
   } else {
-    oa.total_chunks = emit(everything, oa.active, oa.coef, &oa.act, &oa.n_act);
+    if (split) oa.total_chunks = emit(tables_only, oa.active, oa.coef, &oa.act, &oa.n_act);
+    else oa.total_chunks = emit(everything, oa.active, oa.coef, &oa.act, &oa.n_act);
     rc = upload_staging();
     if (rc != GQE_OK) return rc;
     if (timed) {
       rc = timing_begin(ctx, 2, st);
       if (rc != GQE_OK) return rc;
     }
-    HIP_TRY(ctx, gqe_launch_opt(oa));
+    if (oa.total_chunks > 0) HIP_TRY(ctx, gqe_launch_opt(oa));
     if (timed) {
       rc = timing_end(ctx, 2, st);
+      if (rc != GQE_OK) return rc;
+    }
+    if (split) {
+      rc = dense_on_side();
       if (rc != GQE_OK) return rc;
     }
     if (mode == GQE_OPT_ADAM)
@@ -1238,6 +1339,12 @@ int gqe_destroy(gqe_ctx* ctx) {
       (void)hipEventDestroy(ctx->plan_free[k]);
     }
     (void)hipStreamDestroy(ctx->up);
+  }
+  if (ctx->side) {
+    (void)hipStreamSynchronize(ctx->side);
+    (void)hipEventDestroy(ctx->fork_ev);
+    (void)hipEventDestroy(ctx->join_ev);
+    (void)hipStreamDestroy(ctx->side);
   }
   for (auto& tv : ctx->timed)
     for (auto& t : tv) ctx->event_pool.push_back(t);
@@ -1358,6 +1465,18 @@ int gqe_set_lazy_adam(gqe_ctx* ctx, int32_t enable) {
   return GQE_OK;
 }
 
+int gqe_set_overlap(gqe_ctx* ctx, int32_t enable) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (ctx->gemm_pending) return fail(ctx, GQE_ERR_STATE, "a margin call is in flight: step (or gqe_join) first");
+  ctx->overlap = enable != 0;
+  return GQE_OK;
+}
+
+int gqe_join(gqe_ctx* ctx, void* stream) {
+  if (!ctx) return GQE_ERR_ARG;
+  return join_side(ctx, reinterpret_cast<hipStream_t>(stream));
+}
+
 int gqe_optimizer_sync(gqe_ctx* ctx, void* stream) {
   if (!ctx) return GQE_ERR_ARG;
   if (!ctx->lazy || !ctx->ws) return GQE_OK;
@@ -1402,6 +1521,10 @@ int gqe_export_entries(gqe_ctx* ctx, int64_t* slab_entries_out, int64_t* contrib
   if (ctx->world < 2) return fail(ctx, GQE_ERR_STATE, "gqe_set_exchange(world > 1) has not been called");
   if (ctx->entries_used == 0 || ctx->step_slab == 0) return fail(ctx, GQE_ERR_STATE, "no margin call is pending");
   const Layout& L = ctx->lay;
+  {
+    int rcj = join_side(ctx, reinterpret_cast<hipStream_t>(stream));  // the dense gradients must be complete
+    if (rcj != GQE_OK) return rcj;
+  }
   if (!ctx->step_exported) {
     // flush the deferred work that still adds into the dense gradients, then pack the slab's tails
     HIP_TRY(ctx, gqe_launch_export(reinterpret_cast<float*>(ctx->ws + L.contrib_off), reinterpret_cast<const int32_t*>(ctx->ws + L.rows_off),
