@@ -148,10 +148,10 @@ class Workload(object):
         n_rel = sum(len(v) for v in g.relations.values())
         return "%d modes, %d nodes, %d directed relations, seed 0" % (len(g.modes), sum(g.mode_sizes.values()), n_rel)
 
-    def engine(self, rank=0, world=1, lazy=False, overlap=False):
+    def engine(self, rank=0, world=1, lazy=False):
         from graphqembed_amd.engine import Engine
         eng = Engine(self.d, self.decoder, self.inter, self.layout, max_queries=self.qpi, max_batches=len(self.mix),
-                     rank=rank, world=world, lazy_adam=lazy, bags=self.bags, overlap=overlap)
+                     rank=rank, world=world, lazy_adam=lazy, bags=self.bags)
         init_params(eng, self.d, seed=0)                           # same seed on every rank: replicas start equal
         return eng
 
@@ -324,7 +324,7 @@ def measure(wl, args, dist, rank, world, exchange="sparse", lazy=False, steps=No
     steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
     sparse = world > 1 and exchange == "sparse"
-    eng = wl.engine(rank=rank if sparse else 0, world=world if sparse else 1, lazy=lazy, overlap=args.overlap)
+    eng = wl.engine(rank=rank if sparse else 0, world=world if sparse else 1, lazy=lazy)
     prepared = wl.prepare(eng)
     ex_events = [] if dist is not None else None
     step = make_step(eng, prepared, dist, exchange, wl.n_distinct, ex_events)
@@ -485,8 +485,6 @@ def main():
                     "the dense arena; the other form is measured next to it")
     ap.add_argument("--lazy-adam", action="store_true", help="run the MAIN measurement in lazy-Adam mode (non-default; the config "
                     "then says so).  Works with --gpus N and the sparse exchange.")
-    ap.add_argument("--overlap", action="store_true", help="gqe_set_overlap: pair GEMM on the library's side stream, next to the table "
-                    "part of the optimiser pass")
     ap.add_argument("--no-lazy", action="store_true", help="skip the secondary measurement of the lazy (deferred, bit-exact) Adam mode")
     ap.add_argument("--no-configs", action="store_true", help="skip the other SURVEY §8d configurations (N=1)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the gqe_feeder_run measurement (N=1)")

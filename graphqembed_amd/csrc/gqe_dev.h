@@ -8,8 +8,8 @@
 #include "../../include/gqe.h"
 
 #define GQE_TQ 16            // queries per tile (= per workgroup of the fused kernel)
-#define GQE_FWAVES 16        // wave64s per workgroup of the fused kernel: one query row per wave
-#define GQE_FTHREADS 1024
+#define GQE_FWAVES 16        // most wave64s per workgroup of the fused kernel (one query row per wave; the 8-wave shape: two)
+#define GQE_FW8_MIN_TILES 512  // d = 128: launches with more tiles than this use the 8-wave shape (two workgroups per CU)
 #define GQE_WAVES 4          // wave64s per workgroup of the pair-GEMM / optimiser kernels
 #define GQE_THREADS 256
 #define GQE_OPT_CHUNK 1024   // floats per optimiser chunk (256 threads x float4)

@@ -2,7 +2,7 @@
 //
 // What is computed follows netquery/model.py:70-127, encoders.py:40-43, decoders.py:142-150,
 // 200-208, 228-236, 288-319 (maths: SURVEY.md Appendix B / oracle/netquery_numpy.py).  How:
-//   * one workgroup = 16 wave64 (GQE_FWAVES) owns a TILE of 16 queries of ONE batch (= one Formula), so every
+//   * one workgroup = 16 wave64 (GQE_FW) owns a TILE of 16 queries of ONE batch (= one Formula), so every
 //     relation parameter is workgroup-uniform; one grouped launch covers all batches of an iteration;
 //   * the tile's table rows are fetched with one coalesced index read, then EVERY embedding row the
 //     tile needs (target, negative, up to 3 anchors per query) is requested at once — one wave per row,
@@ -24,7 +24,15 @@
 
 #include "gqe_common.h"
 
-#define RPW (GQE_TQ / GQE_FWAVES)  // query rows owned by one wave
+// Waves per workgroup of this translation unit's kernels (gqe_fused_inst.hip is compiled once per (decoder, MLP, GQE_FW)):
+//   16 = one query row per wave: the shortest dependent chain per tile, 1024-thread workgroups (<= 128 VGPRs per lane);
+//    8 = two rows per wave, 512-thread workgroups (<= 256 VGPRs): d > 128 without spills, and two workgroups per CU at
+//        d = 128 (2 x 74 KB LDS) when a launch has more tiles than the chip has CUs.
+#ifndef GQE_FW
+#define GQE_FW 16
+#endif
+#define GQE_FWT (64 * GQE_FW)
+#define RPW (GQE_TQ / GQE_FW)  // query rows owned by one wave
 
 struct TileEnv {
   GqeDynBatch b;  // by value: the plan is a kernel argument, never take its address
@@ -55,18 +63,19 @@ __device__ __forceinline__ float* scratch_row(const TileEnv& e, int slot, int r)
 // ------------------------------------------------------------------------------------------
 template <bool TRANS, int KB>
 __device__ __forceinline__ void load_a_slab(float4 (&a)[KB], const float* __restrict__ M, int d, int nkb, int i0, int lq,
-                                            int lk) {
+                                            int lk, int kb0) {
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb) {
+  for (int j = 0; j < KB; ++j) {
+    const int kb = kb0 + j;
     if (kb < nkb) {
       if (!TRANS) {
-        a[kb] = *reinterpret_cast<const float4*>(M + (size_t)(i0 + lq) * d + kb * 16 + 4 * lk);
+        a[j] = *reinterpret_cast<const float4*>(M + (size_t)(i0 + lq) * d + kb * 16 + 4 * lk);
       } else {
         const float* mp = M + (size_t)(kb * 16 + 4 * lk) * d + i0 + lq;
-        a[kb] = make_float4(mp[0], mp[d], mp[2 * d], mp[3 * d]);
+        a[j] = make_float4(mp[0], mp[d], mp[2 * d], mp[3 * d]);
       }
     } else {
-      a[kb] = make_float4(0.f, 0.f, 0.f, 0.f);
+      a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 }
@@ -79,21 +88,29 @@ __device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 a
   return acc;
 }
 
+// The A slab of an output row block is fetched in groups of <= KG k-blocks (KG float4 per lane in flight): all of it
+// at d <= 128, two / three / four rounds beyond — a 16-float4 slab (d = 256) next to the rows a wave keeps in registers
+// would spill.
+#define GQE_KG 8
+
 // dst[q][i] = sum_k A[i][k] src[q][k]   (one source tile)
 template <bool TRANS, int NC>
 __device__ __forceinline__ void tile_matmul(float* __restrict__ dst, const float* __restrict__ M,
                                             const float* __restrict__ src, int d, int DP, int wave, int lane) {
-  constexpr int KB = 4 * NC;
+  constexpr int KB = 4 * NC, KG = KB < GQE_KG ? KB : GQE_KG;
   const int lq = lane & 15, lk = lane >> 4, nkb = d >> 4;
-  for (int i0 = wave * 16; i0 < d; i0 += GQE_FWAVES * 16) {
-    float4 a[KB];
-    load_a_slab<TRANS, KB>(a, M, d, nkb, i0, lq, lk);
+  for (int i0 = wave * 16; i0 < d; i0 += GQE_FW * 16) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      if (kb < nkb) {
-        const float4 b = *reinterpret_cast<const float4*>(src + lq * DP + kb * 16 + 4 * lk);
-        acc = mfma4(a[kb], b, acc);
+    for (int g0 = 0; g0 < KB; g0 += KG) {
+      float4 a[KG];
+      load_a_slab<TRANS, KG>(a, M, d, nkb, i0, lq, lk, g0);
+#pragma unroll
+      for (int kb = 0; kb < KG; ++kb) {
+        if (g0 + kb < nkb) {
+          const float4 b = *reinterpret_cast<const float4*>(src + lq * DP + (g0 + kb) * 16 + 4 * lk);
+          acc = mfma4(a[kb], b, acc);
+        }
       }
     }
     *reinterpret_cast<float4*>(dst + lq * DP + i0 + 4 * lk) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -107,21 +124,24 @@ template <int NC, int NB>
 __device__ __forceinline__ void pre_intersect(float* __restrict__ th, int* __restrict__ tmeta,
                                               const float* __restrict__ P, float* const (&te)[GQE_MAX_BRANCH], int d,
                                               int DP, int wave, int lane, int inter_min) {
-  constexpr int KB = 4 * NC;
+  constexpr int KB = 4 * NC, KG = KB < GQE_KG ? KB : GQE_KG;
   const int lq = lane & 15, lk = lane >> 4, nkb = d >> 4;
-  for (int i0 = wave * 16; i0 < d; i0 += GQE_FWAVES * 16) {
-    float4 a[KB];
-    load_a_slab<false, KB>(a, P, d, nkb, i0, lq, lk);
+  for (int i0 = wave * 16; i0 < d; i0 += GQE_FW * 16) {
     f32x4 acc[NB];
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi) acc[bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      if (kb < nkb) {
+    for (int g0 = 0; g0 < KB; g0 += KG) {
+      float4 a[KG];
+      load_a_slab<false, KG>(a, P, d, nkb, i0, lq, lk, g0);
 #pragma unroll
-        for (int bi = 0; bi < NB; ++bi) {
-          const float4 b = *reinterpret_cast<const float4*>(te[bi] + lq * DP + kb * 16 + 4 * lk);
-          acc[bi] = mfma4(a[kb], b, acc[bi]);
+      for (int kb = 0; kb < KG; ++kb) {
+        if (g0 + kb < nkb) {
+#pragma unroll
+          for (int bi = 0; bi < NB; ++bi) {
+            const float4 b = *reinterpret_cast<const float4*>(te[bi] + lq * DP + (g0 + kb) * 16 + 4 * lk);
+            acc[bi] = mfma4(a[kb], b, acc[bi]);
+          }
         }
       }
     }
@@ -165,25 +185,28 @@ template <int NC, int NB>
 __device__ __forceinline__ void pre_intersect_bwd(float* const (&te)[GQE_MAX_BRANCH], const float* __restrict__ P,
                                                   const float* __restrict__ tgh, const int* __restrict__ tmeta, int d,
                                                   int DP, int wave, int lane, int inter_min) {
-  constexpr int KB = 4 * NC;
+  constexpr int KB = 4 * NC, KG = KB < GQE_KG ? KB : GQE_KG;
   const int lq = lane & 15, lk = lane >> 4, nkb = d >> 4;
   const float inv_n = 1.f / (float)NB;
-  for (int i0 = wave * 16; i0 < d; i0 += GQE_FWAVES * 16) {
-    float4 a[KB];
-    load_a_slab<true, KB>(a, P, d, nkb, i0, lq, lk);
+  for (int i0 = wave * 16; i0 < d; i0 += GQE_FW * 16) {
     f32x4 acc[NB];
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi) acc[bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      if (kb < nkb) {
-        const float4 gh = *reinterpret_cast<const float4*>(tgh + lq * DP + kb * 16 + 4 * lk);
-        const int4 mt = *reinterpret_cast<const int4*>(tmeta + lq * DP + kb * 16 + 4 * lk);
+    for (int g0 = 0; g0 < KB; g0 += KG) {
+      float4 a[KG];
+      load_a_slab<true, KG>(a, P, d, nkb, i0, lq, lk, g0);
 #pragma unroll
-        for (int bi = 0; bi < NB; ++bi) {
-          const float4 b = make_float4(mask_gz(gh.x, mt.x, bi, inter_min, inv_n, true), mask_gz(gh.y, mt.y, bi, inter_min, inv_n, true),
-                                       mask_gz(gh.z, mt.z, bi, inter_min, inv_n, true), mask_gz(gh.w, mt.w, bi, inter_min, inv_n, true));
-          acc[bi] = mfma4(a[kb], b, acc[bi]);
+      for (int kb = 0; kb < KG; ++kb) {
+        if (g0 + kb < nkb) {
+          const float4 gh = *reinterpret_cast<const float4*>(tgh + lq * DP + (g0 + kb) * 16 + 4 * lk);
+          const int4 mt = *reinterpret_cast<const int4*>(tmeta + lq * DP + (g0 + kb) * 16 + 4 * lk);
+#pragma unroll
+          for (int bi = 0; bi < NB; ++bi) {
+            const float4 b = make_float4(mask_gz(gh.x, mt.x, bi, inter_min, inv_n, true), mask_gz(gh.y, mt.y, bi, inter_min, inv_n, true),
+                                         mask_gz(gh.z, mt.z, bi, inter_min, inv_n, true), mask_gz(gh.w, mt.w, bi, inter_min, inv_n, true));
+            acc[bi] = mfma4(a[kb], b, acc[bi]);
+          }
         }
       }
     }
@@ -202,8 +225,7 @@ template <int NC>
 struct RowSet {
   Vec<NC> x[RPW];
   float nrm[RPW];
-  int row[RPW];
-  int bag_p0[RPW], bag_len[RPW];  // bag modes: the row is bag `row` = ids[p0 .. p0+len)
+  int row[RPW];  // bag modes: the row is bag `row` = ids[ptr[row] .. ptr[row + 1])
 };
 
 template <int NC>
@@ -242,8 +264,6 @@ __device__ __forceinline__ void rows_issue_bag(RowSet<NC>& rs, const TileEnv& e,
       const float inv = 1.f / (float)len;
       VEC_OP(acc, acc.v[c] * inv);
     }
-    rs.bag_p0[rr] = p0;
-    rs.bag_len[rr] = len;
     rs.x[rr] = acc;
   }
 }
@@ -296,7 +316,7 @@ __device__ __forceinline__ void eval_candidates(const TileEnv& e, const GqeBagTa
     const int c0 = cand_ptr[q];
     const long long len = cand_ptr[q + 1] - c0;
     const int cb = c0 + (int)(len * split / nsplit), ce = c0 + (int)(len * (split + 1) / nsplit);
-    for (int ci = cb + e.wave * GQE_EVAL_U; ci < ce; ci += GQE_FWAVES * GQE_EVAL_U) {
+    for (int ci = cb + e.wave * GQE_EVAL_U; ci < ce; ci += GQE_FW * GQE_EVAL_U) {
       const int m = min(GQE_EVAL_U, ce - ci);
       Vec<NC> x[GQE_EVAL_U];
       if (bag < 0) {
@@ -372,9 +392,11 @@ __device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_
 // bag mode: one contribution (already divided by the bag length: EmbeddingBag mean backward) shared by every
 // word row of the bag through link nodes: node -> (contribution entry, next).  Nodes come from a bump allocator.
 template <int NC>
-__device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t head_base, int role, int r, int p0, int len,
-                                                     const int32_t* __restrict__ ids, const Vec<NC>& xhat, float nrm,
-                                                     const Vec<NC>& g, int bag_slot, int bag_index) {
+__device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t head_base, int role, int r,
+                                                     const int32_t* __restrict__ ptr, const int32_t* __restrict__ ids,
+                                                     const Vec<NC>& xhat, float nrm, const Vec<NC>& g, int bag_slot,
+                                                     int bag_index) {
+  const int p0 = ptr[bag_index], len = ptr[bag_index + 1] - p0;  // re-read (L2 hit) rather than carried in registers
   const float pg = vdot<NC>(xhat, g);
   const float inv = 1.f / (nrm * (float)len);
   Vec<NC> gx;
@@ -406,8 +428,7 @@ __device__ __forceinline__ void scatter_row(const TileEnv& e, const GqeBagTable&
   if (bag < 0)
     scatter_norm_bwd<NC>(e, head_base, role, r, rs.row[rr], rs.x[rr], rs.nrm[rr], g, old_head);
   else
-    scatter_norm_bwd_bag<NC>(e, head_base, role, r, rs.bag_p0[rr], rs.bag_len[rr], bags.ids[bag], rs.x[rr], rs.nrm[rr], g, bag,
-                             rs.row[rr]);
+    scatter_norm_bwd_bag<NC>(e, head_base, role, r, bags.ptr[bag], bags.ids[bag], rs.x[rr], rs.nrm[rr], g, bag, rs.row[rr]);
 }
 
 // next[entry] = previous head, for every contribution this wave pushed
@@ -433,13 +454,12 @@ struct VecGrads {
   int64_t param[GQE_VG_SLOTS];  // -1 = unused (workgroup-uniform)
 };
 
+// g[k] is only defined once param[k] >= 0: nothing is zero-initialised, so the slots cost no registers before the
+// backward assigns them (at d = 256 the seven slots would otherwise hold 28 VGPRs through every MFMA phase).
 template <int NC>
 __device__ __forceinline__ void vecgrads_init(VecGrads<NC>& vg) {
 #pragma unroll
-  for (int k = 0; k < GQE_VG_SLOTS; ++k) {
-    vg.g[k] = vzero<NC>();
-    vg.param[k] = -1;
-  }
+  for (int k = 0; k < GQE_VG_SLOTS; ++k) vg.param[k] = -1;
 }
 
 template <int NC>
@@ -448,17 +468,17 @@ __device__ __forceinline__ void vecgrads_commit(const TileEnv& e, float* lds /* 
   __syncthreads();  // every wave is done with the tiles this staging area overlays
 #pragma unroll
   for (int k = 0; k < GQE_VG_SLOTS; ++k) {
-    if (vg.param[k] >= 0) vstore<NC>(lds + (size_t)(k * GQE_FWAVES + e.wave) * e.d, vg.g[k], e.d, e.lane);
+    if (vg.param[k] >= 0) vstore<NC>(lds + (size_t)(k * GQE_FW + e.wave) * e.d, vg.g[k], e.d, e.lane);
     if (threadIdx.x == 0) s_param[k] = vg.param[k];
   }
   __syncthreads();
   if (e.wave < GQE_VG_SLOTS) {
     const long long param = s_param[e.wave];
     if (param >= 0) {
-      Vec<NC> s = vload<NC>(lds + (size_t)(e.wave * GQE_FWAVES) * e.d, e.d, e.lane);
+      Vec<NC> s = vload<NC>(lds + (size_t)(e.wave * GQE_FW) * e.d, e.d, e.lane);
 #pragma unroll
-      for (int w = 1; w < GQE_FWAVES; ++w) {
-        Vec<NC> t = vload<NC>(lds + (size_t)(e.wave * GQE_FWAVES + w) * e.d, e.d, e.lane);
+      for (int w = 1; w < GQE_FW; ++w) {
+        Vec<NC> t = vload<NC>(lds + (size_t)(e.wave * GQE_FW + w) * e.d, e.d, e.lane);
         VEC_OP(s, s.v[c] + t.v[c]);
       }
       vatomic_add<NC>(e.grads + param, s, e.d, e.lane);
@@ -475,8 +495,8 @@ __device__ __forceinline__ void tile_to_scratch(const TileEnv& e, int slot, cons
   }
 }
 
-template <int DEC, bool MLP, int NC, bool FULL, bool BWD>
-__global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPlan plan,
+template <int DEC, bool MLP, int NC, bool FULL, bool BWD, int FW>
+__global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan plan,
                                                                 const GqeDevFormula* __restrict__ formulas,
                                                                 const float* __restrict__ params,
                                                                 float* __restrict__ grads, float* __restrict__ ws,
@@ -488,6 +508,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
                                                                 int32_t* __restrict__ link_contrib,
                                                                 int32_t* __restrict__ link_counter, int max_entries,
                                                                 long long* __restrict__ prof) {
+  static_assert(FW == GQE_FW, "FW only distinguishes the kernels of the per-GQE_FW translation units");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #define GQE_STAMP(k)                                                                                              \
   do {                                                                                                            \
@@ -542,7 +563,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
   float* tg = tq + GQE_TQ * DP;       // g_q
   int* tmeta = reinterpret_cast<int*>(tg + GQE_TQ * DP);
   float* red = reinterpret_cast<float*>(tmeta + GQE_TQ * DP);
-  int* s_idx = reinterpret_cast<int*>(red + GQE_FWAVES * d);  // [5][16]: target, negative, anchor 0..2
+  int* s_idx = reinterpret_cast<int*>(red + GQE_FW * d);  // [5][16]: target, negative, anchor 0..2
 
   // ---- the tile's table rows: one coalesced read, then every gather is issued at once ----
   if (threadIdx.x < 5 * GQE_TQ) {
@@ -1128,7 +1149,7 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
     if (threadIdx.x == 0) {
       float l = 0.f;
 #pragma unroll
-      for (int w = 0; w < GQE_FWAVES; ++w) l += red[w];
+      for (int w = 0; w < GQE_FW; ++w) l += red[w];
       tile_loss[blockIdx.x] = l;  // summed per batch by the finalize block of the pair-GEMM launch
     }
   }
@@ -1141,18 +1162,18 @@ __global__ __launch_bounds__(GQE_FTHREADS) void gqe_fused_kernel(const GqeDynPla
 // ------------------------------------------------------------------------------------------
 inline size_t gqe_fused_lds_bytes_impl(int d) {
   const int DP = d + 4;
-  return (size_t)(8 * GQE_TQ * DP + GQE_FWAVES * d + 5 * GQE_TQ) * sizeof(float);
+  return (size_t)(8 * GQE_TQ * DP + GQE_FW * d + 5 * GQE_TQ) * sizeof(float);
 }
 
 template <int DEC, bool MLP, int NC, bool FULL>
 static hipError_t launch_fused_v(const GqeFusedArgs& a) {
   const size_t lds = gqe_fused_lds_bytes_impl(a.d);
   if (a.bwd)
-    hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true>), dim3(a.plan.tiles), dim3(GQE_FTHREADS), lds, a.stream, a.plan,
+    hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true, GQE_FW>), dim3(a.plan.tiles), dim3(GQE_FWT), lds, a.stream, a.plan,
                        a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags, a.link_contrib, a.link_counter,
                        a.max_entries, a.prof);
   else
-    hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, false>), dim3(a.plan.tiles), dim3(GQE_FTHREADS), lds, a.stream, a.plan,
+    hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, false, GQE_FW>), dim3(a.plan.tiles), dim3(GQE_FWT), lds, a.stream, a.plan,
                        a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags, a.link_contrib, a.link_counter,
                        a.max_entries, a.prof);
   return hipGetLastError();
@@ -1162,12 +1183,21 @@ template <int DEC, bool MLP>
 static hipError_t launch_fused_dm(const GqeFusedArgs& a) {
   const int nc = (a.d + 63) / 64;
   const bool full = (a.d % 64) == 0;
-  switch (nc) {
+#if GQE_FW == 16
+  switch (nc) {  // d <= 128 and d = 256 (straight-line code, 125 VGPRs, no scratch)
     case 1: return full ? launch_fused_v<DEC, MLP, 1, true>(a) : launch_fused_v<DEC, MLP, 1, false>(a);
     case 2: return full ? launch_fused_v<DEC, MLP, 2, true>(a) : launch_fused_v<DEC, MLP, 2, false>(a);
-    case 3: return launch_fused_v<DEC, MLP, 3, false>(a);
-    default: return full ? launch_fused_v<DEC, MLP, 4, true>(a) : launch_fused_v<DEC, MLP, 4, false>(a);
+    case 4: return full ? launch_fused_v<DEC, MLP, 4, true>(a) : hipErrorInvalidValue;
+    default: return hipErrorInvalidValue;
   }
+#else
+  switch (nc) {  // d = 128 with many tiles (two workgroups per CU) and the guarded d in (128, 256) variants
+    case 2: return full ? launch_fused_v<DEC, MLP, 2, true>(a) : hipErrorInvalidValue;
+    case 3: return launch_fused_v<DEC, MLP, 3, false>(a);
+    case 4: return full ? hipErrorInvalidValue : launch_fused_v<DEC, MLP, 4, false>(a);
+    default: return hipErrorInvalidValue;
+  }
+#endif
 }
 
 #endif

@@ -119,12 +119,6 @@ struct gqe_ctx {
   hipEvent_t plan_ready[2] = {nullptr, nullptr}, plan_free[2] = {nullptr, nullptr};
   bool plan_free_set[2] = {false, false};
   int plan_buf = 0;
-  // overlap mode (gqe_set_overlap): the deferred matrix-gradient GEMM runs on a side stream, next to the table part
-  // of the following optimiser pass (which does not depend on it)
-  bool overlap = false;
-  hipStream_t side = nullptr;
-  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
-  bool gemm_pending = false;  // work is in flight on `side` that the caller's stream has not been ordered after yet
   std::string err;
   long long* prof = nullptr;  // optional per-workgroup phase stamps (gqe_debug_profile)
   std::map<int64_t, int> adam_steps;          // per-tensor step counters for callers that pass step <= 0
@@ -279,15 +273,6 @@ int ring_acquire(gqe_ctx* ctx, size_t bytes, RingSlot** out) {
   }
   if (!s.done) HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   *out = &s;
-  return GQE_OK;
-}
-
-// order the caller's stream after everything the library put on its side stream (overlap mode)
-int join_side(gqe_ctx* ctx, hipStream_t st) {
-  if (!ctx->gemm_pending) return GQE_OK;
-  HIP_TRY(ctx, hipEventRecord(ctx->join_ev, ctx->side));
-  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->join_ev, 0));
-  ctx->gemm_pending = false;
   return GQE_OK;
 }
 
@@ -626,8 +611,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     return fail(ctx, GQE_ERR_WORKSPACE, "gradient contribution buffer full (%lld + %lld > %lld entries): step or "
                 "gqe_materialize_grads first", (long long)ctx->entries_used, (long long)entries, (long long)L.max_entries);
 
-  int rc = join_side(ctx, st);  // a previous call's GEMM reads the pair scratch this call overwrites
-  if (rc != GQE_OK) return rc;
+  int rc;
   // ---- new / replaced formula descriptors -> device table (rare): contiguous runs of stale slots, one copy each ----
   if (!ctx->formulas_dirty.empty()) {
     std::vector<int>& dirty = ctx->formulas_dirty;
@@ -823,27 +807,11 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     if (rc != GQE_OK) return rc;
     if (bwd) {
       // deferred matrix gradients + the finalize block that turns per-tile hinge sums into losses[]
-      hipStream_t gs = st;
-      if (ctx->overlap && n_batches <= GQE_LAUNCH_BATCHES) {
-        // overlap mode: on the side stream, so that the table part of the optimiser pass (which needs the row
-        // gradient lists, not the matrix gradients) can start right behind the fused kernel
-        if (!ctx->side) {
-          HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-          HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
-          HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming));
-        }
-        HIP_TRY(ctx, hipEventRecord(ctx->fork_ev, st));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->fork_ev, 0));
-        gs = ctx->side;
-        ctx->gemm_pending = true;
-      }
-      fa.stream = gs;
-      rc = timing_begin(ctx, 1, gs);
+      rc = timing_begin(ctx, 1, st);
       if (rc != GQE_OK) return rc;
       HIP_TRY(ctx, gqe_launch_pair_gemm(fa, losses));
-      rc = timing_end(ctx, 1, gs);
+      rc = timing_end(ctx, 1, st);
       if (rc != GQE_OK) return rc;
-      fa.stream = st;
     }
   }
   if (bwd) {
@@ -910,13 +878,6 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     b1 = ctx->lz_b1;
     b2 = ctx->lz_b2;
     eps = ctx->lz_eps;
-  }
-  // overlap mode: an Adam / SGD step is split — tables on the caller's stream (next to the GEMM still running on the
-  // side stream), the relation / Pre / Post tensors on the side stream behind the GEMM that produces their gradients
-  bool split = ctx->gemm_pending && !flush && (mode == GQE_OPT_ADAM || mode == GQE_OPT_SGD);
-  if (!split) {
-    int rcj = join_side(ctx, st);
-    if (rcj != GQE_OK) return rcj;
   }
   GqeOptArgs oa;
   oa.lazy = false;
@@ -986,9 +947,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
           return fail(ctx, GQE_ERR_STATE, "table at offset %lld has pending gradients but is not among the stepped segments",
                       (long long)ctx->tables[t].offset);
   }
-  bool universe_sent = false;
   if (ctx->universe_uploaded != ctx->universe.size()) {
-    universe_sent = true;
     const size_t seg_bytes = sizeof(GqeDevSeg) * ctx->universe.size();
     RingSlot* slot;  // happens only when a tensor is stepped for the first time
     rc = ring_acquire(ctx, seg_bytes, &slot);
@@ -1017,12 +976,6 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
   // <= GQE_MAX_STEP_GROUPS distinct step counts: nothing is uploaded) or as a list of the active tensors that is
   // uploaded with the step (large schemas: dozens of relation types whose step counters diverge).
   const bool table_form = nu > GQE_MAX_SEGS || distinct.size() > GQE_MAX_STEP_GROUPS;
-  if (split && (table_form || universe_sent)) {
-    // the tensor table / the active list travel on the caller's stream: keep everything there
-    int rcj = join_side(ctx, st);
-    if (rcj != GQE_OK) return rcj;
-    split = false;
-  }
   std::vector<GqeActSeg> staging;
   const GqeActSeg* act_dev = reinterpret_cast<const GqeActSeg*>(ctx->ws + ctx->lay.act_off);
   auto emit = [&](auto keep, GqeOptActive& active, GqeStepCoef& coef, const GqeActSeg** act, int* n_act) -> long long {
@@ -1099,20 +1052,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
   oa.eps = eps;
   oa.stream = st;
   auto everything = [](size_t) { return true; };
-  auto tables_only = [&](size_t ui) { return ctx->universe[ui].is_table != 0; };
   auto dense_only = [&](size_t ui) { return ctx->universe[ui].is_table == 0; };
-  // overlap mode: the relation / Pre / Post tensors are stepped on the side stream, behind the GEMM that is still
-  // producing their gradients; the caller's stream is ordered after both at the end of this call
-  auto dense_on_side = [&]() -> int {
-    GqeOptArgs od = oa;
-    od.lazy = false;
-    od.lists = false;
-    od.dense_tables = false;
-    od.stream = ctx->side;
-    od.total_chunks = emit(dense_only, od.active, od.coef, &od.act, &od.n_act);
-    if (od.total_chunks > 0) HIP_TRY(ctx, gqe_launch_opt(od));
-    return join_side(ctx, st);
-  };
   const bool timed = !flush && mode != GQE_OPT_MATERIALIZE && mode != GQE_OPT_ZERO;  // kernel 2 = the optimiser step proper
   bool sparse = false;
   if (ctx->lazy && mode == GQE_OPT_ADAM) {
@@ -1188,7 +1128,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       // the small dense tensors ride in extra workgroups of the (first) row launch: the ordinary pass, tables masked out
       ra.dsegs = oa.segs;
       ra.n_dsegs = oa.n_segs;
-      ra.dense_chunks = split ? 0 : emit(dense_only, ra.dactive, ra.dcoef, &ra.dact, &ra.n_dact);
+      ra.dense_chunks = emit(dense_only, ra.dactive, ra.dcoef, &ra.dact, &ra.n_dact);
       rc = upload_staging();
       if (rc != GQE_OK) return rc;
       rc = timing_begin(ctx, 2, st);
@@ -1201,10 +1141,6 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       rc = timing_end(ctx, 2, st);
       if (rc != GQE_OK) return rc;
       if (ctx->feed_buf >= 0) HIP_TRY(ctx, hipEventRecord(ctx->plan_free[ctx->feed_buf], st));  // the staged feed may go now
-      if (split) {
-        rc = dense_on_side();
-        if (rc != GQE_OK) return rc;
-      }
       if (ob.total_chunks > 0) {
         ob.lazy = false;
         rc = timing_begin(ctx, 3, st);
@@ -1231,8 +1167,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
         oa.lz.t.grad_step[t] = (seen[t] && !flush) ? ctx->tables[t].lstep + 1 : -1;
         oa.lz.t.eager[t] = lazy_table_ok(ctx, (int)t) ? 0 : 1;
       }
-      if (split) oa.total_chunks = emit(tables_only, oa.active, oa.coef, &oa.act, &oa.n_act);
-      else oa.total_chunks = emit(everything, oa.active, oa.coef, &oa.act, &oa.n_act);
+      oa.total_chunks = emit(everything, oa.active, oa.coef, &oa.act, &oa.n_act);
       rc = upload_staging();
       if (rc != GQE_OK) return rc;
       if (timed) {
@@ -1244,10 +1179,6 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
         rc = timing_end(ctx, 2, st);
         if (rc != GQE_OK) return rc;
       }
-      if (split) {
-        rc = dense_on_side();
-        if (rc != GQE_OK) return rc;
-      }
       for (size_t t = 0; t < ctx->tables.size(); ++t)
         if (seen[t]) {
           if (!flush) ++ctx->tables[t].lstep;
@@ -1257,8 +1188,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     }
     if (flush) return GQE_OK;
   } else {
-    if (split) oa.total_chunks = emit(tables_only, oa.active, oa.coef, &oa.act, &oa.n_act);
-    else oa.total_chunks = emit(everything, oa.active, oa.coef, &oa.act, &oa.n_act);
+    oa.total_chunks = emit(everything, oa.active, oa.coef, &oa.act, &oa.n_act);
     rc = upload_staging();
     if (rc != GQE_OK) return rc;
     if (timed) {
@@ -1268,10 +1198,6 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     if (oa.total_chunks > 0) HIP_TRY(ctx, gqe_launch_opt(oa));
     if (timed) {
       rc = timing_end(ctx, 2, st);
-      if (rc != GQE_OK) return rc;
-    }
-    if (split) {
-      rc = dense_on_side();
       if (rc != GQE_OK) return rc;
     }
     if (mode == GQE_OPT_ADAM)
@@ -1339,12 +1265,6 @@ int gqe_destroy(gqe_ctx* ctx) {
       (void)hipEventDestroy(ctx->plan_free[k]);
     }
     (void)hipStreamDestroy(ctx->up);
-  }
-  if (ctx->side) {
-    (void)hipStreamSynchronize(ctx->side);
-    (void)hipEventDestroy(ctx->fork_ev);
-    (void)hipEventDestroy(ctx->join_ev);
-    (void)hipStreamDestroy(ctx->side);
   }
   for (auto& tv : ctx->timed)
     for (auto& t : tv) ctx->event_pool.push_back(t);
@@ -1465,18 +1385,6 @@ int gqe_set_lazy_adam(gqe_ctx* ctx, int32_t enable) {
   return GQE_OK;
 }
 
-int gqe_set_overlap(gqe_ctx* ctx, int32_t enable) {
-  if (!ctx) return GQE_ERR_ARG;
-  if (ctx->gemm_pending) return fail(ctx, GQE_ERR_STATE, "a margin call is in flight: step (or gqe_join) first");
-  ctx->overlap = enable != 0;
-  return GQE_OK;
-}
-
-int gqe_join(gqe_ctx* ctx, void* stream) {
-  if (!ctx) return GQE_ERR_ARG;
-  return join_side(ctx, reinterpret_cast<hipStream_t>(stream));
-}
-
 int gqe_optimizer_sync(gqe_ctx* ctx, void* stream) {
   if (!ctx) return GQE_ERR_ARG;
   if (!ctx->lazy || !ctx->ws) return GQE_OK;
@@ -1521,10 +1429,6 @@ int gqe_export_entries(gqe_ctx* ctx, int64_t* slab_entries_out, int64_t* contrib
   if (ctx->world < 2) return fail(ctx, GQE_ERR_STATE, "gqe_set_exchange(world > 1) has not been called");
   if (ctx->entries_used == 0 || ctx->step_slab == 0) return fail(ctx, GQE_ERR_STATE, "no margin call is pending");
   const Layout& L = ctx->lay;
-  {
-    int rcj = join_side(ctx, reinterpret_cast<hipStream_t>(stream));  // the dense gradients must be complete
-    if (rcj != GQE_OK) return rcj;
-  }
   if (!ctx->step_exported) {
     // flush the deferred work that still adds into the dense gradients, then pack the slab's tails
     HIP_TRY(ctx, gqe_launch_export(reinterpret_cast<float*>(ctx->ws + L.contrib_off), reinterpret_cast<const int32_t*>(ctx->ws + L.rows_off),

@@ -426,18 +426,42 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
 // ------------------------------------------------------------------------------------------
 // launchers (called from gqe_host.cpp)
 // ------------------------------------------------------------------------------------------
-#define GQE_DECL(DEC, MLP) hipError_t gqe_launch_fused_##DEC##_##MLP(const GqeFusedArgs& a);
+#define GQE_DECL(DEC, MLP) \
+  hipError_t gqe_launch_fused_##DEC##_##MLP##_w16(const GqeFusedArgs& a); \
+  hipError_t gqe_launch_fused_##DEC##_##MLP##_w8(const GqeFusedArgs& a);
 GQE_DECL(0, 0) GQE_DECL(0, 1) GQE_DECL(1, 0) GQE_DECL(1, 1) GQE_DECL(2, 0) GQE_DECL(2, 1)
 #undef GQE_DECL
 
+// Which workgroup shape runs a launch (gqe_fused.h): 16 waves (one query row per wave) up to d = 128 and at d = 256;
+// 8 waves (two rows per wave, 256 VGPRs) for the guarded d in (128, 256) variants, and at d = 128 when the launch has
+// so many tiles that two co-resident workgroups per CU (2 x 74 KB of LDS, 2 x 8 waves at <= 128 VGPRs) beat the shorter
+// per-tile chain of the 16-wave shape.
+int gqe_fused_waves(int d, int tiles) {
+  if (d == 256) return 16;  // FULL variant: fits 128 VGPRs without scratch; every wave owns an MFMA row block
+  if (d > 128) return 8;    // guarded variants
+  if (d == 128 && tiles > GQE_FW8_MIN_TILES) return 8;
+  return 16;
+}
+
 hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a) {
-  switch (dec * 2 + (mlp ? 1 : 0)) {
-    case 0: return gqe_launch_fused_0_0(a);
-    case 1: return gqe_launch_fused_0_1(a);
-    case 2: return gqe_launch_fused_1_0(a);
-    case 3: return gqe_launch_fused_1_1(a);
-    case 4: return gqe_launch_fused_2_0(a);
-    default: return gqe_launch_fused_2_1(a);
+  const int key = dec * 2 + (mlp ? 1 : 0);
+  if (gqe_fused_waves(a.d, a.plan.tiles) == 8) {
+    switch (key) {
+      case 0: return gqe_launch_fused_0_0_w8(a);
+      case 1: return gqe_launch_fused_0_1_w8(a);
+      case 2: return gqe_launch_fused_1_0_w8(a);
+      case 3: return gqe_launch_fused_1_1_w8(a);
+      case 4: return gqe_launch_fused_2_0_w8(a);
+      default: return gqe_launch_fused_2_1_w8(a);
+    }
+  }
+  switch (key) {
+    case 0: return gqe_launch_fused_0_0_w16(a);
+    case 1: return gqe_launch_fused_0_1_w16(a);
+    case 2: return gqe_launch_fused_1_0_w16(a);
+    case 3: return gqe_launch_fused_1_1_w16(a);
+    case 4: return gqe_launch_fused_2_0_w16(a);
+    default: return gqe_launch_fused_2_1_w16(a);
   }
 }
 

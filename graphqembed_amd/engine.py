@@ -72,8 +72,6 @@ SYMBOLS = OrderedDict([
     ("gqe_workspace_bytes", (C.c_int64, [_P, C.c_int64, C.c_int32])),
     ("gqe_bind_workspace", (C.c_int, [_P, _P, C.c_int64, _P])),
     ("gqe_materialize_grads", (C.c_int, [_P, _P])),
-    ("gqe_set_overlap", (C.c_int, [_P, C.c_int32])),
-    ("gqe_join", (C.c_int, [_P, _P])),
     ("gqe_set_lazy_adam", (C.c_int, [_P, C.c_int32])),
     ("gqe_optimizer_sync", (C.c_int, [_P, _P])),
     ("gqe_set_exchange", (C.c_int, [_P, C.c_int32, C.c_int32])),
@@ -158,7 +156,7 @@ class Engine(object):
     """One gqe_ctx + the tensors it borrows."""
 
     def __init__(self, dim, decoder, inter_decoder, layout, device=None, max_queries=8192, max_batches=16, bags=None,
-                 rank=0, world=1, lazy_adam=False, max_formulas=0, overlap=False):
+                 rank=0, world=1, lazy_adam=False, max_formulas=0):
         """``bags``: {table key: (ptr int32[n+1], ids int32[nnz])} for modes whose feature is an
         nn.EmbeddingBag (mean over table rows) — an index into such a mode is a bag index.
         ``world`` > 1 (and no bags): size the gradient-entry space for the data-parallel exchange
@@ -211,11 +209,6 @@ class Engine(object):
         if lazy_adam:
             self._check(self.lib.gqe_set_lazy_adam(self.ctx, 1))
             self.lazy_adam = True
-        # overlap mode (include/gqe.h, gqe_set_overlap): the pair GEMM of a margin call runs next to the table part of
-        # the following optimiser pass; margin_fwd_bwd() joins before it returns tensors, run_margin() does not
-        self.overlap = bool(overlap)
-        if self.overlap:
-            self._check(self.lib.gqe_set_overlap(self.ctx, 1))
         self.workspace = None
         self.max_queries = self.max_batches = 0
         self.reserve(max_queries, max_batches)
@@ -357,8 +350,6 @@ class Engine(object):
             pp, pn = pos.data_ptr(), neg.data_ptr()
         self._check(self.lib.gqe_margin_fwd_bwd(self.ctx, arr, len(descs), ptr, n_idx, on_dev, losses.data_ptr(),
                                                 pp, pn, self._stream()))
-        if self.overlap:      # the returned tensors are read by the caller: complete them on this stream
-            self.join()
         return losses, pos, neg
 
     # -- pre-packed steps (lowest host overhead: bench / steady-state trainer) ------
@@ -388,11 +379,6 @@ class Engine(object):
         """step <= 0 in the prepared segments: libgqe keeps the per-tensor Adam step counters."""
         self._check(self.lib.gqe_adam_step(self.ctx, pa["arr"], pa["n"], lr, betas[0], betas[1], eps,
                                            stream if stream is not None else self._stream()))
-
-    def join(self):
-        """Overlap mode: order the current stream after the library's side stream (losses / dense gradients of the
-        pending margin call become readable)."""
-        self._check(self.lib.gqe_join(self.ctx, self._stream()))
 
     def materialize(self):
         """Fold pending per-row gradient lists into the dense gradient arena (gqe_materialize_grads)."""

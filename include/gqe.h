@@ -172,19 +172,6 @@ int gqe_margin_fwd_bwd(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches
                        const int32_t* idx, int64_t n_idx, int32_t idx_on_device,
                        float* losses, float* pos_scores, float* neg_scores, void* stream);
 
-/* ---- overlap mode (optional) ----------------------------------------------------------------------------------
- * The reference runs one backward and one optimiser step back to back (train_helpers.py:78-79).  Here the backward
- * leaves two independent pieces of work: the deferred d x d matrix gradients (pair GEMM: relation matrices, Pre / Post)
- * and the optimiser pass over the embedding tables, which needs the row-gradient lists but not the matrix gradients.
- * With gqe_set_overlap(ctx, 1), gqe_margin_fwd_bwd puts the pair GEMM (and the loss finalisation it carries) on a stream
- * of the library, and the following gqe_adam_step / gqe_sgd_step steps the tables on the caller's stream at once and
- * the relation / Pre / Post tensors behind the GEMM on the library's stream; the caller's stream is ordered after both
- * when the step call returns.  Everything is still stream-ordered for the caller EXCEPT: losses[] and the dense
- * gradients of a margin call are complete only after the next optimiser / materialize / export call or gqe_join.
- * Results are identical to the serial schedule. */
-int gqe_set_overlap(gqe_ctx* ctx, int32_t enable);
-int gqe_join(gqe_ctx* ctx, void* stream);   /* order `stream` after the library's side stream */
-
 /* Fold the pending per-row gradient lists of the tables into the dense gradient arena (+=), for callers
  * that need a dense gradient: torch.optim compatibility (param.grad), the data-parallel all-reduce, tests.
  * The next optimiser pass then also reads (and re-zeroes) the dense table gradient. */

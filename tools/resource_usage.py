@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel register / scratch / occupancy table of the gfx950 build (hipcc -Rpass-analysis=kernel-resource-usage).
-    python tools/resource_usage.py [DEC MLP]        # fused variants of one (decoder, MLP) pair (default 0 1) + gqe_kernels.hip
+    python tools/resource_usage.py [DEC MLP] [--all]   # fused variants of one (decoder, MLP) pair (default 0 1) [+ gqe_kernels.hip]
 """
 import os
 import re
@@ -37,7 +37,11 @@ def demangle(name):
 
 def main():
     dec, mlp = (sys.argv[1], sys.argv[2]) if len(sys.argv) > 2 else ("0", "1")
-    rows = report("gqe_fused_inst.hip", ["-DGQE_DEC=" + dec, "-DGQE_MLP=" + mlp]) + report("gqe_kernels.hip", [])
+    rows = []
+    for fw in ("16", "8"):
+        rows += report("gqe_fused_inst.hip", ["-DGQE_DEC=" + dec, "-DGQE_MLP=" + mlp, "-DGQE_FW=" + fw])
+    if "--all" in sys.argv:
+        rows += report("gqe_kernels.hip", [])
     print("%-78s %5s %5s %8s %5s %7s %7s" % ("kernel", "VGPR", "AGPR", "scratch", "occ", "vspill", "sspill"))
     for r in rows:
         nm = re.sub(r"\(.*", "", demangle(r["name"])).replace("void ", "")
