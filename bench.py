@@ -72,12 +72,14 @@ def pmc_traffic(kernel, tag):
     return None
 
 
-def build_layout(g, d, decoder, inter):
+def build_layout(g, d, decoder, inter, shard_world=1):
+    """``shard_world`` > 1: the layout of ONE rank's shards in row-sharded mode (ceil(rows / world) rows per table)."""
     from graphqembed_amd.engine import ArenaLayout
+    from graphqembed_amd.parallel import shard_rows
     from graphqembed_amd.tensorize import post_key, pre_key, rel_key, table_key
     layout = ArenaLayout()
     for m in g.modes:
-        layout.add(table_key(m), (g.table_rows[m], d))            # bio/data_utils.py:14-17, reddit/data_utils_new.py:154-158
+        layout.add(table_key(m), (shard_rows(g.table_rows[m], shard_world), d))   # bio/data_utils.py:14-17, reddit/data_utils_new.py:154-158
     for m in g.relations:                                         # decoders.py:136-140 order
         for (to, name) in g.relations[m]:
             layout.add(rel_key((m, name, to)), (d, d) if decoder == "bilinear" else (d,))
@@ -139,7 +141,6 @@ class Workload(object):
         self.qpi = B * len(mix)
         self.n_distinct = n_distinct
         self.item_sets = [synth.mix_iteration(self.pools, mix, s, B, rank=rank, world=world) for s in range(n_distinct)]
-        self.plans = {}
         from graphqembed_amd.tensorize import table_key
         self.bags = {table_key(m): csr for m, csr in self.g.bags.items()}
 
@@ -148,26 +149,39 @@ class Workload(object):
         n_rel = sum(len(v) for v in g.relations.values())
         return "%d modes, %d nodes, %d directed relations, seed 0" % (len(g.modes), sum(g.mode_sizes.values()), n_rel)
 
-    def engine(self, rank=0, world=1, lazy=False):
+    def engine(self, rank=0, world=1, lazy=False, shard=None):
+        """``shard`` = (rank, world): row-sharded mode — the engine holds this rank's shards of the tables."""
         from graphqembed_amd.engine import Engine
-        eng = Engine(self.d, self.decoder, self.inter, self.layout, max_queries=self.qpi, max_batches=len(self.mix),
-                     rank=rank, world=world, lazy_adam=lazy, bags=self.bags)
-        init_params(eng, self.d, seed=0)                           # same seed on every rank: replicas start equal
+        layout = build_layout(self.g, self.d, self.decoder, self.inter, shard[1]) if shard else self.layout
+        eng = Engine(self.d, self.decoder, self.inter, layout, max_queries=self.qpi, max_batches=len(self.mix),
+                     rank=rank, world=world, lazy_adam=lazy, bags=self.bags, shard=shard)
+        init_params(eng, self.d, seed=0 if not shard else 1000 + shard[0])   # replicas start equal; shards are what they are
+        if shard:                                                  # ... but the replicated relation / Pre / Post tensors start equal
+            import torch
+            gen = torch.Generator(device=eng.device)
+            gen.manual_seed(0)
+            for off, n in eng.dense_spans():
+                eng.params[off:off + n].uniform_(-0.1, 0.1, generator=gen)
         return eng
 
-    def prepare(self, eng):
+    def prepare(self, eng, dist=None):
         import torch
+        from graphqembed_amd import parallel
         from graphqembed_amd.tensorize import FormulaPlan, pack_margin_batches, table_key
         bag_len = {m: np.diff(ptr) for m, (ptr, ids) in self.g.bags.items()}
         prepared = []
+        plans = {}
         for items in self.item_sets:
             packed = []
             for (f, t, ng, a, w, m) in items:
-                if f not in self.plans:
-                    self.plans[f] = FormulaPlan(f, self.layout, self.inter)
-                packed.append((self.plans[f], t, ng, a, w, m))
+                if f not in plans:
+                    plans[f] = FormulaPlan(f, eng.layout, self.inter)
+                packed.append((plans[f], t, ng, a, w, m))
             descs, idx, _ = pack_margin_batches(packed)
-            ps = eng.prepare_margin(descs, torch.from_numpy(idx).to(eng.device))
+            if eng.shard_world > 1:                                # sort the feed by owner, tell the owners (once per pre-sampled iteration)
+                ps = parallel.shard_prepare(eng, dist, descs, idx)
+            else:
+                ps = eng.prepare_margin(descs, torch.from_numpy(idx).to(eng.device))
             ps["adam"] = eng.prepare_adam(set().union(*[p[0].touched for p in packed]))
             # ---- algorithmic bytes / flops of this iteration ----
             d = self.d
@@ -190,9 +204,9 @@ class Workload(object):
                 ff += x
                 gf += y
             keys = ps["adam"]["keys"]
-            p_tab = sum(self.layout.numel(k) for k in keys if k.startswith("enc."))
-            p_den = sum(self.layout.numel(k) for k in keys if not k.startswith("enc."))
-            rows_tab = sum(self.layout.entries[k][1][0] for k in keys if k.startswith("enc."))
+            p_tab = sum(eng.layout.numel(k) for k in keys if k.startswith("enc."))
+            p_den = sum(eng.layout.numel(k) for k in keys if not k.startswith("enc."))
+            rows_tab = sum(eng.layout.entries[k][1][0] for k in keys if k.startswith("enc."))
             ps["n_entries"], ps["aq_bytes"], ps["fused_flops"], ps["gemm_flops"] = direct + bagged, aq, ff, gf
             ps["p_touched"] = p_tab + p_den
             # the fused Adam pass: p, m, v of every table parameter in and out; p, g, m, v in / p, m, v, g := 0 out for the
@@ -309,13 +323,34 @@ def make_step(eng, prepared, dist, exchange, n_distinct, ex_events=None):
                 e0.record()
             if exchange == "sparse":                               # contribution entries all-gathered over xGMI
                 parallel.exchange_sparse(eng, dist)
-            else:                                                  # lists -> dense arena, RCCL sum over xGMI
+            elif exchange == "dense":                              # lists -> dense arena, RCCL sum over xGMI
                 parallel.exchange_gradients(eng.grads, dist, engine=eng)
+            else:                                                  # contributions to the rows' owners, small tensors all-reduced
+                parallel.shard_exchange(eng, dist, ps)
             if rec:
                 e1.record()
                 ex_events.append((e0, e1))
         eng.run_adam(ps["adam"])
-    return step
+
+    def sharded_step(i):                                           # row-sharded: the rows of the batch are fetched first
+        ps = prepared[i % n_distinct]
+        rec = ex_events is not None and (i % 4) == 0
+        if rec:
+            import torch
+            e0, e1, e2, e3 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e0.record()
+        parallel.shard_fetch(eng, dist, ps)
+        if rec:
+            e1.record()
+        eng.run_margin(ps)
+        if rec:
+            e2.record()
+        parallel.shard_exchange(eng, dist, ps)
+        if rec:
+            e3.record()
+            ex_events.append((e0, e1, e2, e3))
+        eng.run_adam(ps["adam"])
+    return sharded_step if exchange == "sharded" and dist is not None else step
 
 
 def measure(wl, args, dist, rank, world, exchange="sparse", lazy=False, steps=None, warmup=None, min_seconds=0.5, check_replicas=False):
@@ -324,8 +359,9 @@ def measure(wl, args, dist, rank, world, exchange="sparse", lazy=False, steps=No
     steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
     sparse = world > 1 and exchange == "sparse"
-    eng = wl.engine(rank=rank if sparse else 0, world=world if sparse else 1, lazy=lazy)
-    prepared = wl.prepare(eng)
+    sharded = world > 1 and exchange == "sharded"
+    eng = wl.engine(rank=rank if sparse else 0, world=world if sparse else 1, lazy=lazy, shard=(rank, world) if sharded else None)
+    prepared = wl.prepare(eng, dist)
     ex_events = [] if dist is not None else None
     step = make_step(eng, prepared, dist, exchange, wl.n_distinct, ex_events)
     loop = Loop(eng, dist, world)
@@ -342,16 +378,23 @@ def measure(wl, args, dist, rank, world, exchange="sparse", lazy=False, steps=No
     out["final_loss"] = round(loss, 6)
     if ex_events:
         torch.cuda.synchronize()
-        ms = [a.elapsed_time(b) for a, b in ex_events[len(ex_events) // 5:]]
-        out["exchange_ms_per_step"] = round(float(np.mean(ms)), 4)
+        ev = ex_events[len(ex_events) // 5:]
+        if sharded:                                                # rows in (before the fused kernel) + contributions out (after it)
+            out["exchange_ms_per_step"] = round(float(np.mean([e[0].elapsed_time(e[1]) + e[2].elapsed_time(e[3]) for e in ev])), 4)
+            out["exchange_parts_ms"] = {"fetch_rows": round(float(np.mean([e[0].elapsed_time(e[1]) for e in ev])), 4),
+                                        "contributions_and_small_tensors": round(float(np.mean([e[2].elapsed_time(e[3]) for e in ev])), 4)}
+        else:
+            out["exchange_ms_per_step"] = round(float(np.mean([a.elapsed_time(b) for a, b in ev])), 4)
     if dist is not None:
         ones = torch.ones(1, device=eng.device)
         dist.all_reduce(ones)
         out["ranks_seen"] = int(ones.item())
         if check_replicas:
-            ref = eng.params.clone()
+            # replicated state must be bit-identical on every rank: everything, or (row-sharded) the relation / Pre / Post tensors
+            mine = torch.cat([eng.params[o:o + n] for o, n in eng.dense_spans()]) if sharded else eng.params
+            ref = mine.clone()
             dist.broadcast(ref, 0)
-            same = torch.tensor([int(torch.equal(ref, eng.params))], device=eng.device)
+            same = torch.tensor([int(torch.equal(ref, mine))], device=eng.device)
             dist.all_reduce(same, op=dist.ReduceOp.MIN)
             out["replicas_identical"] = bool(same.item() == 1)
     return out, eng, prepared
@@ -480,9 +523,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to "
                     "smoke-test the multi-rank path when several ranks share one GPU)")
-    ap.add_argument("--exchange", default="sparse", choices=["sparse", "dense"],
-                    help="--gpus > 1, main measurement: all-gather the gradient contribution entries (sparse) or all-reduce "
-                    "the dense arena; the other form is measured next to it")
+    ap.add_argument("--exchange", default="sharded", choices=["sharded", "sparse", "dense"],
+                    help="--gpus > 1, main measurement: row-sharded tables with owner-computes Adam (sharded: rows and gradient "
+                    "contributions travel by all-to-all, optimiser bytes per rank fall as 1/N), replicated tables with an all-gather of "
+                    "the gradient contribution entries (sparse), or with an all-reduce of the dense arena (dense); the other "
+                    "forms are measured next to it (shorter)")
     ap.add_argument("--lazy-adam", action="store_true", help="run the MAIN measurement in lazy-Adam mode (non-default; the config "
                     "then says so).  Works with --gpus N and the sparse exchange.")
     ap.add_argument("--no-lazy", action="store_true", help="skip the secondary measurement of the lazy (deferred, bit-exact) Adam mode")
@@ -511,11 +556,14 @@ def main():
     rank, world, local_rank, dist = parallel.init_from_env(backend)
 
     reddit = args.workload == "reddit-synth"
+    if reddit and args.exchange == "sharded":
+        args.exchange = "sparse"                                   # EmbeddingBag tables are not sharded (include/gqe.h)
     d = args.dim or (256 if reddit else 128)
     B = args.batch_size
     wl = Workload(args.workload, d, args.decoder, args.inter_decoder, synth.FULL_MIX, B, rank=rank, world=world)
     res, eng, prepared = measure(wl, args, dist, rank, world, exchange=args.exchange, lazy=args.lazy_adam, check_replicas=world > 1)
     sparse = world > 1 and args.exchange == "sparse"
+    sharded = world > 1 and args.exchange == "sharded"
     res["roofline"]["traffic"] = None if (args.lazy_adam or (d, B, args.decoder, args.inter_decoder) != ((256 if reddit else 128), 512, "bilinear-diag", "min")) \
         else pmc_traffic("gqe_opt_kernel", args.workload)
     label = "Reddit" if reddit else "Bio"
@@ -531,6 +579,10 @@ def main():
                    "backend": None if world == 1 else backend,
                    "optimizer": "lazy (deferred, bit-exact) Adam — NON-DEFAULT mode" if args.lazy_adam else "eager dense Adam",
                    "gradient_exchange": "none" if world == 1 else
+                   ("row-sharded tables (rank k owns rows r %% %d == k and their Adam moments): per step one all-to-all of the %d "
+                    "rows the batch reads (%d floats each), one all-to-all of their gradient contributions back to the owners, one "
+                    "all-reduce of the relation/Pre/Post gradients; the fused Adam pass streams 1/%d of the tables per rank"
+                    % (world, prepared[0]["n_entries"], d, world)) if sharded else
                    ("one all-gather per step of per-rank slabs: %d contribution entries x (%d floats + row id) + the dense "
                     "relation/Pre/Post gradients" % (prepared[0]["n_entries"], d)) if sparse else
                    "all-reduce of the %d-float gradient arena" % wl.layout.total},
@@ -539,20 +591,23 @@ def main():
     }
     if backend_note:
         out["config"]["backend_note"] = backend_note
-    for key in ("exchange_ms_per_step", "ranks_seen", "replicas_identical"):
+    for key in ("exchange_ms_per_step", "exchange_parts_ms", "ranks_seen", "replicas_identical"):
         if key in res:
             out[key] = res[key]
     short = dict(steps=max(20, min(args.steps, 100)), warmup=min(args.warmup, 10), min_seconds=0.25)
     if world > 1:
-        # both exchange forms in one line: the other one, shorter
-        other = "dense" if args.exchange == "sparse" else "sparse"
+        # every exchange form in one line: the other ones, shorter
         eng.close()
-        r2, e2, _ = measure(wl, args, dist, rank, world, exchange=other, lazy=False, check_replicas=True, **short)
-        e2.close()
-        out["exchange"] = {args.exchange: {"ms_per_step": res["ms_per_step"], "exchange_ms_per_step": res.get("exchange_ms_per_step"),
-                                           "value": res["value"], "replicas_identical": res.get("replicas_identical")},
-                           other: {"ms_per_step": r2["ms_per_step"], "exchange_ms_per_step": r2.get("exchange_ms_per_step"),
-                                   "value": r2["value"], "replicas_identical": r2.get("replicas_identical")}}
+        forms = {args.exchange: res}
+        for other in ("sharded", "sparse", "dense"):
+            if other == args.exchange or (reddit and other == "sharded"):   # bag tables are not sharded
+                continue
+            r2, e2, _ = measure(wl, args, dist, rank, world, exchange=other, lazy=False, check_replicas=True, **short)
+            e2.close()
+            forms[other] = r2
+        out["exchange"] = {name: {"ms_per_step": r["ms_per_step"], "exchange_ms_per_step": r.get("exchange_ms_per_step"), "value": r["value"],
+                                  "optimiser_ms": r["roofline"]["avg_launch_ms"], "optimiser_bytes_per_launch": r["roofline"]["algorithmic_bytes_per_launch"],
+                                  "replicas_identical": r.get("replicas_identical")} for name, r in forms.items()}
         eng = None
     if world == 1 and not args.no_lazy and not args.lazy_adam:
         rl, el, _ = measure(wl, args, None, 0, 1, lazy=True)
@@ -589,7 +644,8 @@ def main():
             eng.close()
             eng = None
         wr = Workload("reddit-synth", 256, args.decoder, args.inter_decoder, synth.FULL_MIX, B, rank=rank, world=world, n_distinct=16)
-        rr, er, _ = measure(wr, args, dist, rank, world, exchange=args.exchange, check_replicas=world > 1, **short)
+        rr, er, _ = measure(wr, args, dist, rank, world, exchange="sparse" if args.exchange == "sharded" else args.exchange,
+                            check_replicas=world > 1, **short)
         er.close()
         rs = slim(rr)
         rs["config"] = ("BASELINE config 5 workload: reddit-synth (%s; EmbeddingBag post features over a %d-word table, bags U[5,30]), "

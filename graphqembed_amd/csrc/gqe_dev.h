@@ -216,6 +216,7 @@ struct GqeFusedArgs {
   int32_t* link_contrib;  // link node -> contribution entry it stands for
   int32_t* link_counter;  // bump allocator of link nodes
   int32_t max_entries;
+  const float* fetched;   // row-sharded mode: the rows of this call, fetched from their owners (else NULL)
 };
 
 hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a);
@@ -227,6 +228,14 @@ struct GqeSpans {
   int n;  // < 0: more than 8 spans (unsupported)
   long long off[8], len[8], total;
 };
+// row-sharded data parallelism: serve rows of the local shards / link received contributions onto the local lists
+struct GqeShardTabs {
+  int n;
+  long long offset[GQE_LAZY_TABLES], head_base[GQE_LAZY_TABLES];  // local tables in gqe_set_tables order
+};
+hipError_t gqe_launch_shard_serve(const float* params, const int32_t* req, long long n, float* out, int d, const GqeShardTabs& t,
+                                  hipStream_t stream);
+hipError_t gqe_launch_shard_link(int32_t* head, int32_t* next, const int32_t* req, long long n, hipStream_t stream);
 hipError_t gqe_launch_export(float* contrib, const int32_t* rows, const float* grads, int d, long long slab_base, int32_t n,
                              const GqeSpans& sp, hipStream_t stream);
 struct GqeImportBags {  // bag tables on the importing side: CSR + where the word table's list heads start

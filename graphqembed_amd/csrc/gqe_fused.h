@@ -38,6 +38,12 @@ struct TileEnv {
   GqeDynBatch b;  // by value: the plan is a kernel argument, never take its address
   const GqeDevFormula* f;
   const float* params;
+  // Row-sharded data parallelism (gqe_set_shard): the embedding rows of this call were fetched from their owner ranks
+  // into one buffer, in the order of the index feed; an index is then a position in that buffer (whatever its table),
+  // the row's gradient contribution is written to the same position of the send buffer, and nothing is linked here —
+  // the owner links what it receives.
+  const float* rows;  // where rows are gathered from: the parameter arena, or the fetched-row buffer
+  bool sharded;
   float* grads;
   float* ws;  // scratch (floats)
   int32_t* head;
@@ -234,7 +240,7 @@ __device__ __forceinline__ void rows_issue(RowSet<NC>& rs, const TileEnv& e, int
   for (int rr = 0; rr < RPW; ++rr) {
     const int row = s_rows[e.wave * RPW + rr];
     rs.row[rr] = row;
-    rs.x[rr] = vload<NC>(e.params + table + (size_t)(row < 0 ? 0 : row) * e.d, e.d, e.lane);
+    rs.x[rr] = vload<NC>(e.rows + (e.sharded ? 0 : table) + (size_t)(row < 0 ? 0 : row) * e.d, e.d, e.lane);
   }
 }
 
@@ -273,7 +279,7 @@ template <int NC>
 __device__ __forceinline__ Vec<NC> candidate_row(const TileEnv& e, const GqeBagTable& bags, int bag, int64_t table, int row) {
   Vec<NC> x = vzero<NC>();
   if (bag < 0) {
-    x = vload<NC>(e.params + table + (size_t)row * e.d, e.d, e.lane);
+    x = vload<NC>(e.rows + (e.sharded ? 0 : table) + (size_t)row * e.d, e.d, e.lane);
   } else {
     const int32_t* __restrict__ ptr = bags.ptr[bag];
     const int32_t* __restrict__ ids = bags.ids[bag];
@@ -323,7 +329,7 @@ __device__ __forceinline__ void eval_candidates(const TileEnv& e, const GqeBagTa
         const int idv = (e.lane < m) ? cand_rows[ci + e.lane] : 0;
 #pragma unroll
         for (int u = 0; u < GQE_EVAL_U; ++u)
-          if (u < m) x[u] = vload<NC>(e.params + table + (size_t)__builtin_amdgcn_readlane(idv, u) * e.d, e.d, e.lane);
+          if (u < m) x[u] = vload<NC>(e.rows + (e.sharded ? 0 : table) + (size_t)__builtin_amdgcn_readlane(idv, u) * e.d, e.d, e.lane);
       }
 #pragma unroll
       for (int u = 0; u < GQE_EVAL_U; ++u) {
@@ -379,11 +385,11 @@ __device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_
   const float inv = 1.f / nrm;
   Vec<NC> gx;
   VEC_OP(gx, (g.v[c] - xhat.v[c] * pg) * inv);
-  const int64_t entry = e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
+  const int64_t entry = e.sharded ? (int64_t)row : e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
   vstore<NC>(e.contrib + entry * e.d, gx, e.d, e.lane);
   // The returned previous head is only needed for next[entry]; that store is deferred to the end of the
   // kernel (push_links) so that the wave never stalls on the atomic's round trip.
-  if (e.lane == 0) {
+  if (e.lane == 0 && !e.sharded) {
     old_head = __hip_atomic_exchange(e.head + head_base + row, (int)entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     e.next[entry - e.max_entries] = (int)(head_base + row);  // entry -> list head, for the data-parallel exchange
   }
@@ -507,6 +513,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
                                                                 float* __restrict__ contrib, const GqeBagTable bags,
                                                                 int32_t* __restrict__ link_contrib,
                                                                 int32_t* __restrict__ link_counter, int max_entries,
+                                                                const float* __restrict__ fetched,
                                                                 long long* __restrict__ prof) {
   static_assert(FW == GQE_FW, "FW only distinguishes the kernels of the per-GQE_FW translation units");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -525,6 +532,8 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   e.b = b;
   e.f = f;
   e.params = params;
+  e.rows = fetched ? fetched : params;
+  e.sharded = fetched != nullptr;
   e.grads = grads;
   e.ws = ws;
   e.head = head;
@@ -1171,11 +1180,11 @@ static hipError_t launch_fused_v(const GqeFusedArgs& a) {
   if (a.bwd)
     hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true, GQE_FW>), dim3(a.plan.tiles), dim3(GQE_FWT), lds, a.stream, a.plan,
                        a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags, a.link_contrib, a.link_counter,
-                       a.max_entries, a.prof);
+                       a.max_entries, a.fetched, a.prof);
   else
     hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, false, GQE_FW>), dim3(a.plan.tiles), dim3(GQE_FWT), lds, a.stream, a.plan,
                        a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags, a.link_contrib, a.link_counter,
-                       a.max_entries, a.prof);
+                       a.max_entries, a.fetched, a.prof);
   return hipGetLastError();
 }
 

@@ -65,6 +65,8 @@ struct Bag {
 
 struct Layout {  // byte offsets inside the bound workspace
   size_t idx_cap, tloss_off, scratch_off, scratch_cap;  // [staged indices x2 | tile losses | pair scratch]
+  size_t shard_req_send, shard_req_recv, shard_fetch, shard_csend;  // row-sharded mode (0 otherwise)
+  int64_t shard_cap_send, shard_cap_recv;                          // entries
   size_t seg_off, act_off, formula_off, head_off, rows_off, next_off, contrib_off, linkc_off, counter_off, last_off, ring_off, total;
   int64_t max_entries, max_links;  // max_entries = per-rank capacity x world (the exchange gathers every rank's entries)
 };
@@ -99,6 +101,11 @@ struct gqe_ctx {
   bool imported = false;       // the pending lists include every rank's entries (gqe_import_entries ran)
   int64_t imported_n = 0, imported_slab = 0;
   int64_t slab_hint = 0;       // gqe_exchange_reserve: slab size for the next margin call (0 = its own entry count)
+  // row-sharded data parallelism (gqe_set_shard): the registered tables are this rank's shards (local row i = global
+  // row i * world + rank); rows are fetched from / contributions sent to their owners by the host's transport
+  int shard_rank = 0, shard_world = 1;
+  bool shard_sent = false;   // a margin call's contributions sit in the send buffer (not yet linked by their owners)
+  std::vector<int> shard_tables;  // tables that margin call named (every rank runs the same formulas: these receive lists)
   bool dense_dirty = false;  // the dense gradient of some table may be non-zero (after materialize)
   RingSlot ring[kRing];
   int ring_next = 0;
@@ -242,6 +249,15 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
     const GqeSpans sp = dense_spans(ctx);
     L.max_entries = (int64_t)align_up((size_t)slab_entries(ctx, L.max_entries, sp.n < 0 ? 0 : sp.total), 64) * ctx->world;
   }
+  L.shard_cap_send = L.shard_cap_recv = 0;
+  if (ctx->shard_world > 1) {
+    // a rank requests at most one row per index of a call; in the worst case every rank's requests land on one owner.
+    // The contribution entries that owner receives are the ctx's entry space (the lists link into it); it doubles as
+    // the buffer the served rows are gathered into (rows are served before the fused kernel, contributions arrive after)
+    L.shard_cap_send = L.max_entries;
+    L.max_entries *= ctx->shard_world;
+    L.shard_cap_recv = L.max_entries;
+  }
   // entry -> list head it was pushed on (-1: not pushed); sits exactly max_entries ints below next[], so the
   // kernels address it as next[entry - max_entries]
   L.rows_off = L.head_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
@@ -255,6 +271,14 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
   L.last_off = L.counter_off + 256;  // lazy Adam: per-row step counts + per-table coefficient rings
   L.ring_off = L.last_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
   L.total = L.ring_off + align_up(sizeof(float) * 2 * GQE_LAZY_TABLES * GQE_LAZY_RING, 256);
+  L.shard_req_send = L.shard_req_recv = L.shard_fetch = L.shard_csend = 0;
+  if (ctx->shard_world > 1) {
+    L.shard_req_send = L.total;
+    L.shard_req_recv = L.shard_req_send + align_up(sizeof(int32_t) * (size_t)L.shard_cap_send, 256);
+    L.shard_fetch = L.shard_req_recv + align_up(sizeof(int32_t) * (size_t)L.shard_cap_recv, 256);
+    L.shard_csend = L.shard_fetch + align_up(sizeof(float) * (size_t)L.shard_cap_send * ctx->cfg.dim, 256);
+    L.total = L.shard_csend + align_up(sizeof(float) * (size_t)L.shard_cap_send * ctx->cfg.dim, 256);
+  }
   return L;
 }
 
@@ -607,7 +631,16 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     if (slab_entries(ctx, slab, sp.total) * ctx->world > L.max_entries)
       return fail(ctx, GQE_ERR_WORKSPACE, "gradient contribution buffer too small for %d ranks x %lld entries", ctx->world, (long long)slab);
   }
-  if (bwd && ctx->entries_used + entries > L.max_entries)
+  const bool shard = ctx->shard_world > 1;
+  if (shard) {
+    if (!idx_on_device) return fail(ctx, GQE_ERR_ARG, "row-sharded mode: the index feed is the device-resident position feed of gqe_shard_plan");
+    if (!ctx->bags.empty()) return fail(ctx, GQE_ERR_STATE, "row-sharded mode does not support bag (EmbeddingBag) tables");
+    if (ctx->lazy) return fail(ctx, GQE_ERR_STATE, "row-sharded mode and lazy Adam are mutually exclusive");
+    if (n_idx > L.shard_cap_send) return fail(ctx, GQE_ERR_WORKSPACE, "row-sharded mode: %lld indices exceed the fetched-row buffer (%lld rows)", (long long)n_idx, (long long)L.shard_cap_send);
+    for (int bi = 0; bi < n_batches; ++bi)
+      if (batches[bi].n_candidates > 0) return fail(ctx, GQE_ERR_ARG, "row-sharded mode: candidate lists are not supported (expand the candidates)");
+  }
+  if (bwd && !shard && ctx->entries_used + entries > L.max_entries)
     return fail(ctx, GQE_ERR_WORKSPACE, "gradient contribution buffer full (%lld + %lld > %lld entries): step or "
                 "gqe_materialize_grads first", (long long)ctx->entries_used, (long long)entries, (long long)L.max_entries);
 
@@ -705,7 +738,8 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   fa.stream = st;
   fa.head = reinterpret_cast<int32_t*>(ctx->ws + L.head_off);
   fa.next = reinterpret_cast<int32_t*>(ctx->ws + L.next_off);
-  fa.contrib = reinterpret_cast<float*>(ctx->ws + L.contrib_off);
+  fa.contrib = reinterpret_cast<float*>(ctx->ws + (shard ? L.shard_csend : L.contrib_off));
+  fa.fetched = shard ? reinterpret_cast<const float*>(ctx->ws + L.shard_fetch) : nullptr;
   memset(&fa.bags, 0, sizeof fa.bags);
   for (size_t k = 0; k < ctx->bags.size(); ++k) {
     fa.bags.ptr[k] = ctx->bags[k].ptr;
@@ -717,7 +751,13 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   if (bwd && !ctx->bags.empty()) ctx->links_used = true;
 
   // ---- launches of <= GQE_LAUNCH_BATCHES batches; per-call data travels as kernel arguments ----
-  int64_t entry = ctx->entries_used;
+  int64_t entry = shard ? 0 : ctx->entries_used;
+  if (bwd && shard) {
+    if (ctx->shard_sent) return fail(ctx, GQE_ERR_STATE, "row-sharded mode: one gqe_margin_fwd_bwd per optimiser step (send the contributions and gqe_shard_link first)");
+    ctx->shard_sent = true;
+    // contributions of queries whose hinge is inactive are never written: the send buffer must read zero there
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.shard_csend, 0, sizeof(float) * (size_t)n_idx * d, st));
+  }
   if (bwd && ctx->world > 1) {
     // this rank's slab of the gathered entry space; entries that are not pushed (inactive hinge) must read -1
     const int64_t slab = ctx->slab_hint ? ctx->slab_hint : entries;
@@ -814,7 +854,8 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       if (rc != GQE_OK) return rc;
     }
   }
-  if (bwd) {
+  if (bwd && shard) ctx->shard_tables = touched_tables;
+  if (bwd && !shard) {
     ctx->entries_used = ctx->world > 1 ? ctx->step_slab * ctx->world : entry;
     for (int t : touched_tables) ctx->tables[t].pending = true;
   }
@@ -1030,7 +1071,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
   };
   oa.mode = mode;
   oa.lists = lists;
-  oa.sorted = ctx->world > 1;  // replicas must sum a row's contributions in the same order
+  oa.sorted = ctx->world > 1 || ctx->shard_world > 1;  // replicas / reruns must sum a row's contributions in the same order
   // the FLUSH pass only replays deferred steps: it must neither read nor re-zero a materialised dense gradient
   // that is still waiting for its optimiser step
   oa.dense_tables = !flush && (ctx->dense_dirty || mode == GQE_OPT_ZERO);
@@ -1395,6 +1436,7 @@ int gqe_set_exchange(gqe_ctx* ctx, int32_t rank, int32_t world) {
   if (!ctx) return GQE_ERR_ARG;
   if (world < 1 || world > 1024 || rank < 0 || rank >= world) return fail(ctx, GQE_ERR_ARG, "need 0 <= rank < world <= 1024, got rank %d world %d", rank, world);
   if (ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_set_exchange must precede gqe_workspace_bytes / gqe_bind_workspace");
+  if (ctx->shard_world > 1 && world > 1) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard and gqe_set_exchange are mutually exclusive");
   ctx->rank = rank;
   ctx->world = world;
   return GQE_OK;
@@ -1412,6 +1454,120 @@ int gqe_set_limits(gqe_ctx* ctx, int32_t max_tensors, int32_t max_formulas) {
       return fail(ctx, GQE_ERR_ARG, "max_formulas must be in [%d, %d]", GQE_MAX_BATCHES, 1 << 22);
     ctx->cap_formulas = max_formulas;
     drop_formulas(ctx);
+  }
+  return GQE_OK;
+}
+
+int gqe_set_shard(gqe_ctx* ctx, int32_t rank, int32_t world) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (world < 1 || world > 1024 || rank < 0 || rank >= world) return fail(ctx, GQE_ERR_ARG, "need 0 <= rank < world <= 1024, got rank %d world %d", rank, world);
+  if (ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard must precede gqe_workspace_bytes / gqe_bind_workspace");
+  if (ctx->world > 1 && world > 1) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard and gqe_set_exchange are mutually exclusive");
+  if (world > 1 && (int)ctx->tables.size() > GQE_LAZY_TABLES) return fail(ctx, GQE_ERR_ARG, "row-sharded mode supports at most %d tables", GQE_LAZY_TABLES);
+  ctx->shard_rank = rank;
+  ctx->shard_world = world;
+  return GQE_OK;
+}
+
+int gqe_shard_layout(gqe_ctx* ctx, gqe_shard_buffers* out) {
+  if (!ctx || !out) return GQE_ERR_ARG;
+  if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
+  if (ctx->shard_world < 2) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard(world > 1) has not been called");
+  const Layout& L = ctx->lay;
+  out->req_send = (int64_t)L.shard_req_send;
+  out->req_recv = (int64_t)L.shard_req_recv;
+  out->rows_send = (int64_t)L.contrib_off;   // served rows are gathered into the (then idle) contribution entry space
+  out->fetched = (int64_t)L.shard_fetch;
+  out->contrib_send = (int64_t)L.shard_csend;
+  out->contrib_recv = (int64_t)L.contrib_off;
+  out->cap_send = L.shard_cap_send;
+  out->cap_recv = L.shard_cap_recv;
+  return GQE_OK;
+}
+
+int gqe_shard_plan(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx, int32_t with_negatives,
+                   int32_t* positions, int32_t* requests, int64_t* send_counts) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (ctx->shard_world < 2) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard(world > 1) has not been called");
+  if (!batches || n_batches < 1 || n_batches > GQE_MAX_BATCHES || !idx || n_idx < 1 || !positions || !requests || !send_counts)
+    return fail(ctx, GQE_ERR_ARG, "gqe_shard_plan: bad arguments");
+  const int W = ctx->shard_world;
+  // which table every index of the feed names (the layout of gqe_batch's index block)
+  std::vector<int8_t> table_of_idx((size_t)n_idx, -1);
+  for (int bi = 0; bi < n_batches; ++bi) {
+    const gqe_batch& s = batches[bi];
+    const int na = anchors_of(s.qtype);
+    if (na < 0 || s.n_anchors != na || s.n_queries < 1) return fail(ctx, GQE_ERR_ARG, "batch %d: bad query type / anchors / size", bi);
+    if (s.n_candidates != 0) return fail(ctx, GQE_ERR_ARG, "batch %d: candidate lists are not supported in row-sharded mode", bi);
+    const int lead = with_negatives ? 2 : 1;
+    const int64_t B = s.n_queries, o = s.idx_offset;
+    if (o < 0 || o + (lead + na) * B > n_idx) return fail(ctx, GQE_ERR_ARG, "batch %d: index range exceeds the %lld indices given", bi, (long long)n_idx);
+    const int tt = table_of(ctx, s.target_table);
+    if (tt < 0) return fail(ctx, GQE_ERR_STATE, "batch %d: target_table is not a registered table", bi);
+    for (int64_t k = 0; k < lead * B; ++k) table_of_idx[(size_t)(o + k)] = (int8_t)tt;
+    for (int i = 0; i < na; ++i) {
+      const int ta = table_of(ctx, s.anchor_table[i]);
+      if (ta < 0) return fail(ctx, GQE_ERR_STATE, "batch %d: anchor_table[%d] is not a registered table", bi, i);
+      for (int64_t k = 0; k < B; ++k) table_of_idx[(size_t)(o + (lead + i) * B + k)] = (int8_t)ta;
+    }
+  }
+  // counting sort of the feed by owner: request = list-head index of the row in the owner's shard, position = where
+  // the fetched row (and later its gradient contribution) sits in the owner-grouped buffers
+  std::vector<int64_t> count((size_t)W, 0), at((size_t)W, 0);
+  for (int64_t e = 0; e < n_idx; ++e) {
+    if (table_of_idx[(size_t)e] < 0) return fail(ctx, GQE_ERR_ARG, "index %lld of the feed belongs to no batch", (long long)e);
+    if (idx[e] < 0) return fail(ctx, GQE_ERR_ARG, "index %lld of the feed is negative", (long long)e);
+    ++count[(size_t)(idx[e] % W)];
+  }
+  int64_t run = 0;
+  for (int o = 0; o < W; ++o) {
+    at[(size_t)o] = run;
+    run += count[(size_t)o];
+    send_counts[o] = count[(size_t)o];
+  }
+  for (int64_t e = 0; e < n_idx; ++e) {
+    const int64_t r = idx[e];
+    const int o = (int)(r % W);
+    const Table& tb = ctx->tables[(size_t)table_of_idx[(size_t)e]];
+    const int64_t local = r / W;
+    if (local >= tb.rows) return fail(ctx, GQE_ERR_ARG, "index %lld: global row %lld is outside the table (%lld local rows x %d ranks)", (long long)e, (long long)r, (long long)tb.rows, W);
+    const int64_t pos = at[(size_t)o]++;
+    positions[e] = (int32_t)pos;
+    requests[pos] = (int32_t)(tb.head_base + local);
+  }
+  return GQE_OK;
+}
+
+int gqe_shard_serve(gqe_ctx* ctx, const int32_t* requests, int64_t n, float* rows_out, void* stream) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (!ctx->ws || !ctx->params) return fail(ctx, GQE_ERR_STATE, "arena / workspace not bound");
+  if (ctx->shard_world < 2) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard(world > 1) has not been called");
+  if (n < 0 || n > ctx->lay.shard_cap_recv || (n > 0 && (!requests || !rows_out))) return fail(ctx, GQE_ERR_ARG, "gqe_shard_serve: bad arguments");
+  if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "row-sharded mode: received contributions are still pending (step first)");
+  GqeShardTabs t;
+  memset(&t, 0, sizeof t);
+  t.n = (int)ctx->tables.size();
+  for (size_t k = 0; k < ctx->tables.size(); ++k) {
+    t.offset[k] = ctx->tables[k].offset;
+    t.head_base[k] = ctx->tables[k].head_base;
+  }
+  HIP_TRY(ctx, gqe_launch_shard_serve(ctx->params, requests, n, rows_out, ctx->cfg.dim, t, reinterpret_cast<hipStream_t>(stream)));
+  return GQE_OK;
+}
+
+int gqe_shard_link(gqe_ctx* ctx, const int32_t* requests, int64_t n, void* stream) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
+  if (ctx->shard_world < 2) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard(world > 1) has not been called");
+  if (n < 0 || n > ctx->lay.shard_cap_recv || (n > 0 && !requests)) return fail(ctx, GQE_ERR_ARG, "gqe_shard_link: bad arguments");
+  if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "row-sharded mode: the previous step's contributions are still linked (step first)");
+  const Layout& L = ctx->lay;
+  HIP_TRY(ctx, gqe_launch_shard_link(reinterpret_cast<int32_t*>(ctx->ws + L.head_off), reinterpret_cast<int32_t*>(ctx->ws + L.next_off), requests, n,
+                                     reinterpret_cast<hipStream_t>(stream)));
+  ctx->shard_sent = false;
+  if (n > 0) {
+    ctx->entries_used = n;
+    for (int t : ctx->shard_tables) ctx->tables[(size_t)t].pending = true;  // every rank ran the same formulas
   }
   return GQE_OK;
 }

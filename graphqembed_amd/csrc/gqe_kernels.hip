@@ -661,6 +661,52 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_import_kernel(int32_t* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// row-sharded data parallelism ("owner computes", gqe_set_shard).  A request names a row of a local shard by its list
+// head index (head_base of the local table + local row), which is also where its gradient contribution is linked.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GQE_THREADS) void gqe_shard_serve_kernel(const float* __restrict__ p, const int32_t* __restrict__ req,
+                                                                     long long n, float* __restrict__ out, int d, const GqeShardTabs t) {
+  const int tpr = d >> 2;
+  const long long g = (long long)blockIdx.x * GQE_THREADS + threadIdx.x;
+  const long long j = g / tpr;
+  if (j >= n) return;
+  const int c4 = (int)(g - j * tpr) * 4;
+  const int h = req[j];
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (h >= 0) {
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < GQE_LAZY_TABLES; ++i) k += (i < t.n && h >= t.head_base[i]) ? 1 : 0;
+    v = *reinterpret_cast<const float4*>(p + t.offset[k] + (long long)(h - t.head_base[k]) * d + c4);
+  }
+  *reinterpret_cast<float4*>(out + j * d + c4) = v;
+}
+
+__global__ __launch_bounds__(GQE_THREADS) void gqe_shard_link_kernel(int32_t* __restrict__ head, int32_t* __restrict__ next,
+                                                                    const int32_t* __restrict__ req, long long n) {
+  const long long j = (long long)blockIdx.x * GQE_THREADS + threadIdx.x;
+  if (j >= n) return;
+  const int h = req[j];
+  if (h >= 0) next[j] = __hip_atomic_exchange(head + h, (int)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+hipError_t gqe_launch_shard_serve(const float* params, const int32_t* req, long long n, float* out, int d, const GqeShardTabs& t,
+                                  hipStream_t stream) {
+  if (n < 1) return hipSuccess;
+  const long long threads = n * (d >> 2);
+  hipLaunchKernelGGL(gqe_shard_serve_kernel, dim3((unsigned)((threads + GQE_THREADS - 1) / GQE_THREADS)), dim3(GQE_THREADS), 0, stream,
+                     params, req, n, out, d, t);
+  return hipGetLastError();
+}
+
+hipError_t gqe_launch_shard_link(int32_t* head, int32_t* next, const int32_t* req, long long n, hipStream_t stream) {
+  if (n < 1) return hipSuccess;
+  hipLaunchKernelGGL(gqe_shard_link_kernel, dim3((unsigned)((n + GQE_THREADS - 1) / GQE_THREADS)), dim3(GQE_THREADS), 0, stream, head,
+                     next, req, n);
+  return hipGetLastError();
+}
+
 hipError_t gqe_launch_export(float* contrib, const int32_t* rows, const float* grads, int d, long long slab_base, int32_t n,
                              const GqeSpans& sp, hipStream_t stream) {
   const long long total = (long long)n + sp.total;

@@ -54,6 +54,11 @@ class gqe_batch(C.Structure):
                 ("out_offset", C.c_int32), ("n_candidates", C.c_int32)]
 
 
+class gqe_shard_buffers(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("req_send", "req_recv", "rows_send", "fetched", "contrib_send", "contrib_recv",
+                                         "cap_send", "cap_recv")]
+
+
 class gqe_segment(C.Structure):
     _fields_ = [("offset", C.c_int64), ("numel", C.c_int64), ("step", C.c_int32), ("reserved", C.c_int32)]
 
@@ -78,6 +83,11 @@ SYMBOLS = OrderedDict([
     ("gqe_exchange_reserve", (C.c_int, [_P, C.c_int64])),
     ("gqe_export_entries", (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P])),
     ("gqe_import_entries", (C.c_int, [_P, C.c_int64, _P])),
+    ("gqe_set_shard", (C.c_int, [_P, C.c_int32, C.c_int32])),
+    ("gqe_shard_layout", (C.c_int, [_P, C.POINTER(gqe_shard_buffers)])),
+    ("gqe_shard_plan", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P, _P])),
+    ("gqe_shard_serve", (C.c_int, [_P, _P, C.c_int64, _P, _P])),
+    ("gqe_shard_link", (C.c_int, [_P, _P, C.c_int64, _P])),
     ("gqe_forward", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P])),
     ("gqe_margin_fwd_bwd", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P, _P, _P])),
     ("gqe_adam_step", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P])),
@@ -156,13 +166,16 @@ class Engine(object):
     """One gqe_ctx + the tensors it borrows."""
 
     def __init__(self, dim, decoder, inter_decoder, layout, device=None, max_queries=8192, max_batches=16, bags=None,
-                 rank=0, world=1, lazy_adam=False, max_formulas=0):
+                 rank=0, world=1, lazy_adam=False, max_formulas=0, shard=None):
         """``bags``: {table key: (ptr int32[n+1], ids int32[nnz])} for modes whose feature is an
         nn.EmbeddingBag (mean over table rows) — an index into such a mode is a bag index.
         ``world`` > 1 (and no bags): size the gradient-entry space for the data-parallel exchange
         (include/gqe.h, gqe_set_exchange) and make the optimiser sum lists in a replica-independent order.
         ``lazy_adam``: deferred bit-exact Adam (include/gqe.h, gqe_set_lazy_adam); ``params`` / ``exp_avg`` /
-        ``exp_avg_sq`` then synchronise on access."""
+        ``exp_avg_sq`` then synchronise on access.
+        ``shard`` = (rank, world): row-sharded data parallelism (include/gqe.h, gqe_set_shard): ``layout`` describes this
+        rank's SHARDS (tables with ceil(rows / world) rows: local row i = global row i * world + rank); index feeds name
+        global rows and go through ``shard_plan`` (graphqembed_amd/parallel.py drives the protocol)."""
         import torch
         if not torch.cuda.is_available():
             raise GqeLibraryError("no HIP device visible to torch; the query path only runs on an MI355X "
@@ -206,6 +219,10 @@ class Engine(object):
         self.sparse_exchange = self.world > 1
         if self.sparse_exchange:
             self._check(self.lib.gqe_set_exchange(self.ctx, self.rank, self.world))
+        self.shard_rank, self.shard_world = (int(shard[0]), int(shard[1])) if shard else (0, 1)
+        if self.shard_world > 1:
+            self._check(self.lib.gqe_set_shard(self.ctx, self.shard_rank, self.shard_world))
+        self._shard_views = None
         if lazy_adam:
             self._check(self.lib.gqe_set_lazy_adam(self.ctx, 1))
             self.lazy_adam = True
@@ -257,6 +274,63 @@ class Engine(object):
         self.workspace = self.torch.empty(int(nbytes) + 256, dtype=self.torch.uint8, device=self.device)
         ptr = _align(self.workspace.data_ptr(), 256)
         self._check(self.lib.gqe_bind_workspace(self.ctx, ptr, int(nbytes), self._stream()))
+        self._shard_views = None
+
+    # -- row-sharded data parallelism (gqe_set_shard) ---------------------------------------------
+    def shard_views(self):
+        """The transport buffers of the row-sharded protocol as views of the workspace (include/gqe.h,
+        gqe_shard_buffers): int32 requests sent / received, served rows, fetched rows, contributions sent / received."""
+        if self._shard_views is None:
+            b = gqe_shard_buffers()
+            self._check(self.lib.gqe_shard_layout(self.ctx, C.byref(b)))
+            base = _align(self.workspace.data_ptr(), 256) - self.workspace.data_ptr()
+            t, d = self.torch, self.dim
+
+            def view(off, n, dtype, cols):
+                raw = self.workspace[base + off: base + off + 4 * n * cols].view(dtype)
+                return raw if cols == 1 else raw.view(n, cols)
+            self._shard_views = {
+                "req_send": view(b.req_send, b.cap_send, t.int32, 1), "req_recv": view(b.req_recv, b.cap_recv, t.int32, 1),
+                "rows_send": view(b.rows_send, b.cap_recv, t.float32, d), "fetched": view(b.fetched, b.cap_send, t.float32, d),
+                "contrib_send": view(b.contrib_send, b.cap_send, t.float32, d),
+                "contrib_recv": view(b.contrib_recv, b.cap_recv, t.float32, d),
+                "cap_send": int(b.cap_send), "cap_recv": int(b.cap_recv)}
+        return self._shard_views
+
+    def shard_plan(self, descs, idx, with_negatives=True):
+        """Sort a step's index feed (numpy int32, GLOBAL rows) by owner: returns (positions[n] — the feed for the
+        kernels, requests[n] grouped by owner, send_counts[world])."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        total = sum(dsc["n"] for dsc in descs)
+        self.reserve(total, len(descs))
+        arr = self.make_batches(descs)
+        pos = np.empty(idx.size, dtype=np.int32)
+        req = np.empty(idx.size, dtype=np.int32)
+        counts = np.zeros(self.shard_world, dtype=np.int64)
+        self._check(self.lib.gqe_shard_plan(self.ctx, arr, len(descs), C.c_void_p(idx.ctypes.data), int(idx.size),
+                                            1 if with_negatives else 0, C.c_void_p(pos.ctypes.data), C.c_void_p(req.ctypes.data),
+                                            C.c_void_p(counts.ctypes.data)))
+        return pos, req, counts
+
+    def shard_serve(self, requests, n, rows_out):
+        self._check(self.lib.gqe_shard_serve(self.ctx, C.c_void_p(requests.data_ptr()), int(n), C.c_void_p(rows_out.data_ptr()), self._stream()))
+
+    def shard_link(self, requests, n):
+        self._check(self.lib.gqe_shard_link(self.ctx, C.c_void_p(requests.data_ptr()), int(n), self._stream()))
+
+    def dense_spans(self):
+        """(offset, length) runs of the arena that are NOT embedding tables (relation vectors / matrices, Pre / Post):
+        what replicas all-reduce in row-sharded mode."""
+        spans = []
+        for k, (off, shape) in self.layout.entries.items():
+            if k.startswith("enc.") and len(shape) == 2 and shape[1] == self.dim:
+                continue
+            n = _align(int(np.prod(shape)), self.layout.ALIGN)
+            if spans and spans[-1][0] + spans[-1][1] == off:
+                spans[-1] = (spans[-1][0], spans[-1][1] + n)
+            else:
+                spans.append((off, n))
+        return [(o, min(n, self.layout.total - o)) for o, n in spans]
 
     # -- data-parallel exchange (gqe_set_exchange) ---------------------------------------------
     def exchange_reserve(self, slab_entries):

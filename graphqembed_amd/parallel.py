@@ -17,6 +17,13 @@ Two exchange forms (both leave bit-identical replicas):
            parts summed in rank order (gqe_import_entries).  At the Bio d=128 full mix a slab is
            ~10 MB per rank instead of the 50 MB arena.
 
+  sharded: "owner computes" (include/gqe.h, gqe_set_shard): the tables are NOT replicated — rank k owns the rows
+           r % W == k of every table together with their Adam moments.  Per step a rank fetches the rows its batch
+           reads from their owners (all-to-all), sends each row's gradient contribution back to its owner
+           (all-to-all), all-reduces the small relation / Pre / Post gradients, and runs the fused Adam pass over its
+           own shards only.  Optimiser bytes per rank fall as 1/W and the inbound traffic is two batches' worth of
+           rows, independent of W.
+
 The collectives are ``torch.distributed`` ones — backend "nccl" is RCCL over xGMI on ROCm,
 "gloo" in the CPU tests.
 """
@@ -82,3 +89,115 @@ def exchange_gradients(flat_grads, dist, engine=None):
     if dist is not None:
         dist.all_reduce(flat_grads)
     return flat_grads
+
+
+# ---- row-sharded data parallelism ("owner computes") ---------------------------------------------------------
+def shard_rows(n_rows, world):
+    """Local rows of a table of ``n_rows`` global rows: the same on every rank (the last ranks' tails are padding)."""
+    return -(-int(n_rows) // int(world))
+
+
+def shard_of(full, rank, world):
+    """Rows rank, rank + world, ... of a [rows, d] array / tensor, zero-padded to shard_rows(rows, world) rows."""
+    part = full[rank::world]
+    need = shard_rows(full.shape[0], world) - part.shape[0]
+    if need == 0:
+        return part
+    if hasattr(part, "new_zeros"):
+        import torch
+        return torch.cat([part, part.new_zeros((need,) + tuple(part.shape[1:]))])
+    import numpy as np
+    return np.concatenate([part, np.zeros((need,) + part.shape[1:], dtype=part.dtype)])
+
+
+def shard_plan_numpy(idx, table_of_idx, head_base, world):
+    """What gqe_shard_plan computes, in numpy (host logic of the row-sharded protocol; CPU tests, cross-check of the
+    library): idx[n] global rows, table_of_idx[n] the table each index names, head_base[t] the first list-head index of
+    local table t.  Returns (positions[n], requests[n] grouped by owner, send_counts[world]): a stable counting sort of
+    the feed by owner = row % world; a request is head_base[table] + row // world."""
+    import numpy as np
+    idx = np.asarray(idx, dtype=np.int64)
+    owner = idx % world
+    order = np.argsort(owner, kind="stable")
+    positions = np.empty(len(idx), dtype=np.int32)
+    positions[order] = np.arange(len(idx), dtype=np.int32)
+    req = (np.asarray(head_base, dtype=np.int64)[np.asarray(table_of_idx)] + idx // world)[order].astype(np.int32)
+    return positions, req, np.bincount(owner, minlength=world).astype(np.int64)
+
+
+def _all_to_all(dist, out, inp, out_splits, in_splits):
+    """all_to_all_single along dim 0; gloo moves host memory only, so device tensors are staged (test boxes where
+    several ranks share one GPU — RCCL takes the device buffers directly)."""
+    if inp.is_cuda and dist.get_backend() == "gloo":
+        o = out.cpu()
+        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits)
+
+
+def shard_prepare(engine, dist, descs, idx, with_negatives=True):
+    """Plan one call in row-sharded mode: sort its index feed (numpy int32, GLOBAL rows) by owner, tell every owner
+    which of its rows this rank will request (one all-to-all of counts, one of row ids) and freeze the launch
+    descriptors.  The result is reusable for as long as the batch is (bench.py replays pre-sampled iterations; a trainer
+    prepares the next iteration while the current one runs)."""
+    import torch
+    pos, req, send = engine.shard_plan(descs, idx, with_negatives)
+    dev = engine.device
+    send_counts = [int(c) for c in send]
+    cs = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+    cr = torch.empty_like(cs)
+    _all_to_all(dist, cr, cs, None, None)
+    recv_counts = [int(c) for c in cr.tolist()]
+    n_send, n_recv = int(sum(send_counts)), int(sum(recv_counts))
+    v = engine.shard_views()
+    if n_recv > v["cap_recv"]:
+        raise RuntimeError("row-sharded mode: %d rows requested from rank %d exceed its receive capacity %d"
+                           % (n_recv, engine.shard_rank, v["cap_recv"]))
+    req_send = torch.from_numpy(req).to(dev)
+    req_recv = torch.empty(n_recv, dtype=torch.int32, device=dev)
+    _all_to_all(dist, req_recv, req_send, recv_counts, send_counts)
+    total = sum(dsc["n"] for dsc in descs)
+    pos_dev = torch.from_numpy(pos).to(dev)
+    ps = {"arr": engine.make_batches(descs), "n": len(descs), "idx": pos_dev, "idx_ptr": __import__("ctypes").c_void_p(pos_dev.data_ptr()),
+          "n_idx": int(pos_dev.numel()), "queries": total,
+          "losses": torch.zeros(len(descs) + 1, dtype=torch.float32, device=dev),
+          "send_counts": send_counts, "recv_counts": recv_counts, "n_send": n_send, "n_recv": n_recv, "req_recv": req_recv}
+    return ps
+
+
+def shard_fetch(engine, dist, ps):
+    """Serve the rows the other ranks asked this one for, and receive the rows this rank's batch reads."""
+    v = engine.shard_views()
+    engine.shard_serve(ps["req_recv"], ps["n_recv"], v["rows_send"])
+    _all_to_all(dist, v["fetched"][:ps["n_send"]], v["rows_send"][:ps["n_recv"]], ps["send_counts"], ps["recv_counts"])
+
+
+def shard_exchange(engine, dist, ps):
+    """After the margin launch: every row's gradient contribution goes to the row's owner, which links it onto its
+    lists; the relation / Pre / Post gradients (replicated tensors) are summed over the ranks."""
+    v = engine.shard_views()
+    _all_to_all(dist, v["contrib_recv"][:ps["n_recv"]], v["contrib_send"][:ps["n_send"]], ps["recv_counts"], ps["send_counts"])
+    engine.shard_link(ps["req_recv"], ps["n_recv"])
+    for off, n in engine.dense_spans():
+        dist.all_reduce(engine.grads[off:off + n])
+
+
+def shard_margin_step(engine, dist, ps, adam=None, lr=0.01, betas=(0.9, 0.999), eps=1e-8):
+    """One training iteration in row-sharded mode on a prepared batch: fetch rows, fused forward / backward on the
+    fetched rows, route the contributions to their owners, step the own shards."""
+    shard_fetch(engine, dist, ps)
+    engine.run_margin(ps)
+    shard_exchange(engine, dist, ps)
+    if adam is not None:
+        engine.run_adam(adam, lr, betas, eps)
+    return ps["losses"]
+
+
+def shard_forward(engine, dist, ps, n_scores, out=None):
+    """gqe_forward in row-sharded mode (``ps`` from shard_prepare(..., with_negatives=False))."""
+    import torch
+    shard_fetch(engine, dist, ps)
+    scores = out if out is not None else torch.empty(n_scores, dtype=torch.float32, device=engine.device)
+    engine._check(engine.lib.gqe_forward(engine.ctx, ps["arr"], ps["n"], ps["idx_ptr"], ps["n_idx"], 1, scores.data_ptr(), engine._stream()))
+    return scores

@@ -218,6 +218,47 @@ int gqe_exchange_reserve(gqe_ctx* ctx, int64_t n_contributions);
 int gqe_export_entries(gqe_ctx* ctx, int64_t* slab_entries, int64_t* contrib_offset, void* stream);
 int gqe_import_entries(gqe_ctx* ctx, int64_t slab_entries, void* stream);
 
+/* ---- row-sharded data parallelism: "owner computes" (sharded optimiser; the reference is single-process)
+ * Instead of replicating the tables, each of `world` ranks OWNS the rows r with r % world == rank of every embedding
+ * table (local row r / world) together with their Adam moments, and keeps a replica of the small relation / Pre / Post
+ * tensors only.  An iteration on a rank:
+ *
+ *   gqe_shard_plan(...)        host only: sort the step's index feed by owner -> the rows to REQUEST from each owner
+ *                              (list-head indices in the owner's shard), and the POSITION feed that replaces the index
+ *                              feed (where each fetched row will sit)
+ *   [all-to-all: requests]     requests of all ranks for my rows -> workspace + req_recv
+ *   gqe_shard_serve(...)       gather the requested rows of my shards                   -> workspace + rows_send
+ *   [all-to-all: rows]         -> workspace + fetched, grouped by owner in request order = the position feed's order
+ *   gqe_margin_fwd_bwd(idx = position feed, device)   rows are read from `fetched`; the gradient contribution of the
+ *                              row at position p is written to workspace + contrib_send at p; nothing is linked here
+ *   [all-to-all: contributions]  -> the owners' workspace + contrib_recv, in the order of the requests they received
+ *   gqe_shard_link(...)        link the received contributions onto my rows' gradient lists
+ *   [all-reduce of the relation / Pre / Post gradients: the non-table spans of the gradient arena]
+ *   gqe_adam_step(local segments)   the ordinary fused pass over MY shards (24 B per OWNED parameter) + the small tensors
+ *
+ * Per rank and step the optimiser streams 1/world of the tables and the inbound traffic is (rows + contributions of one
+ * rank's batch) instead of growing with world as the all-gather of gqe_set_exchange does.  Lists are summed
+ * order-independently (integer accumulation), so a run is bit-reproducible and equals the single-rank step on the
+ * concatenated batch up to fp32 summation order.  The transport is the caller's (torch.distributed all_to_all_single over
+ * RCCL in graphqembed_amd/parallel.py); the library only names the buffers.  Bag (EmbeddingBag) tables, candidate
+ * lists and lazy Adam are not available in this mode; tables must be registered with their LOCAL row counts,
+ * ceil(global rows / world), the same on every rank. */
+typedef struct {
+  int64_t req_send, req_recv;         /* byte offsets in the workspace: int32 requests I send / receive            */
+  int64_t rows_send, fetched;         /* float rows I serve / rows I fetched (dim floats each)                      */
+  int64_t contrib_send, contrib_recv; /* float contributions of my batch / contributions for my rows               */
+  int64_t cap_send, cap_recv;         /* capacities in entries (rows): one rank's feed / what one owner can receive */
+} gqe_shard_buffers;
+int gqe_set_shard(gqe_ctx* ctx, int32_t rank, int32_t world);   /* before gqe_workspace_bytes */
+int gqe_shard_layout(gqe_ctx* ctx, gqe_shard_buffers* out);     /* after gqe_bind_workspace */
+/* idx: HOST index feed of GLOBAL table rows laid out as gqe_batch describes (with_negatives: margin layout).  Outputs
+ * (host): positions[n_idx] — the feed to hand to gqe_margin_fwd_bwd / gqe_forward (device copy); requests[n_idx] — grouped
+ * by owner, send_counts[world] of them per owner. */
+int gqe_shard_plan(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx, int32_t with_negatives,
+                   int32_t* positions, int32_t* requests, int64_t* send_counts);
+int gqe_shard_serve(gqe_ctx* ctx, const int32_t* requests, int64_t n, float* rows_out, void* stream);   /* device pointers */
+int gqe_shard_link(gqe_ctx* ctx, const int32_t* requests, int64_t n, void* stream);
+
 /* replaces: optimizer.step() + optimizer.zero_grad() for torch.optim.Adam
  * (bio/train.py:62, train_helpers.py:50,79): one fused pass p,g,m,v -> p,m,v and g := 0
  * over the listed segments only. */

@@ -31,9 +31,12 @@ def test_bench_two_ranks_self_launch():
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2
     assert out["replicas_identical"] is True
     assert out["config"]["queries_per_step_per_gpu"] == 4608 and out["value"] > 0
-    assert set(out["exchange"]) == {"sparse", "dense"}
+    assert set(out["exchange"]) == {"sharded", "sparse", "dense"}
     for form in out["exchange"].values():
         assert form["replicas_identical"] is True and form["exchange_ms_per_step"] > 0
+    # row-sharded tables: the optimiser pass of a rank covers half of the table bytes of the replicated forms
+    assert out["exchange"]["sharded"]["optimiser_bytes_per_launch"] < 0.6 * out["exchange"]["dense"]["optimiser_bytes_per_launch"]
+    assert "row-sharded" in out["config"]["gradient_exchange"]
     assert out["reddit_synth"]["ranks_seen"] == 2 and out["reddit_synth"]["replicas_identical"] is True
     assert out["scaling"] == "weak" and out["cpu_baseline"] is None
 

@@ -1,0 +1,179 @@
+"""-m gpu: row-sharded data parallelism ("owner computes", include/gqe.h gqe_set_shard) on 2 gloo ranks sharing cuda:0.
+
+  * gqe_shard_plan == the numpy statement of the plan; fetched rows are the rows the index feed names;
+  * the gradients that arrive at the owners (lists folded into the local dense gradient) + the all-reduced relation / Pre /
+    Post gradients == the single-rank oracle gradient of the CONCATENATED batch, shard by shard;
+  * after the fused Adam pass over the own shards, the shards equal the rows of a single-rank engine stepped on the
+    concatenated batch (up to the summation-order noise Adam amplifies), and two identical sharded runs agree BIT FOR BIT;
+  * forward scores on fetched rows equal the single-rank engine's;
+  * state machine: a second margin call before the contributions were linked is refused.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out_dir, dec, inter, d):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from graphqembed_amd import parallel
+    from graphqembed_amd.engine import ArenaLayout, Engine, GqeError
+    from graphqembed_amd.tensorize import pack_forward_batches, pack_margin_batches
+    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, read_arena, toy_batch
+    from oracle import netquery_numpy as O
+    r, w, _, dist = parallel.init_from_env("gloo")
+    rng = np.random.RandomState(21)
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
+    tables = [k for k in params if k.startswith("enc.")]
+
+    def sharded_engine():
+        layout = ArenaLayout()
+        for k, v in params.items():
+            layout.add(k, (parallel.shard_rows(v.shape[0], w), d) if k in tables else v.shape)
+        eng = Engine(d, dec, inter, layout, shard=(r, w), max_queries=1024, max_batches=8)
+        for k, v in params.items():
+            src = parallel.shard_of(v, r, w) if k in tables else v
+            layout.view(eng.params, k).copy_(torch.from_numpy(np.ascontiguousarray(src)))
+        return eng
+
+    def gather_full(eng):
+        """The whole model a sharded engine's ranks hold together (tables re-interleaved), as numpy arrays."""
+        out = {}
+        for k in params:
+            mine = eng.layout.view(eng.params, k).cpu()
+            if k in tables:
+                parts = [torch.zeros_like(mine) for _ in range(w)]
+                dist.all_gather(parts, mine)
+                full_t = torch.zeros(params[k].shape[0], d)
+                for rr in range(w):
+                    full_t[rr::w] = parts[rr][:len(full_t[rr::w])]
+                out[k] = full_t.numpy()
+            else:
+                out[k] = mine.numpy().copy()
+        return out
+
+    single = engine_from_params(params, d, dec, inter)                 # the reference: one rank, the concatenated batch
+    runs = [sharded_engine(), sharded_engine()]                        # two identical sharded runs (bit-reproducibility)
+    mix = [("1-chain", 1.0), ("2-chain", 0.3), ("2-inter", 0.5), ("3-inter", 0.5), ("3-inter_chain", 0.5), ("3-chain_inter", 0.2)]
+    n_pool, B = 400, 64
+    ref_params = {k: v.astype(np.float64) for k, v in params.items()}
+    for step in range(3):
+        items, cat_items = [], []
+        full = O.zero_grads_like(params)
+        cur = gather_full(runs[0])                                     # what the sharded ranks hold together right now
+        want_loss = 0.0
+        for qtype, wgt in mix:
+            t, g, a = toy_batch(rng, qtype, n_pool, hub=(qtype == "2-inter" and step == 0))   # hub rows: long lists at one owner
+            s, e = parallel.rank_slice(n_pool, B, step + 5, r, w)      # step 6 wraps around the pool: unequal slices
+            cat = np.concatenate([np.arange(*parallel.rank_slice(n_pool, B, step + 5, rr, w)) for rr in range(w)])
+            items.append((qtype, t[s:e], g[s:e], a[:, s:e], wgt * (e - s) / float(len(cat))))
+            cat_items.append((qtype, t[cat], g[cat], a[:, cat], wgt))
+            l, _, _, _ = O.margin_fwd_bwd(cur, O.make_plan(qtype, TOY_FORMULAS[qtype]), dec, inter, t[cat], g[cat], a[:, cat], weight=wgt, grads=full)
+            want_loss += wgt * l
+        # ---- the reference engine on the concatenated batch ----
+        packed = [(plan_for(single, q, TOY_FORMULAS[q]), t, g, a, wgt, 1.0) for (q, t, g, a, wgt) in cat_items]
+        descs, idx, n_sc = pack_margin_batches(packed)
+        ref_losses, _, _ = single.margin_fwd_bwd(descs, idx, n_sc)
+        keys = set().union(*[p[0].touched for p in packed])
+        # ---- the sharded engines ----
+        shard_losses = []
+        for eng in runs:
+            packed = [(plan_for(eng, q, TOY_FORMULAS[q]), t, g, a, wgt, 1.0) for (q, t, g, a, wgt) in items]
+            descs, idx, _ = pack_margin_batches(packed)
+            ps = parallel.shard_prepare(eng, dist, descs, idx)
+            if eng is runs[0]:                                         # the library's plan == the numpy statement of it
+                pos, req, cnt = eng.shard_plan(descs, idx)
+                hb, tid, run = {}, [], 0
+                for k in eng.layout.entries:
+                    if k in tables:
+                        hb[eng.layout.offset(k)] = (len(hb), run)
+                        run += eng.layout.entries[k][1][0]
+                for dsc in descs:
+                    tid += [hb[dsc["target_table"]][0]] * (2 * dsc["n"])
+                    for at in dsc["anchor_table"]:
+                        tid += [hb[at][0]] * dsc["n"]
+                base = [v[1] for v in sorted(hb.values())]
+                p2, r2, c2 = parallel.shard_plan_numpy(idx, tid, base, w)
+                assert np.array_equal(pos, p2) and np.array_equal(req, r2) and np.array_equal(cnt, c2)
+            parallel.shard_fetch(eng, dist, ps)
+            if eng is runs[0]:                                         # fetched rows = the rows the feed names
+                torch.cuda.synchronize()
+                fetched = eng.shard_views()["fetched"][:ps["n_send"]].cpu().numpy()
+                off = 0
+                cur32 = cur
+                for (q, t, g, a, wgt), dsc in zip(items, descs):
+                    plan = O.make_plan(q, TOY_FORMULAS[q])
+                    segs = [(plan["target_mode"], t), (plan["target_mode"], g)] + [(m, a[i]) for i, m in enumerate(plan["anchor_modes"])]
+                    for mode, rows in segs:
+                        want = cur32[O.table_key(mode)][rows]
+                        got = fetched[ps["idx"][off:off + len(rows)].cpu().numpy()]
+                        assert np.array_equal(got, want), (step, q, mode)
+                        off += len(rows)
+            eng.run_margin(ps)
+            with pytest.raises(GqeError):                              # one margin call per step in this mode
+                eng.run_margin(ps)
+            parallel.shard_exchange(eng, dist, ps)
+            shard_losses.append(ps["losses"].clone())
+            if eng is runs[0]:                                         # gradients at the owners == the oracle's, shard by shard
+                got = read_arena(eng, eng.grads)                       # (folds the lists into the local dense gradient)
+                for k in params:
+                    want = parallel.shard_of(full[k], r, w) if k in tables else full[k]
+                    scale = max(1e-6, float(np.abs(full[k]).max()))
+                    np.testing.assert_allclose(got[k], want, rtol=0, atol=2e-4 * scale, err_msg="step %d %s" % (step, k))
+            eng.adam_step(keys, 0.01)
+        single.adam_step(keys, 0.01)
+        torch.cuda.synchronize()
+        # per-rank mean losses recombine to the concatenated batch's: sum_r (n_r / n) * mean_r (the weights carry n_r / n)
+        tot = shard_losses[0][-1:].clone().cpu()
+        dist.all_reduce(tot)
+        np.testing.assert_allclose(float(tot.item()), want_loss, rtol=2e-4)
+        if step == 0:                                                  # identical parameters so far: the reference engine agrees too
+            np.testing.assert_allclose(float(tot.item()), float(ref_losses[-1].item()), rtol=2e-4)
+        assert torch.equal(shard_losses[0], shard_losses[1])
+    # ---- the shards after three steps ----
+    a0, a1 = read_arena(runs[0], runs[0].params), read_arena(runs[1], runs[1].params)
+    want = read_arena(single, single.params)
+    for name in ("params", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(getattr(runs[0], name), getattr(runs[1], name)), "two identical sharded runs differ in " + name
+    worst, frac = 0.0, 0.0
+    for k in params:
+        w_k = parallel.shard_of(want[k], r, w) if k in tables else want[k]
+        diff = np.abs(a0[k] - w_k)
+        worst = max(worst, float(diff.max()))
+        frac = max(frac, float((diff > 1e-4).mean()))
+    # Adam turns summation-order noise of near-zero gradients into lr-sized steps (tests/test_oracle_golden.py::
+    # test_adam_three_steps): everything else agrees to fp32 rounding
+    assert worst < 0.04 and frac < 0.02, (worst, frac)
+    # ---- forward on fetched rows == the single-rank forward (same kernel, same row values) ----
+    sync = {k: torch.from_numpy(v) for k, v in gather_full(runs[0]).items()}
+    for k, v in sync.items():
+        single.layout.view(single.params, k).copy_(v)
+    for qtype in ("2-chain", "3-inter", "3-chain_inter"):
+        t, g, a = toy_batch(rng, qtype, 40 + 7 * r)
+        descs, idx, n = pack_forward_batches([(plan_for(runs[0], qtype, TOY_FORMULAS[qtype]), t, a)])
+        ps = parallel.shard_prepare(runs[0], dist, descs, idx, with_negatives=False)
+        got = parallel.shard_forward(runs[0], dist, ps, n)
+        descs, idx, n = pack_forward_batches([(plan_for(single, qtype, TOY_FORMULAS[qtype]), t, a)])
+        ref = single.forward(descs, idx, n)
+        assert torch.equal(got, ref), qtype
+    with open(os.path.join(out_dir, "ok%d" % rank), "w") as f:
+        f.write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+    for e in runs + [single]:
+        e.close()
+
+
+@pytest.mark.parametrize("dec,inter,d", [("bilinear-diag", "min", 32), ("bilinear", "mean", 32), ("transe", "min-simple", 64)])
+def test_row_sharded_two_ranks(tmp_path, dec, inter, d):
+    port = 29400 + os.getpid() % 150
+    mp.spawn(_worker, args=(2, port, str(tmp_path), dec, inter, d), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")

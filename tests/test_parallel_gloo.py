@@ -83,3 +83,91 @@ def test_rank_slice_matches_reference_rule():
             end = min(((it + 1) * 64) % n, n)
             end = n if end <= start else end
             assert (s, e) == (start, end)
+
+
+def _shard_worker(rank, world, port, out_dir):
+    """Row-sharded protocol ("owner computes", graphqembed_amd/parallel.py) on CPU with the real gloo collectives:
+    plan -> request all-to-all -> owners serve rows -> contributions back to the owners -> sharded Adam.  The per-entry
+    arithmetic is a stand-in (the fused kernel is GPU-only); ownership, ordering, split sizes and the optimiser
+    equivalence are what is under test."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from graphqembed_amd import parallel
+    from oracle import netquery_numpy as O
+    r, w, _, d_ = parallel.init_from_env("gloo")
+    rng = np.random.RandomState(7)                      # same stream on every rank: same tables, both ranks' feeds known
+    d = 8
+    rows = [53, 20, 31]                                 # three tables; 53 and 31 are not multiples of the world size
+    tables = [rng.randn(n, d) for n in rows]
+    local_rows = [parallel.shard_rows(n, w) for n in rows]
+    head_base = np.concatenate([[0], np.cumsum(local_rows)[:-1]])
+    shards = [parallel.shard_of(t, r, w) for t in tables]
+    assert all(s.shape[0] == n for s, n in zip(shards, local_rows))
+    feeds = []
+    for rr in range(w):                                 # rank rr's index feed: ragged, with hub rows (duplicates)
+        n = 40 + 9 * rr
+        tid = rng.randint(0, 3, size=n)
+        idx = np.array([rng.randint(0, rows[t]) for t in tid])
+        idx[: n // 4] = idx[0]
+        tid[: n // 4] = tid[0]
+        feeds.append((idx, tid, rng.randn(n, d)))      # ... and a gradient contribution per index
+    idx, tid, contrib = feeds[r]
+    pos, req, send = parallel.shard_plan_numpy(idx, tid, head_base, w)
+    # requests are grouped by owner, and a request is the owner-local list head of the row
+    owner_sorted = (idx % w)[np.argsort(pos)]
+    assert np.all(np.diff(owner_sorted) >= 0) and np.array_equal(np.bincount(idx % w, minlength=w), send)
+    assert np.array_equal(req[pos], head_base[tid] + idx // w)
+    # counts, then the requests themselves
+    cs, cr = torch.tensor(send), torch.zeros(w, dtype=torch.int64)
+    d_.all_to_all_single(cr, cs)
+    recv = [int(c) for c in cr]
+    for rr in range(w):                                 # what I receive from rr is what rr's plan sends me
+        assert recv[rr] == int(np.bincount(feeds[rr][0] % w, minlength=w)[r])
+    req_recv = torch.zeros(sum(recv), dtype=torch.int32)
+    d_.all_to_all_single(req_recv, torch.from_numpy(req), output_split_sizes=recv, input_split_sizes=[int(c) for c in send])
+    # serve: a request names (table, local row) through the local head index
+    flat_shard = np.concatenate(shards)                 # local rows in head order
+    served = torch.from_numpy(flat_shard[req_recv.numpy()])
+    fetched = torch.zeros(len(idx), d, dtype=torch.float64)
+    d_.all_to_all_single(fetched, served, output_split_sizes=[int(c) for c in send], input_split_sizes=recv)
+    want_rows = np.stack([tables[t][i] for i, t in zip(idx, tid)])
+    np.testing.assert_array_equal(fetched.numpy()[pos], want_rows)      # the position feed finds every row of the index feed
+    # contributions: written at the row's position, sent back along the same splits, linked (here: added) by the owner
+    csend = torch.zeros(len(idx), d, dtype=torch.float64)
+    csend[torch.from_numpy(pos).long()] = torch.from_numpy(contrib)
+    crecv = torch.zeros(sum(recv), d, dtype=torch.float64)
+    d_.all_to_all_single(crecv, csend, output_split_sizes=recv, input_split_sizes=[int(c) for c in send])
+    grad_local = np.zeros_like(flat_shard)
+    np.add.at(grad_local, req_recv.numpy(), crecv.numpy())
+    grad_full = [np.zeros_like(t) for t in tables]      # the single-rank statement: every rank's contributions scattered
+    for (i2, t2, c2) in feeds:
+        for i, t, c in zip(i2, t2, c2):
+            grad_full[t][i] += c
+    want_local = np.concatenate([parallel.shard_of(g, r, w) for g in grad_full])
+    np.testing.assert_allclose(grad_local, want_local, rtol=1e-12, atol=1e-12)
+    # Adam on the own shards == the rows of Adam on the whole tables (dense: every row moves, gradient or not)
+    full_p = {"t%d" % k: t.copy() for k, t in enumerate(tables)}
+    full_g = {"t%d" % k: g for k, g in enumerate(grad_full)}
+    st_full = {}
+    loc_p = {"t%d" % k: s.copy() for k, s in enumerate(shards)}
+    off = np.concatenate([[0], np.cumsum(local_rows)])
+    loc_g = {"t%d" % k: grad_local[off[k]:off[k + 1]] for k in range(3)}
+    st_loc = {}
+    for _ in range(3):
+        O.adam_step(full_p, full_g, st_full, list(full_p))
+        O.adam_step(loc_p, loc_g, st_loc, list(loc_p))
+    for k in range(3):
+        got, want = loc_p["t%d" % k], parallel.shard_of(full_p["t%d" % k], r, w)
+        n_real = len(tables[k][r::w])
+        np.testing.assert_allclose(got[:n_real], want[:n_real], rtol=1e-12, atol=1e-12)
+    with open(os.path.join(out_dir, "shard_ok%d" % rank), "w") as f:
+        f.write("ok")
+    d_.barrier()
+    d_.destroy_process_group()
+
+
+def test_two_rank_row_sharded_protocol(tmp_path):
+    port = 29300 + os.getpid() % 90
+    mp.spawn(_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "shard_ok0") and os.path.exists(tmp_path / "shard_ok1")
