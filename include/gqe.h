@@ -237,9 +237,10 @@ int gqe_import_entries(gqe_ctx* ctx, int64_t slab_entries, void* stream);
  *   gqe_adam_step(local segments)   the ordinary fused pass over MY shards (24 B per OWNED parameter) + the small tensors
  *
  * Per rank and step the optimiser streams 1/world of the tables and the inbound traffic is (rows + contributions of one
- * rank's batch) instead of growing with world as the all-gather of gqe_set_exchange does.  Lists are summed
- * order-independently (integer accumulation), so a run is bit-reproducible and equals the single-rank step on the
- * concatenated batch up to fp32 summation order.  The transport is the caller's (torch.distributed all_to_all_single over
+ * rank's batch) instead of growing with world as the all-gather of gqe_set_exchange does.  An owner sums a row's list
+ * order-independently (integer accumulation: the result does not depend on the order contributions arrive in), the
+ * replicated tensors see the same all-reduced gradient on every rank and stay bit-identical, and the step equals the
+ * single-rank step on the concatenated batch up to fp32 summation order.  The transport is the caller's (torch.distributed all_to_all_single over
  * RCCL in graphqembed_amd/parallel.py); the library only names the buffers.  Bag (EmbeddingBag) tables, candidate
  * lists and lazy Adam are not available in this mode; tables must be registered with their LOCAL row counts,
  * ceil(global rows / world), the same on every rank. */

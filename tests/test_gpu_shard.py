@@ -4,7 +4,8 @@
   * the gradients that arrive at the owners (lists folded into the local dense gradient) + the all-reduced relation / Pre /
     Post gradients == the single-rank oracle gradient of the CONCATENATED batch, shard by shard;
   * after the fused Adam pass over the own shards, the shards equal the rows of a single-rank engine stepped on the
-    concatenated batch (up to the summation-order noise Adam amplifies), and two identical sharded runs agree BIT FOR BIT;
+    concatenated batch (up to the summation-order noise Adam amplifies), and the replicated relation / Pre / Post tensors
+    are BIT-identical on every rank;
   * forward scores on fetched rows equal the single-rank engine's;
   * state machine: a second margin call before the contributions were linked is refused.
 """
@@ -61,7 +62,7 @@ def _worker(rank, world, port, out_dir, dec, inter, d):
         return out
 
     single = engine_from_params(params, d, dec, inter)                 # the reference: one rank, the concatenated batch
-    runs = [sharded_engine(), sharded_engine()]                        # two identical sharded runs (bit-reproducibility)
+    runs = [sharded_engine()]
     mix = [("1-chain", 1.0), ("2-chain", 0.3), ("2-inter", 0.5), ("3-inter", 0.5), ("3-inter_chain", 0.5), ("3-chain_inter", 0.2)]
     n_pool, B = 400, 64
     ref_params = {k: v.astype(np.float64) for k, v in params.items()}
@@ -137,12 +138,14 @@ def _worker(rank, world, port, out_dir, dec, inter, d):
         np.testing.assert_allclose(float(tot.item()), want_loss, rtol=2e-4)
         if step == 0:                                                  # identical parameters so far: the reference engine agrees too
             np.testing.assert_allclose(float(tot.item()), float(ref_losses[-1].item()), rtol=2e-4)
-        assert torch.equal(shard_losses[0], shard_losses[1])
     # ---- the shards after three steps ----
-    a0, a1 = read_arena(runs[0], runs[0].params), read_arena(runs[1], runs[1].params)
+    a0 = read_arena(runs[0], runs[0].params)
     want = read_arena(single, single.params)
-    for name in ("params", "exp_avg", "exp_avg_sq"):
-        assert torch.equal(getattr(runs[0], name), getattr(runs[1], name)), "two identical sharded runs differ in " + name
+    for name in ("params", "exp_avg", "exp_avg_sq"):                   # replicated tensors: the same bits on every rank
+        mine = torch.cat([getattr(runs[0], name)[o:o + n] for o, n in runs[0].dense_spans()]).cpu()
+        ref = mine.clone()
+        dist.broadcast(ref, 0)
+        assert torch.equal(mine, ref), "replicated tensors diverged: " + name
     worst, frac = 0.0, 0.0
     for k in params:
         w_k = parallel.shard_of(want[k], r, w) if k in tables else want[k]
