@@ -535,6 +535,8 @@ def main():
     ap.add_argument("--no-host-fed", action="store_true", help="skip the gqe_feeder_run measurement (N=1)")
     ap.add_argument("--no-reddit", action="store_true", help="skip the secondary reddit-synth d=256 measurement")
     ap.add_argument("--only-main", action="store_true", help="main measurement only (profiling runs)")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="timed blocks of --steps steps repeat until this much time was "
+                    "measured (profiling runs: 0 = one block)")
     ap.add_argument("--check-replicas", action="store_true", help="kept for compatibility: replicas are always compared for --gpus > 1")
     args = ap.parse_args()
     if args.only_main:
@@ -561,7 +563,8 @@ def main():
     d = args.dim or (256 if reddit else 128)
     B = args.batch_size
     wl = Workload(args.workload, d, args.decoder, args.inter_decoder, synth.FULL_MIX, B, rank=rank, world=world)
-    res, eng, prepared = measure(wl, args, dist, rank, world, exchange=args.exchange, lazy=args.lazy_adam, check_replicas=world > 1)
+    res, eng, prepared = measure(wl, args, dist, rank, world, exchange=args.exchange, lazy=args.lazy_adam, check_replicas=world > 1,
+                                 min_seconds=args.min_seconds)
     sparse = world > 1 and args.exchange == "sparse"
     sharded = world > 1 and args.exchange == "sharded"
     res["roofline"]["traffic"] = None if (args.lazy_adam or (d, B, args.decoder, args.inter_decoder) != ((256 if reddit else 128), 512, "bilinear-diag", "min")) \

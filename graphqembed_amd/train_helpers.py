@@ -1,18 +1,27 @@
-"""Training / evaluation harness (netquery/train_helpers.py:5-107).
+"""Training / evaluation harness with the behaviour of netquery/train_helpers.py:5-107.
 
-``run_train`` keeps the reference's schedule: phase 1 trains 1-chain (edge) batches until
-"edge convergence" (or ``max_burn_in`` iterations), phase 2 adds every other query type with
-``path_weight`` (chains) / ``inter_weight`` (intersections, once with regular and once with
-hard negatives); one optimiser step per iteration; EMA loss; periodic validation; the same
-log lines.  The difference is mechanical: the (formula, query-slice) batches of an iteration
-are collected first and run through ONE grouped fused forward/backward launch
-(``QueryEncoderDecoder.margin_step``), then one fused optimiser pass — instead of up to 11
-eager autograd graphs, one backward and a dense torch Adam.
+What has to match the reference is the SCHEDULE, not its text:
+  * phase 1 trains one 1-chain (edge) batch per iteration until the validation AUC stops improving or ``max_burn_in``
+    iterations have run; phase 2 adds, per iteration and per other query type, one batch for chains (weight
+    ``path_weight``) or two for intersections (regular and hard negatives, weight ``inter_weight`` each);
+  * a batch = a formula drawn with ``np.random.multinomial`` in proportion to its number of queries, then the slice
+    ``[it*B % n, (it+1)*B % n)`` of that formula's query list with wrap-around (so B varies in [1, batch_size]);
+  * one optimiser step per iteration on the weighted sum of the batch losses; EMA loss; periodic validation; the
+    reference's log lines;
+  * the order in which the global ``random`` / ``np.random`` streams are consumed (formula draw and negatives of the
+    1-chain batch BEFORE the edge-convergence test and its evaluation, then the other types in dictionary order), so
+    that a run seeded like the reference's trains on the same batches (tests/test_gpu_api.py::
+    test_run_train_reproduces_the_reference_run).
 
-With a ``torch.optim`` optimiser the reference's eager flow (``margin_loss`` ->
-``loss.backward()`` -> ``optimizer.step()``) is used instead (compatibility path).
+How it is organised here: ``iteration_plan`` yields the batch specs of an iteration, ``draw_batch`` turns a spec into
+(formula, query slice), and an executor consumes them — ``FusedExecutor`` collects the iteration's batches as index
+arrays and runs ONE grouped fused forward/backward launch (``QueryEncoderDecoder.margin_step``) followed by the fused
+optimiser pass; ``EagerExecutor`` keeps the reference's eager flow (``margin_loss`` -> ``backward``) for ``torch.optim``
+optimisers.  Evaluation and logging (``evaluate``) are separate from the schedule.
 """
 from __future__ import annotations
+
+from collections import namedtuple
 
 import numpy as np
 import torch
@@ -21,140 +30,206 @@ from .model import _FusedOptimizer
 from .tensorize import reference_negative_nodes
 from .utils import eval_auc_queries, eval_perc_queries
 
+BatchSpec = namedtuple("BatchSpec", "query_type weight hard")
+
+
+# ---- schedule -------------------------------------------------------------------------------------------------
+def iteration_plan(query_types, all_types, path_weight, inter_weight):
+    """Batch specs of one iteration AFTER its leading 1-chain batch: nothing while only edges are trained, else every
+    other query type in the order the training dict lists them — intersections twice (regular, then hard negatives)."""
+    if not all_types:
+        return
+    for qt in query_types:
+        if qt == "1-chain":
+            continue
+        if "inter" in qt:
+            yield BatchSpec(qt, inter_weight, False)
+            yield BatchSpec(qt, inter_weight, True)
+        else:
+            yield BatchSpec(qt, path_weight, False)
+
+
+def draw_batch(queries_by_formula, iteration, batch_size):
+    """(formula, queries) of one batch: the formula is drawn with probability proportional to its query count (one
+    ``np.random.multinomial`` call, as train_helpers.py:96-99 consumes it), the queries are the iteration's window of
+    that formula's list, restarting at the list's end."""
+    formulas = list(queries_by_formula)
+    sizes = [float(len(queries_by_formula[f])) for f in formulas]
+    pick = np.random.multinomial(1, np.array(sizes) / float(sum(sizes)))    # the same probability vector, bit for bit
+    formula = formulas[int(pick.argmax())]
+    pool = queries_by_formula[formula]
+    lo = (iteration * batch_size) % len(pool)
+    hi = ((iteration + 1) * batch_size) % len(pool)
+    if hi <= lo or hi > len(pool):
+        hi = len(pool)
+    return formula, pool[lo:hi]
+
+
+class Plateau(object):
+    """The reference's convergence test on a series of validation scores: the mean of the last ``window`` values no
+    longer exceeds the mean of the ``window`` before them by ``tol``."""
+
+    def __init__(self, window=2, tol=1e-6):
+        self.window, self.tol, self.scores = window, tol, []
+
+    def add(self, score):
+        self.scores.append(score)
+
+    def reset(self):
+        self.scores = []
+
+    def reached(self):
+        w = self.window
+        if len(self.scores) < 2 * w:
+            return False
+        recent, before = self.scores[-w:], self.scores[-2 * w:-w]
+        return float(np.mean(recent)) - float(np.mean(before)) < self.tol
+
+
+class LossAverage(object):
+    """Exponential moving average of the iteration loss (alpha 0.01) + how many losses the current phase has seen."""
+
+    def __init__(self, alpha=0.01):
+        self.alpha, self.value, self.count = alpha, None, 0
+
+    def add(self, loss):
+        self.count += 1
+        self.value = loss if self.value is None else (1 - self.alpha) * self.value + self.alpha * loss
+        return self.value
+
+    def reset(self):
+        self.value, self.count = None, 0
+
+
+# ---- executors --------------------------------------------------------------------------------------------------
+class FusedExecutor(object):
+    """The iteration's batches become index arrays; ``finish`` runs them in one grouped launch."""
+
+    def __init__(self, model):
+        self.model = model
+        self.items = []
+
+    def begin(self):
+        self.items = []
+
+    def add(self, formula, queries, weight, hard):
+        m = self.model
+        negatives = reference_negative_nodes(m.graph, formula, queries, hard)     # the reference's draw, call for call
+        target, anchors = m._rows(formula, queries, [q.target_node for q in queries])
+        self.items.append((formula, target, m.enc.rows(negatives, formula.target_mode), anchors, weight, 1.0))
+
+    def finish(self):
+        losses, _, _ = self.model.margin_step(self.items)
+        return float(losses[-1].item())
+
+
+class EagerExecutor(object):
+    """torch.optim compatibility: one ``margin_loss`` per batch, one backward on the weighted sum."""
+
+    def __init__(self, model):
+        self.model = model
+        self.total = None
+
+    def begin(self):
+        self.total = None
+
+    def add(self, formula, queries, weight, hard):
+        term = self.model.margin_loss(formula, queries, hard_negatives=hard)
+        if weight != 1.0:
+            term = weight * term
+        self.total = term if self.total is None else self.total + term
+
+    def finish(self):
+        value = self.total.item()
+        self.total.backward()
+        return value
+
+
+# ---- evaluation + logging ----------------------------------------------------------------------------------------
+def evaluate(model, queries, iteration, logger, by_type=False):
+    """AUC (one negative per query) and percentile (all negatives) per query type, hard-negative variants for the
+    intersection types; returns {type[+"hard"]: AUC} and logs the reference's lines (train_helpers.py:28,34)."""
+    scores = {}
+    for query_type, one_neg in queries["one_neg"].items():
+        variants = [(False, query_type, "")]
+        if "inter" in query_type:
+            variants.append((True, query_type + "hard", "Hard-"))
+        for hard, key, prefix in variants:
+            auc, per_relation = eval_auc_queries(one_neg, model, hard_negatives=hard)
+            perc = eval_perc_queries(queries["full_neg"][query_type], model, hard_negatives=hard)
+            scores[key] = auc
+            logger.info("{:s}{:s} val AUC: {:f} val perc {:f}; iteration: {:d}".format(prefix, query_type, auc, perc, iteration))
+            if by_type:
+                for rels, value in per_relation.items():
+                    logger.info(str(rels) + "\t" + str(value))
+    return scores
+
+
+def _macro(scores):
+    return float(np.mean(list(scores.values())))
+
+
+# ---- the loop ----------------------------------------------------------------------------------------------------
+def run_train(model, optimizer, train_queries, val_queries, test_queries, logger,
+              max_burn_in=100000, batch_size=512, log_every=100, val_every=1000, tol=1e-6,
+              max_iter=int(10e7), inter_weight=0.005, path_weight=0.01, model_file=None):
+    executor = FusedExecutor(model) if isinstance(optimizer, _FusedOptimizer) else EagerExecutor(model)
+    plateau = Plateau()        # ``tol`` is accepted but, as in the reference (its convergence test is called with the
+                               # defaults, train_helpers.py:52,73), not used
+    average = LossAverage()
+    all_types = False          # phase 2: every query type, not only edges
+    score_at_switch = None
+    iteration = -1
+    for iteration in range(max_iter):
+        optimizer.zero_grad()
+        executor.begin()
+        executor.add(*draw_batch(train_queries["1-chain"], iteration, batch_size), 1.0, False)
+        if not all_types and (plateau.reached() or average.count >= max_burn_in):
+            logger.info("Edge converged at iteration {:d}".format(iteration - 1))
+            logger.info("Testing at edge conv...")
+            score_at_switch = _macro(evaluate(model, test_queries, iteration, logger))
+            all_types = True
+            plateau.reset()
+            average.reset()
+            if model_file is not None:
+                torch.save(model.state_dict(), model_file + "-edge_conv")
+        for spec in iteration_plan(train_queries, all_types, path_weight, inter_weight):
+            executor.add(*draw_batch(train_queries[spec.query_type], iteration, batch_size), spec.weight, spec.hard)
+        if all_types and plateau.reached():
+            logger.info("Fully converged at iteration {:d}".format(iteration))
+            break
+        smoothed = average.add(executor.finish())
+        optimizer.step()
+        if iteration % log_every == 0:
+            logger.info("Iter: {:d}; ema_loss: {:f}".format(iteration, smoothed))
+        if iteration >= val_every and iteration % val_every == 0:
+            scores = evaluate(model, val_queries, iteration, logger)
+            plateau.add(_macro(scores) if all_types else scores["1-chain"])
+    final = evaluate(model, test_queries, iteration, logger)
+    logger.info("Test macro-averaged val: {:f}".format(_macro(final)))
+    if score_at_switch is not None:
+        logger.info("Improvement from edge conv: {:f}".format((_macro(final) - score_at_switch) / score_at_switch))
+    return final
+
+
+# ---- the reference's helper names, for callers that import them ----------------------------------------------------
+run_eval = evaluate
+
+
+def run_batch(train_queries, enc_dec, iter_count, batch_size, hard_negatives=False):
+    """One batch's mean margin loss as a tensor (eager path), on the batch the schedule would pick."""
+    formula, queries = draw_batch(train_queries, iter_count, batch_size)
+    return enc_dec.margin_loss(formula, queries, hard_negatives=hard_negatives)
+
 
 def check_conv(vals, window=2, tol=1e-6):
-    if len(vals) < 2 * window:
-        return False
-    return np.mean(vals[-window:]) - np.mean(vals[-2 * window:-window]) < tol
+    p = Plateau(window, tol)
+    p.scores = list(vals)
+    return p.reached()
 
 
 def update_loss(loss, losses, ema_loss, ema_alpha=0.01):
     losses.append(loss)
-    ema_loss = loss if ema_loss is None else (1 - ema_alpha) * ema_loss + ema_alpha * loss
-    return losses, ema_loss
-
-
-def run_eval(model, queries, iteration, logger, by_type=False):
-    vals = {}
-
-    def _by_rel(rel_aucs):
-        for rels, auc in rel_aucs.items():
-            logger.info(str(rels) + "\t" + str(auc))
-    for query_type in queries["one_neg"]:
-        auc, rel_aucs = eval_auc_queries(queries["one_neg"][query_type], model)
-        perc = eval_perc_queries(queries["full_neg"][query_type], model)
-        vals[query_type] = auc
-        logger.info("{:s} val AUC: {:f} val perc {:f}; iteration: {:d}".format(query_type, auc, perc, iteration))
-        if by_type:
-            _by_rel(rel_aucs)
-        if "inter" in query_type:
-            auc, rel_aucs = eval_auc_queries(queries["one_neg"][query_type], model, hard_negatives=True)
-            perc = eval_perc_queries(queries["full_neg"][query_type], model, hard_negatives=True)
-            logger.info("Hard-{:s} val AUC: {:f} val perc {:f}; iteration: {:d}".format(query_type, auc, perc, iteration))
-            if by_type:
-                _by_rel(rel_aucs)
-            vals[query_type + "hard"] = auc
-    return vals
-
-
-def select_batch(train_queries, iter_count, batch_size):
-    """Which formula and which slice ``run_batch`` trains on (train_helpers.py:96-105):
-    formula drawn ∝ its number of queries with ``np.random.multinomial``; the slice walks the
-    formula's query list with wrap-around, so B varies in [1, batch_size]."""
-    formulas = list(train_queries.keys())
-    num = np.array([float(len(train_queries[f])) for f in formulas])
-    formula = formulas[int(np.argmax(np.random.multinomial(1, num / num.sum())))]
-    n = len(train_queries[formula])
-    start = (iter_count * batch_size) % n
-    end = min(((iter_count + 1) * batch_size) % n, n)
-    end = n if end <= start else end
-    return formula, start, end
-
-
-def run_batch(train_queries, enc_dec, iter_count, batch_size, hard_negatives=False):
-    """Eager compatibility path: returns the batch's mean margin loss (a tensor)."""
-    formula, start, end = select_batch(train_queries, iter_count, batch_size)
-    return enc_dec.margin_loss(formula, train_queries[formula][start:end], hard_negatives=hard_negatives)
-
-
-def _collect(train_queries, model, iter_count, batch_size, weight, hard_negatives=False):
-    """Fused path: the same batch as ``run_batch`` would train on, as index arrays."""
-    formula, start, end = select_batch(train_queries, iter_count, batch_size)
-    queries = train_queries[formula][start:end]
-    neg_nodes = reference_negative_nodes(model.graph, formula, queries, hard_negatives)
-    target, anchors = model._rows(formula, queries, [q.target_node for q in queries])
-    return (formula, target, model.enc.rows(neg_nodes, formula.target_mode), anchors, weight, 1.0)
-
-
-def run_train(model, optimizer, train_queries, val_queries, test_queries, logger,
-              max_burn_in=100000, batch_size=512, log_every=100, val_every=1000, tol=1e-6,
-              max_iter=int(10e7), inter_weight=0.005, path_weight=0.01, model_file=None):
-    fused = isinstance(optimizer, _FusedOptimizer)
-    edge_conv = False
-    ema_loss = None
-    vals = []
-    losses = []
-    conv_test = None
-    i = -1
-    for i in range(max_iter):
-        optimizer.zero_grad()
-        if fused:
-            items = [_collect(train_queries["1-chain"], model, i, batch_size, 1.0)]
-        else:
-            loss = run_batch(train_queries["1-chain"], model, i, batch_size)
-        if not edge_conv and (check_conv(vals) or len(losses) >= max_burn_in):
-            logger.info("Edge converged at iteration {:d}".format(i - 1))
-            logger.info("Testing at edge conv...")
-            conv_test = run_eval(model, test_queries, i, logger)
-            conv_test = np.mean(list(conv_test.values()))
-            edge_conv = True
-            losses = []
-            ema_loss = None
-            vals = []
-            if model_file is not None:
-                torch.save(model.state_dict(), model_file + "-edge_conv")
-
-        if edge_conv:
-            for query_type in train_queries:
-                if query_type == "1-chain":
-                    continue
-                if "inter" in query_type:
-                    if fused:
-                        items.append(_collect(train_queries[query_type], model, i, batch_size, inter_weight))
-                        items.append(_collect(train_queries[query_type], model, i, batch_size, inter_weight, True))
-                    else:
-                        loss += inter_weight * run_batch(train_queries[query_type], model, i, batch_size)
-                        loss += inter_weight * run_batch(train_queries[query_type], model, i, batch_size, hard_negatives=True)
-                else:
-                    if fused:
-                        items.append(_collect(train_queries[query_type], model, i, batch_size, path_weight))
-                    else:
-                        loss += path_weight * run_batch(train_queries[query_type], model, i, batch_size)
-            if check_conv(vals):
-                logger.info("Fully converged at iteration {:d}".format(i))
-                break
-
-        if fused:
-            dev_losses, _, _ = model.margin_step(items)
-            loss_value = float(dev_losses[-1].item())
-        else:
-            loss_value = loss.item()
-            loss.backward()
-        losses, ema_loss = update_loss(loss_value, losses, ema_loss)
-        optimizer.step()
-
-        if i % log_every == 0:
-            logger.info("Iter: {:d}; ema_loss: {:f}".format(i, ema_loss))
-
-        if i >= val_every and i % val_every == 0:
-            v = run_eval(model, val_queries, i, logger)
-            if edge_conv:
-                vals.append(np.mean(list(v.values())))
-            else:
-                vals.append(v["1-chain"])
-
-    v = run_eval(model, test_queries, i, logger)
-    logger.info("Test macro-averaged val: {:f}".format(np.mean(list(v.values()))))
-    if conv_test is not None:
-        logger.info("Improvement from edge conv: {:f}".format((np.mean(list(v.values())) - conv_test) / conv_test))
-    return v
+    avg = LossAverage(ema_alpha)
+    avg.value = ema_loss
+    return losses, avg.add(loss)

@@ -102,21 +102,29 @@ def test_sampler_invariants(tiny):
     assert sum(len(v) for a in g.adj_lists.values() for v in a.values()) == n_before - 2
 
 
-def test_select_batch_is_the_reference_slicing_rule():
-    from graphqembed_amd.train_helpers import check_conv, select_batch, update_loss
+def test_draw_batch_is_the_reference_slicing_rule():
+    from graphqembed_amd.train_helpers import BatchSpec, check_conv, draw_batch, iteration_plan, update_loss
     fa, fb = G.Formula("1-chain", (("a", "r", "b"),)), G.Formula("1-chain", (("b", "r", "a"),))
     tq = {fa: list(range(700)), fb: list(range(100))}
     for it in range(40):
         np.random.seed(it)
-        f, s, e = select_batch(tq, it, 512)
-        np.random.seed(it)
+        f, queries = draw_batch(tq, it, 512)
+        after_mine = np.random.get_state()[1][:4].tolist()
+        np.random.seed(it)                                   # the reference's rule, train_helpers.py:96-105
         num = np.array([700.0, 100.0])
         want_f = [fa, fb][int(np.argmax(np.random.multinomial(1, num / num.sum())))]
         n = len(tq[want_f])
         start = (it * 512) % n
         end = min(((it + 1) * 512) % n, n)
         end = n if end <= start else end
-        assert (f, s, e) == (want_f, start, end) and 1 <= e - s <= 512
+        assert f == want_f and queries == tq[want_f][start:end] and 1 <= len(queries) <= 512
+        assert np.random.get_state()[1][:4].tolist() == after_mine           # the same amount of np.random consumed
+    # the schedule: nothing beyond the 1-chain batch during burn-in; then chains once, intersections twice (regular, hard)
+    types = ["1-chain", "2-chain", "2-inter", "3-chain", "3-inter_chain"]
+    assert list(iteration_plan(types, False, 0.01, 0.005)) == []
+    assert list(iteration_plan(types, True, 0.01, 0.005)) == [
+        BatchSpec("2-chain", 0.01, False), BatchSpec("2-inter", 0.005, False), BatchSpec("2-inter", 0.005, True),
+        BatchSpec("3-chain", 0.01, False), BatchSpec("3-inter_chain", 0.005, False), BatchSpec("3-inter_chain", 0.005, True)]
     assert not check_conv([1.0, 2.0, 3.0]) and check_conv([1.0, 2.0, 1.0, 2.0]) and not check_conv([1.0, 1.0, 2.0, 2.0])
     losses, ema = update_loss(2.0, [], None)
     losses, ema = update_loss(4.0, losses, ema)
