@@ -22,7 +22,9 @@ Fixture schema (all index arrays are TABLE ROWS = node_maps[mode][node] + 1):
        it<i>/n, it<i>/b<j>/{meta,target,neg,anchors,loss}, it<i>/loss,
        delta/<key> (final - initial), touched/<key> = per-tensor Adam step count
   eval_<dec>_<inter>_d<D>.npz      eval_auc_queries / eval_perc_queries captures.
-  reddit_<dec>_<inter>_d32.npz     Reddit-shaped world (post features = nn.EmbeddingBag mean over word ids):
+  adam1_<dec>_<inter>_d32.npz      per case: grad/<key> (the reference's dense gradient) and after/<key> (the parameter after
+     ONE torch.optim.Adam step on that gradient).
+  reddit_<dec>_<inter>_d{32,128}.npz  Reddit-shaped world (post features = nn.EmbeddingBag mean over word ids):
        param/* (all tables incl. the word table enc.feat-post.weight), bag/post/{ptr,ids} (CSR of the posts'
        word ids; a post's index row = its bag index), cases as in model_*.npz.
 """
@@ -431,7 +433,8 @@ class RedditWorld(object):
     build_model = World.build_model
 
 
-def gen_reddit_cases(d, B):
+def gen_reddit_cases(d, B, combos=(("bilinear-diag", "min"), ("bilinear", "mean"), ("transe", "mean-simple")),
+                     hard_types=("2-inter", "3-chain_inter"), do_adam=True):
     """margin_loss / backward / 3 Adam steps on the Reddit-shaped world (EmbeddingBag post features)."""
     from collections import defaultdict
     from netquery.graph import Query
@@ -442,7 +445,7 @@ def gen_reddit_cases(d, B):
     by = defaultdict(lambda: defaultdict(list))
     for q in qs:
         by[q.formula.query_type][q.formula].append(q)
-    for dec, inter in (("bilinear-diag", "min"), ("bilinear", "mean"), ("transe", "mean-simple")):
+    for dec, inter in combos:
         out = {"bag/post/ptr": world.bag_ptr, "bag/post/ids": world.bag_ids}
         model = world.build_model(dec, inter)
         p0 = state_np(model)
@@ -452,7 +455,7 @@ def gen_reddit_cases(d, B):
             # prefer formulas that involve posts on both sides, then the best populated
             cands = sorted(by[qtype].items(), key=lambda kv: (-(str(kv[0]).count("post")), -len(kv[1]), str(kv[0])))
             formula, queries = cands[0][0], cands[0][1][:B]
-            for hard in ((False, True) if qtype in ("2-inter", "3-chain_inter") else (False,)):
+            for hard in ((False, True) if qtype in hard_types else (False,)):
                 case = qtype + (".hard" if hard else "")
                 model = world.build_model(dec, inter)
                 spy = Spy(model)
@@ -467,6 +470,8 @@ def gen_reddit_cases(d, B):
                 for k, p in model.named_parameters():
                     if p.grad is not None:
                         out[case + "/grad/" + k] = p.grad.detach().numpy().copy()
+                if not do_adam:
+                    continue
                 model = world.build_model(dec, inter)
                 spy = Spy(model)
                 opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.01)
@@ -489,10 +494,59 @@ def gen_reddit_cases(d, B):
         print("reddit", dec, inter, d, flush=True)
 
 
+def gen_adam1_case(world, by_formula, dec, inter, B, cases=("2-chain", "3-inter.hard", "3-chain_inter")):
+    """One torch.optim.Adam step (lr 0.01, torch defaults) from the reference's own gradient: per case the dense gradient
+    of every touched tensor and the parameters AFTER the step -> adam1_<dec>_<inter>_d<D>.npz.  Lets the device optimiser
+    be checked in isolation: golden gradient in -> one step -> golden parameters out."""
+    out = {}
+    for case in cases:
+        qtype, hard = (case[:-5], True) if case.endswith(".hard") else (case, False)
+        model = world.build_model(dec, inter)
+        formula, queries = pick_formula(by_formula, qtype, B)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.01)
+        seed_all(31)
+        opt.zero_grad()
+        loss = model.margin_loss(formula, queries, hard_negatives=hard)
+        loss.backward()
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                out[case + "/grad/" + k] = p.grad.detach().numpy().copy()
+        opt.step()
+        after = state_np(model)
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                out[case + "/after/" + k] = after[k]
+    np.savez_compressed(os.path.join(OUT, "adam1_%s_%s_d%d.npz" % (dec, inter, world.d)), **out)
+
+
+def gen_round2():
+    """Fixtures added in round 2 (each builds its own worlds, so the files above are unaffected):
+      eval_bilinear-diag_min_d128.npz   eval_auc_queries / eval_perc_queries at the BASELINE dimension
+      adam1_<dec>_<inter>_d32.npz       golden gradient -> one Adam step -> golden parameters
+      reddit_<dec>_<inter>_d128.npz     Reddit-shaped world at d=128, hard negatives for every intersection type"""
+    world = World(128)
+    sample_queries(world)
+    gen_eval_case(world, sample_test_queries(world), "bilinear-diag", "min")
+    print("eval bilinear-diag min 128", flush=True)
+    world = World(32)
+    by_formula = sample_queries(world)
+    for dec, inter in (("bilinear-diag", "min"), ("bilinear", "mean"), ("transe", "min-simple")):
+        gen_adam1_case(world, by_formula, dec, inter, 23)
+        print("adam1", dec, inter, flush=True)
+    gen_reddit_cases(128, 40, combos=(("bilinear-diag", "min"),),
+                     hard_types=("2-inter", "3-inter", "3-inter_chain", "3-chain_inter"), do_adam=False)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     tmp = import_reference()
     logging.disable(logging.CRITICAL)
+    if "--round2-only" in sys.argv:          # the round-2 fixtures alone (bit-identical to what the full run writes)
+        try:
+            gen_round2()
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        return
     try:
         decs = ["bilinear-diag", "transe", "bilinear"]
         inters = ["min", "mean", "min-simple", "mean-simple"]
@@ -521,6 +575,7 @@ def main():
                     gen_eval_case(world, test_queries, dec, inter)
                 print("train/eval", dec, inter, d, flush=True)
         gen_reddit_cases(32, 23)
+        gen_round2()
         with open(os.path.join(OUT, "META.json"), "w") as f:
             json.dump(meta, f, indent=1)
     finally:

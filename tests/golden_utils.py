@@ -70,3 +70,28 @@ def load_reddit_params(z, with_bags=True):
     if with_bags:
         params["__bags__"] = {"post": (z["bag/post/ptr"], z["bag/post/ids"])}
     return params
+
+
+def eval_files():
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLDEN, "eval_*.npz"))):
+        _, dec, inter, dd = os.path.basename(p)[:-4].split("_")
+        out.append((p, dec, inter, int(dd[1:])))
+    return out
+
+
+def adam1_files():
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLDEN, "adam1_*.npz"))):
+        _, dec, inter, dd = os.path.basename(p)[:-4].split("_")
+        out.append((p, dec, inter, int(dd[1:])))
+    return out
+
+
+def eval_calls(z):
+    """The forward calls an eval fixture recorded: [(type, rels, target rows, anchor rows [k, n], scores)]."""
+    n = 0
+    while "call%d/meta" % n in z.files:
+        meta = json.loads(str(z["call%d/meta" % n]))
+        yield n, meta["type"], to_rels(meta["rels"]), z["call%d/target" % n], z["call%d/anchors" % n], z["call%d/scores" % n]
+        n += 1

@@ -64,36 +64,55 @@ def rebuild_queries():
     return train, test
 
 
-def test_forward_matches_reference_eval_calls_and_auc():
-    """eval_auc_queries / eval_perc_queries: same negatives (seeded like the reference), same scores,
-    AUC and percentile within 1e-4 / 1e-2 of what the reference logged."""
+@pytest.mark.parametrize("dec,inter,d", [("bilinear-diag", "min", 32), ("bilinear", "mean", 32), ("transe", "min-simple", 32),
+                                         ("bilinear-diag", "min", 128)])
+def test_forward_matches_reference_eval_calls_and_auc(dec, inter, d):
+    """eval_auc_queries / eval_perc_queries (utils.py:35-91) for three decoder families at d=32 and at d=128: same negatives
+    (seeded like the reference), the same scores call by call, AUC and percentile within 1e-4 / 1e-2 of what the reference
+    logged — through the per-candidate forward AND through the fused candidate-list evaluation, whose scores are compared
+    with the reference's directly."""
     import torch
     from graphqembed_amd import utils
-    model, z = build_world("bilinear-diag", "min", 32, "eval_bilinear-diag_min_d32.npz")
-    _, test = rebuild_queries()
+    model, z = build_world(dec, inter, d, "eval_%s_%s_d%d.npz" % (dec, inter, d))
+    _, test = rebuild_queries()                      # the query sets do not depend on d (same graph, same sampler seeds)
     summary = json.loads(str(z["summary"]))
+    assert len(summary) == 11
     for tag, want in summary.items():
         qtype, hard = (tag[:-5], True) if tag.endswith(".hard") else (tag, False)
-        calls = []
-        orig = model.forward
+        calls, cand_calls = [], []
+        orig, orig_cand = model.forward, model.forward_candidates
 
         def spy(formula, queries, nodes):
             out = orig(formula, queries, nodes)
             calls.append(out.detach().cpu().numpy())
             return out
+
+        def spy_cand(formula, queries, candidate_nodes):
+            scores, ptr = orig_cand(formula, queries, candidate_nodes)
+            cand_calls.append((scores.detach().cpu().numpy(), np.asarray(ptr)))
+            return scores, ptr
         model.forward = spy
         auc, _ = utils.eval_auc_queries(test["one_neg"][qtype], model, hard_negatives=hard)
         n_auc = len(calls)
         perc = utils.eval_perc_queries(test["full_neg"][qtype], model, hard_negatives=hard, fused=False)
         model.forward = orig
-        # the fused candidate-list evaluation (query side computed once) gives the same statistic
-        perc_fused = utils.eval_perc_queries(test["full_neg"][qtype], model, hard_negatives=hard)
-        assert abs(perc_fused - perc) < 1e-6, (tag, perc_fused, perc)
         assert n_auc == len(want["auc_calls"]) and len(calls) - n_auc == len(want["perc_calls"]), tag
         for got, ci in zip(calls, want["auc_calls"] + want["perc_calls"]):
             np.testing.assert_allclose(got, z["call%d/scores" % ci], atol=2e-5, rtol=1e-4, err_msg=tag)
         assert abs(auc - want["auc"]) <= 1e-4, (tag, auc, want["auc"])
         assert abs(perc - want["perc"]) <= 1e-2, (tag, perc, want["perc"])
+        # the fused candidate-list evaluation (query side computed once per query): the same statistic, and its scores
+        # against the reference's own — [pos_0.., negs of query 0, negs of query 1, ..] in the reference's call layout
+        model.forward_candidates = spy_cand
+        perc_fused = utils.eval_perc_queries(test["full_neg"][qtype], model, hard_negatives=hard)
+        model.forward_candidates = orig_cand
+        assert abs(perc_fused - perc) < 1e-6, (tag, perc_fused, perc)
+        assert len(cand_calls) == len(want["perc_calls"]), tag
+        for (flat, ptr), ci in zip(cand_calls, want["perc_calls"]):
+            ref = z["call%d/scores" % ci]
+            n = len(ptr) - 1
+            regrouped = np.concatenate([flat[ptr[:-1]]] + [flat[ptr[i] + 1:ptr[i + 1]] for i in range(n)])
+            np.testing.assert_allclose(regrouped, ref, atol=2e-5, rtol=1e-4, err_msg=tag + " (fused candidates)")
 
 
 @pytest.mark.parametrize("dec,inter", [("bilinear-diag", "min"), ("bilinear", "mean"), ("transe", "min-simple")])

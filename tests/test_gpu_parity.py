@@ -4,7 +4,7 @@ arbitrary order): scores atol 2e-5, loss rtol 1e-4, gradients rtol 2e-3 + atol 1
 import numpy as np
 import pytest
 
-from golden_utils import case_names, load_case, load_params, load_reddit_params, model_files, reddit_files
+from golden_utils import GOLDEN, adam1_files, case_names, load_case, load_params, load_reddit_params, model_files, reddit_files
 from oracle import netquery_numpy as O
 
 pytestmark = pytest.mark.gpu
@@ -127,6 +127,8 @@ def test_golden_reddit_embedding_bag(path, dec, inter, d):
         assert_grads_close(got, c["grads"], case)
         for k in set(got) - set(c["grads"]):
             assert not got[k].any(), (case, k)
+        if "adam_neg" not in c:       # the d=128 fixture (hard negatives for every intersection type) carries no trajectory
+            continue
         # Adam: lists (incl. bag link nodes) consumed directly by the optimiser pass
         eng.zero_grads(list(eng.layout.entries))
         for step in range(3):
@@ -138,6 +140,39 @@ def test_golden_reddit_embedding_bag(path, dec, inter, d):
         for k, delta in c["adam_delta"].items():
             diff = np.abs(now[k].astype(np.float64) - params[k] - delta)
             assert diff.max() < 4e-2 and np.median(diff) < 5e-4, (case, k, diff.max(), np.median(diff))
+    eng.close()
+
+
+@pytest.mark.parametrize("path,dec,inter,d", adam1_files(), ids=_ids)
+def test_one_adam_step_from_the_golden_gradient(path, dec, inter, d):
+    """The reference's own gradient written into the dense gradient arena, ONE gqe_adam_step, against the reference's
+    parameters after one torch.optim.Adam step: atol 1e-6 (gqe_adam1 uses v_sqrt_f32 / v_rcp_f32, 1 ulp, not IEEE —
+    csrc/gqe_adam.h; the step is lr-sized, so that is ~1e-9 here), and every other tensor must not move."""
+    import os
+    import torch
+    from gpu_utils import engine_from_params, load_params as put, read_arena
+    z = np.load(path)
+    p0 = load_params(np.load(os.path.join(GOLDEN, "model_%s_%s_d%d.npz" % (dec, inter, d))), d)
+    eng = engine_from_params(p0, d, dec, inter)
+    for case in sorted(set(k.split("/")[0] for k in z.files)):
+        put(eng, p0)
+        eng.exp_avg.zero_(); eng.exp_avg_sq.zero_()
+        eng.steps = {k: 0 for k in eng.steps}
+        eng.zero_grads(list(eng.layout.entries))
+        eng.materialize()                              # the dense gradient is authoritative: it is written by hand
+        keys = []
+        for k in z.files:
+            if k.startswith(case + "/grad/"):
+                name = k[len(case) + 6:]
+                eng.layout.view(eng.grads, name).copy_(torch.from_numpy(z[k]))
+                keys.append(name)
+        eng.adam_step(keys)
+        got = read_arena(eng, eng.params)
+        for name in keys:
+            np.testing.assert_allclose(got[name], z[case + "/after/" + name], rtol=0, atol=1e-6, err_msg="%s %s" % (case, name))
+        for name in set(got) - set(keys):
+            assert np.array_equal(got[name], p0[name]), (case, name)
+        assert float(eng.grads.abs().max()) == 0.0
     eng.close()
 
 

@@ -8,7 +8,8 @@ import os
 import numpy as np
 import pytest
 
-from golden_utils import GOLDEN, case_names, load_case, load_params, load_reddit_params, model_files, reddit_files
+from golden_utils import (GOLDEN, adam1_files, case_names, eval_calls, eval_files, load_case, load_params, load_reddit_params,
+                          load_tables, model_files, reddit_files)
 from oracle import netquery_numpy as O
 
 # fp32 reference vs fp64 oracle
@@ -123,7 +124,8 @@ def test_reddit_embedding_bag_cases(path, dec, inter, d):
     z = np.load(path)
     params = load_reddit_params(z)
     names = case_names(z)
-    assert len(names) == 9
+    assert len(names) == (9 if d == 32 else 11)          # d=128: hard negatives for all four intersection types
+    assert d == 32 or {"3-inter.hard", "3-inter_chain.hard"} <= set(names)
     for case in names:
         c = load_case(z, case)
         plan = O.make_plan(c["type"], c["rels"])
@@ -140,6 +142,8 @@ def test_reddit_embedding_bag_cases(path, dec, inter, d):
             scale = max(np.abs(g).max(), 1e-12)
             np.testing.assert_allclose(grads[k], g, rtol=GRAD_RTOL, atol=GRAD_ATOL + 1e-5 * scale, err_msg="%s %s" % (case, k))
             np.testing.assert_allclose(tg[k], g, rtol=1e-4, atol=1e-7 + 1e-5 * scale, err_msg="torch port %s %s" % (case, k))
+        if "adam_neg" not in c:
+            continue
         # Adam trajectory
         p = {k: (v.astype(np.float64) if k != O.BAGS_KEY else v) for k, v in params.items()}
         state = {}
@@ -151,3 +155,48 @@ def test_reddit_embedding_bag_cases(path, dec, inter, d):
         for k, delta in c["adam_delta"].items():
             diff = np.abs(p[k] - params[k].astype(np.float64) - delta)
             assert diff.max() < 4e-2 and np.median(diff) < 5e-4, (case, k)
+
+
+_npz_id = lambda v: os.path.basename(v) if isinstance(v, str) and v.endswith(".npz") else None
+
+
+@pytest.mark.parametrize("path,dec,inter,d", eval_files(), ids=_npz_id)
+def test_eval_fixture_scores(path, dec, inter, d):
+    """Every forward call eval_auc_queries / eval_perc_queries made in the reference (utils.py:35-91), d=32 for three
+    decoder families and d=128: the oracle reproduces the scores; the recorded AUC follows from the recorded scores."""
+    from graphqembed_amd.utils import _auc
+    z = np.load(path)
+    params = load_params(z, d)
+    by_call = {}
+    for n, qtype, rels, target, anchors, scores in eval_calls(z):
+        got = O.forward_scores(params, O.make_plan(qtype, rels), dec, inter, target, anchors)
+        np.testing.assert_allclose(got, scores, atol=SCORE_ATOL, rtol=1e-5, err_msg="call %d (%s)" % (n, qtype))
+        by_call[n] = scores
+    assert len(by_call) > 20
+    summary = json.loads(str(z["summary"]))
+    for tag, info in summary.items():                      # AUC protocol: first half of a call = positives, second half = negatives
+        labels, preds = [], []
+        for ci in info["auc_calls"]:
+            sc = by_call[ci]
+            labels += [1] * (len(sc) // 2) + [0] * (len(sc) // 2)
+            preds += list(np.nan_to_num(sc))
+        assert abs(_auc(np.asarray(labels), np.asarray(preds)) - info["auc"]) < 1e-9, tag
+
+
+@pytest.mark.parametrize("path,dec,inter,d", adam1_files(), ids=_npz_id)
+def test_adam_one_step_from_the_golden_gradient(path, dec, inter, d):
+    """adam1_*.npz: the reference's gradient and its parameters after ONE torch.optim.Adam step — the restated Adam
+    (oracle adam_step, the formula the device kernel implements) maps one onto the other to fp32 rounding."""
+    z = np.load(path)
+    model = np.load(os.path.join(GOLDEN, "model_%s_%s_d%d.npz" % (dec, inter, d)))
+    p0 = load_params(model, d)
+    cases = sorted(set(k.split("/")[0] for k in z.files))
+    assert len(cases) == 3
+    for case in cases:
+        grads = {k[len(case) + 6:]: z[k].astype(np.float64) for k in z.files if k.startswith(case + "/grad/")}
+        after = {k[len(case) + 7:]: z[k] for k in z.files if k.startswith(case + "/after/")}
+        assert set(grads) == set(after) and grads
+        params = {k: p0[k].astype(np.float64) for k in grads}
+        O.adam_step(params, grads, {}, list(grads))
+        for k in grads:
+            np.testing.assert_allclose(params[k], after[k], rtol=0, atol=2e-7, err_msg="%s %s" % (case, k))
