@@ -752,3 +752,82 @@ def test_lazy_adam_with_a_bag_mode():
     assert float(diff.mean()) <= 3.0 * float(noise.mean()) + 1e-4, (float(diff.mean()), float(noise.mean()))
     for e in (eager, eager2, lazy):
         e.close()
+
+
+def test_reddit_synth_config5_full_size():
+    """BASELINE config 5 at its real size: reddit-synth (500 k users / 400 k posts / 2 k communities, the 12 directed
+    relations of reddit/data_utils_new.py:193-197, posts = EmbeddingBag mean over 5..30 of 50 k words), d=256, the full
+    9 x 512 mix in ONE grouped launch with the index feed resident in HBM.
+      * scores and losses against the fp64 oracle (the oracle only gathers the rows a batch names);
+      * gradients against the oracle on every row the iteration touches (and nothing elsewhere);
+      * linearity (weights x 2), and a fused Adam step that leaves no gradient behind and moves every row that had one,
+        including the rows of the word table, which are reached only through bags."""
+    import torch
+    import bench
+    from graphqembed_amd import synth
+    from graphqembed_amd.tensorize import FormulaPlan, pack_margin_batches, table_key
+    d, B = 256, 512
+    wl = bench.Workload("reddit-synth", d, "bilinear-diag", "min", synth.FULL_MIX, B, n_distinct=1)
+    assert wl.layout.total > 141 * 10 ** 6 and sum(len(v) for v in wl.g.relations.values()) == 12
+    eng = wl.engine()
+    items = wl.item_sets[0]
+    host = eng.params.cpu().numpy()
+    params = {k: host[off:off + int(np.prod(shape))].reshape(shape) for k, (off, shape) in eng.layout.entries.items()}
+    params[O.BAGS_KEY] = {m: csr for m, csr in wl.g.bags.items()}
+    grads = {k: np.zeros(v.shape, dtype=np.float32) for k, v in params.items() if k != O.BAGS_KEY}
+    grads[O.BAGS_KEY] = params[O.BAGS_KEY]
+    packed, want_l, want_p, want_n = [], [], [], []
+    for (f, t, ng, a, w, m) in items:
+        packed.append((FormulaPlan(f, eng.layout, "min"), t, ng, a, w, m))
+        l, sp, sn, _ = O.margin_fwd_bwd(params, O.make_plan(f.query_type, f.rels), "bilinear-diag", "min", t, ng, a, margin=m, weight=w, grads=grads)
+        want_l.append(l)
+        want_p.append(sp)
+        want_n.append(sn)
+    descs, idx, n = pack_margin_batches(packed)
+    didx = torch.from_numpy(idx).cuda()
+    losses, pos, neg = eng.margin_fwd_bwd(descs, didx, n, want_scores=True)
+    np.testing.assert_allclose(pos.cpu().numpy(), np.concatenate(want_p), atol=SCORE_ATOL, rtol=1e-4)
+    np.testing.assert_allclose(neg.cpu().numpy(), np.concatenate(want_n), atol=SCORE_ATOL, rtol=1e-4)
+    np.testing.assert_allclose(losses.cpu().numpy()[:-1], want_l, rtol=LOSS_RTOL)
+    eng.materialize()
+    g1 = eng.grads.clone()
+    got = g1.cpu().numpy()
+    for k, (off, shape) in eng.layout.entries.items():
+        gk, wk = got[off:off + int(np.prod(shape))].reshape(shape), grads[k]
+        scale = max(float(np.abs(wk).max()), 1e-12)
+        if k.startswith("enc."):
+            rows = np.flatnonzero(np.abs(wk).max(axis=1) > 0)
+            assert len(rows) > 100, k
+            np.testing.assert_allclose(gk[rows], wk[rows], rtol=3e-3, atol=3e-5 * scale, err_msg=k)
+            rest = np.ones(shape[0], dtype=bool)
+            rest[rows] = False
+            # untouched rows hold nothing; a touched row whose contributions cancel to an exact 0 in the oracle may keep
+            # cancellation noise on the device (seen: 1e-13 against gradients of 1e-4)
+            assert float(np.abs(gk[rest]).max()) <= 1e-7 * scale, k
+        else:
+            np.testing.assert_allclose(gk, wk, rtol=3e-3, atol=3e-5 * scale, err_msg=k)
+    # linearity in the loss weight
+    eng.zero_grads(list(eng.layout.entries))
+    descs2, _, _ = pack_margin_batches([(pl, t, ng, a, 2.0 * w, m) for (pl, t, ng, a, w, m) in packed])
+    eng.margin_fwd_bwd(descs2, didx, n)
+    eng.materialize()
+    assert float((eng.grads - 2.0 * g1).abs().max()) <= 3e-5 * 2.0 * float(g1.abs().max())
+    # a fused Adam step: no gradient left anywhere, every row with a gradient moved (a first step leaves zero-gradient
+    # rows where they are: lr * 0), nothing became non-finite
+    keys = set().union(*[p[0].touched for p in packed])
+    before = eng.params.clone()
+    eng.adam_step(keys)
+    eng.materialize()
+    assert float(eng.grads.abs().max()) == 0.0
+    moved = (eng.params != before)
+    for k in keys:
+        off, shape = eng.layout.entries[k]
+        if not k.startswith("enc."):
+            continue
+        gmax = np.abs(grads[k]).reshape(shape[0], -1).max(axis=1)       # (a gradient of 1e-16 moves nothing: lr * g / (|g| + 1e-8))
+        touched = torch.from_numpy(gmax > 1e-4 * gmax.max()).cuda()
+        m_k = moved[off:off + int(np.prod(shape))].view(shape[0], -1).any(dim=1)
+        bad = torch.nonzero(touched & ~m_k).flatten()[:4].tolist()
+        assert not bad, (k, bad, [float(gmax[r]) for r in bad], float(gmax.max()))
+    assert bool(torch.isfinite(eng.params).all())
+    eng.close()
