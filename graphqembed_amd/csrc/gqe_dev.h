@@ -61,9 +61,9 @@ struct GqeDynBatch {
   int64_t scratch_base;  // float offset of this batch's scratch rows in the workspace
   float margin, grad_scale, inv_B, loss_weight;
   int32_t loss_index;    // where this batch's loss goes in the caller's losses[]
-  int32_t n_candidates;  // > 0: evaluation against candidate lists (forward only)
-  int32_t eval_splits;   // evaluation: workgroups per query tile (each takes a slice of every candidate list)
-  int32_t pad;
+  int32_t n_candidates;  // > 0: evaluation against candidate lists (forward only): scratch_base = this batch's query
+                         // records, unit_begin = its first block of the candidate-scoring kernel
+  int32_t pad[2];
 };
 
 // Bag modes (Reddit posts: nn.EmbeddingBag mean over word rows, reddit/data_utils_new.py:155,162-169):
@@ -221,6 +221,10 @@ struct GqeFusedArgs {
 
 hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a);
 hipError_t gqe_launch_pair_gemm(const GqeFusedArgs& a, float* losses);
+#define GQE_EVAL_BLOCK 512   // candidates one workgroup of the scoring kernel covers (= GQE_EVAL_UB in gqe_kernels.hip)
+hipError_t gqe_launch_eval_score(const GqeFusedArgs& a, int dec, float* scores);   // plan.unit_begin / units = candidate blocks
+hipError_t gqe_launch_rank(const float* scores, const int32_t* ptr, int nq, double* percentile, hipStream_t stream);
+hipError_t gqe_launch_auc(const float* pos, long long n_pos, const float* neg, long long n_neg, unsigned long long* count2, hipStream_t stream);
 hipError_t gqe_launch_opt(const GqeOptArgs& a);
 hipError_t gqe_launch_rows(const GqeRowsArgs& a);
 // non-table floats of the arena (dense gradients that travel with the exchanged slab)

@@ -274,86 +274,20 @@ __device__ __forceinline__ void rows_issue_bag(RowSet<NC>& rs, const TileEnv& e,
   }
 }
 
-// one candidate target row (evaluation against candidate lists): gather (direct or bag) + normalise
+// Evaluation against candidate lists (gqe_forward with n_candidates > 0): this kernel only computes the QUERY side,
+// once per query, and leaves a record per query in the workspace; gqe_eval_score_kernel (gqe_kernels.hip) then streams
+// the candidate rows.  Record of query q of a batch: ws[scratch_base + q * (d + 4) ...] = d floats v, then 3 scalars:
+//   intersections      v = the intersected (and projected) query vector, s0 = max(|v|, eps)       score = cos(t, v)
+//   bilinear-diag chain v = a (.) prod w                                                          score = t . v
+//   TransE chain       v = a, s0 = max(|a|, eps), s1 = a . sum w, s2 = |sum w|^2                 score = cos(a, t + sum w)
 template <int NC>
-__device__ __forceinline__ Vec<NC> candidate_row(const TileEnv& e, const GqeBagTable& bags, int bag, int64_t table, int row) {
-  Vec<NC> x = vzero<NC>();
-  if (bag < 0) {
-    x = vload<NC>(e.rows + (e.sharded ? 0 : table) + (size_t)row * e.d, e.d, e.lane);
-  } else {
-    const int32_t* __restrict__ ptr = bags.ptr[bag];
-    const int32_t* __restrict__ ids = bags.ids[bag];
-    const int p0 = ptr[row], len = ptr[row + 1] - p0;
-    for (int c0 = 0; c0 < len; c0 += 64) {
-      const int m = min(64, len - c0);
-      const int wid = (e.lane < m) ? ids[p0 + c0 + e.lane] : 0;
-      for (int k = 0; k < m; ++k) {
-        const int w = __builtin_amdgcn_readlane(wid, k);
-        const Vec<NC> v = vload<NC>(e.params + table + (size_t)w * e.d, e.d, e.lane);
-        VEC_OP(x, x.v[c] + v.v[c]);
-      }
-    }
-    const float il = 1.f / (float)len;
-    VEC_OP(x, x.v[c] * il);
-  }
-  const float inv = 1.f / sqrtf(vdot<NC>(x, x));
-  VEC_OP(x, x.v[c] * inv);
-  return x;
-}
-
-// Evaluation against candidate lists: the 16 query-side vectors of the tile are in an LDS tile; every wave of
-// the workgroup takes GQE_EVAL_U consecutive candidates of the current query at a time, fetches their row ids
-// with one load, issues all row gathers back to back and scores them.
-//   KIND 0: cos(t, v) with |v| in s_scal (intersections)      KIND 1: dot(t, v) (bilinear-diag chains, v = a (.) prod w)
-//   KIND 2: cos(v, t + wsum) with |v| in s_scal (TransE chains, v = a)
-#define GQE_EVAL_U 8
-template <int NC, int KIND>
-__device__ __forceinline__ void eval_candidates(const TileEnv& e, const GqeBagTable& bags, const float* __restrict__ tv,
-                                                const float* __restrict__ s_scal, const Vec<NC>& wsum,
-                                                const int32_t* __restrict__ cand_ptr, const int32_t* __restrict__ cand_rows,
-                                                int split, int nsplit, float* __restrict__ out) {
-  const int bag = e.f->target_bag;
-  const int64_t table = e.f->target_table;
-  for (int r = 0; r < GQE_TQ; ++r) {
-    const int q = e.q0 + r;
-    if (q >= e.b.B) break;
-    const Vec<NC> qv = vload<NC>(tv + r * e.DP, e.d, e.lane);
-    const float qs = s_scal[r];
-    const int c0 = cand_ptr[q];
-    const long long len = cand_ptr[q + 1] - c0;
-    const int cb = c0 + (int)(len * split / nsplit), ce = c0 + (int)(len * (split + 1) / nsplit);
-    for (int ci = cb + e.wave * GQE_EVAL_U; ci < ce; ci += GQE_FW * GQE_EVAL_U) {
-      const int m = min(GQE_EVAL_U, ce - ci);
-      Vec<NC> x[GQE_EVAL_U];
-      if (bag < 0) {
-        const int idv = (e.lane < m) ? cand_rows[ci + e.lane] : 0;
-#pragma unroll
-        for (int u = 0; u < GQE_EVAL_U; ++u)
-          if (u < m) x[u] = vload<NC>(e.rows + (e.sharded ? 0 : table) + (size_t)__builtin_amdgcn_readlane(idv, u) * e.d, e.d, e.lane);
-      }
-#pragma unroll
-      for (int u = 0; u < GQE_EVAL_U; ++u) {
-        if (u >= m) continue;
-        Vec<NC> t;
-        if (bag < 0) {
-          const float inv = 1.f / sqrtf(vdot<NC>(x[u], x[u]));   // encoders.py:41-43
-          VEC_OP(t, x[u].v[c] * inv);
-        } else {
-          t = candidate_row<NC>(e, bags, bag, table, cand_rows[ci + u]);
-        }
-        float sc;
-        if (KIND == 0) {
-          sc = vdot<NC>(t, qv) / (fmaxf(sqrtf(vdot<NC>(t, t)), COS_EPS) * qs);
-        } else if (KIND == 1) {
-          sc = vdot<NC>(t, qv);
-        } else {
-          Vec<NC> uu;
-          VEC_OP(uu, t.v[c] + wsum.v[c]);
-          sc = vdot<NC>(qv, uu) / (qs * fmaxf(sqrtf(vdot<NC>(uu, uu)), COS_EPS));
-        }
-        if (e.lane == 0) out[e.b.out_offset + ci + u] = sc;
-      }
-    }
+__device__ __forceinline__ void store_query_record(const TileEnv& e, int r, const Vec<NC>& v, float s0, float s1, float s2) {
+  float* rec = e.ws + e.b.scratch_base + (size_t)(e.q0 + r) * (e.d + 4);
+  vstore<NC>(rec, v, e.d, e.lane);
+  if (e.lane == 0) {
+    rec[e.d] = s0;
+    rec[e.d + 1] = s1;
+    rec[e.d + 2] = s2;
   }
 }
 
@@ -546,10 +480,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   e.DP = d + 4;
   e.wave = threadIdx.x >> 6;
   e.lane = threadIdx.x & 63;
-  const int nsplit = b.eval_splits > 1 ? b.eval_splits : 1;  // evaluation: several workgroups share one query tile
-  const int local_tile = (int)blockIdx.x - b.tile_begin;
-  const int eval_split = local_tile % nsplit;
-  e.q0 = (local_tile / nsplit) * GQE_TQ;
+  e.q0 = ((int)blockIdx.x - b.tile_begin) * GQE_TQ;
   const int DP = e.DP, lane = e.lane, wave = e.wave;
   const int B = b.B;
   const bool has_neg = b.has_neg != 0;
@@ -558,8 +489,6 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   // every query is scored against its own list, the query side being computed once (the reference re-encodes
   // and re-projects the anchors for every candidate, utils.py:50-60,78-88)
   const bool eval_mode = !BWD && b.n_candidates > 0;
-  const int32_t* __restrict__ cand_ptr = idx + b.idx_offset + (size_t)n * B;
-  const int32_t* __restrict__ cand_rows = cand_ptr + B + 1;
 
   // ---- LDS carve: 7 float tiles [16][DP] + meta tile + red[8][d] + index block ----
   float* te[GQE_MAX_BRANCH];
@@ -689,11 +618,11 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
             sn = vdot<NC>(a, un) / (nap * nun);
           }
         }
-        if (eval_mode) {  // park the query-side vector of this row for the candidate loop below
+        if (eval_mode) {  // the query side of this row, for the candidate-scoring kernel
           Vec<NC> v = a;
           if (DEC == DEC_DIAG) VEC_OP(v, a.v[c] * wcomb.v[c]);
-          vstore<NC>(te[0] + (wave * RPW + rr) * DP, v, d, lane);
-          if (lane == 0) red[wave * RPW + rr] = nap;
+          const float aw = (DEC == DEC_DIAG) ? 0.f : vdot<NC>(a, wcomb), ww = (DEC == DEC_DIAG) ? 0.f : vdot<NC>(wcomb, wcomb);
+          store_query_record<NC>(e, wave * RPW + rr, v, nap, aw, ww);
           continue;
         }
         if (lane == 0) {
@@ -726,13 +655,6 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
           scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1]);
           scatter_row<NC>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2]);
         }
-      }
-      if (eval_mode) {
-        __syncthreads();
-        if (DEC == DEC_DIAG)
-          eval_candidates<NC, 1>(e, bags, te[0], red, wcomb, cand_ptr, cand_rows, eval_split, nsplit, pos_out);
-        else
-          eval_candidates<NC, 2>(e, bags, te[0], red, wcomb, cand_ptr, cand_rows, eval_split, nsplit, pos_out);
       }
       if (BWD) {
 #pragma unroll
@@ -963,7 +885,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
       Vec<NC> qv = vload<NC>(tqq + r * DP, d, lane);
       const float nq = fmaxf(sqrtf(vdot<NC>(qv, qv)), COS_EPS);
       if (eval_mode) {
-        if (lane == 0) red[r] = nq;
+        if (q < B) store_query_record<NC>(e, r, qv, nq, 0.f, 0.f);
         continue;
       }
       const Vec<NC>& tp = RT.x[rr];
@@ -992,10 +914,6 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
         scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0]);
         scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1]);
       }
-    }
-    if (eval_mode) {
-      __syncthreads();
-      eval_candidates<NC, 0>(e, bags, tqq, red, vzero<NC>(), cand_ptr, cand_rows, eval_split, nsplit, pos_out);
     }
     GQE_STAMP(5);
     if (BWD) {

@@ -781,6 +781,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     // hardware starts workgroups in blockIdx order, and with more tiles than workgroup slots (one 1024-thread
     // workgroup per CU at d >= 128) the tiles that start late should be the short chain tiles (~8 us), not the
     // ~30 us three-branch intersection tiles.
+    bool any_candidates = false;
     GqeDynBatch tmp[GQE_LAUNCH_BATCHES];
     int tiles_of[GQE_LAUNCH_BATCHES], units_of[GQE_LAUNCH_BATCHES], cost[GQE_LAUNCH_BATCHES], order[GQE_LAUNCH_BATCHES];
     for (int k = 0; k < nb; ++k) {
@@ -802,17 +803,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       b.grad_scale = s.loss_weight / (float)s.n_queries;
       b.loss_index = b0 + k;
       b.n_candidates = s.n_candidates;
-      b.eval_splits = 1;
-      if (s.n_candidates > 0) {
-        // long candidate lists: several workgroups per query tile so that a 1000-query evaluation fills 256 CUs
-        const int tiles_q = b.Bpad / GQE_TQ;
-        const int64_t per_tile = (int64_t)s.n_candidates / tiles_q;
-        int want = (512 + tiles_q - 1) / tiles_q;
-        if (want > 32) want = 32;
-        while (want > 1 && per_tile / want < 8 * GQE_FWAVES * 8) --want;   // keep >= 8 rounds of work per workgroup
-        b.eval_splits = want;
-      }
-      tiles_of[k] = (b.Bpad / GQE_TQ) * b.eval_splits;
+      tiles_of[k] = b.Bpad / GQE_TQ;
       units_of[k] = 0;
       // relative length of one tile's dependent chain: contraction phases dominate (intersections: Pre / Post and
       // their transposes; full Bilinear: one per hop and score side), then the rows gathered / scattered
@@ -825,6 +816,12 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
         entry += (int64_t)(2 + f.n_anchors) * s.n_queries;
         scratch += (int64_t)f.n_slots * b.Bpad * d;
         units_of[k] = f.n_jobs * ((b.Bpad + GQE_GEMM_KCHUNK - 1) / GQE_GEMM_KCHUNK) * macros_sq;
+      } else if (s.n_candidates > 0) {
+        // evaluation against candidate lists: the fused kernel leaves one record (d + 4 floats) per query in the
+        // scratch region, the scoring kernel covers the batch's candidates in blocks
+        scratch += (int64_t)b.Bpad * (d + 4);
+        units_of[k] = (s.n_candidates + GQE_EVAL_BLOCK - 1) / GQE_EVAL_BLOCK;
+        any_candidates = true;
       }
       order[k] = k;
     }
@@ -845,6 +842,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     HIP_TRY(ctx, gqe_launch_fused(ctx->cfg.decoder, is_mlp(ctx) ? 1 : 0, fa));
     rc = timing_end(ctx, 0, st);
     if (rc != GQE_OK) return rc;
+    if (any_candidates) HIP_TRY(ctx, gqe_launch_eval_score(fa, ctx->cfg.decoder, pos));
     if (bwd) {
       // deferred matrix gradients + the finalize block that turns per-tile hinge sums into losses[]
       rc = timing_begin(ctx, 1, st);
@@ -1636,6 +1634,20 @@ int gqe_forward(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
 int gqe_margin_fwd_bwd(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx,
                        int32_t idx_on_device, float* losses, float* pos_scores, float* neg_scores, void* stream) {
   return run_queries(ctx, batches, n_batches, idx, n_idx, idx_on_device, true, losses, pos_scores, neg_scores, stream);
+}
+
+int gqe_rank_candidates(gqe_ctx* ctx, const float* scores, const int32_t* cand_ptr, int32_t n_queries, double* percentile, void* stream) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (n_queries < 0 || (n_queries > 0 && (!scores || !cand_ptr || !percentile))) return fail(ctx, GQE_ERR_ARG, "gqe_rank_candidates: bad arguments");
+  HIP_TRY(ctx, gqe_launch_rank(scores, cand_ptr, n_queries, percentile, reinterpret_cast<hipStream_t>(stream)));
+  return GQE_OK;
+}
+
+int gqe_auc_pair_counts(gqe_ctx* ctx, const float* pos, int64_t n_pos, const float* neg, int64_t n_neg, uint64_t* count2, void* stream) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (n_pos < 0 || n_neg < 0 || !count2 || (n_pos > 0 && !pos) || (n_neg > 0 && !neg)) return fail(ctx, GQE_ERR_ARG, "gqe_auc_pair_counts: bad arguments");
+  HIP_TRY(ctx, gqe_launch_auc(pos, n_pos, neg, n_neg, reinterpret_cast<unsigned long long*>(count2), reinterpret_cast<hipStream_t>(stream)));
+  return GQE_OK;
 }
 
 int gqe_materialize_grads(gqe_ctx* ctx, void* stream) {

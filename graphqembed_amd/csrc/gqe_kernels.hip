@@ -662,6 +662,233 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_import_kernel(int32_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------
+// Evaluation against candidate lists (replaces the inner loops of eval_auc_queries / eval_perc_queries, utils.py:35-91).
+// The fused kernel left one record per query (its query-side vector + scalars, gqe_fused.h); this kernel streams the
+// candidate rows: a group of LPR = pow2 >= d/4 lanes owns a row (one float4 per lane), a wave keeps U loads per lane in
+// flight (64/LPR * U rows), the dot products are reduced inside the group with DPP steps, and the group's last lane
+// writes the score — no cross-lane broadcast, no LDS, no barrier.  Work = flat blocks of GQE_EVAL_UB candidates of a
+// batch; a wave finds the query of its first candidate with a 64-ary search in cand_ptr and then walks the segments.
+//   score (decoders.py:142-147,200-205,228-233; model.py:97,108), with t = x / |x| (encoders.py:41-43):
+//   KIND 0  cos(t, v) = (x.v / |x|) / (max(|t|, eps) * s0)                          intersections
+//   KIND 1  t . v     =  x.v / |x|                                                  bilinear-diag chains
+//   KIND 2  cos(v, t + w) = (x.v / |x| + s1) / (s0 * max(|t + w|, eps))             TransE chains, w = sum of the hops
+// ------------------------------------------------------------------------------------------
+template <int LPR>
+__device__ __forceinline__ float group_sum(float x) {
+  // sum over the LPR consecutive lanes of a group; valid (at least) in the group's LAST lane
+  x += dpp_get<0xB1, 0xF>(x);                   // quad_perm [1,0,3,2]
+  x += dpp_get<0x4E, 0xF>(x);                   // quad_perm [2,3,0,1]   -> 4 lanes
+  if (LPR >= 8) x += dpp_get<0x141, 0xF>(x);    // row_half_mirror        -> 8
+  if (LPR >= 16) x += dpp_get<0x140, 0xF>(x);   // row_mirror             -> 16
+  if (LPR >= 32) x += dpp_get<0x142, 0xA>(x);   // row_bcast15 -> rows 1,3: lanes 16-31 / 48-63 hold 32-lane sums
+  if (LPR >= 64) x += dpp_get<0x143, 0xC>(x);   // row_bcast31 -> row 3 holds the wave's sum
+  return x;
+}
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+  return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+
+#define GQE_EVAL_UB 512   // candidates per workgroup (4 waves x 128)
+#define GQE_EVAL_U 8      // row loads a lane keeps in flight
+
+template <int LPR>
+__global__ __launch_bounds__(GQE_THREADS) void gqe_eval_score_kernel(const GqeDynPlan plan, const GqeDevFormula* __restrict__ formulas,
+                                                                    const float* __restrict__ params, const float* __restrict__ rows_base,
+                                                                    const float* __restrict__ ws, const int32_t* __restrict__ idx,
+                                                                    float* __restrict__ out, int d, int dec, const GqeBagTable bags) {
+  constexpr int RW = 64 / LPR;  // rows per wave-wide load
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int bi = 0;
+#pragma unroll
+  for (int k = 1; k < GQE_LAUNCH_BATCHES; ++k) bi += ((int)blockIdx.x >= plan.unit_begin[k]) ? 1 : 0;
+  const GqeDynBatch b = plan.b[bi];
+  if (b.n_candidates <= 0) return;
+  const GqeDevFormula* __restrict__ f = formulas + b.formula;
+  const int B = b.B, n = f->n_anchors;
+  const int32_t* __restrict__ cand_ptr = idx + b.idx_offset + (size_t)n * B;
+  const int32_t* __restrict__ cand_rows = cand_ptr + B + 1;
+  const bool chain = f->qtype <= 2;
+  const int kind = !chain ? 0 : (dec == DEC_DIAG ? 1 : 2);
+  const int g = lane / LPR, c4 = (lane % LPR) * 4;
+  const bool act = c4 < d;
+  const bool writer = (lane % LPR) == LPR - 1;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // this wave's flat range of the batch's candidates
+  const long long blk = (long long)((int)blockIdx.x - b.unit_begin) * GQE_EVAL_UB + wave * (GQE_EVAL_UB / 4);
+  int c = (int)min((long long)b.n_candidates, blk);
+  const int c_end = (int)min((long long)b.n_candidates, blk + GQE_EVAL_UB / 4);
+  if (c >= c_end) return;
+  // TransE chains: w = sum of the hop vectors (batch-uniform)
+  float4 w4 = zero4;
+  if (kind == 2 && act)
+    for (int h = 0; h < f->n_hops[0]; ++h) {
+      const float4 t = *reinterpret_cast<const float4*>(params + f->hop_param[0][h] + c4);
+      w4.x += t.x; w4.y += t.y; w4.z += t.z; w4.w += t.w;
+    }
+  // query of the first candidate: largest q with cand_ptr[q] <= c (64-ary search, the lanes probe in parallel)
+  int lo = 0, hi = B;  // invariant: cand_ptr[lo] <= c < cand_ptr[hi] (cand_ptr[B] = n_candidates > c)
+  while (hi - lo > 1) {
+    const int step = (hi - lo + 63) / 64;
+    const int probe = min(lo + (lane + 1) * step, hi);
+    const bool le = probe < hi && cand_ptr[probe] <= c;
+    const int k = __popcll(__ballot(le));
+    const int nlo = lo + k * step;
+    hi = min(nlo + step, hi);
+    lo = nlo;
+  }
+  int q = lo;
+  const int tbag = f->target_bag;
+  const float* __restrict__ table = rows_base + f->target_table;
+  while (c < c_end) {
+    const int seg_end = min(cand_ptr[q + 1], c_end);
+    if (seg_end <= c) {  // (empty candidate list)
+      ++q;
+      continue;
+    }
+    const float* __restrict__ rec = ws + b.scratch_base + (size_t)q * (d + 4);
+    const float4 v4 = act ? *reinterpret_cast<const float4*>(rec + c4) : zero4;
+    const float s0 = rec[d], s1 = rec[d + 1], s2 = rec[d + 2];
+    for (; c < seg_end; c += RW * GQE_EVAL_U) {
+      float4 x[GQE_EVAL_U];
+      if (tbag < 0) {
+        int row[GQE_EVAL_U];
+#pragma unroll
+        for (int u = 0; u < GQE_EVAL_U; ++u) {
+          const int ci = c + u * RW + g;
+          row[u] = cand_rows[ci < seg_end ? ci : c];
+        }
+#pragma unroll
+        for (int u = 0; u < GQE_EVAL_U; ++u) x[u] = act ? *reinterpret_cast<const float4*>(table + (size_t)row[u] * d + c4) : zero4;
+      } else {
+        // bag mode (Reddit posts): a candidate's raw vector is the mean of its word rows
+        const int32_t* __restrict__ bptr = bags.ptr[tbag];
+        const int32_t* __restrict__ bids = bags.ids[tbag];
+#pragma unroll
+        for (int u = 0; u < GQE_EVAL_U; ++u) {
+          const int ci = c + u * RW + g;
+          const int bag = cand_rows[ci < seg_end ? ci : c];
+          const int p0 = bptr[bag], len = bptr[bag + 1] - p0;
+          float4 acc = zero4;
+          for (int k = 0; k < len; ++k) {
+            const float4 t = act ? *reinterpret_cast<const float4*>(table + (size_t)bids[p0 + k] * d + c4) : zero4;
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+          }
+          const float il = 1.f / (float)len;
+          x[u] = make_float4(acc.x * il, acc.y * il, acc.z * il, acc.w * il);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < GQE_EVAL_U; ++u) {
+        const int ci = c + u * RW + g;
+        const float xx = group_sum<LPR>(dot4(x[u], x[u]));
+        const float xv = group_sum<LPR>(dot4(x[u], v4));
+        const float inv = 1.f / sqrtf(xx);                       // encoders.py:41-43: t = x / |x|
+        float sc;
+        if (kind == 1) {
+          sc = xv * inv;
+        } else if (kind == 0) {
+          const float nt = fmaxf(sqrtf(xx * inv * inv), COS_EPS);  // |t|, 1 up to rounding
+          sc = xv * inv / (nt * s0);
+        } else {
+          const float xw = group_sum<LPR>(dot4(x[u], w4));
+          const float nu = fmaxf(sqrtf(fmaf(2.f * xw, inv, xx * inv * inv) + s2), COS_EPS);   // |t + w|
+          sc = fmaf(xv, inv, s1) / (s0 * nu);
+        }
+        if (writer && ci < seg_end) out[b.out_offset + ci] = sc;
+      }
+    }
+    c = seg_end;
+    ++q;
+  }
+}
+
+hipError_t gqe_launch_eval_score(const GqeFusedArgs& a, int dec, float* scores) {
+  if (a.plan.units < 1) return hipSuccess;
+  const float* rows_base = a.fetched ? a.fetched : a.params;
+  int lpr = 4;
+  while (lpr * 4 < a.d) lpr *= 2;
+#define GO(L)                                                                                                                 \
+  hipLaunchKernelGGL((gqe_eval_score_kernel<L>), dim3(a.plan.units), dim3(GQE_THREADS), 0, a.stream, a.plan, a.formulas, a.params, \
+                     rows_base, a.ws, a.idx, scores, a.d, dec, a.bags)
+  switch (lpr) {
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    case 32: GO(32); break;
+    default: GO(64); break;
+  }
+#undef GO
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Ranking statistics on the device: only query-level numbers leave the GPU.
+//   percentile (utils.py:26-33: scipy.stats.percentileofscore, kind 'rank') of a list's FIRST score among the others;
+//   pair counts for the ROC AUC (utils.py:63,66: sklearn roc_auc_score = Mann-Whitney with ties at 1/2):
+//   count2 += sum_i sum_j 2 [p_i > n_j] + [p_i == n_j], NaN scores read as 0 (np.nan_to_num).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GQE_THREADS) void gqe_rank_kernel(const float* __restrict__ scores, const int32_t* __restrict__ ptr, int nq,
+                                                              double* __restrict__ percentile) {
+  const int q = (int)(((long long)blockIdx.x * GQE_THREADS + threadIdx.x) >> 6);
+  if (q >= nq) return;
+  const int lane = threadIdx.x & 63;
+  const int p0 = ptr[q], p1 = ptr[q + 1];
+  const float s = scores[p0];
+  float left = 0.f, right = 0.f;   // counts < 2^24: exact in fp32
+  for (int i = p0 + 1 + lane; i < p1; i += 64) {
+    const float x = scores[i];
+    left += (x < s) ? 1.f : 0.f;
+    right += (x <= s) ? 1.f : 0.f;
+  }
+  left = wave_sum(left);
+  right = wave_sum(right);
+  const int n = p1 - p0 - 1;
+  if (lane == 0) percentile[q] = n > 0 ? ((double)left + (double)right + (right > left ? 1.0 : 0.0)) * 50.0 / (double)n : nan("");
+}
+
+__global__ __launch_bounds__(GQE_THREADS) void gqe_auc_kernel(const float* __restrict__ pos, long long n_pos, const float* __restrict__ neg,
+                                                             long long n_neg, unsigned long long* __restrict__ count2) {
+  __shared__ float s_neg[1024];
+  const long long i = (long long)blockIdx.x * GQE_THREADS + threadIdx.x;
+  float p = i < n_pos ? pos[i] : 0.f;
+  if (p != p) p = 0.f;
+  unsigned long long acc = 0;
+  const long long j0 = (long long)blockIdx.y * 16384, j1 = min(n_neg, j0 + 16384);
+  for (long long t0 = j0; t0 < j1; t0 += 1024) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < 1024; k += GQE_THREADS) {
+      float x = t0 + k < j1 ? neg[t0 + k] : 0.f;
+      s_neg[k] = (x != x) ? 0.f : x;
+    }
+    __syncthreads();
+    const int m = (int)min((long long)1024, j1 - t0);
+    unsigned int a = 0;
+    for (int k = 0; k < m; ++k) a += (p > s_neg[k]) ? 2u : ((p == s_neg[k]) ? 1u : 0u);
+    acc += a;
+  }
+  if (i >= n_pos) acc = 0;
+  // wave reduction of the 64-bit counts, then one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(count2, acc);
+}
+
+hipError_t gqe_launch_rank(const float* scores, const int32_t* ptr, int nq, double* percentile, hipStream_t stream) {
+  if (nq < 1) return hipSuccess;
+  const long long threads = (long long)nq * 64;
+  hipLaunchKernelGGL(gqe_rank_kernel, dim3((unsigned)((threads + GQE_THREADS - 1) / GQE_THREADS)), dim3(GQE_THREADS), 0, stream, scores, ptr,
+                     nq, percentile);
+  return hipGetLastError();
+}
+
+hipError_t gqe_launch_auc(const float* pos, long long n_pos, const float* neg, long long n_neg, unsigned long long* count2, hipStream_t stream) {
+  if (n_pos < 1 || n_neg < 1) return hipSuccess;
+  dim3 grid((unsigned)((n_pos + GQE_THREADS - 1) / GQE_THREADS), (unsigned)((n_neg + 16383) / 16384));
+  hipLaunchKernelGGL(gqe_auc_kernel, grid, dim3(GQE_THREADS), 0, stream, pos, n_pos, neg, n_neg, count2);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // row-sharded data parallelism ("owner computes", gqe_set_shard).  A request names a row of a local shard by its list
 // head index (head_base of the local table + local row), which is also where its gradient contribution is linked.
 // ------------------------------------------------------------------------------------------

@@ -88,6 +88,8 @@ SYMBOLS = OrderedDict([
     ("gqe_shard_plan", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P, _P])),
     ("gqe_shard_serve", (C.c_int, [_P, _P, C.c_int64, _P, _P])),
     ("gqe_shard_link", (C.c_int, [_P, _P, C.c_int64, _P])),
+    ("gqe_rank_candidates", (C.c_int, [_P, _P, _P, C.c_int32, _P, _P])),
+    ("gqe_auc_pair_counts", (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, _P])),
     ("gqe_forward", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P])),
     ("gqe_margin_fwd_bwd", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P, _P, _P])),
     ("gqe_adam_step", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P])),
@@ -406,6 +408,30 @@ class Engine(object):
         scores = out if out is not None else self.torch.empty(n_scores, dtype=self.torch.float32, device=self.device)
         self._check(self.lib.gqe_forward(self.ctx, arr, len(descs), ptr, n_idx, on_dev, scores.data_ptr(), self._stream()))
         return scores
+
+    # -- ranking statistics on the device (only query-level numbers are read back) ---------------
+    def rank_candidates(self, scores, ptr):
+        """Percentile (scipy percentileofscore, kind 'rank') of each list's FIRST score among the list's others;
+        ``scores`` device float32 (flat, candidate order), ``ptr`` int32[n+1] (numpy or device).  Returns a device tensor[n]."""
+        t = self.torch
+        if isinstance(ptr, np.ndarray):
+            ptr = t.from_numpy(np.ascontiguousarray(ptr, dtype=np.int32)).to(self.device)
+        n = int(ptr.numel()) - 1
+        out = t.empty(n, dtype=t.float64, device=self.device)
+        self._check(self.lib.gqe_rank_candidates(self.ctx, scores.data_ptr(), ptr.data_ptr(), n, out.data_ptr(), self._stream()))
+        return out
+
+    def auc(self, pos, neg):
+        """ROC AUC of positive vs negative scores (device tensors), ties count 1/2, NaN reads as 0 — sklearn's
+        roc_auc_score on np.nan_to_num(scores) (utils.py:63,66).  One 8-byte read-back."""
+        t = self.torch
+        if pos.numel() == 0 or neg.numel() == 0:
+            raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
+        pos, neg = pos.contiguous(), neg.contiguous()
+        count = t.zeros(1, dtype=t.int64, device=self.device)
+        self._check(self.lib.gqe_auc_pair_counts(self.ctx, pos.data_ptr(), int(pos.numel()), neg.data_ptr(), int(neg.numel()),
+                                                 count.data_ptr(), self._stream()))
+        return float(count.item()) / (2.0 * float(pos.numel()) * float(neg.numel()))
 
     def margin_fwd_bwd(self, descs, idx, n_scores=0, want_scores=False, losses=None):
         """gqe_margin_fwd_bwd: grads += d(sum_i w_i loss_i); returns (losses[n+1], pos, neg)."""

@@ -185,6 +185,13 @@ class QueryEncoderDecoder(nn.Module):
         descs, idx, n = pack_candidate_batches([(self.plan(formula), anchors, ptr, rows)])
         return self.engine.forward(descs, idx, n), ptr
 
+    def candidate_percentiles(self, formula, queries, candidate_nodes):
+        """For each query, the percentile rank (utils.py:26-33) of its FIRST candidate's score among its other
+        candidates, computed on the device: fused candidate-list evaluation + gqe_rank_candidates; only one float per
+        query comes back.  Returns a device tensor[len(queries)]."""
+        scores, ptr = self.forward_candidates(formula, queries, candidate_nodes)
+        return self.engine.rank_candidates(scores, ptr)
+
     def score_batches(self, items):
         """items: [(formula, target_rows, anchor_rows)] -> one scores tensor (concatenated)."""
         packed = [(self.plan(f), t, a) for (f, t, a) in items]

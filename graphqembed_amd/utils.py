@@ -91,44 +91,62 @@ def _chunks(formula_queries, batch_size):
         yield formula_queries[offset:offset + batch_size]
 
 
-def eval_auc_queries(test_queries, enc_dec, batch_size=1000, hard_negatives=False, seed=0):
+def eval_auc_queries(test_queries, enc_dec, batch_size=1000, hard_negatives=False, seed=0, on_device=None):
     """Overall and per-formula ROC AUC with ONE random negative per query; the negative
-    draw replays the reference's ``random.seed(seed)`` / ``random.choice`` sequence."""
+    draw replays the reference's ``random.seed(seed)`` / ``random.choice`` sequence.
+    ``on_device`` (default: whenever the model has an ``engine``): the scores never leave the GPU — the pair counts
+    behind each AUC are accumulated there (gqe_auc_pair_counts) and one number per AUC is read back."""
+    if on_device is None:
+        on_device = hasattr(enc_dec, "engine")
     predictions, labels, formula_aucs = [], [], {}
+    pos_all, neg_all = [], []
     random.seed(seed)
     for formula in test_queries:
-        f_labels, f_preds = [], []
+        f_labels, f_preds, f_pos, f_neg = [], [], [], []
         for batch in _chunks(test_queries[formula], batch_size):
             if hard_negatives:
                 negatives = [random.choice(q.hard_neg_samples) for q in batch]
             else:
                 negatives = [random.choice(q.neg_samples) for q in batch]
-            f_labels.extend([1] * len(batch) + [0] * len(negatives))
             scores = enc_dec.forward(formula, batch + batch, [q.target_node for q in batch] + negatives)
+            if on_device:
+                f_pos.append(scores[:len(batch)])
+                f_neg.append(scores[len(batch):])
+                continue
+            f_labels.extend([1] * len(batch) + [0] * len(negatives))
             f_preds.extend(scores.detach().cpu().tolist())
+        if on_device:
+            import torch
+            p, n = torch.cat(f_pos), torch.cat(f_neg)
+            formula_aucs[formula] = enc_dec.engine.auc(p, n)
+            pos_all.append(p)
+            neg_all.append(n)
+            continue
         formula_aucs[formula] = _auc(f_labels, np.nan_to_num(f_preds))
         labels.extend(f_labels)
         predictions.extend(f_preds)
+    if on_device:
+        import torch
+        return enc_dec.engine.auc(torch.cat(pos_all), torch.cat(neg_all)), formula_aucs
     return _auc(labels, np.nan_to_num(predictions)), formula_aucs
 
 
 def eval_perc_queries(test_queries, enc_dec, batch_size=1000, hard_negatives=False, fused=None):
     """Mean percentile rank of the true target among ALL stored negatives of its query.
-    ``fused`` (default: whenever the model offers ``forward_candidates``): score each query against its
+    ``fused`` (default: whenever the model offers ``candidate_percentiles``): score each query against its
     candidate list [target] + negatives in one fused evaluation launch instead of repeating the query per
-    negative as the reference does; same scores, the query side is computed once."""
+    negative as the reference does (same scores, the query side is computed once) and rank on the device: one
+    percentile per query is read back."""
     perc_scores = []
     if fused is None:
-        fused = hasattr(enc_dec, "forward_candidates")
+        fused = hasattr(enc_dec, "candidate_percentiles")
     for formula in test_queries:
         for batch in _chunks(test_queries[formula], batch_size):
             lists = [q.hard_neg_samples if hard_negatives else q.neg_samples for q in batch]
             lengths = [len(l) for l in lists]
             if fused:
-                scores, ptr = enc_dec.forward_candidates(formula, batch, [[q.target_node] + list(l) for q, l in zip(batch, lists)])
-                scores = scores.detach().cpu().numpy()
-                for i in range(len(batch)):
-                    perc_scores.append(_percentile_of_score(scores[ptr[i] + 1:ptr[i + 1]], scores[ptr[i]]))
+                perc = enc_dec.candidate_percentiles(formula, batch, [[q.target_node] + list(l) for q, l in zip(batch, lists)])
+                perc_scores.extend(perc.detach().cpu().tolist())
                 continue
             negatives = [n for l in lists for n in l]
             rep = [q for q, k in zip(batch, lengths) for _ in range(k)]

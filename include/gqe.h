@@ -162,6 +162,16 @@ int gqe_forward(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches,
                 const int32_t* idx, int64_t n_idx, int32_t idx_on_device,
                 float* scores, void* stream);
 
+/* Ranking statistics of an evaluation on the device, so that only query-level numbers are read back.
+ * gqe_rank_candidates: replaces _get_perc_scores (utils.py:26-33, scipy.stats.percentileofscore kind 'rank'): for each of
+ *   n_queries lists (cand_ptr[n_queries + 1], device) the percentile of the list's FIRST score among the others —
+ *   eval_perc_queries puts the true target first (utils.py:86-88).
+ * gqe_auc_pair_counts: replaces roc_auc_score (utils.py:63,66) for a set of positive and negative scores:
+ *   *count2 += sum_i sum_j (2 [pos_i > neg_j] + [pos_i == neg_j]); AUC = count2 / (2 n_pos n_neg); NaN scores read as 0
+ *   (np.nan_to_num).  count2: device, zeroed by the caller. */
+int gqe_rank_candidates(gqe_ctx* ctx, const float* scores, const int32_t* cand_ptr, int32_t n_queries, double* percentile, void* stream);
+int gqe_auc_pair_counts(gqe_ctx* ctx, const float* pos, int64_t n_pos, const float* neg, int64_t n_neg, uint64_t* count2, void* stream);
+
 /* replaces: margin_loss forward (model.py:112-127) + loss.backward() (train_helpers.py:78)
  * for n_batches (formula, query-slice) pairs in ONE grouped launch.  Gradients of
  * sum_i loss_weight_i * loss_i are ACCUMULATED: relation / Pre / Post gradients into the bound grads arena,

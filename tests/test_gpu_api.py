@@ -92,8 +92,11 @@ def test_forward_matches_reference_eval_calls_and_auc(dec, inter, d):
             cand_calls.append((scores.detach().cpu().numpy(), np.asarray(ptr)))
             return scores, ptr
         model.forward = spy
-        auc, _ = utils.eval_auc_queries(test["one_neg"][qtype], model, hard_negatives=hard)
+        auc, f_aucs = utils.eval_auc_queries(test["one_neg"][qtype], model, hard_negatives=hard)      # pair counts on the device
         n_auc = len(calls)
+        auc_host, f_aucs_host = utils.eval_auc_queries(test["one_neg"][qtype], model, hard_negatives=hard, on_device=False)
+        del calls[n_auc:]
+        assert abs(auc - auc_host) < 1e-12 and all(abs(f_aucs[f] - f_aucs_host[f]) < 1e-12 for f in f_aucs), tag
         perc = utils.eval_perc_queries(test["full_neg"][qtype], model, hard_negatives=hard, fused=False)
         model.forward = orig
         assert n_auc == len(want["auc_calls"]) and len(calls) - n_auc == len(want["perc_calls"]), tag
@@ -106,7 +109,7 @@ def test_forward_matches_reference_eval_calls_and_auc(dec, inter, d):
         model.forward_candidates = spy_cand
         perc_fused = utils.eval_perc_queries(test["full_neg"][qtype], model, hard_negatives=hard)
         model.forward_candidates = orig_cand
-        assert abs(perc_fused - perc) < 1e-6, (tag, perc_fused, perc)
+        assert abs(perc_fused - perc) < 1e-9, (tag, perc_fused, perc)      # ranked on the device (gqe_rank_candidates)
         assert len(cand_calls) == len(want["perc_calls"]), tag
         for (flat, ptr), ci in zip(cand_calls, want["perc_calls"]):
             ref = z["call%d/scores" % ci]
