@@ -80,8 +80,18 @@ def phase_profile(mix, B, label):
     t0 = st[:, 0].min()
     names = ["start", "idx", "rows", "branches", "post/final", "score", "postT", "branches_bwd", "loss"]
     print("== phase profile %s B=%d (us since first block start; per batch type: median over its tiles)" % (label, B))
+    # tiles are laid out longest batch first (gqe_host.cpp, run_queries): intersections by branch count, chains last
+    n_anchor = {"1-chain": 1, "2-chain": 1, "3-chain": 1, "2-inter": 2, "3-inter": 3, "3-inter_chain": 2, "3-chain_inter": 2}
+    mlp = not args.inter.endswith("simple")
+    hops = {"1-chain": 1, "2-chain": 2, "3-chain": 3, "2-inter": 2, "3-inter": 3, "3-inter_chain": 3, "3-chain_inter": 3}
+    bil = args.decoder == "bilinear"
+    def cost(qt):
+        na, chain = n_anchor[qt], qt.endswith("chain") and "inter" not in qt
+        extra = (4 * hops[qt] if bil else 0) if chain else ((6 + 2 * na) if mlp else 2) + (2 * hops[qt] if bil else 0)
+        return 2 + na + extra
+    order = sorted(range(len(mix)), key=lambda k: -cost(mix[k][0]))
     off = 0
-    for (qt, w, hard) in mix:
+    for (qt, w, hard) in [mix[k] for k in order]:
         nt = (B + 15) // 16
         blk = st[off:off + nt]; off += nt
         rel = (blk - t0) / 100.0
