@@ -222,7 +222,7 @@ CONFIGS = [("bilinear-diag", "min"), ("bilinear-diag", "mean-simple"), ("transe"
            ("transe", "min-simple"), ("bilinear", "min"), ("bilinear", "mean-simple")]
 
 
-@pytest.mark.parametrize("d", [16, 64, 128, 256])
+@pytest.mark.parametrize("d", [16, 64, 128, 192, 256])
 @pytest.mark.parametrize("dec,inter", CONFIGS)
 def test_random_schema_vs_oracle(dec, inter, d):
     """Every query type, ragged / tiny / hub-heavy batches, all in ONE grouped launch, against
@@ -264,6 +264,39 @@ def test_random_schema_vs_oracle(dec, inter, d):
         eng.margin_fwd_bwd(descs, idx, n)
     single = read_arena(eng, eng.grads)
     assert_grads_close(single, grouped, "single vs grouped")
+    eng.close()
+
+
+@pytest.mark.parametrize("dec,inter,d,B", [("bilinear-diag", "min", 128, 1200), ("bilinear", "mean", 128, 1200), ("transe", "min-simple", 128, 1200),
+                                           ("bilinear-diag", "mean", 144, 40), ("bilinear", "min", 208, 40)])
+def test_eight_wave_workgroups_vs_oracle(dec, inter, d, B):
+    """The 8-wave shape of the fused kernel (two query rows per wave; csrc/gqe_fused.h): d = 128 launches with more than
+    512 tiles (two workgroups per CU; here 7 x 1200 queries = 525 tiles, ragged last tiles) and the guarded d in (128, 256)
+    variants — every query type in one grouped launch against the fp64 oracle, like the 16-wave shape."""
+    from gpu_utils import (TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, read_arena,
+                           toy_batch)
+    from graphqembed_amd.tensorize import pack_margin_batches
+    rng = np.random.RandomState(d + B)
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
+    eng = engine_from_params(params, d, dec, inter, max_queries=7 * B + 64, max_batches=8)
+    items, want_l, want_p, want_n = [], [], [], []
+    grads, grads32 = O.zero_grads_like(params), O.zero_grads_like(params, np.float32)
+    for j, qtype in enumerate(sorted(TOY_FORMULAS)):
+        n = B - 3 * j
+        t, g, a = toy_batch(rng, qtype, n, hub=(j == 2))
+        w = [1.0, 0.01, 0.5, 0.005, 0.005, 0.3, 2.0][j]
+        items.append((plan_for(eng, qtype, TOY_FORMULAS[qtype]), t, g, a, w, 1.0))
+        l, sp, sn, _ = O.margin_fwd_bwd(params, O.make_plan(qtype, TOY_FORMULAS[qtype]), dec, inter, t, g, a, weight=w, grads=grads)
+        O.margin_fwd_bwd(params, O.make_plan(qtype, TOY_FORMULAS[qtype]), dec, inter, t, g, a, weight=w, grads=grads32, dtype=np.float32)
+        want_l.append(l); want_p.append(sp); want_n.append(sn)
+    descs, idx, n = pack_margin_batches(items)
+    if d == 128:
+        assert sum((len(it[1]) + 15) // 16 for it in items) > 512       # what selects the 8-wave shape at d = 128
+    losses, pos, neg = eng.margin_fwd_bwd(descs, idx, n, want_scores=True)
+    np.testing.assert_allclose(pos.cpu().numpy(), np.concatenate(want_p), atol=SCORE_ATOL, rtol=1e-4)
+    np.testing.assert_allclose(neg.cpu().numpy(), np.concatenate(want_n), atol=SCORE_ATOL, rtol=1e-4)
+    np.testing.assert_allclose(losses.cpu().numpy()[:-1], want_l, rtol=LOSS_RTOL, atol=1e-6)
+    assert_grads_close(read_arena(eng, eng.grads), grads, "%s/%s d=%d B=%d" % (dec, inter, d, B), want32=grads32)
     eng.close()
 
 
