@@ -12,6 +12,7 @@
 // the tables is never written, re-read or re-zeroed.  gqe_materialize_grads() folds the lists into the
 // dense gradient arena for callers that need it (torch.optim compatibility, the DP all-reduce, tests).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1652,6 +1653,32 @@ int gqe_auc_pair_counts(gqe_ctx* ctx, const float* pos, int64_t n_pos, const flo
 
 int gqe_materialize_grads(gqe_ctx* ctx, void* stream) {
   return run_opt(ctx, GQE_OPT_MATERIALIZE, nullptr, 0, 0.f, 0.f, 0.f, 0.f, stream);
+}
+
+// RCCL is bound at run time (dlopen): the library links against the HIP runtime only, and a single-GPU user never
+// needs librccl.  Signature of ncclAllReduce (rccl.h): (sendbuff, recvbuff, count, datatype, op, comm, stream).
+typedef int (*gqe_nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+
+int gqe_allreduce_grads(gqe_ctx* ctx, void* nccl_comm, void* stream) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (!nccl_comm) return fail(ctx, GQE_ERR_ARG, "gqe_allreduce_grads: communicator is NULL");
+  if (!ctx->grads) return fail(ctx, GQE_ERR_STATE, "no gradient arena bound");
+  if (ctx->world > 1 || ctx->shard_world > 1)
+    return fail(ctx, GQE_ERR_STATE, "gqe_allreduce_grads is the dense exchange of replicated tables: not in gqe_set_exchange / gqe_set_shard mode");
+  static gqe_nccl_allreduce_fn allreduce = nullptr;
+  if (!allreduce) {
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(ctx, GQE_ERR_STATE, "cannot load librccl.so: %s", dlerror());
+    allreduce = reinterpret_cast<gqe_nccl_allreduce_fn>(dlsym(h, "ncclAllReduce"));
+    if (!allreduce) return fail(ctx, GQE_ERR_STATE, "librccl.so has no ncclAllReduce");
+  }
+  int rc = run_opt(ctx, GQE_OPT_MATERIALIZE, nullptr, 0, 0.f, 0.f, 0.f, 0.f, stream);   // row lists -> dense gradient
+  if (rc != GQE_OK) return rc;
+  const int nccl_float32 = 7, nccl_sum = 0;   // ncclDataType_t / ncclRedOp_t (rccl.h)
+  const int nr = allreduce(ctx->grads, ctx->grads, (size_t)ctx->n_arena, nccl_float32, nccl_sum, nccl_comm, reinterpret_cast<hipStream_t>(stream));
+  if (nr != 0) return fail(ctx, GQE_ERR_HIP, "ncclAllReduce failed with ncclResult_t %d", nr);
+  return GQE_OK;
 }
 
 int gqe_adam_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, float lr, float beta1, float beta2, float eps, void* stream) {

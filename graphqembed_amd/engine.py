@@ -92,6 +92,7 @@ SYMBOLS = OrderedDict([
     ("gqe_auc_pair_counts", (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, _P])),
     ("gqe_forward", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P])),
     ("gqe_margin_fwd_bwd", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P, _P, _P])),
+    ("gqe_allreduce_grads", (C.c_int, [_P, _P, _P])),
     ("gqe_adam_step", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P])),
     ("gqe_sgd_step", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, C.c_float, _P])),
     ("gqe_zero_grads", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, _P])),
@@ -479,6 +480,11 @@ class Engine(object):
         """step <= 0 in the prepared segments: libgqe keeps the per-tensor Adam step counters."""
         self._check(self.lib.gqe_adam_step(self.ctx, pa["arr"], pa["n"], lr, betas[0], betas[1], eps,
                                            stream if stream is not None else self._stream()))
+
+    def allreduce_grads(self, nccl_comm):
+        """gqe_allreduce_grads: lists -> dense gradient arena, then ncclAllReduce (RCCL) over ``nccl_comm`` (an
+        ncclComm_t as an integer / c_void_p, e.g. from parallel.RcclComm)."""
+        self._check(self.lib.gqe_allreduce_grads(self.ctx, C.c_void_p(int(nccl_comm)), self._stream()))
 
     def materialize(self):
         """Fold pending per-row gradient lists into the dense gradient arena (gqe_materialize_grads)."""

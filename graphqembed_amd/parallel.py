@@ -91,6 +91,46 @@ def exchange_gradients(flat_grads, dist, engine=None):
     return flat_grads
 
 
+class RcclComm(object):
+    """An RCCL communicator of the library's own (for gqe_allreduce_grads): ncclGetUniqueId on rank 0, the id handed to
+    the other ranks through ``torch.distributed`` (or nothing for a single rank), ncclCommInitRank on every rank."""
+
+    def __init__(self, rank=0, world=1, dist=None, device=None):
+        import ctypes as C
+        import torch
+        self._C = C
+        self.lib = C.CDLL("librccl.so")
+        uid = (C.c_char * 128)()
+        if rank == 0:
+            rc = self.lib.ncclGetUniqueId(C.byref(uid))
+            if rc != 0:
+                raise RuntimeError("ncclGetUniqueId failed: %d" % rc)
+        if world > 1:
+            if dist is None:
+                raise ValueError("RcclComm(world > 1) needs torch.distributed to hand out the unique id")
+            t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=device if dist.get_backend() == "nccl" else "cpu")
+            dist.broadcast(t, 0)
+            uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
+
+        class _Id(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        self.comm = C.c_void_p()
+        self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _Id, C.c_int]
+        rc = self.lib.ncclCommInitRank(C.byref(self.comm), world, _Id(bytes(uid)), rank)
+        if rc != 0:
+            raise RuntimeError("ncclCommInitRank failed: %d" % rc)
+
+    @property
+    def handle(self):
+        return self.comm.value
+
+    def close(self):
+        if self.comm:
+            self.lib.ncclCommDestroy.argtypes = [self._C.c_void_p]
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
 # ---- row-sharded data parallelism ("owner computes") ---------------------------------------------------------
 def shard_rows(n_rows, world):
     """Local rows of a table of ``n_rows`` global rows: the same on every rank (the last ranks' tails are padding)."""

@@ -270,6 +270,12 @@ int gqe_shard_plan(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
 int gqe_shard_serve(gqe_ctx* ctx, const int32_t* requests, int64_t n, float* rows_out, void* stream);   /* device pointers */
 int gqe_shard_link(gqe_ctx* ctx, const int32_t* requests, int64_t n, void* stream);
 
+/* The dense exchange named by the north star, as one call: fold the row-gradient lists into the dense gradient arena
+ * (gqe_materialize_grads) and sum the arena over the ranks of `nccl_comm` (an ncclComm_t of RCCL, created by the caller:
+ * ncclGetUniqueId / ncclCommInitRank) with ncclAllReduce on `stream`.  Sits between gqe_margin_fwd_bwd and the
+ * optimiser step (train_helpers.py:78-79).  librccl.so is loaded on first use (dlopen); replicated tables only. */
+int gqe_allreduce_grads(gqe_ctx* ctx, void* nccl_comm, void* stream);
+
 /* replaces: optimizer.step() + optimizer.zero_grad() for torch.optim.Adam
  * (bio/train.py:62, train_helpers.py:50,79): one fused pass p,g,m,v -> p,m,v and g := 0
  * over the listed segments only. */

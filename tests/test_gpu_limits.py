@@ -242,3 +242,35 @@ def test_load_state_dict_settles_deferred_steps_first():
     model.sync()
     for k, v in model.state_dict().items():
         assert torch.equal(v, sd[k]), k
+
+
+def test_allreduce_grads_entry_point_over_rccl():
+    """gqe_allreduce_grads (the dense exchange the north star names, as one library call): lists folded into the dense
+    arena + ncclAllReduce over an RCCL communicator.  One GPU here, so the communicator has one rank (the sum is the
+    identity) — what is checked is the entry point itself: librccl bound at run time, the call enqueued on the caller's
+    stream, the gradient afterwards equal to the materialised gradient, and the optimiser step still consuming it."""
+    import torch
+    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, read_arena, toy_batch
+    from graphqembed_amd import parallel
+    from graphqembed_amd.tensorize import pack_margin_batches
+    rng = np.random.RandomState(6)
+    d = 64
+    params = random_params(rng, d, "bilinear-diag", "min", TOY_SIZES, TOY_KINDS)
+    a, b = engine_from_params(params, d, "bilinear-diag", "min"), engine_from_params(params, d, "bilinear-diag", "min")
+    comm = parallel.RcclComm(0, 1)
+    t, g, anc = toy_batch(rng, "3-inter", 100)
+    for eng in (a, b):
+        plan = plan_for(eng, "3-inter", TOY_FORMULAS["3-inter"])
+        descs, idx, n = pack_margin_batches([(plan, t, g, anc, 1.0, 1.0)])
+        eng.margin_fwd_bwd(descs, idx, n)
+    a.allreduce_grads(comm.handle)
+    ga, gb = read_arena(a, a.grads), read_arena(b, b.grads)
+    for k in ga:
+        scale = max(1e-12, float(np.abs(gb[k]).max()))
+        np.testing.assert_allclose(ga[k], gb[k], rtol=0, atol=2e-5 * scale, err_msg=k)      # (atomics order differs between engines)
+    a.adam_step(plan.touched)
+    a.materialize()
+    assert float(a.grads.abs().max()) == 0.0
+    comm.close()
+    a.close()
+    b.close()
