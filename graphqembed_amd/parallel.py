@@ -100,23 +100,26 @@ class RcclComm(object):
         import torch
         self._C = C
         self.lib = C.CDLL("librccl.so")
-        uid = (C.c_char * 128)()
+
+        class _Id(C.Structure):                     # ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank
+            _fields_ = [("internal", C.c_ubyte * 128)]
+        uid = _Id()
         if rank == 0:
+            self.lib.ncclGetUniqueId.argtypes = [C.POINTER(_Id)]
             rc = self.lib.ncclGetUniqueId(C.byref(uid))
             if rc != 0:
                 raise RuntimeError("ncclGetUniqueId failed: %d" % rc)
         if world > 1:
             if dist is None:
                 raise ValueError("RcclComm(world > 1) needs torch.distributed to hand out the unique id")
-            t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=device if dist.get_backend() == "nccl" else "cpu")
+            t = torch.tensor(list(uid.internal), dtype=torch.uint8, device=device if dist.get_backend() == "nccl" else "cpu")
             dist.broadcast(t, 0)
-            uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
-
-        class _Id(C.Structure):
-            _fields_ = [("internal", C.c_char * 128)]
+            for i, v in enumerate(t.cpu().tolist()):
+                uid.internal[i] = v
         self.comm = C.c_void_p()
         self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _Id, C.c_int]
-        rc = self.lib.ncclCommInitRank(C.byref(self.comm), world, _Id(bytes(uid)), rank)
+        self.lib.ncclCommInitRank.restype = C.c_int
+        rc = self.lib.ncclCommInitRank(C.byref(self.comm), world, uid, rank)
         if rc != 0:
             raise RuntimeError("ncclCommInitRank failed: %d" % rc)
 
