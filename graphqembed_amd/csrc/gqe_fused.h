@@ -258,13 +258,23 @@ __device__ __forceinline__ void rows_issue_bag(RowSet<NC>& rs, const TileEnv& e,
     if (row >= 0) {
       p0 = ptr[row];
       len = ptr[row + 1] - p0;
+      // the word rows are requested BU at a time (all loads of a group in flight before the first add; the adds keep
+      // the word order, so the sum is the same as a one-by-one loop's): a post has 5-30 words, one dependent HBM round
+      // trip per word would put ~17 of them on the tile's critical path
+      constexpr int BU = NC <= 2 ? 8 : 4;
       for (int c0 = 0; c0 < len; c0 += 64) {
         const int m = min(64, len - c0);
         const int wid = (e.lane < m) ? ids[p0 + c0 + e.lane] : 0;
-        for (int k = 0; k < m; ++k) {
-          const int w = __builtin_amdgcn_readlane(wid, k);
-          const Vec<NC> v = vload<NC>(e.params + table + (size_t)w * e.d, e.d, e.lane);
-          VEC_OP(acc, acc.v[c] + v.v[c]);
+        for (int k0 = 0; k0 < m; k0 += BU) {
+          Vec<NC> v[BU];
+#pragma unroll
+          for (int u = 0; u < BU; ++u) {
+            const int w = __builtin_amdgcn_readlane(wid, min(k0 + u, m - 1));
+            v[u] = vload<NC>(e.params + table + (size_t)w * e.d, e.d, e.lane);
+          }
+#pragma unroll
+          for (int u = 0; u < BU; ++u)
+            if (k0 + u < m) VEC_OP(acc, acc.v[c] + v[u].v[c]);
         }
       }
       const float inv = 1.f / (float)len;

@@ -51,7 +51,10 @@ class TensorizedTrainer(object):
         Data parallel: pass ``dist`` (torch.distributed), ``rank``, ``world`` and build the model /
         Engine with the same rank and world.  Every rank draws the same formula per batch, trains on slice
         ``it*world + rank`` of it with loss weight n_rank / n_all_ranks, and the gradients are exchanged between the
-        margin launch and the optimiser step (parallel.exchange_sparse, or the dense all-reduce for bag modes)."""
+        margin launch and the optimiser step (parallel.exchange_sparse, or the dense all-reduce for bag modes).
+        With an Engine built with ``shard=(rank, world)`` (row-sharded tables, owner-computes Adam) the trainer drives
+        the row-sharded protocol instead: ``plan_of(formula)`` must then return the FormulaPlan on the engine's (local)
+        layout, and ``optimizer.step()`` steps the rank's own shards."""
         self.model = model_or_engine
         self.opt = optimizer
         self.types = list(pools_by_type.keys())
@@ -69,6 +72,10 @@ class TensorizedTrainer(object):
         if self.world > 1 and (self.dist is None or self.engine is None):
             raise Exception("data-parallel training needs dist= and an Engine (model.engine or engine=)")
         self._slab = 0
+        self.plan_of = plan_of
+        self.sharded = self.engine is not None and getattr(self.engine, "shard_world", 1) > 1
+        if self.sharded and plan_of is None:
+            raise Exception("row-sharded training needs plan_of(formula) -> FormulaPlan on the engine's layout")
         self.ema_loss = None
         self.iterations = 0
         self.queries_seen = 0
@@ -102,6 +109,8 @@ class TensorizedTrainer(object):
     def step(self, it, edge_conv=True):
         """One iteration: sample on the host, one grouped fused launch, one fused optimiser pass."""
         items = self.items(it, edge_conv)
+        if self.sharded:
+            return self._sharded_step(items)
         if self.world > 1 and self.engine.sparse_exchange:
             slab = sum((2 + x[3].shape[0]) * self.B for x in items)     # the most entries any rank can produce
             if slab != self._slab:
@@ -117,6 +126,25 @@ class TensorizedTrainer(object):
         self.iterations += 1
         self.queries_seen += sum(len(x[1]) for x in items)
         return losses
+
+    def _sharded_step(self, items):
+        """Row-sharded tables: plan the iteration (sort its index feed by owner, tell the owners), fetch the rows, one
+        grouped fused launch on the fetched rows, contributions back to the owners, Adam on the own shards."""
+        packed = [(self.plan_of(f), t, ng, a, w, m) for (f, t, ng, a, w, m) in items]
+        descs, idx, _ = pack_margin_batches(packed)
+        ps = parallel.shard_prepare(self.engine, self.dist, descs, idx)
+        parallel.shard_fetch(self.engine, self.dist, ps)
+        self.engine.run_margin(ps)
+        parallel.shard_exchange(self.engine, self.dist, ps)
+        if hasattr(self.model, "_mark_touched"):
+            for p in packed:
+                self.model._mark_touched(p[0].touched)
+        else:
+            self.model.touched = getattr(self.model, "touched", set()) | set().union(*[p[0].touched for p in packed])
+        self.opt.step()
+        self.iterations += 1
+        self.queries_seen += sum(len(x[1]) for x in items)
+        return ps["losses"]
 
     def run(self, max_iter, burn_in=0, log_every=100, logger=None):
         t0 = time.time()
