@@ -178,7 +178,7 @@ class Workload(object):
                     plans[f] = FormulaPlan(f, eng.layout, self.inter)
                 packed.append((plans[f], t, ng, a, w, m))
             descs, idx, _ = pack_margin_batches(packed)
-            if eng.shard_world > 1:                                # sort the feed by owner, tell the owners (once per pre-sampled iteration)
+            if eng.sharded:                                        # sort the feed by owner, tell the owners (once per pre-sampled iteration)
                 ps = parallel.shard_prepare(eng, dist, descs, idx)
             else:
                 ps = eng.prepare_margin(descs, torch.from_numpy(idx).to(eng.device))

@@ -105,6 +105,7 @@ struct gqe_ctx {
   // row-sharded data parallelism (gqe_set_shard): the registered tables are this rank's shards (local row i = global
   // row i * world + rank); rows are fetched from / contributions sent to their owners by the host's transport
   int shard_rank = 0, shard_world = 1;
+  bool shard_on = false;  // gqe_set_shard was called (world = 1 is the degenerate case: this rank owns every row)
   bool shard_sent = false;   // a margin call's contributions sit in the send buffer (not yet linked by their owners)
   std::vector<int> shard_tables;  // tables that margin call named (every rank runs the same formulas: these receive lists)
   bool dense_dirty = false;  // the dense gradient of some table may be non-zero (after materialize)
@@ -251,7 +252,7 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
     L.max_entries = (int64_t)align_up((size_t)slab_entries(ctx, L.max_entries, sp.n < 0 ? 0 : sp.total), 64) * ctx->world;
   }
   L.shard_cap_send = L.shard_cap_recv = 0;
-  if (ctx->shard_world > 1) {
+  if (ctx->shard_on) {
     // a rank requests at most one row per index of a call; in the worst case every rank's requests land on one owner.
     // The contribution entries that owner receives are the ctx's entry space (the lists link into it); it doubles as
     // the buffer the served rows are gathered into (rows are served before the fused kernel, contributions arrive after)
@@ -273,7 +274,7 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
   L.ring_off = L.last_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
   L.total = L.ring_off + align_up(sizeof(float) * 2 * GQE_LAZY_TABLES * GQE_LAZY_RING, 256);
   L.shard_req_send = L.shard_req_recv = L.shard_fetch = L.shard_csend = 0;
-  if (ctx->shard_world > 1) {
+  if (ctx->shard_on) {
     L.shard_req_send = L.total;
     L.shard_req_recv = L.shard_req_send + align_up(sizeof(int32_t) * (size_t)L.shard_cap_send, 256);
     L.shard_fetch = L.shard_req_recv + align_up(sizeof(int32_t) * (size_t)L.shard_cap_recv, 256);
@@ -632,7 +633,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     if (slab_entries(ctx, slab, sp.total) * ctx->world > L.max_entries)
       return fail(ctx, GQE_ERR_WORKSPACE, "gradient contribution buffer too small for %d ranks x %lld entries", ctx->world, (long long)slab);
   }
-  const bool shard = ctx->shard_world > 1;
+  const bool shard = ctx->shard_on;
   if (shard) {
     if (!idx_on_device) return fail(ctx, GQE_ERR_ARG, "row-sharded mode: the index feed is the device-resident position feed of gqe_shard_plan");
     if (!ctx->bags.empty()) return fail(ctx, GQE_ERR_STATE, "row-sharded mode does not support bag (EmbeddingBag) tables");
@@ -1070,7 +1071,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
   };
   oa.mode = mode;
   oa.lists = lists;
-  oa.sorted = ctx->world > 1 || ctx->shard_world > 1;  // replicas / reruns must sum a row's contributions in the same order
+  oa.sorted = ctx->world > 1 || ctx->shard_on;  // replicas / reruns must sum a row's contributions in the same order
   // the FLUSH pass only replays deferred steps: it must neither read nor re-zero a materialised dense gradient
   // that is still waiting for its optimiser step
   oa.dense_tables = !flush && (ctx->dense_dirty || mode == GQE_OPT_ZERO);
@@ -1435,7 +1436,7 @@ int gqe_set_exchange(gqe_ctx* ctx, int32_t rank, int32_t world) {
   if (!ctx) return GQE_ERR_ARG;
   if (world < 1 || world > 1024 || rank < 0 || rank >= world) return fail(ctx, GQE_ERR_ARG, "need 0 <= rank < world <= 1024, got rank %d world %d", rank, world);
   if (ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_set_exchange must precede gqe_workspace_bytes / gqe_bind_workspace");
-  if (ctx->shard_world > 1 && world > 1) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard and gqe_set_exchange are mutually exclusive");
+  if (ctx->shard_on && world > 1) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard and gqe_set_exchange are mutually exclusive");
   ctx->rank = rank;
   ctx->world = world;
   return GQE_OK;
@@ -1461,17 +1462,18 @@ int gqe_set_shard(gqe_ctx* ctx, int32_t rank, int32_t world) {
   if (!ctx) return GQE_ERR_ARG;
   if (world < 1 || world > 1024 || rank < 0 || rank >= world) return fail(ctx, GQE_ERR_ARG, "need 0 <= rank < world <= 1024, got rank %d world %d", rank, world);
   if (ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard must precede gqe_workspace_bytes / gqe_bind_workspace");
-  if (ctx->world > 1 && world > 1) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard and gqe_set_exchange are mutually exclusive");
-  if (world > 1 && (int)ctx->tables.size() > GQE_LAZY_TABLES) return fail(ctx, GQE_ERR_ARG, "row-sharded mode supports at most %d tables", GQE_LAZY_TABLES);
+  if (ctx->world > 1) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard and gqe_set_exchange are mutually exclusive");
+  if ((int)ctx->tables.size() > GQE_LAZY_TABLES) return fail(ctx, GQE_ERR_ARG, "row-sharded mode supports at most %d tables", GQE_LAZY_TABLES);
   ctx->shard_rank = rank;
   ctx->shard_world = world;
+  ctx->shard_on = true;
   return GQE_OK;
 }
 
 int gqe_shard_layout(gqe_ctx* ctx, gqe_shard_buffers* out) {
   if (!ctx || !out) return GQE_ERR_ARG;
   if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
-  if (ctx->shard_world < 2) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard(world > 1) has not been called");
+  if (!ctx->shard_on) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard has not been called");
   const Layout& L = ctx->lay;
   out->req_send = (int64_t)L.shard_req_send;
   out->req_recv = (int64_t)L.shard_req_recv;
@@ -1487,7 +1489,7 @@ int gqe_shard_layout(gqe_ctx* ctx, gqe_shard_buffers* out) {
 int gqe_shard_plan(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx, int32_t with_negatives,
                    int32_t* positions, int32_t* requests, int64_t* send_counts) {
   if (!ctx) return GQE_ERR_ARG;
-  if (ctx->shard_world < 2) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard(world > 1) has not been called");
+  if (!ctx->shard_on) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard has not been called");
   if (!batches || n_batches < 1 || n_batches > GQE_MAX_BATCHES || !idx || n_idx < 1 || !positions || !requests || !send_counts)
     return fail(ctx, GQE_ERR_ARG, "gqe_shard_plan: bad arguments");
   const int W = ctx->shard_world;
@@ -1540,7 +1542,7 @@ int gqe_shard_plan(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
 int gqe_shard_serve(gqe_ctx* ctx, const int32_t* requests, int64_t n, float* rows_out, void* stream) {
   if (!ctx) return GQE_ERR_ARG;
   if (!ctx->ws || !ctx->params) return fail(ctx, GQE_ERR_STATE, "arena / workspace not bound");
-  if (ctx->shard_world < 2) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard(world > 1) has not been called");
+  if (!ctx->shard_on) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard has not been called");
   if (n < 0 || n > ctx->lay.shard_cap_recv || (n > 0 && (!requests || !rows_out))) return fail(ctx, GQE_ERR_ARG, "gqe_shard_serve: bad arguments");
   if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "row-sharded mode: received contributions are still pending (step first)");
   GqeShardTabs t;
@@ -1557,7 +1559,7 @@ int gqe_shard_serve(gqe_ctx* ctx, const int32_t* requests, int64_t n, float* row
 int gqe_shard_link(gqe_ctx* ctx, const int32_t* requests, int64_t n, void* stream) {
   if (!ctx) return GQE_ERR_ARG;
   if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
-  if (ctx->shard_world < 2) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard(world > 1) has not been called");
+  if (!ctx->shard_on) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard has not been called");
   if (n < 0 || n > ctx->lay.shard_cap_recv || (n > 0 && !requests)) return fail(ctx, GQE_ERR_ARG, "gqe_shard_link: bad arguments");
   if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "row-sharded mode: the previous step's contributions are still linked (step first)");
   const Layout& L = ctx->lay;
@@ -1663,7 +1665,7 @@ int gqe_allreduce_grads(gqe_ctx* ctx, void* nccl_comm, void* stream) {
   if (!ctx) return GQE_ERR_ARG;
   if (!nccl_comm) return fail(ctx, GQE_ERR_ARG, "gqe_allreduce_grads: communicator is NULL");
   if (!ctx->grads) return fail(ctx, GQE_ERR_STATE, "no gradient arena bound");
-  if (ctx->world > 1 || ctx->shard_world > 1)
+  if (ctx->world > 1 || ctx->shard_on)
     return fail(ctx, GQE_ERR_STATE, "gqe_allreduce_grads is the dense exchange of replicated tables: not in gqe_set_exchange / gqe_set_shard mode");
   static gqe_nccl_allreduce_fn allreduce = nullptr;
   if (!allreduce) {

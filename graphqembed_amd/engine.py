@@ -223,7 +223,8 @@ class Engine(object):
         if self.sparse_exchange:
             self._check(self.lib.gqe_set_exchange(self.ctx, self.rank, self.world))
         self.shard_rank, self.shard_world = (int(shard[0]), int(shard[1])) if shard else (0, 1)
-        if self.shard_world > 1:
+        self.sharded = shard is not None             # world = 1 is allowed: the degenerate case, every row owned by this rank
+        if self.sharded:
             self._check(self.lib.gqe_set_shard(self.ctx, self.shard_rank, self.shard_world))
         self._shard_views = None
         if lazy_adam:

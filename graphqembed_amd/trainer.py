@@ -73,7 +73,7 @@ class TensorizedTrainer(object):
             raise Exception("data-parallel training needs dist= and an Engine (model.engine or engine=)")
         self._slab = 0
         self.plan_of = plan_of
-        self.sharded = self.engine is not None and getattr(self.engine, "shard_world", 1) > 1
+        self.sharded = self.engine is not None and getattr(self.engine, "sharded", False)
         if self.sharded and plan_of is None:
             raise Exception("row-sharded training needs plan_of(formula) -> FormulaPlan on the engine's layout")
         self.ema_loss = None

@@ -260,7 +260,7 @@ typedef struct {
   int64_t contrib_send, contrib_recv; /* float contributions of my batch / contributions for my rows               */
   int64_t cap_send, cap_recv;         /* capacities in entries (rows): one rank's feed / what one owner can receive */
 } gqe_shard_buffers;
-int gqe_set_shard(gqe_ctx* ctx, int32_t rank, int32_t world);   /* before gqe_workspace_bytes */
+int gqe_set_shard(gqe_ctx* ctx, int32_t rank, int32_t world);   /* before gqe_workspace_bytes; world = 1: every row is this rank's */
 int gqe_shard_layout(gqe_ctx* ctx, gqe_shard_buffers* out);     /* after gqe_bind_workspace */
 /* idx: HOST index feed of GLOBAL table rows laid out as gqe_batch describes (with_negatives: margin layout).  Outputs
  * (host): positions[n_idx] — the feed to hand to gqe_margin_fwd_bwd / gqe_forward (device copy); requests[n_idx] — grouped

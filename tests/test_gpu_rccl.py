@@ -1,0 +1,91 @@
+"""-m gpu: the data-parallel code paths over the REAL transport — torch.distributed's ``nccl`` backend, which is RCCL on
+ROCm.  A test box has one GPU, so the process group has one rank: every collective degenerates to a copy, but it is
+RCCL that executes it, with the same calls, dtypes, split sizes, in-place views of the workspace and stream ordering
+the N-GPU run issues (the 2-rank tests use gloo, which stages through the host and accepts things RCCL may not)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from graphqembed_amd import parallel
+    from graphqembed_amd.tensorize import pack_forward_batches, pack_margin_batches
+    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, read_arena, toy_batch
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    assert dist.get_backend() == "nccl"
+    rng = np.random.RandomState(4)
+    d, dec, inter = 64, "bilinear-diag", "min"
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
+    mix = [("1-chain", 1.0), ("2-inter", 0.5), ("3-inter_chain", 0.5), ("3-chain", 0.2)]
+    batches = [(q,) + toy_batch(rng, q, 96, hub=(q == "2-inter")) + (wgt,) for q, wgt in mix]
+    ref = engine_from_params(params, d, dec, inter)                       # no exchange at all
+    engines = {"sharded": engine_from_params(params, d, dec, inter, shard=(0, 1)),
+               "sparse": engine_from_params(params, d, dec, inter), "dense": engine_from_params(params, d, dec, inter)}
+
+    def packed_for(eng):
+        return [(plan_for(eng, q, TOY_FORMULAS[q]), t, g, a, wgt, 1.0) for (q, t, g, a, wgt) in batches]
+    descs, idx, n_sc = pack_margin_batches(packed_for(ref))
+    ref_losses, _, _ = ref.margin_fwd_bwd(descs, idx, n_sc)
+    keys = set().union(*[p[0].touched for p in packed_for(ref)])
+    want = read_arena(ref, ref.grads)
+    # ---- row-sharded protocol over RCCL: counts + requests + rows + contributions by all_to_all_single, small tensors all-reduced
+    eng = engines["sharded"]
+    descs, idx, _ = pack_margin_batches(packed_for(eng))
+    ps = parallel.shard_prepare(eng, dist, descs, idx)
+    assert ps["n_recv"] == ps["n_send"] == len(idx)
+    parallel.shard_fetch(eng, dist, ps)
+    eng.run_margin(ps)
+    parallel.shard_exchange(eng, dist, ps)
+    torch.cuda.synchronize()
+    assert torch.allclose(ps["losses"], ref_losses, rtol=1e-6, atol=1e-7)
+    got = read_arena(eng, eng.grads)
+    for k in want:
+        scale = max(1e-12, float(np.abs(want[k]).max()))
+        np.testing.assert_allclose(got[k], want[k], rtol=0, atol=2e-5 * scale, err_msg="sharded " + k)
+    t, g, a = toy_batch(rng, "3-inter", 50)
+    descs_f, idx_f, n_f = pack_forward_batches([(plan_for(eng, "3-inter", TOY_FORMULAS["3-inter"]), t, a)])
+    psf = parallel.shard_prepare(eng, dist, descs_f, idx_f, with_negatives=False)
+    eng.adam_step(keys)
+    ref.adam_step(keys)
+    sf = parallel.shard_forward(eng, dist, psf, n_f)
+    descs_r, idx_r, _ = pack_forward_batches([(plan_for(ref, "3-inter", TOY_FORMULAS["3-inter"]), t, a)])
+    assert torch.allclose(sf, ref.forward(descs_r, idx_r, n_f), rtol=1e-5, atol=1e-6)
+    # ---- replicated tables: the slab all-gather (in place, on a view of the workspace) needs exchange mode with world > 1 to
+    # exist at all, so with one rank what is exercised is the dense form: lists -> arena -> RCCL all-reduce of the arena
+    eng = engines["dense"]
+    descs, idx, n_sc = pack_margin_batches(packed_for(eng))
+    eng.margin_fwd_bwd(descs, idx, n_sc)
+    parallel.exchange_gradients(eng.grads, dist, engine=eng)
+    got = read_arena(eng, eng.grads)
+    for k in want:
+        scale = max(1e-12, float(np.abs(want[k]).max()))
+        np.testing.assert_allclose(got[k], want[k], rtol=0, atol=2e-5 * scale, err_msg="dense " + k)
+    # ... and in-place all_gather_into_tensor on a workspace view with the split this rank's slab would have
+    buf = torch.arange(4096, dtype=torch.float32, device="cuda").view(64, 64)
+    dist.all_gather_into_tensor(buf, buf[0:64])
+    torch.cuda.synchronize()
+    assert float(buf[63, 63]) == 4095.0
+    with open(os.path.join(out_dir, "ok"), "w") as f:
+        f.write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+    for e in list(engines.values()) + [ref]:
+        e.close()
+
+
+def test_exchange_paths_over_rccl_single_rank(tmp_path):
+    port = 29150 + os.getpid() % 40
+    mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(tmp_path / "ok")
