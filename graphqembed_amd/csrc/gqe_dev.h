@@ -20,6 +20,7 @@
 
 #define GQE_LAUNCH_BATCHES 16  // batches per fused launch: their dynamic descriptors travel as kernel arguments
 #define GQE_DEFAULT_FORMULAS 2048  // default capacity of the device formula-descriptor cache (gqe_set_limits); LRU beyond
+#define GQE_NT_STREAM_BYTES (192ll << 20)  // optimiser pass: p + m + v of the stepped tables above this -> non-temporal policy
 #define GQE_DEFAULT_TENSORS 256    // default number of distinct parameter tensors the optimiser can be asked to step
 #define GQE_MAX_JOBS 8         // deferred matrix-gradient jobs one batch can generate
 #define GQE_MAX_BAGS 4         // tables whose rows are bags (nn.EmbeddingBag modes)
@@ -191,6 +192,7 @@ struct GqeOptArgs {
   const GqeActSeg* act;  // table form of coef / active (NULL: kernel-argument form)
   int n_act;
   bool lazy;          // tables carry per-row step counts (GqeLazyArgs)
+  bool nt;            // stream p / m / v of the tables with the non-temporal policy (tables larger than the Infinity Cache)
   GqeLazyArgs lz;
   hipStream_t stream;
 };

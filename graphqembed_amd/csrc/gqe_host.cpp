@@ -1070,6 +1070,13 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     return GQE_OK;
   };
   oa.mode = mode;
+  {
+    // the bytes of p, m, v the pass streams through the tables it steps: beyond the Infinity Cache -> non-temporal policy
+    long long stream = 0;
+    for (size_t ui = 0; ui < nu; ++ui)
+      if (ustep[ui] && ctx->universe[ui].is_table) stream += 12ll * ctx->universe[ui].numel;
+    oa.nt = mode == GQE_OPT_ADAM && stream > GQE_NT_STREAM_BYTES;
+  }
   oa.lists = lists;
   oa.sorted = ctx->world > 1 || ctx->shard_on;  // replicas / reruns must sum a row's contributions in the same order
   // the FLUSH pass only replays deferred steps: it must neither read nor re-zero a materialised dense gradient
