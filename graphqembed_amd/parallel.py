@@ -205,25 +205,29 @@ def shard_prepare(engine, dist, descs, idx, with_negatives=True):
     ps = {"arr": engine.make_batches(descs), "n": len(descs), "idx": pos_dev, "idx_ptr": __import__("ctypes").c_void_p(pos_dev.data_ptr()),
           "n_idx": int(pos_dev.numel()), "queries": total,
           "losses": torch.zeros(len(descs) + 1, dtype=torch.float32, device=dev),
-          "send_counts": send_counts, "recv_counts": recv_counts, "n_send": n_send, "n_recv": n_recv, "req_recv": req_recv}
+          "send_counts": send_counts, "recv_counts": recv_counts, "n_send": n_send, "n_recv": n_recv, "req_recv": req_recv,
+          # the views the per-step collectives move (sliced once: the step itself should cost no Python beyond the calls)
+          "workspace": engine.workspace, "rows_send": v["rows_send"][:n_recv], "fetched": v["fetched"][:n_send],
+          "contrib_send": v["contrib_send"][:n_send], "contrib_recv": v["contrib_recv"][:n_recv],
+          "dense": [engine.grads[off:off + n] for off, n in engine.dense_spans()]}
     return ps
 
 
 def shard_fetch(engine, dist, ps):
     """Serve the rows the other ranks asked this one for, and receive the rows this rank's batch reads."""
-    v = engine.shard_views()
-    engine.shard_serve(ps["req_recv"], ps["n_recv"], v["rows_send"])
-    _all_to_all(dist, v["fetched"][:ps["n_send"]], v["rows_send"][:ps["n_recv"]], ps["send_counts"], ps["recv_counts"])
+    if ps["workspace"] is not engine.workspace:
+        raise RuntimeError("the engine's workspace was re-bound after shard_prepare: prepare the batch again")
+    engine.shard_serve(ps["req_recv"], ps["n_recv"], ps["rows_send"])
+    _all_to_all(dist, ps["fetched"], ps["rows_send"], ps["send_counts"], ps["recv_counts"])
 
 
 def shard_exchange(engine, dist, ps):
     """After the margin launch: every row's gradient contribution goes to the row's owner, which links it onto its
     lists; the relation / Pre / Post gradients (replicated tensors) are summed over the ranks."""
-    v = engine.shard_views()
-    _all_to_all(dist, v["contrib_recv"][:ps["n_recv"]], v["contrib_send"][:ps["n_send"]], ps["recv_counts"], ps["send_counts"])
+    _all_to_all(dist, ps["contrib_recv"], ps["contrib_send"], ps["recv_counts"], ps["send_counts"])
     engine.shard_link(ps["req_recv"], ps["n_recv"])
-    for off, n in engine.dense_spans():
-        dist.all_reduce(engine.grads[off:off + n])
+    for span in ps["dense"]:
+        dist.all_reduce(span)
 
 
 def shard_margin_step(engine, dist, ps, adam=None, lr=0.01, betas=(0.9, 0.999), eps=1e-8):

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""What the row-sharded protocol costs when nothing has to travel: ONE rank over the real nccl (RCCL) backend, so every
+all-to-all / all-reduce is a self-copy executed by RCCL — serve, fetch, fused launch on fetched rows, contributions back,
+link, all-reduce, Adam — against the plain single-GPU step on the same batches.  The difference is the fixed cost of the
+three collectives + two small kernels + one memset per step (launch latencies and host time), i.e. the floor under the
+exchange time of an N-GPU run.   python tools/shard_overhead_bench.py"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.distributed as dist
+import bench
+from graphqembed_amd import parallel, synth
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29877")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+wl = bench.Workload("bio-synth", 128, "bilinear-diag", "min", synth.FULL_MIX, 512)
+for label, shard in (("plain", None), ("row-sharded protocol, 1 rank over RCCL", (0, 1))):
+    eng = wl.engine(shard=shard)
+    prepared = wl.prepare(eng, dist)
+
+    def step(i):
+        ps = prepared[i % wl.n_distinct]
+        if shard:
+            parallel.shard_fetch(eng, dist, ps)
+        eng.run_margin(ps)
+        if shard:
+            parallel.shard_exchange(eng, dist, ps)
+        eng.run_adam(ps["adam"])
+    for i in range(50):
+        step(i)
+    torch.cuda.synchronize()
+    times = []
+    for rep in range(20):
+        t0 = time.perf_counter()
+        for i in range(100):
+            step(50 + rep * 100 + i)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) / 100)
+    t0 = time.perf_counter()                                  # host time alone: enqueue without waiting
+    for i in range(200):
+        step(i)
+    host = (time.perf_counter() - t0) / 200
+    torch.cuda.synchronize()
+    print("%-42s %7.1f us/step (median of 20 x 100 steps), host enqueue %6.1f us/step" % (label, np.median(times) * 1e6, host * 1e6), flush=True)
+    eng.close()
+dist.destroy_process_group()
