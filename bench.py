@@ -20,7 +20,7 @@ timing    = W warm-up steps, then blocks of EXACTLY K steps, each bracketed by b
 value     = whole-job queries/s = K * 4608 * N / median block time (weak scaling: every rank trains its own 4 608
             queries per step; gradients are averaged).
 roofline  = the dominant kernel, the fused Adam pass.  ``achieved`` = the bytes the pass has to move / its mean
-            launch duration (hipEvents recorded by the library on the launch stream, every 4th launch of the timed
+            launch duration (hipEvents recorded by the library on the launch stream, every 16th launch of the timed
             region).  Bytes: 24 B per table parameter (p, m, v read + written; the dense table gradient does not
             exist: row gradients are per-row lists) + 32 B per relation / Pre / Post parameter + 4 B list head per
             table row + (4 d + 8) B per gradient contribution.  ``frac`` is against the 8 TB/s spec,
@@ -276,7 +276,9 @@ class Loop(object):
     def run(self, step, warmup, steps, min_seconds=0.5, max_blocks=400):
         import torch
         eng = self.eng
-        eng.timing_enable(4)                                       # every 4th launch; hipEvent pairs are recycled
+        # hipEvent pairs around every 16th launch of each kernel (recycled).  Denser sampling perturbs what it measures:
+        # every 4th launch cost 4 us of a 88 us step (profiles/r02_experiment_event_stride.log)
+        eng.timing_enable(int(os.environ.get("GQE_BENCH_EVENT_STRIDE", "16")))
         for i in range(warmup):
             step(i)
         self.fence()

@@ -372,6 +372,13 @@ __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t h
   }
 }
 
+// Row-sharded mode: every fetched row owns a slot of the send buffer, and the owner links whatever arrives — a query
+// whose hinge is inactive has to send zeros (the buffer still holds the previous step's contribution there).
+template <int NC>
+__device__ __forceinline__ void sharded_zero(const TileEnv& e, int row) {
+  if (e.sharded && row >= 0) vstore<NC>(e.contrib + (size_t)row * e.d, vzero<NC>(), e.d, e.lane);
+}
+
 template <int NC>
 __device__ __forceinline__ void scatter_row(const TileEnv& e, const GqeBagTable& bags, int bag, int64_t head_base, int role, int r,
                                             const RowSet<NC>& rs, int rr, const Vec<NC>& g, int& old_head) {
@@ -664,6 +671,10 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
           scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0]);
           scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1]);
           scatter_row<NC>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2]);
+        } else {
+          sharded_zero<NC>(e, RT.row[rr]);
+          sharded_zero<NC>(e, RN.row[rr]);
+          sharded_zero<NC>(e, RA[0].row[rr]);
         }
       }
       if (BWD) {
@@ -749,6 +760,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
           vstore<NC>(cur[s] + r * DP, gu, d, lane);
         }
         if (act) scatter_row<NC>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2]);
+        else if (q < B) sharded_zero<NC>(e, RA[0].row[rr]);
       }
       if (BWD) {
         // back through the hops: act_{h+1} = act_h M_h  =>  g_act_h = g_act_{h+1} M_h^T (= M . g per row),
@@ -923,6 +935,9 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
         VEC_OP(gtn, cn * (qv.v[c] * inq - tn.v[c] * inn));
         scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0]);
         scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1]);
+      } else if (q < B) {
+        sharded_zero<NC>(e, RT.row[rr]);
+        sharded_zero<NC>(e, RN.row[rr]);
       }
     }
     GQE_STAMP(5);

@@ -756,9 +756,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   int64_t entry = shard ? 0 : ctx->entries_used;
   if (bwd && shard) {
     if (ctx->shard_sent) return fail(ctx, GQE_ERR_STATE, "row-sharded mode: one gqe_margin_fwd_bwd per optimiser step (send the contributions and gqe_shard_link first)");
-    ctx->shard_sent = true;
-    // contributions of queries whose hinge is inactive are never written: the send buffer must read zero there
-    HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.shard_csend, 0, sizeof(float) * (size_t)n_idx * d, st));
+    ctx->shard_sent = true;   // (queries whose hinge is inactive write zero contributions themselves: no memset)
   }
   if (bwd && ctx->world > 1) {
     // this rank's slab of the gathered entry space; entries that are not pushed (inactive hinge) must read -1
