@@ -317,6 +317,8 @@ def make_step(eng, prepared, dist, exchange, n_distinct, ex_events=None):
     def step(i):
         ps = prepared[i % n_distinct]
         eng.run_margin(ps)
+        if eng.lazy_adam and dist is None:                         # the next iteration's rows ride in this step's row launch
+            eng.lazy_prefetch(prepared[(i + 1) % n_distinct])
         if dist is not None:
             rec = ex_events is not None and (i % 4) == 0
             if rec:

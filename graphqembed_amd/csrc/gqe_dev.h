@@ -138,7 +138,7 @@ struct GqeRowSegs {       // the table rows named by an index feed: segment k = 
                           // (tid -1: skip; -2: the values are list heads of any table — exchanged slabs)
   int n, total;
   int begin[GQE_LAZY_SEGS + 1];  // prefix sums of the counts
-  int idx_begin[GQE_LAZY_SEGS];
+  long long idx_begin[GQE_LAZY_SEGS];  // int32 offset from the launch's idx pointer (64-bit: a launch may span two feeds)
   int8_t tid[GQE_LAZY_SEGS];
 };
 struct GqeRowsArgs {

@@ -93,6 +93,12 @@ struct gqe_ctx {
   const int32_t* feed_idx = nullptr; // ... and where its (device) index feed lives
   int feed_buf = -1;                 // staging buffer holding it (-1: caller's device buffer)
   bool feed_valid = false;           // the pending gradient lists come from exactly that call
+  // gqe_lazy_prefetch: the (device-resident) index feed of the NEXT call, to be caught up by the coming row launch
+  std::vector<SavedFeed> next_feed;
+  const int32_t* next_idx = nullptr;
+  int64_t next_n_idx = 0;
+  const int32_t* caught_idx = nullptr;   // feed whose rows the last optimiser step already brought up to date
+  int64_t caught_n_idx = 0;
   float lz_lr = 0.f, lz_b1 = 0.f, lz_b2 = 0.f, lz_eps = 0.f;  // hyper-parameters the coefficient ring was written with
   bool lz_hyper = false;
   int rank = 0, world = 1;     // gqe_set_exchange: data-parallel replica id / count
@@ -521,7 +527,7 @@ void build_feed(const gqe_ctx* ctx, const gqe_batch* batches, int n_batches, boo
     }
     GqeRowSegs& g = cur.segs;
     const int t = table_of(ctx, table_offset);
-    g.idx_begin[g.n] = (int)idx_begin;
+    g.idx_begin[g.n] = (long long)idx_begin;
     g.tid[g.n] = (int8_t)(lazy_table_ok(ctx, t) ? t : -1);
     g.begin[g.n] = g.total;
     g.total += (int)count;
@@ -703,7 +709,10 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     std::vector<SavedFeed> feed;
     const bool dirty = lazy_any_dirty(ctx);
     if (dirty || bwd) build_feed(ctx, batches, n_batches, bwd, fid, feed);
-    if (dirty) {
+    // (gqe_lazy_prefetch: the previous optimiser step already brought this very feed's rows up to date)
+    const bool caught = idx_on_device && ctx->caught_idx == idx && ctx->caught_n_idx == n_idx;
+    ctx->caught_idx = nullptr;
+    if (dirty && !caught) {
       GqeRowsArgs ra;
       lazy_rows_args(ctx, ra, st);
       ra.idx = d_idx;
@@ -918,6 +927,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     b2 = ctx->lz_b2;
     eps = ctx->lz_eps;
   }
+  if (!flush) ctx->caught_idx = nullptr;   // rows move on: what an earlier step caught up is no longer current
   GqeOptArgs oa;
   oa.lazy = false;
   memset(&oa.lz, 0, sizeof oa.lz);
@@ -1148,7 +1158,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
             memset(&cur, 0, sizeof cur);
           }
           GqeRowSegs& g = cur.segs;
-          g.idx_begin[g.n] = (int)((k * S + n) * d);   // int32 view of the contribution array: the slab's head tail
+          g.idx_begin[g.n] = (long long)((k * S + n) * d);   // int32 view of the contribution array: the slab's head tail
           g.tid[g.n] = -2;
           g.begin[g.n] = g.total;
           g.total += (int)n;
@@ -1179,10 +1189,45 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       if (rc != GQE_OK) return rc;
       rc = timing_begin(ctx, 2, st);
       if (rc != GQE_OK) return rc;
+      bool merged = false;
+      if (ctx->next_idx && feeds.size() == 1 && ctx->next_feed.size() == 1 &&
+          feeds[0].segs.n + ctx->next_feed[0].segs.n <= GQE_LAZY_SEGS) {
+        // gqe_lazy_prefetch, the usual case: rows(t) and rows(t+1) in ONE launch — the next feed's segments are
+        // addressed relative to this feed's pointer
+        GqeRowSegs both = feeds[0].segs;
+        const GqeRowSegs& nx = ctx->next_feed[0].segs;
+        const long long shift = ctx->next_idx - ra.idx;
+        for (int k = 0; k < nx.n; ++k) {
+          both.idx_begin[both.n] = nx.idx_begin[k] + shift;
+          both.tid[both.n] = nx.tid[k];
+          both.begin[both.n] = both.total;
+          both.total += nx.begin[k + 1] - nx.begin[k];
+          both.begin[++both.n] = both.total;
+        }
+        ra.segs = both;
+        HIP_TRY(ctx, gqe_launch_rows(ra));
+        ra.dense_chunks = 0;
+        merged = true;
+        ctx->caught_idx = ctx->next_idx;
+        ctx->caught_n_idx = ctx->next_n_idx;
+      }
       for (const SavedFeed& sf : feeds) {
+        if (merged) break;
         ra.segs = sf.segs;
         HIP_TRY(ctx, gqe_launch_rows(ra));
         ra.dense_chunks = 0;
+      }
+      if (ctx->next_idx && !merged) {
+        // gqe_lazy_prefetch: the rows of the NEXT call ride in the same launches — with-gradient semantics, so that a
+        // row named by both feeds is stepped by whichever entry claims it first; rows of the next feed alone have empty
+        // lists and are simply replayed up to the step count this pass establishes
+        ra.idx = ctx->next_idx;
+        for (const SavedFeed& sf : ctx->next_feed) {
+          ra.segs = sf.segs;
+          HIP_TRY(ctx, gqe_launch_rows(ra));
+        }
+        ctx->caught_idx = ctx->next_idx;
+        ctx->caught_n_idx = ctx->next_n_idx;
       }
       rc = timing_end(ctx, 2, st);
       if (rc != GQE_OK) return rc;
@@ -1250,6 +1295,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       for (size_t t = 0; t < ctx->tables.size(); ++t)
         if (seen[t]) ctx->tables[t].lstep = ctx->adam_steps[ctx->tables[t].offset];  // keeps gqe_set_lazy_adam(1) possible later
   }
+  ctx->next_idx = nullptr;                            // a prefetch declaration holds for one optimiser step
   if (mode != GQE_OPT_ADAM) ctx->feed_valid = false;  // lists were dropped / folded: the saved feed no longer describes them
   // bookkeeping: which lists are consumed now
   bool any_pending = false;
@@ -1428,6 +1474,30 @@ int gqe_set_lazy_adam(gqe_ctx* ctx, int32_t enable) {
     return fail(ctx, GQE_ERR_STATE, "rows still owe Adam steps: call gqe_optimizer_sync before leaving lazy mode");
   }
   ctx->lazy = enable != 0;
+  return GQE_OK;
+}
+
+int gqe_lazy_prefetch(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx, int32_t with_negatives) {
+  if (!ctx) return GQE_ERR_ARG;
+  ctx->next_idx = nullptr;
+  if (!ctx->lazy) return GQE_OK;   // nothing is deferred in eager mode
+  if (!batches || n_batches < 1 || n_batches > GQE_MAX_BATCHES || !idx || n_idx < 1) return fail(ctx, GQE_ERR_ARG, "gqe_lazy_prefetch: bad arguments");
+  if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
+  std::vector<int> fid((size_t)n_batches);
+  ++ctx->call_stamp;
+  for (int bi = 0; bi < n_batches; ++bi) {
+    const gqe_batch& s = batches[bi];
+    if (s.n_queries < 1) return fail(ctx, GQE_ERR_ARG, "batch %d: empty batch", bi);
+    int rc = formula_of(ctx, s, bi, &fid[(size_t)bi]);
+    if (rc != GQE_OK) return rc;
+    const int na = ctx->formulas[(size_t)fid[(size_t)bi]].n_anchors;
+    const int64_t need = s.n_candidates > 0 ? (int64_t)s.idx_offset + (int64_t)na * s.n_queries + s.n_queries + 1 + s.n_candidates
+                                            : (int64_t)s.idx_offset + (int64_t)(na + (with_negatives ? 2 : 1)) * s.n_queries;
+    if (s.idx_offset < 0 || need > n_idx) return fail(ctx, GQE_ERR_ARG, "batch %d: index range exceeds the %lld indices given", bi, (long long)n_idx);
+  }
+  build_feed(ctx, batches, n_batches, with_negatives != 0, fid, ctx->next_feed);
+  ctx->next_idx = idx;
+  ctx->next_n_idx = n_idx;
   return GQE_OK;
 }
 

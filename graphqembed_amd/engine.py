@@ -79,6 +79,7 @@ SYMBOLS = OrderedDict([
     ("gqe_materialize_grads", (C.c_int, [_P, _P])),
     ("gqe_set_lazy_adam", (C.c_int, [_P, C.c_int32])),
     ("gqe_optimizer_sync", (C.c_int, [_P, _P])),
+    ("gqe_lazy_prefetch", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32])),
     ("gqe_set_exchange", (C.c_int, [_P, C.c_int32, C.c_int32])),
     ("gqe_exchange_reserve", (C.c_int, [_P, C.c_int64])),
     ("gqe_export_entries", (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P])),
@@ -469,6 +470,13 @@ class Engine(object):
         self._check(self.lib.gqe_margin_fwd_bwd(self.ctx, ps["arr"], ps["n"], ps["idx_ptr"], ps["n_idx"], 1,
                                                 ps["losses"].data_ptr(), None, None,
                                                 stream if stream is not None else self._stream()))
+
+    def lazy_prefetch(self, ps, with_negatives=True):
+        """Lazy Adam: name the prepared batch the NEXT margin / forward call will run (include/gqe.h,
+        gqe_lazy_prefetch) — call between run_margin and run_adam; the step's row launch then also catches up that
+        batch's rows and the next call skips its own catch-up launch.  No-op in eager mode."""
+        if self.lazy_adam:
+            self._check(self.lib.gqe_lazy_prefetch(self.ctx, ps["arr"], ps["n"], ps["idx_ptr"], ps["n_idx"], 1 if with_negatives else 0))
 
     def prepare_adam(self, keys):
         keys = [k for k in self.layout.entries if k in set(keys)]

@@ -201,9 +201,16 @@ int gqe_materialize_grads(gqe_ctx* ctx, void* stream);
  *
  * gqe_set_lazy_adam(ctx, 1)     switch on (any time no gradients are pending); 0 switches off (sync first)
  * gqe_optimizer_sync(ctx, st)   bring every row up to date — before the caller reads or writes the parameter /
- *                               moment arenas directly (checkpoints, state_dict, tests) */
+ *                               moment arenas directly (checkpoints, state_dict, tests)
+ * gqe_lazy_prefetch(ctx, ..)      optional, between a margin call and its optimiser step: names the DEVICE-resident
+ *                               index feed of the NEXT gqe_margin_fwd_bwd / gqe_forward call (same batch layout rules).
+ *                               The step's row launch then also brings that feed's rows up to date and the next call — if
+ *                               it passes the same device pointer and size — skips its own catch-up launch: one launch
+ *                               over rows(t) U rows(t+1) instead of two.  The feed must not change in between; the
+ *                               declaration holds for one optimiser step.  Results are unchanged (bit-identical). */
 int gqe_set_lazy_adam(gqe_ctx* ctx, int32_t enable);
 int gqe_optimizer_sync(gqe_ctx* ctx, void* stream);
+int gqe_lazy_prefetch(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx, int32_t with_negatives);
 
 /* ---- data-parallel gradient exchange (the reference is single-process) -------------------
  * Replicas exchange the gradients in the form the fused kernel produces them — contribution entries (dim floats

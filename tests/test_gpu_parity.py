@@ -595,6 +595,10 @@ def test_lazy_adam_is_bit_identical_to_the_eager_schedule(dec, inter, d):
     eager = engine_from_params(params, d, dec, inter)
     lazy = engine_from_params(params, d, dec, inter, lazy_adam=True)
     assert lazy.lazy_adam and not eager.lazy_adam
+    # a second lazy engine that names every next batch before the step (gqe_lazy_prefetch): the step's row launch also
+    # catches up the next batch's rows and the next call skips its catch-up launch — same bits
+    ahead = engine_from_params(params, d, dec, inter, lazy_adam=True)
+    schedule = []
     # no 3-inter: its three branches add into the same Pre gradient with atomics, the only order-dependent sum
     # left at one tile per launch — a run-to-run effect that has nothing to do with the optimiser mode
     types = ["1-chain", "2-inter", "2-chain", "3-inter_chain", "3-chain", "3-chain_inter"]
@@ -605,6 +609,7 @@ def test_lazy_adam_is_bit_identical_to_the_eager_schedule(dec, inter, d):
         # phase A: low third of every table; phase B (after 80 steps): upper two thirds; phase C: everything
         lo, hi = (0.0, 0.4) if step < 80 else ((0.35, 1.0) if step < 120 else (0.0, 1.0))
         t, g, a = _disjoint_batch(rng, qt, B, lo, hi)
+        schedule.append((qt, t, g, a))
         outs = []
         for eng in (eager, lazy):
             plan = plan_for(eng, qt, TOY_FORMULAS[qt])
@@ -621,7 +626,20 @@ def test_lazy_adam_is_bit_identical_to_the_eager_schedule(dec, inter, d):
                 descs, idx, n = pack_forward_batches([(plan_for(eng, "2-inter", TOY_FORMULAS["2-inter"]), tt, aa)])
                 sc.append(eng.forward(descs, idx, n).clone())
             assert torch.equal(sc[0], sc[1])
+    # the same schedule on the prefetching engine, batches device-resident (what gqe_lazy_prefetch names is a device feed)
+    prepared = []
+    for (qt, t, g, a) in schedule:
+        plan = plan_for(ahead, qt, TOY_FORMULAS[qt])
+        descs, idx, _ = pack_margin_batches([(plan, t, g, a, 1.0, 1.0)])
+        prepared.append((ahead.prepare_margin(descs, torch.from_numpy(idx).to(ahead.device)), ahead.prepare_adam(plan.touched)))
+    for step, (ps, pa) in enumerate(prepared):
+        ahead.run_margin(ps)
+        if step + 1 < len(prepared) and step % 11 != 7:          # (now and then no declaration: the catch-up launch runs)
+            ahead.lazy_prefetch(prepared[step + 1][0])
+        ahead.run_adam(pa, 0.01)
     torch.cuda.synchronize()
+    assert torch.equal(ahead.params, eager.params) and torch.equal(ahead.exp_avg, eager.exp_avg) and torch.equal(ahead.exp_avg_sq, eager.exp_avg_sq)
+    ahead.close()
     # lazy really was lazy: before the sync its arena differs from the eager one ...
     assert not torch.equal(lazy._params, eager._params)
     # ... and after it (the properties synchronise) everything is bit-identical
