@@ -405,36 +405,44 @@ def measure(wl, args, dist, rank, world, exchange="sparse", lazy=False, steps=No
 
 
 def host_fed(wl, args):
-    """The same schedule driven by the native feeder (gqe_feeder_run): formula draw, wrap-around slice, negative
-    draw and packing on a host core, index feed through the pinned staging ring + side-stream hipMemcpyAsync,
-    launches and the Adam step from C++ — everything inside the timed region (north star)."""
+    """The same schedule driven by the native feeder (gqe_feeder_run): formula draw, wrap-around slice, negative draw and
+    packing on a host core, launches and the Adam step from C++ — everything inside the timed region (SURVEY.md §8f-3,
+    north star).  The index feed reaches the kernels either straight from pinned host memory (default: the kernels
+    read it over PCIe; no copy, no cross-stream dependency) or through the pinned staging ring + hipMemcpyAsync on the
+    library's upload stream (``pinned_hipMemcpyAsync``)."""
     import torch
     from graphqembed_amd.tensorize import FormulaPlan, table_key
-    eng = wl.engine()
-    plist = []
-    for t in wl.types:
-        for p in wl.pools[t]:
-            plist.append((FormulaPlan(p.formula, wl.layout, wl.inter), p))
-    all_rows = {table_key(m): np.arange(1, wl.g.mode_sizes[m] + 1, dtype=np.int32) for m in wl.g.modes}
-    feeder = eng.make_feeder(plist, all_rows, batch_size=wl.B, seed=0)
-    eng.feeder_run(feeder, 0, max(args.warmup, 10))
-    torch.cuda.synchronize()
-    times, it = [], max(args.warmup, 10)
-    while sum(times) < 0.5 and len(times) < 200:
-        t0 = time.perf_counter()
-        losses = eng.feeder_run(feeder, it, args.steps)
+    out = None
+    for feed in ("zero-copy", "copy"):
+        eng = wl.engine()
+        plist = []
+        for t in wl.types:
+            for p in wl.pools[t]:
+                plist.append((FormulaPlan(p.formula, wl.layout, wl.inter), p))
+        all_rows = {table_key(m): np.arange(1, wl.g.mode_sizes[m] + 1, dtype=np.int32) for m in wl.g.modes}
+        feeder = eng.make_feeder(plist, all_rows, batch_size=wl.B, seed=0, feed=feed)
+        eng.feeder_run(feeder, 0, max(args.warmup, 10))
         torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
-        it += args.steps
-    med, blocks = summarize(times, args.steps)
-    n_batches = 1 + sum(2 if "inter" in t else 1 for t in wl.types if t != "1-chain")
-    out = {"value": round(args.steps * n_batches * wl.B / med, 1), "unit": "queries/s", "ms_per_step": round(med * 1e3 / args.steps, 4),
-           "timing": blocks, "final_loss": round(float(losses[n_batches].item()), 6),
-           "note": "gqe_feeder_run: per iteration the host draws a formula per batch (prob ~ pool size), slices it by the "
-                   "reference's wrap-around rule, draws 1-chain negatives, packs the index feed; libgqe uploads it through "
-                   "pinned staging on a side stream while the previous iteration computes"}
-    eng.feeder_destroy(feeder)
-    eng.close()
+        times, it = [], max(args.warmup, 10)
+        while sum(times) < 0.5 and len(times) < 200:
+            t0 = time.perf_counter()
+            losses = eng.feeder_run(feeder, it, args.steps)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+            it += args.steps
+        med, blocks = summarize(times, args.steps)
+        n_batches = 1 + sum(2 if "inter" in t else 1 for t in wl.types if t != "1-chain")
+        res = {"value": round(args.steps * n_batches * wl.B / med, 1), "unit": "queries/s", "ms_per_step": round(med * 1e3 / args.steps, 4),
+               "timing": blocks, "final_loss": round(float(losses[n_batches].item()), 6)}
+        eng.feeder_destroy(feeder)
+        eng.close()
+        if out is None:
+            out = res
+            out["feed"] = "pinned host memory read by the kernels (gqe_feeder_set_feed 1)"
+            out["note"] = ("gqe_feeder_run: per iteration the host draws a formula per batch (prob ~ pool size), slices it by the "
+                           "reference's wrap-around rule, draws 1-chain negatives and packs the index feed into a pinned slot")
+        else:
+            out["pinned_hipMemcpyAsync"] = res
     return out
 
 

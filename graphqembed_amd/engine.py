@@ -101,6 +101,7 @@ SYMBOLS = OrderedDict([
     ("gqe_feeder_destroy", (C.c_int, [_P])),
     ("gqe_feeder_add_pool", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int64, _P, _P, _P, _P])),
     ("gqe_feeder_set_mode_rows", (C.c_int, [_P, C.c_int64, _P, C.c_int64])),
+    ("gqe_feeder_set_feed", (C.c_int, [_P, C.c_int32])),
     ("gqe_feeder_run", (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P])),
     ("gqe_timing_enable", (C.c_int, [_P, C.c_int32])),
     ("gqe_debug_profile", (C.c_int, [_P, _P])),
@@ -528,11 +529,13 @@ class Engine(object):
         self._check(self.lib.gqe_zero_grads(self.ctx, arr, len(keys), self._stream()))
 
     # -- native training feed ---------------------------------------------------------
-    def make_feeder(self, pools_by_plan, mode_rows, batch_size=512, path_weight=0.01, inter_weight=0.005, seed=0):
+    def make_feeder(self, pools_by_plan, mode_rows, batch_size=512, path_weight=0.01, inter_weight=0.005, seed=0, feed="zero-copy"):
         """pools_by_plan: [(FormulaPlan, pool)] with pool.target[n], pool.anchors[k,n], pool.neg[n] or None,
         pool.hard[n] or None (int32 rows); mode_rows: {table key: int32 rows} for 1-chain negatives."""
         h = _P()
         self._check(self.lib.gqe_feeder_create(self.ctx, seed, batch_size, path_weight, inter_weight, C.byref(h)))
+        # "zero-copy": the kernels read each iteration's feed from pinned host memory; "copy": pinned staging + hipMemcpyAsync
+        self._check(self.lib.gqe_feeder_set_feed(h, {"copy": 0, "zero-copy": 1}[feed]))
         for plan, pool in pools_by_plan:
             arr = self.make_batches([plan.batch(1, 0, 0)])
             c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)

@@ -307,6 +307,10 @@ int gqe_feeder_destroy(gqe_feeder* f);
 int gqe_feeder_add_pool(gqe_feeder* f, const gqe_batch* formula, int64_t n, const int32_t* target, const int32_t* anchors,
                         const int32_t* neg, const int32_t* hard);
 int gqe_feeder_set_mode_rows(gqe_feeder* f, int64_t table_offset, const int32_t* rows, int64_t n);
+/* How an iteration's index feed reaches the kernels: 0 = pinned staging ring + hipMemcpyAsync on the library's upload
+ * stream (as gqe_margin_fwd_bwd does for any host feed); 1 (default) = the kernels read the feed straight from pinned host
+ * memory (8 slots, an event every 4 iterations guards their re-use). */
+int gqe_feeder_set_feed(gqe_feeder* f, int32_t mode);
 int gqe_feeder_run(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations, int32_t burn_in, float lr, float beta1,
                    float beta2, float eps, float* losses, void* stream);
 
