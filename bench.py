@@ -78,8 +78,9 @@ def build_layout(g, d, decoder, inter, shard_world=1):
     from graphqembed_amd.parallel import shard_rows
     from graphqembed_amd.tensorize import post_key, pre_key, rel_key, table_key
     layout = ArenaLayout()
-    for m in g.modes:
-        layout.add(table_key(m), (shard_rows(g.table_rows[m], shard_world), d))   # bio/data_utils.py:14-17, reddit/data_utils_new.py:154-158
+    for m in g.modes:                                             # (bag tables — the posts' word table — stay replicated)
+        rows = g.table_rows[m] if m in g.bags else shard_rows(g.table_rows[m], shard_world)
+        layout.add(table_key(m), (rows, d))                       # bio/data_utils.py:14-17, reddit/data_utils_new.py:154-158
     for m in g.relations:                                         # decoders.py:136-140 order
         for (to, name) in g.relations[m]:
             layout.add(rel_key((m, name, to)), (d, d) if decoder == "bilinear" else (d,))
@@ -156,12 +157,14 @@ class Workload(object):
         eng = Engine(self.d, self.decoder, self.inter, layout, max_queries=self.qpi, max_batches=len(self.mix),
                      rank=rank, world=world, lazy_adam=lazy, bags=self.bags, shard=shard)
         init_params(eng, self.d, seed=0 if not shard else 1000 + shard[0])   # replicas start equal; shards are what they are
-        if shard:                                                  # ... but the replicated relation / Pre / Post tensors start equal
-            import torch
+        if shard:                                                  # ... but what is replicated starts equal: relation / Pre / Post
+            import torch                                           # tensors and the bag (word) tables
             gen = torch.Generator(device=eng.device)
             gen.manual_seed(0)
             for off, n in eng.dense_spans():
                 eng.params[off:off + n].uniform_(-0.1, 0.1, generator=gen)
+            for k in eng.bag_keys:
+                eng.layout.view(eng.params, k).normal_(0, 1.0 / self.d, generator=gen)
         return eng
 
     def prepare(self, eng, dist=None):
@@ -395,7 +398,8 @@ def measure(wl, args, dist, rank, world, exchange="sparse", lazy=False, steps=No
         out["ranks_seen"] = int(ones.item())
         if check_replicas:
             # replicated state must be bit-identical on every rank: everything, or (row-sharded) the relation / Pre / Post tensors
-            mine = torch.cat([eng.params[o:o + n] for o, n in eng.dense_spans()]) if sharded else eng.params
+            mine = torch.cat([eng.params[o:o + n] for o, n in eng.dense_spans()] +
+                             [eng.layout.view(eng.params, k).reshape(-1) for k in eng.bag_keys]) if sharded else eng.params
             ref = mine.clone()
             dist.broadcast(ref, 0)
             same = torch.tensor([int(torch.equal(ref, mine))], device=eng.device)
@@ -570,8 +574,6 @@ def main():
     rank, world, local_rank, dist = parallel.init_from_env(backend)
 
     reddit = args.workload == "reddit-synth"
-    if reddit and args.exchange == "sharded":
-        args.exchange = "sparse"                                   # EmbeddingBag tables are not sharded (include/gqe.h)
     d = args.dim or (256 if reddit else 128)
     B = args.batch_size
     wl = Workload(args.workload, d, args.decoder, args.inter_decoder, synth.FULL_MIX, B, rank=rank, world=world)
@@ -615,7 +617,7 @@ def main():
         eng.close()
         forms = {args.exchange: res}
         for other in ("sharded", "sparse", "dense"):
-            if other == args.exchange or (reddit and other == "sharded"):   # bag tables are not sharded
+            if other == args.exchange:
                 continue
             r2, e2, _ = measure(wl, args, dist, rank, world, exchange=other, lazy=False, check_replicas=True, **short)
             e2.close()
@@ -659,8 +661,7 @@ def main():
             eng.close()
             eng = None
         wr = Workload("reddit-synth", 256, args.decoder, args.inter_decoder, synth.FULL_MIX, B, rank=rank, world=world, n_distinct=16)
-        rr, er, _ = measure(wr, args, dist, rank, world, exchange="sparse" if args.exchange == "sharded" else args.exchange,
-                            check_replicas=world > 1, **short)
+        rr, er, _ = measure(wr, args, dist, rank, world, exchange=args.exchange, check_replicas=world > 1, **short)
         er.close()
         rs = slim(rr)
         rs["config"] = ("BASELINE config 5 workload: reddit-synth (%s; EmbeddingBag post features over a %d-word table, bags U[5,30]), "

@@ -219,6 +219,8 @@ struct GqeFusedArgs {
   int32_t* link_counter;  // bump allocator of link nodes
   int32_t max_entries;
   const float* fetched;   // row-sharded mode: the rows of this call, fetched from their owners (else NULL)
+  float* contrib_bag;     // where bag contributions go (= contrib, except in row-sharded mode: the optimiser's entry space)
+  long long bag_shift;    // ... and the first entry index they may use there
 };
 
 hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a);

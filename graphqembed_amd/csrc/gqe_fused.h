@@ -44,6 +44,11 @@ struct TileEnv {
   // the owner links what it receives.
   const float* rows;  // where rows are gathered from: the parameter arena, or the fetched-row buffer
   bool sharded;
+  // Bag (EmbeddingBag) tables stay replicated in row-sharded mode: their rows are gathered from the local replica, and a
+  // bag's contribution is linked onto the LOCAL word-row lists — it lives in the entry space the optimiser walks, behind
+  // the entries received from the other ranks (bag_shift), not in the send buffer.
+  float* contrib_bag;
+  long long bag_shift;
   float* grads;
   float* ws;  // scratch (floats)
   int32_t* head;
@@ -351,8 +356,8 @@ __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t h
   const float inv = 1.f / (nrm * (float)len);
   Vec<NC> gx;
   VEC_OP(gx, (g.v[c] - xhat.v[c] * pg) * inv);
-  const int64_t entry = e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
-  vstore<NC>(e.contrib + entry * e.d, gx, e.d, e.lane);
+  const int64_t entry = e.bag_shift + e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
+  vstore<NC>(e.contrib_bag + entry * e.d, gx, e.d, e.lane);
   int base = 0;
   if (e.lane == 0) {
     base = __hip_atomic_fetch_add(e.link_counter, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -375,8 +380,8 @@ __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t h
 // Row-sharded mode: every fetched row owns a slot of the send buffer, and the owner links whatever arrives — a query
 // whose hinge is inactive has to send zeros (the buffer still holds the previous step's contribution there).
 template <int NC>
-__device__ __forceinline__ void sharded_zero(const TileEnv& e, int row) {
-  if (e.sharded && row >= 0) vstore<NC>(e.contrib + (size_t)row * e.d, vzero<NC>(), e.d, e.lane);
+__device__ __forceinline__ void sharded_zero(const TileEnv& e, int bag, int row) {
+  if (e.sharded && bag < 0 && row >= 0) vstore<NC>(e.contrib + (size_t)row * e.d, vzero<NC>(), e.d, e.lane);
 }
 
 template <int NC>
@@ -465,6 +470,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
                                                                 int32_t* __restrict__ link_contrib,
                                                                 int32_t* __restrict__ link_counter, int max_entries,
                                                                 const float* __restrict__ fetched,
+                                                                float* __restrict__ contrib_bag, long long bag_shift,
                                                                 long long* __restrict__ prof) {
   static_assert(FW == GQE_FW, "FW only distinguishes the kernels of the per-GQE_FW translation units");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -485,6 +491,8 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   e.params = params;
   e.rows = fetched ? fetched : params;
   e.sharded = fetched != nullptr;
+  e.contrib_bag = contrib_bag;
+  e.bag_shift = bag_shift;
   e.grads = grads;
   e.ws = ws;
   e.head = head;
@@ -672,9 +680,9 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
           scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1]);
           scatter_row<NC>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2]);
         } else {
-          sharded_zero<NC>(e, RT.row[rr]);
-          sharded_zero<NC>(e, RN.row[rr]);
-          sharded_zero<NC>(e, RA[0].row[rr]);
+          sharded_zero<NC>(e, f->target_bag, RT.row[rr]);
+          sharded_zero<NC>(e, f->target_bag, RN.row[rr]);
+          sharded_zero<NC>(e, f->anchor_bag[0], RA[0].row[rr]);
         }
       }
       if (BWD) {
@@ -760,7 +768,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
           vstore<NC>(cur[s] + r * DP, gu, d, lane);
         }
         if (act) scatter_row<NC>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2]);
-        else if (q < B) sharded_zero<NC>(e, RA[0].row[rr]);
+        else if (q < B) sharded_zero<NC>(e, f->anchor_bag[0], RA[0].row[rr]);
       }
       if (BWD) {
         // back through the hops: act_{h+1} = act_h M_h  =>  g_act_h = g_act_{h+1} M_h^T (= M . g per row),
@@ -936,8 +944,8 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
         scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0]);
         scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1]);
       } else if (q < B) {
-        sharded_zero<NC>(e, RT.row[rr]);
-        sharded_zero<NC>(e, RN.row[rr]);
+        sharded_zero<NC>(e, f->target_bag, RT.row[rr]);
+        sharded_zero<NC>(e, f->target_bag, RN.row[rr]);
       }
     }
     GQE_STAMP(5);
@@ -1123,11 +1131,11 @@ static hipError_t launch_fused_v(const GqeFusedArgs& a) {
   if (a.bwd)
     hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true, GQE_FW>), dim3(a.plan.tiles), dim3(GQE_FWT), lds, a.stream, a.plan,
                        a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags, a.link_contrib, a.link_counter,
-                       a.max_entries, a.fetched, a.prof);
+                       a.max_entries, a.fetched, a.contrib_bag, a.bag_shift, a.prof);
   else
     hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, false, GQE_FW>), dim3(a.plan.tiles), dim3(GQE_FWT), lds, a.stream, a.plan,
                        a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags, a.link_contrib, a.link_counter,
-                       a.max_entries, a.fetched, a.prof);
+                       a.max_entries, a.fetched, a.contrib_bag, a.bag_shift, a.prof);
   return hipGetLastError();
 }
 

@@ -274,8 +274,9 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
     // The contribution entries that owner receives are the ctx's entry space (the lists link into it); it doubles as
     // the buffer the served rows are gathered into (rows are served before the fused kernel, contributions arrive after)
     L.shard_cap_send = L.max_entries;
-    L.max_entries *= ctx->shard_world;
-    L.shard_cap_recv = L.max_entries;
+    L.shard_cap_recv = L.max_entries * ctx->shard_world;
+    // + one block behind the received entries for the contributions of bag (replicated) tables, which are linked locally
+    L.max_entries = L.shard_cap_recv + (ctx->bags.empty() ? 0 : L.shard_cap_send);
   }
   // entry -> list head it was pushed on (-1: not pushed); sits exactly max_entries ints below next[], so the
   // kernels address it as next[entry - max_entries]
@@ -516,6 +517,12 @@ int formula_of(gqe_ctx* ctx, const gqe_batch& s, int bi, int* out_id) {
   return GQE_OK;
 }
 
+bool is_bag_table(const gqe_ctx* ctx, int t) {
+  for (const Bag& bg : ctx->bags)
+    if (bg.table == t) return true;
+  return false;
+}
+
 // ---- lazy Adam helpers -------------------------------------------------------------------------------
 bool lazy_table_ok(const gqe_ctx* ctx, int t) {
   if (t < 0 || t >= GQE_LAZY_TABLES) return false;
@@ -653,7 +660,6 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   const bool shard = ctx->shard_on;
   if (shard) {
     if (!idx_on_device) return fail(ctx, GQE_ERR_ARG, "row-sharded mode: the index feed is the device-resident position feed of gqe_shard_plan");
-    if (!ctx->bags.empty()) return fail(ctx, GQE_ERR_STATE, "row-sharded mode does not support bag (EmbeddingBag) tables");
     if (ctx->lazy) return fail(ctx, GQE_ERR_STATE, "row-sharded mode and lazy Adam are mutually exclusive");
     if (n_idx > L.shard_cap_send) return fail(ctx, GQE_ERR_WORKSPACE, "row-sharded mode: %lld indices exceed the fetched-row buffer (%lld rows)", (long long)n_idx, (long long)L.shard_cap_send);
     for (int bi = 0; bi < n_batches; ++bi)
@@ -762,6 +768,8 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   fa.next = reinterpret_cast<int32_t*>(ctx->ws + L.next_off);
   fa.contrib = reinterpret_cast<float*>(ctx->ws + (shard ? L.shard_csend : L.contrib_off));
   fa.fetched = shard ? reinterpret_cast<const float*>(ctx->ws + L.shard_fetch) : nullptr;
+  fa.contrib_bag = reinterpret_cast<float*>(ctx->ws + L.contrib_off);
+  fa.bag_shift = shard ? L.shard_cap_recv : 0;
   memset(&fa.bags, 0, sizeof fa.bags);
   for (size_t k = 0; k < ctx->bags.size(); ++k) {
     fa.bags.ptr[k] = ctx->bags[k].ptr;
@@ -872,7 +880,11 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       if (rc != GQE_OK) return rc;
     }
   }
-  if (bwd && shard) ctx->shard_tables = touched_tables;
+  if (bwd && shard) {
+    ctx->shard_tables = touched_tables;
+    for (int t : touched_tables)
+      if (is_bag_table(ctx, t)) ctx->tables[(size_t)t].pending = true;   // bag tables: linked locally by this launch
+  }
   if (bwd && !shard) {
     ctx->entries_used = ctx->world > 1 ? ctx->step_slab * ctx->world : entry;
     for (int t : touched_tables) ctx->tables[t].pending = true;
@@ -973,14 +985,17 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     lists = false;
   } else if (mode == GQE_OPT_MATERIALIZE) {
     bool any = false;
-    for (size_t t = 0; t < ctx->tables.size(); ++t)
-      if (ctx->tables[t].pending) {
+    for (size_t t = 0; t < ctx->tables.size(); ++t) {
+      bool wanted = n_segs == 0;   // segs given (gqe_materialize_tables): only those tables
+      for (int i = 0; i < n_segs; ++i) wanted = wanted || segs[i].offset == ctx->tables[t].offset;
+      if (ctx->tables[t].pending && wanted) {
         rc = activate(ctx->tables[t].offset, ctx->tables[t].rows * d, 1, (int)t);
         if (rc != GQE_OK) return rc;
         any = true;
       }
-    if (!any) {  // nothing pending: the dense gradient simply becomes authoritative
-      ctx->entries_used = 0;
+    }
+    if (!any) {  // nothing (of what was asked for) pending: the dense gradient simply becomes authoritative
+      if (n_segs == 0) ctx->entries_used = 0;
       ctx->dense_dirty = true;
       return GQE_OK;
     }
@@ -1601,10 +1616,12 @@ int gqe_shard_plan(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
   // counting sort of the feed by owner: request = list-head index of the row in the owner's shard, position = where
   // the fetched row (and later its gradient contribution) sits in the owner-grouped buffers
   std::vector<int64_t> count((size_t)W, 0), at((size_t)W, 0);
+  std::vector<char> bag_table(ctx->tables.size(), 0);   // bag tables are replicated: their indices (bag ids) pass through
+  for (const Bag& bg : ctx->bags) bag_table[(size_t)bg.table] = 1;
   for (int64_t e = 0; e < n_idx; ++e) {
     if (table_of_idx[(size_t)e] < 0) return fail(ctx, GQE_ERR_ARG, "index %lld of the feed belongs to no batch", (long long)e);
     if (idx[e] < 0) return fail(ctx, GQE_ERR_ARG, "index %lld of the feed is negative", (long long)e);
-    ++count[(size_t)(idx[e] % W)];
+    if (!bag_table[(size_t)table_of_idx[(size_t)e]]) ++count[(size_t)(idx[e] % W)];
   }
   int64_t run = 0;
   for (int o = 0; o < W; ++o) {
@@ -1614,6 +1631,10 @@ int gqe_shard_plan(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
   }
   for (int64_t e = 0; e < n_idx; ++e) {
     const int64_t r = idx[e];
+    if (bag_table[(size_t)table_of_idx[(size_t)e]]) {
+      positions[e] = (int32_t)r;
+      continue;
+    }
     const int o = (int)(r % W);
     const Table& tb = ctx->tables[(size_t)table_of_idx[(size_t)e]];
     const int64_t local = r / W;
@@ -1656,6 +1677,8 @@ int gqe_shard_link(gqe_ctx* ctx, const int32_t* requests, int64_t n, void* strea
     ctx->entries_used = n;
     for (int t : ctx->shard_tables) ctx->tables[(size_t)t].pending = true;  // every rank ran the same formulas
   }
+  for (const Table& tb : ctx->tables)
+    if (tb.pending && ctx->entries_used == 0) ctx->entries_used = 1;   // (local bag contributions only)
   return GQE_OK;
 }
 
@@ -1741,6 +1764,17 @@ int gqe_auc_pair_counts(gqe_ctx* ctx, const float* pos, int64_t n_pos, const flo
 
 int gqe_materialize_grads(gqe_ctx* ctx, void* stream) {
   return run_opt(ctx, GQE_OPT_MATERIALIZE, nullptr, 0, 0.f, 0.f, 0.f, 0.f, stream);
+}
+
+int gqe_materialize_tables(gqe_ctx* ctx, const int64_t* table_offsets, int32_t n_tables, void* stream) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (!table_offsets || n_tables < 1 || n_tables > GQE_MAX_BATCHES) return fail(ctx, GQE_ERR_ARG, "gqe_materialize_tables: bad table list");
+  std::vector<gqe_segment> segs((size_t)n_tables);
+  for (int i = 0; i < n_tables; ++i) {
+    if (table_of(ctx, table_offsets[i]) < 0) return fail(ctx, GQE_ERR_ARG, "offset %lld is not a registered table", (long long)table_offsets[i]);
+    segs[(size_t)i] = gqe_segment{table_offsets[i], 0, 0, 0};
+  }
+  return run_opt(ctx, GQE_OPT_MATERIALIZE, segs.data(), n_tables, 0.f, 0.f, 0.f, 0.f, stream);
 }
 
 // RCCL is bound at run time (dlopen): the library links against the HIP runtime only, and a single-GPU user never

@@ -77,6 +77,7 @@ SYMBOLS = OrderedDict([
     ("gqe_workspace_bytes", (C.c_int64, [_P, C.c_int64, C.c_int32])),
     ("gqe_bind_workspace", (C.c_int, [_P, _P, C.c_int64, _P])),
     ("gqe_materialize_grads", (C.c_int, [_P, _P])),
+    ("gqe_materialize_tables", (C.c_int, [_P, C.POINTER(C.c_int64), C.c_int32, _P])),
     ("gqe_set_lazy_adam", (C.c_int, [_P, C.c_int32])),
     ("gqe_optimizer_sync", (C.c_int, [_P, _P])),
     ("gqe_lazy_prefetch", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32])),
@@ -211,6 +212,7 @@ class Engine(object):
             rows = (C.c_int64 * len(tables))(*[t[1] for t in tables])
             self._check(self.lib.gqe_set_tables(self.ctx, offs, rows, len(tables)))
         self._bags = {}
+        self.bag_keys = list((bags or {}).keys())    # tables whose indices are bags (replicated in row-sharded mode)
         for key, (ptr, ids) in (bags or {}).items():
             ptr = np.ascontiguousarray(ptr, dtype=np.int32)
             ids = np.ascontiguousarray(ids, dtype=np.int32)
@@ -490,6 +492,11 @@ class Engine(object):
         """step <= 0 in the prepared segments: libgqe keeps the per-tensor Adam step counters."""
         self._check(self.lib.gqe_adam_step(self.ctx, pa["arr"], pa["n"], lr, betas[0], betas[1], eps,
                                            stream if stream is not None else self._stream()))
+
+    def materialize_tables(self, keys):
+        """gqe_materialize_tables: fold the pending gradient lists of the listed tables only into the dense arena."""
+        offs = (C.c_int64 * len(keys))(*[self.layout.offset(k) for k in keys])
+        self._check(self.lib.gqe_materialize_tables(self.ctx, offs, len(keys), self._stream()))
 
     def allreduce_grads(self, nccl_comm):
         """gqe_allreduce_grads: lists -> dense gradient arena, then ncclAllReduce (RCCL) over ``nccl_comm`` (an

@@ -153,18 +153,23 @@ def shard_of(full, rank, world):
     return np.concatenate([part, np.zeros((need,) + part.shape[1:], dtype=part.dtype)])
 
 
-def shard_plan_numpy(idx, table_of_idx, head_base, world):
+def shard_plan_numpy(idx, table_of_idx, head_base, world, bag_tables=()):
     """What gqe_shard_plan computes, in numpy (host logic of the row-sharded protocol; CPU tests, cross-check of the
     library): idx[n] global rows, table_of_idx[n] the table each index names, head_base[t] the first list-head index of
-    local table t.  Returns (positions[n], requests[n] grouped by owner, send_counts[world]): a stable counting sort of
-    the feed by owner = row % world; a request is head_base[table] + row // world."""
+    local table t.  Returns (positions[n], requests grouped by owner, send_counts[world]): a stable counting sort of
+    the feed by owner = row % world; a request is head_base[table] + row // world.  Indices into ``bag_tables``
+    (replicated EmbeddingBag tables) are bag ids: they pass through as their own position and are not requested."""
     import numpy as np
     idx = np.asarray(idx, dtype=np.int64)
-    owner = idx % world
+    tid = np.asarray(table_of_idx)
+    direct = ~np.isin(tid, list(bag_tables)) if len(bag_tables) else np.ones(len(idx), dtype=bool)
+    owner = idx[direct] % world
     order = np.argsort(owner, kind="stable")
-    positions = np.empty(len(idx), dtype=np.int32)
-    positions[order] = np.arange(len(idx), dtype=np.int32)
-    req = (np.asarray(head_base, dtype=np.int64)[np.asarray(table_of_idx)] + idx // world)[order].astype(np.int32)
+    positions = idx.astype(np.int32).copy()
+    pos_direct = np.empty(int(direct.sum()), dtype=np.int32)
+    pos_direct[order] = np.arange(len(order), dtype=np.int32)
+    positions[direct] = pos_direct
+    req = (np.asarray(head_base, dtype=np.int64)[tid[direct]] + idx[direct] // world)[order].astype(np.int32)
     return positions, req, np.bincount(owner, minlength=world).astype(np.int64)
 
 
@@ -197,7 +202,7 @@ def shard_prepare(engine, dist, descs, idx, with_negatives=True):
     if n_recv > v["cap_recv"]:
         raise RuntimeError("row-sharded mode: %d rows requested from rank %d exceed its receive capacity %d"
                            % (n_recv, engine.shard_rank, v["cap_recv"]))
-    req_send = torch.from_numpy(req).to(dev)
+    req_send = torch.from_numpy(req[:n_send]).to(dev)
     req_recv = torch.empty(n_recv, dtype=torch.int32, device=dev)
     _all_to_all(dist, req_recv, req_send, recv_counts, send_counts)
     total = sum(dsc["n"] for dsc in descs)
@@ -209,7 +214,10 @@ def shard_prepare(engine, dist, descs, idx, with_negatives=True):
           # the views the per-step collectives move (sliced once: the step itself should cost no Python beyond the calls)
           "workspace": engine.workspace, "rows_send": v["rows_send"][:n_recv], "fetched": v["fetched"][:n_send],
           "contrib_send": v["contrib_send"][:n_send], "contrib_recv": v["contrib_recv"][:n_recv],
-          "dense": [engine.grads[off:off + n] for off, n in engine.dense_spans()]}
+          "dense": [engine.grads[off:off + n] for off, n in engine.dense_spans()],
+          # bag (EmbeddingBag) tables are replicated: their gradient is folded into the dense arena and all-reduced
+          "bag_keys": list(engine.bag_keys),
+          "bag_grads": [engine.layout.view(engine.grads, k).view(-1) for k in engine.bag_keys]}
     return ps
 
 
@@ -226,6 +234,10 @@ def shard_exchange(engine, dist, ps):
     lists; the relation / Pre / Post gradients (replicated tensors) are summed over the ranks."""
     _all_to_all(dist, ps["contrib_recv"], ps["contrib_send"], ps["recv_counts"], ps["send_counts"])
     engine.shard_link(ps["req_recv"], ps["n_recv"])
+    if ps["bag_keys"]:
+        engine.materialize_tables(ps["bag_keys"])
+        for g in ps["bag_grads"]:
+            dist.all_reduce(g)
     for span in ps["dense"]:
         dist.all_reduce(span)
 

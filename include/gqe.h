@@ -186,6 +186,9 @@ int gqe_margin_fwd_bwd(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches
  * that need a dense gradient: torch.optim compatibility (param.grad), the data-parallel all-reduce, tests.
  * The next optimiser pass then also reads (and re-zeroes) the dense table gradient. */
 int gqe_materialize_grads(gqe_ctx* ctx, void* stream);
+/* ... the same for the listed tables only (row-sharded mode: the replicated bag tables, whose dense gradient is then
+ * all-reduced while the sharded tables keep their lists). */
+int gqe_materialize_tables(gqe_ctx* ctx, const int64_t* table_offsets, int32_t n_tables, void* stream);
 
 /* ---- lazy (deferred, bit-exact) Adam ---------------------------------------------------------------------
  * torch.optim.Adam on a dense embedding gradient moves EVERY row each step — a row without a gradient still
@@ -258,9 +261,13 @@ int gqe_import_entries(gqe_ctx* ctx, int64_t slab_entries, void* stream);
  * order-independently (integer accumulation: the result does not depend on the order contributions arrive in), the
  * replicated tensors see the same all-reduced gradient on every rank and stay bit-identical, and the step equals the
  * single-rank step on the concatenated batch up to fp32 summation order.  The transport is the caller's (torch.distributed all_to_all_single over
- * RCCL in graphqembed_amd/parallel.py); the library only names the buffers.  Bag (EmbeddingBag) tables, candidate
- * lists and lazy Adam are not available in this mode; tables must be registered with their LOCAL row counts,
- * ceil(global rows / world), the same on every rank. */
+ * RCCL in graphqembed_amd/parallel.py); the library only names the buffers.  Tables must be registered with their LOCAL
+ * row counts, ceil(global rows / world), the same on every rank.  Bag (EmbeddingBag) tables are NOT sharded: a bag table
+ * (gqe_set_bag; Reddit: the 50 k-word table behind the posts) stays replicated with its full row count, an index into
+ * it is a bag id that gqe_shard_plan passes through, its rows are gathered from the local replica and its gradient is
+ * linked onto the local lists; before the optimiser step the host folds those lists into the dense gradient
+ * (gqe_materialize_tables), all-reduces that table's span of the gradient arena and steps it like the other replicated
+ * tensors.  Candidate lists and lazy Adam are not available in this mode. */
 typedef struct {
   int64_t req_send, req_recv;         /* byte offsets in the workspace: int32 requests I send / receive            */
   int64_t rows_send, fetched;         /* float rows I serve / rows I fetched (dim floats each)                      */

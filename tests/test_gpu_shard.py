@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_dir, dec, inter, d):
+def _worker(rank, world, port, out_dir, dec, inter, d, bag_modes=()):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -32,15 +32,18 @@ def _worker(rank, world, port, out_dir, dec, inter, d):
     from oracle import netquery_numpy as O
     r, w, _, dist = parallel.init_from_env("gloo")
     rng = np.random.RandomState(21)
-    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
-    tables = [k for k in params if k.startswith("enc.")]
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS, bag_modes=bag_modes)
+    bag_keys = [O.table_key(m) for m in bag_modes]                     # EmbeddingBag tables stay replicated
+    bags = {O.table_key(m): csr for m, csr in params.get(O.BAGS_KEY, {}).items()}
+    params_only = {k: v for k, v in params.items() if k != O.BAGS_KEY}
+    tables = [k for k in params_only if k.startswith("enc.") and k not in bag_keys]    # the sharded ones
 
     def sharded_engine():
         layout = ArenaLayout()
-        for k, v in params.items():
+        for k, v in params_only.items():
             layout.add(k, (parallel.shard_rows(v.shape[0], w), d) if k in tables else v.shape)
-        eng = Engine(d, dec, inter, layout, shard=(r, w), max_queries=1024, max_batches=8)
-        for k, v in params.items():
+        eng = Engine(d, dec, inter, layout, shard=(r, w), max_queries=1024, max_batches=8, bags=bags)
+        for k, v in params_only.items():
             src = parallel.shard_of(v, r, w) if k in tables else v
             layout.view(eng.params, k).copy_(torch.from_numpy(np.ascontiguousarray(src)))
         return eng
@@ -48,7 +51,9 @@ def _worker(rank, world, port, out_dir, dec, inter, d):
     def gather_full(eng):
         """The whole model a sharded engine's ranks hold together (tables re-interleaved), as numpy arrays."""
         out = {}
-        for k in params:
+        if O.BAGS_KEY in params:
+            out[O.BAGS_KEY] = params[O.BAGS_KEY]
+        for k in params_only:
             mine = eng.layout.view(eng.params, k).cpu()
             if k in tables:
                 parts = [torch.zeros_like(mine) for _ in range(w)]
@@ -65,7 +70,6 @@ def _worker(rank, world, port, out_dir, dec, inter, d):
     runs = [sharded_engine()]
     mix = [("1-chain", 1.0), ("2-chain", 0.3), ("2-inter", 0.5), ("3-inter", 0.5), ("3-inter_chain", 0.5), ("3-chain_inter", 0.2)]
     n_pool, B = 400, 64
-    ref_params = {k: v.astype(np.float64) for k, v in params.items()}
     for step in range(3):
         items, cat_items = [], []
         full = O.zero_grads_like(params)
@@ -94,16 +98,18 @@ def _worker(rank, world, port, out_dir, dec, inter, d):
                 pos, req, cnt = eng.shard_plan(descs, idx)
                 hb, tid, run = {}, [], 0
                 for k in eng.layout.entries:
-                    if k in tables:
+                    if k in tables or k in bag_keys:
                         hb[eng.layout.offset(k)] = (len(hb), run)
                         run += eng.layout.entries[k][1][0]
+                bag_ids = [hb[eng.layout.offset(k)][0] for k in bag_keys]
                 for dsc in descs:
                     tid += [hb[dsc["target_table"]][0]] * (2 * dsc["n"])
                     for at in dsc["anchor_table"]:
                         tid += [hb[at][0]] * dsc["n"]
                 base = [v[1] for v in sorted(hb.values())]
-                p2, r2, c2 = parallel.shard_plan_numpy(idx, tid, base, w)
-                assert np.array_equal(pos, p2) and np.array_equal(req, r2) and np.array_equal(cnt, c2)
+                p2, r2, c2 = parallel.shard_plan_numpy(idx, tid, base, w, bag_tables=bag_ids)
+                assert np.array_equal(pos, p2) and np.array_equal(req[:len(r2)], r2) and np.array_equal(cnt, c2)
+                assert ps["n_send"] == len(r2) == int(np.sum(~np.isin(tid, bag_ids)))
             parallel.shard_fetch(eng, dist, ps)
             if eng is runs[0]:                                         # fetched rows = the rows the feed names
                 torch.cuda.synchronize()
@@ -114,9 +120,11 @@ def _worker(rank, world, port, out_dir, dec, inter, d):
                     plan = O.make_plan(q, TOY_FORMULAS[q])
                     segs = [(plan["target_mode"], t), (plan["target_mode"], g)] + [(m, a[i]) for i, m in enumerate(plan["anchor_modes"])]
                     for mode, rows in segs:
-                        want = cur32[O.table_key(mode)][rows]
-                        got = fetched[ps["idx"][off:off + len(rows)].cpu().numpy()]
-                        assert np.array_equal(got, want), (step, q, mode)
+                        feed = ps["idx"][off:off + len(rows)].cpu().numpy()
+                        if mode in bag_modes:                          # bag ids pass through: nothing is fetched for them
+                            assert np.array_equal(feed, rows), (step, q, mode)
+                        else:
+                            assert np.array_equal(fetched[feed], cur32[O.table_key(mode)][rows]), (step, q, mode)
                         off += len(rows)
             eng.run_margin(ps)
             with pytest.raises(GqeError):                              # one margin call per step in this mode
@@ -125,8 +133,8 @@ def _worker(rank, world, port, out_dir, dec, inter, d):
             shard_losses.append(ps["losses"].clone())
             if eng is runs[0]:                                         # gradients at the owners == the oracle's, shard by shard
                 got = read_arena(eng, eng.grads)                       # (folds the lists into the local dense gradient)
-                for k in params:
-                    want = parallel.shard_of(full[k], r, w) if k in tables else full[k]
+                for k in params_only:
+                    want = parallel.shard_of(full[k], r, w) if k in tables else full[k]      # bag tables: the all-reduced whole
                     scale = max(1e-6, float(np.abs(full[k]).max()))
                     np.testing.assert_allclose(got[k], want, rtol=0, atol=2e-4 * scale, err_msg="step %d %s" % (step, k))
             eng.adam_step(keys, 0.01)
@@ -141,13 +149,14 @@ def _worker(rank, world, port, out_dir, dec, inter, d):
     # ---- the shards after three steps ----
     a0 = read_arena(runs[0], runs[0].params)
     want = read_arena(single, single.params)
-    for name in ("params", "exp_avg", "exp_avg_sq"):                   # replicated tensors: the same bits on every rank
-        mine = torch.cat([getattr(runs[0], name)[o:o + n] for o, n in runs[0].dense_spans()]).cpu()
+    for name in ("params", "exp_avg", "exp_avg_sq"):                   # replicated tensors (and bag tables): the same bits on every rank
+        mine = torch.cat([getattr(runs[0], name)[o:o + n] for o, n in runs[0].dense_spans()] +
+                         [runs[0].layout.view(getattr(runs[0], name), k).reshape(-1) for k in bag_keys]).cpu()
         ref = mine.clone()
         dist.broadcast(ref, 0)
         assert torch.equal(mine, ref), "replicated tensors diverged: " + name
     worst, frac = 0.0, 0.0
-    for k in params:
+    for k in params_only:
         w_k = parallel.shard_of(want[k], r, w) if k in tables else want[k]
         diff = np.abs(a0[k] - w_k)
         worst = max(worst, float(diff.max()))
@@ -156,7 +165,7 @@ def _worker(rank, world, port, out_dir, dec, inter, d):
     # test_adam_three_steps): everything else agrees to fp32 rounding
     assert worst < 0.04 and frac < 0.02, (worst, frac)
     # ---- forward on fetched rows == the single-rank forward (same kernel, same row values) ----
-    sync = {k: torch.from_numpy(v) for k, v in gather_full(runs[0]).items()}
+    sync = {k: torch.from_numpy(v) for k, v in gather_full(runs[0]).items() if k != O.BAGS_KEY}
     for k, v in sync.items():
         single.layout.view(single.params, k).copy_(v)
     for qtype in ("2-chain", "3-inter", "3-chain_inter"):
@@ -175,10 +184,13 @@ def _worker(rank, world, port, out_dir, dec, inter, d):
         e.close()
 
 
-@pytest.mark.parametrize("dec,inter,d", [("bilinear-diag", "min", 32), ("bilinear", "mean", 32), ("transe", "min-simple", 64)])
-def test_row_sharded_two_ranks(tmp_path, dec, inter, d):
+@pytest.mark.parametrize("dec,inter,d,bag_modes", [("bilinear-diag", "min", 32, ()), ("bilinear", "mean", 32, ()), ("transe", "min-simple", 64, ()),
+                                                   ("bilinear-diag", "min", 64, ("b",))])
+def test_row_sharded_two_ranks(tmp_path, dec, inter, d, bag_modes):
+    """bag_modes=("b",): mode b is an EmbeddingBag mode (Reddit posts) — its word table stays replicated, its indices pass
+    through the plan as bag ids, its gradient is folded into the dense arena and all-reduced."""
     port = 29400 + os.getpid() % 150
-    mp.spawn(_worker, args=(2, port, str(tmp_path), dec, inter, d), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), dec, inter, d, bag_modes), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
 
 
