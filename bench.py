@@ -581,7 +581,7 @@ def main():
                                  min_seconds=args.min_seconds)
     sparse = world > 1 and args.exchange == "sparse"
     sharded = world > 1 and args.exchange == "sharded"
-    res["roofline"]["traffic"] = None if (args.lazy_adam or (d, B, args.decoder, args.inter_decoder) != ((256 if reddit else 128), 512, "bilinear-diag", "min")) \
+    res["roofline"]["traffic"] = None if (world > 1 or args.lazy_adam or (d, B, args.decoder, args.inter_decoder) != ((256 if reddit else 128), 512, "bilinear-diag", "min")) \
         else pmc_traffic("gqe_opt_kernel", args.workload)
     label = "Reddit" if reddit else "Bio"
     out = {
@@ -667,7 +667,7 @@ def main():
         rs["config"] = ("BASELINE config 5 workload: reddit-synth (%s; EmbeddingBag post features over a %d-word table, bags U[5,30]), "
                         "full mix %d batches x B=%d per GPU, d=256, %s + SetIntersection(%s), P=%d"
                         % (wr.describe(), wr.g.table_rows["post"], len(wr.mix), B, args.decoder, args.inter_decoder, wr.layout.total))
-        rs["optimiser"]["traffic"] = pmc_traffic("gqe_opt_kernel", "reddit-synth")
+        rs["optimiser"]["traffic"] = pmc_traffic("gqe_opt_kernel", "reddit-synth") if world == 1 else None
         out["reddit_synth"] = rs
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not reddit:
         out["cpu_baseline"] = cpu_baseline(eng, args.decoder, args.inter_decoder, wl.item_sets[:8], args.cpu_seconds, wl.qpi)
