@@ -562,6 +562,11 @@ def main():
         raise SystemExit(self_launch(args, sys.argv[1:]))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
+    # stdout carries exactly ONE line, the JSON result: whatever libraries print on file descriptor 1 while they initialise
+    # (RCCL's version banner, gloo's "Rank i is connected" lines) is sent to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     from graphqembed_amd import parallel
@@ -674,7 +679,7 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
