@@ -16,7 +16,7 @@
 #define GQE_MAX_SEGS 96      // tensors the kernel-argument form of an optimiser pass can describe (more: table form)
 #define GQE_GEMM_KCHUNK 128  // queries per pair-GEMM unit
 #define GQE_GEMM_MT 64       // edge of the gradient block one pair-GEMM unit produces
-#define GQE_PROF_SLOTS 16     // wall_clock64 stamps per workgroup (debug profile)
+#define GQE_PROF_SLOTS 64     // wall_clock64 stamps per workgroup (debug profile)
 
 #define GQE_LAUNCH_BATCHES 16  // batches per fused launch: their dynamic descriptors travel as kernel arguments
 #define GQE_DEFAULT_FORMULAS 2048  // default capacity of the device formula-descriptor cache (gqe_set_limits); LRU beyond
@@ -39,18 +39,21 @@ struct GqeDevFormula {
   int64_t anchor_head[GQE_MAX_BRANCH];
   int32_t target_bag;                     // >= 0: the target mode is a bag mode (index into GqeBagTable), else -1
   int32_t anchor_bag[GQE_MAX_BRANCH];
-  // deferred dM += L^T R jobs: parameter + the two scratch slots
+  // deferred dM += L^T R jobs: parameter + the two scratch slots.  Every field is at least 32 bits wide: the kernels read
+  // the descriptor with scalar loads, and a byte field would be fetched with a VECTOR load followed by s_waitcnt vmcnt(0)
+  // — a full memory round trip behind everything the wave has in flight, once per field (round 2: eight of them sat on
+  // an intersection tile's critical path)
   int64_t job_param[GQE_MAX_JOBS];
-  int8_t job_L[GQE_MAX_JOBS], job_R[GQE_MAX_JOBS];
+  int32_t job_L[GQE_MAX_JOBS], job_R[GQE_MAX_JOBS];
   // scratch slots (row blocks of Bpad x d floats); -1 = unused
-  int8_t slot_x[GQE_MAX_BRANCH][GQE_MAX_HOPS];   // bilinear: input of hop h of branch i
-  int8_t slot_gy[GQE_MAX_BRANCH][GQE_MAX_HOPS];  // bilinear: grad wrt output of hop h of branch i
-  int8_t slot_e[GQE_MAX_BRANCH];                 // MLP: e_i (input of Pre)
-  int8_t slot_gz[GQE_MAX_BRANCH];                // MLP: grad wrt Pre.e_i
-  int8_t slot_hh, slot_gq;                       // MLP: h (input of Post), grad wrt q
-  int8_t slot_fx, slot_fg;                       // bilinear final projection: input, grad wrt output
-  int8_t slot_act[2][GQE_MAX_HOPS];              // bilinear chain: act_h of the +/- side
-  int8_t slot_gact[2][GQE_MAX_HOPS];             // bilinear chain: grad wrt act_{h+1}
+  int32_t slot_x[GQE_MAX_BRANCH][GQE_MAX_HOPS];   // bilinear: input of hop h of branch i
+  int32_t slot_gy[GQE_MAX_BRANCH][GQE_MAX_HOPS];  // bilinear: grad wrt output of hop h of branch i
+  int32_t slot_e[GQE_MAX_BRANCH];                 // MLP: e_i (input of Pre)
+  int32_t slot_gz[GQE_MAX_BRANCH];                // MLP: grad wrt Pre.e_i
+  int32_t slot_hh, slot_gq;                       // MLP: h (input of Post), grad wrt q
+  int32_t slot_fx, slot_fg;                       // bilinear final projection: input, grad wrt output
+  int32_t slot_act[2][GQE_MAX_HOPS];              // bilinear chain: act_h of the +/- side
+  int32_t slot_gact[2][GQE_MAX_HOPS];             // bilinear chain: grad wrt act_{h+1}
 };
 
 // Dynamic part of a batch (sizes, offsets of this call), passed BY VALUE in the kernel arguments:

@@ -104,7 +104,156 @@ __device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 a
 // would spill.
 #define GQE_KG 8
 
-// dst[q][i] = sum_k A[i][k] src[q][k]   (one source tile)
+// ---- matrices staged in LDS (the intersection's Pre / Post at d <= 128) -----------------------------------------
+// A d x d matrix every tile of a batch contracts with sits in L2, ~1 us away, and a contraction phase cannot start
+// before its slab arrives.  The staged path takes that round trip off the tile's dependent chain: all threads of the
+// workgroup request the NEXT matrix into registers (MR float4 each) while the current phase runs, and drop it into one
+// LDS buffer [d][d + 4] between two phases; the MFMA A operand is then an LDS read — a `ds_read_b128` for M . x, four
+// `ds_read_b32` down a column for M^T . x (the transposed global read is four 4-byte loads per lane and k-block).
+template <int MR>  // MR = 1 (d = 64) or 4 (d = 128) float4 per thread; named members: the values have to stay in VGPRs
+struct MatRegs {
+  float4 v0, v1, v2, v3;
+};
+
+__device__ __forceinline__ float4 mat_ld(const float* __restrict__ M, int j) {
+  return *reinterpret_cast<const float4*>(M + 4 * ((int)threadIdx.x + GQE_FWT * j));
+}
+
+template <int MR>
+__device__ __forceinline__ void mat_issue(MatRegs<MR>& m, const float* __restrict__ M) {
+  m.v0 = mat_ld(M, 0);
+  if (MR > 1) {
+    m.v1 = mat_ld(M, 1);
+    m.v2 = mat_ld(M, 2);
+    m.v3 = mat_ld(M, 3);
+  }
+}
+
+__device__ __forceinline__ void mat_st(float* __restrict__ mb, int d, int DP, int j, const float4& v) {
+  const int at = 4 * ((int)threadIdx.x + GQE_FWT * j);
+  *reinterpret_cast<float4*>(mb + (at / d) * DP + (at % d)) = v;
+}
+
+template <int MR>
+__device__ __forceinline__ void mat_commit(const MatRegs<MR>& m, float* __restrict__ mb, int d, int DP) {
+  mat_st(mb, d, DP, 0, m.v0);
+  if (MR > 1) {
+    mat_st(mb, d, DP, 1, m.v1);
+    mat_st(mb, d, DP, 2, m.v2);
+    mat_st(mb, d, DP, 3, m.v3);
+  }
+}
+
+template <bool TRANS>
+__device__ __forceinline__ float4 lds_a(const float* __restrict__ mb, int DP, int i0, int lq, int lk, int kb) {
+  if (!TRANS) return *reinterpret_cast<const float4*>(mb + (i0 + lq) * DP + kb * 16 + 4 * lk);
+  const float* mp = mb + (kb * 16 + 4 * lk) * DP + i0 + lq;
+  return make_float4(mp[0], mp[DP], mp[2 * DP], mp[3 * DP]);
+}
+
+// Staged contractions (A from the LDS copy `mb`, row stride DP; FULL dims, 16-wave tiles: waves 0 .. d/16-1 own one
+// output slab each).  The operands of k-block group g+1 are requested before the MFMAs of group g are issued
+// (sched_barrier fences pin the source order: left alone, the scheduler puts each LDS read right in front of its use
+// and every MFMA group then waits a full LDS round trip).
+
+template <bool TRANS, int NC>
+__device__ __forceinline__ void tile_matmul_staged(float* __restrict__ dst, const float* __restrict__ mb,
+                                                   const float* __restrict__ src, int DP, int wave, int lane) {
+  constexpr int KB = 4 * NC, G = 2, NG = KB / G;  // groups of two k-blocks: 8 MFMAs cover the next group's reads
+  const int lq = lane & 15, lk = lane >> 4, i0 = wave * 16;
+  if (i0 >= 64 * NC) return;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float4 a[2][G], b[2][G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    a[0][j] = lds_a<TRANS>(mb, DP, i0, lq, lk, j);
+    b[0][j] = *reinterpret_cast<const float4*>(src + lq * DP + j * 16 + 4 * lk);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        a[(g + 1) & 1][j] = lds_a<TRANS>(mb, DP, i0, lq, lk, (g + 1) * G + j);
+        b[(g + 1) & 1][j] = *reinterpret_cast<const float4*>(src + lq * DP + ((g + 1) * G + j) * 16 + 4 * lk);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < G; ++j) acc = mfma4(a[g & 1][j], b[g & 1][j], acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  *reinterpret_cast<float4*>(dst + lq * DP + i0 + 4 * lk) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+template <int NC, int NB>
+__device__ __forceinline__ void pre_intersect_staged(float* __restrict__ th, int* __restrict__ tmeta,
+                                                     const float* __restrict__ mb, float* const (&te)[GQE_MAX_BRANCH],
+                                                     int DP, int wave, int lane, int inter_min) {
+  constexpr int KB = 4 * NC;
+  const int lq = lane & 15, lk = lane >> 4, i0 = wave * 16;
+  if (i0 >= 64 * NC) return;
+  f32x4 acc[NB];
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi) acc[bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 a[2], b[2][NB];
+  a[0] = lds_a<false>(mb, DP, i0, lq, lk, 0);
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi) b[0][bi] = *reinterpret_cast<const float4*>(te[bi] + lq * DP + 4 * lk);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    if (kb + 1 < KB) {
+      a[(kb + 1) & 1] = lds_a<false>(mb, DP, i0, lq, lk, kb + 1);
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi)
+        b[(kb + 1) & 1][bi] = *reinterpret_cast<const float4*>(te[bi] + lq * DP + (kb + 1) * 16 + 4 * lk);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) acc[bi] = mfma4(a[kb & 1], b[kb & 1][bi], acc[bi]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float hv[4];
+  int mv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float best = fmaxf(acc[0][r], 0.f);
+    int meta = (acc[0][r] > 0.f) << 4;
+#pragma unroll
+    for (int bi = 1; bi < NB; ++bi) {
+      const float z = acc[bi][r];
+      const float v = fmaxf(z, 0.f);
+      meta |= (z > 0.f) << (4 + bi);
+      if (inter_min) {
+        if (v < best) {  // strict: torch.min keeps the FIRST minimum
+          best = v;
+          meta = (meta & ~3) | bi;
+        }
+      } else {
+        best += v;
+      }
+    }
+    hv[r] = inter_min ? best : best / (float)NB;
+    // bits 8 + b: branch b receives this element's gradient (relu'(z_b) and, for min, b is the arg-min) — the backward
+    // contraction then builds its B operand with two VALU ops per element instead of mask_gz's five
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+      const int on = ((meta >> (4 + bi)) & 1) & (inter_min ? (int)((meta & 3) == bi) : 1);
+      meta |= on << (8 + bi);
+    }
+    mv[r] = meta;
+  }
+  *reinterpret_cast<float4*>(th + lq * DP + i0 + 4 * lk) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+  *reinterpret_cast<int4*>(tmeta + lq * DP + i0 + 4 * lk) = make_int4(mv[0], mv[1], mv[2], mv[3]);
+}
+
+__device__ __forceinline__ float keep_if_bit(float g, int meta, int bit) {  // g if bit `bit` of meta is set, else +0
+  return __int_as_float(__float_as_int(g) & ((meta << (31 - bit)) >> 31));
+}
+
+// dst[q][i] = sum_k A[i][k] src[q][k]   (one source tile), A streamed from L2
 template <bool TRANS, int NC>
 __device__ __forceinline__ void tile_matmul(float* __restrict__ dst, const float* __restrict__ M,
                                             const float* __restrict__ src, int d, int DP, int wave, int lane) {
@@ -188,6 +337,46 @@ __device__ __forceinline__ float mask_gz(float gh, int meta, int bi, int inter_m
   float g = inter_min ? (((meta & 3) == bi) ? gh : 0.f) : gh * inv_n;
   if (mlp && !((meta >> (4 + bi)) & 1)) g = 0.f;  // relu'(z) = [z > 0]
   return g;
+}
+
+template <int NC, int NB>
+__device__ __forceinline__ void pre_intersect_bwd_staged(float* const (&te)[GQE_MAX_BRANCH], const float* __restrict__ mb,
+                                                         const float* __restrict__ tgh, const int* __restrict__ tmeta,
+                                                         int DP, int wave, int lane, int inter_min) {
+  constexpr int KB = 4 * NC;
+  const int lq = lane & 15, lk = lane >> 4, i0 = wave * 16;
+  if (i0 >= 64 * NC) return;
+  const float gsc = inter_min ? 1.f : 1.f / (float)NB;  // mean: every live branch gets g_h / n (mask_gz)
+  f32x4 acc[NB];
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi) acc[bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 a[2], gh[2];
+  int4 mt[2];
+  a[0] = lds_a<true>(mb, DP, i0, lq, lk, 0);
+  gh[0] = *reinterpret_cast<const float4*>(tgh + lq * DP + 4 * lk);
+  mt[0] = *reinterpret_cast<const int4*>(tmeta + lq * DP + 4 * lk);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    if (kb + 1 < KB) {
+      a[(kb + 1) & 1] = lds_a<true>(mb, DP, i0, lq, lk, kb + 1);
+      gh[(kb + 1) & 1] = *reinterpret_cast<const float4*>(tgh + lq * DP + (kb + 1) * 16 + 4 * lk);
+      mt[(kb + 1) & 1] = *reinterpret_cast<const int4*>(tmeta + lq * DP + (kb + 1) * 16 + 4 * lk);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float4 g = make_float4(gh[kb & 1].x * gsc, gh[kb & 1].y * gsc, gh[kb & 1].z * gsc, gh[kb & 1].w * gsc);
+    const int4 m = mt[kb & 1];
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+      const float4 b = make_float4(keep_if_bit(g.x, m.x, 8 + bi), keep_if_bit(g.y, m.y, 8 + bi), keep_if_bit(g.z, m.z, 8 + bi),
+                                   keep_if_bit(g.w, m.w, 8 + bi));
+      acc[bi] = mfma4(a[kb & 1], b, acc[bi]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi)
+    *reinterpret_cast<float4*>(te[bi] + lq * DP + i0 + 4 * lk) = make_float4(acc[bi][0], acc[bi][1], acc[bi][2], acc[bi][3]);
 }
 
 // SetIntersection backward for NB branches at once: g_e_b = Pre^T . g_z_b with
@@ -478,6 +667,11 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   do {                                                                                                            \
     if (prof && threadIdx.x == 0) prof[(size_t)blockIdx.x * GQE_PROF_SLOTS + (k)] = (long long)wall_clock64(); \
   } while (0)
+#define GQE_WSTAMP(p)                                                                                               \
+  do {                                                                                                              \
+    if (prof && (threadIdx.x & 255) == 0)                                                                           \
+      prof[(size_t)blockIdx.x * GQE_PROF_SLOTS + 16 + (p) * 4 + (threadIdx.x >> 8)] = (long long)wall_clock64();    \
+  } while (0)
   GQE_STAMP(0);
   const int d = FULL ? 64 * NC : d_arg;
   int bi = 0;  // which batch owns this tile: the plan is a kernel argument (SGPRs), 16 scalar compares
@@ -527,6 +721,12 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   int* tmeta = reinterpret_cast<int*>(tg + GQE_TQ * DP);
   float* red = reinterpret_cast<float*>(tmeta + GQE_TQ * DP);
   int* s_idx = reinterpret_cast<int*>(red + GQE_FW * d);  // [5][16]: target, negative, anchor 0..2
+  // staged matrices (see mat_issue): the MLP intersection's Pre / Post, d <= 128, 16-wave tiles
+  constexpr bool STAGE = MLP && DEC != DEC_BILINEAR && FULL && NC <= 2 && FW == 16;
+  constexpr int MR = STAGE ? NC * NC : 1;
+  float* mbuf = reinterpret_cast<float*>(s_idx + 5 * GQE_TQ);  // [d][DP], only carved for STAGE kernels
+  const bool stage = STAGE && f->qtype > 2;
+  MatRegs<MR> mr;
 
   // ---- the tile's table rows: one coalesced read, then every gather is issued at once ----
   if (threadIdx.x < 5 * GQE_TQ) {
@@ -542,6 +742,21 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   }
   __syncthreads();
   GQE_STAMP(1);
+  // the relation vectors of an intersection tile (<= 2 per branch + the final projection): requested here, in front of
+  // the rows, instead of one dependent L2 round trip per branch in the forward and again in the backward
+  // (16-wave tiles; the 8-wave tiles keep two rows per role in registers and load the vectors where they use them)
+  constexpr bool PREW = FW == 16;
+  Vec<NC> W0[GQE_MAX_BRANCH], W1[GQE_MAX_BRANCH], WF;
+  if (PREW && DEC != DEC_BILINEAR && f->qtype > 2) {
+#pragma unroll
+    for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
+      if (i < n) {
+        W0[i] = vload<NC>(params + f->hop_param[i][0], d, lane);
+        W1[i] = (f->n_hops[i] > 1) ? vload<NC>(params + f->hop_param[i][1], d, lane) : W0[i];
+      }
+    }
+    if (f->n_final) WF = vload<NC>(params + f->final_param, d, lane);
+  }
   RowSet<NC> RA[GQE_MAX_BRANCH], RT, RN;
   const int tbag = f->target_bag;
   if (tbag < 0) {
@@ -576,6 +791,10 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   for (int i = 0; i < GQE_MAX_BRANCH; ++i)
     if (i < n) rows_finish<NC>(RA[i]);
 
+  // Pre is requested once the rows are in (192 tiles pulling the same 64 KB out of the same L2 lines next to the
+  // gathers delayed those by ~1.5 us); it lands while the branch vectors are built
+  if (stage) mat_issue<MR>(mr, params + f->pre_param);
+  GQE_STAMP(9);
   const bool is_chain = f->qtype <= 2;
   const float gscale = b.grad_scale;  // loss_weight / B
   float loss_part = 0.f;
@@ -826,9 +1045,12 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
         }
         if (MLP && BWD) tile_to_scratch<NC>(e, f->slot_e[i], te[i]);
       } else {
-        Vec<NC> w0 = vload<NC>(params + f->hop_param[i][0], d, lane);
-        Vec<NC> w1 = w0;
-        if (nh > 1) w1 = vload<NC>(params + f->hop_param[i][1], d, lane);
+        if (!PREW) {
+          W0[i] = vload<NC>(params + f->hop_param[i][0], d, lane);
+          W1[i] = (nh > 1) ? vload<NC>(params + f->hop_param[i][1], d, lane) : W0[i];
+        }
+        const Vec<NC>& w0 = W0[i];
+        const Vec<NC>& w1 = W1[i];
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
           const int r = wave * RPW + rr;
@@ -842,11 +1064,27 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
     }
     // ---- intersection -> tacc (+ tmeta) ----
     if (MLP) {
+      if (STAGE) {  // Pre arrived while the branch vectors were built; Post is requested now and lands behind the phase
+        mat_commit<MR>(mr, mbuf, d, DP);
+        mat_issue<MR>(mr, params + f->post_param);
+      }
       __syncthreads();
-      if (n == 3)
-        pre_intersect<NC, 3>(tacc, tmeta, params + f->pre_param, te, d, DP, wave, lane, inter_min);
-      else
-        pre_intersect<NC, 2>(tacc, tmeta, params + f->pre_param, te, d, DP, wave, lane, inter_min);
+      GQE_STAMP(10);
+      if (STAGE) {
+        if (n == 3)
+          pre_intersect_staged<NC, 3>(tacc, tmeta, mbuf, te, DP, wave, lane, inter_min);
+        else
+          pre_intersect_staged<NC, 2>(tacc, tmeta, mbuf, te, DP, wave, lane, inter_min);
+        GQE_STAMP(11);
+        __syncthreads();
+        mat_commit<MR>(mr, mbuf, d, DP);                      // Post replaces Pre
+        if (BWD) mat_issue<MR>(mr, params + f->pre_param);    // ... and Pre is requested again for the backward
+      } else {
+        if (n == 3)
+          pre_intersect<NC, 3>(tacc, tmeta, params + f->pre_param, te, d, DP, wave, lane, inter_min);
+        else
+          pre_intersect<NC, 2>(tacc, tmeta, params + f->pre_param, te, d, DP, wave, lane, inter_min);
+      }
       __syncthreads();
     } else {
       // element-wise first-arg-min / mean over the branches, own rows
@@ -882,7 +1120,10 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
     float* tqq = tacc;  // where q lives
     if (MLP) {
       if (BWD) tile_to_scratch<NC>(e, f->slot_hh, tacc);
-      tile_matmul<false, NC>(tq, params + f->post_param, tacc, d, DP, wave, lane);  // q = Post . h
+      if (STAGE)
+        tile_matmul_staged<false, NC>(tq, mbuf, tacc, DP, wave, lane);
+      else
+        tile_matmul<false, NC>(tq, params + f->post_param, tacc, d, DP, wave, lane);  // q = Post . h
       __syncthreads();
       tqq = tq;
     }
@@ -895,7 +1136,8 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
         tile_matmul<false, NC>(te[0], params + f->final_param, tqq, d, DP, wave, lane);
         __syncthreads();
       } else {
-        Vec<NC> w = vload<NC>(params + f->final_param, d, lane);
+        if (!PREW) WF = vload<NC>(params + f->final_param, d, lane);
+        const Vec<NC>& w = WF;
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
           const int r = wave * RPW + rr;
@@ -949,6 +1191,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
       }
     }
     GQE_STAMP(5);
+    GQE_WSTAMP(0);
     if (BWD) {
       // ---- backward of the final projection: g (tile tgc) -> grad wrt q_pre ----
       float* tgc = tg;
@@ -960,7 +1203,8 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
           __syncthreads();
           tgc = te[1];
         } else {
-          Vec<NC> w = vload<NC>(params + f->final_param, d, lane);
+          if (!PREW) WF = vload<NC>(params + f->final_param, d, lane);
+          const Vec<NC>& w = WF;
           Vec<NC> gw = vzero<NC>();
 #pragma unroll
           for (int rr = 0; rr < RPW; ++rr) {
@@ -983,9 +1227,20 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
       float* tgh = tgc;  // grad wrt h (MLP) or wrt the intersection output (simple)
       if (MLP) {
         tile_to_scratch<NC>(e, f->slot_gq, tgc);
+        GQE_WSTAMP(1);
         __syncthreads();
-        tile_matmul<true, NC>(tacc, params + f->post_param, tgc, d, DP, wave, lane);  // g_h = Post^T g_q
-        __syncthreads();
+        if (STAGE) {
+          GQE_WSTAMP(2);
+          tile_matmul_staged<true, NC>(tacc, mbuf, tgc, DP, wave, lane);  // Post is still staged
+          GQE_WSTAMP(3);
+          __syncthreads();
+          GQE_WSTAMP(4);
+          mat_commit<MR>(mr, mbuf, d, DP);  // Pre again; the barrier in front of its contraction is below
+          GQE_WSTAMP(5);
+        } else {
+          tile_matmul<true, NC>(tacc, params + f->post_param, tgc, d, DP, wave, lane);  // g_h = Post^T g_q
+          __syncthreads();
+        }
         tgh = tacc;
       }
       GQE_STAMP(6);
@@ -1006,11 +1261,24 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
             vstore<NC>(scratch_row(e, f->slot_gz[i], r), gz, d, lane);
           }
         }
-        if (n == 3)
-          pre_intersect_bwd<NC, 3>(te, params + f->pre_param, tgh, tmeta, d, DP, wave, lane, inter_min);
-        else
-          pre_intersect_bwd<NC, 2>(te, params + f->pre_param, tgh, tmeta, d, DP, wave, lane, inter_min);
+        if (STAGE) {
+          __syncthreads();
+          GQE_STAMP(12);
+          GQE_WSTAMP(6);
+          if (n == 3)
+            pre_intersect_bwd_staged<NC, 3>(te, mbuf, tgh, tmeta, DP, wave, lane, inter_min);
+          else
+            pre_intersect_bwd_staged<NC, 2>(te, mbuf, tgh, tmeta, DP, wave, lane, inter_min);
+        } else {
+          if (n == 3)
+            pre_intersect_bwd<NC, 3>(te, params + f->pre_param, tgh, tmeta, d, DP, wave, lane, inter_min);
+          else
+            pre_intersect_bwd<NC, 2>(te, params + f->pre_param, tgh, tmeta, d, DP, wave, lane, inter_min);
+        }
+        GQE_STAMP(13);
+        GQE_WSTAMP(7);
         __syncthreads();
+        GQE_STAMP(14);
       } else if (DEC == DEC_BILINEAR) {
         // simple intersection + Bilinear hops: the masked gradient has to be a tile for the MFMA
         if (tgc == te[1]) __syncthreads();
@@ -1055,9 +1323,12 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
           }
           __syncthreads();  // tt / tq are rewritten by the next branch
         } else {
-          Vec<NC> w0 = vload<NC>(params + f->hop_param[i][0], d, lane);
-          Vec<NC> w1 = w0;
-          if (nh > 1) w1 = vload<NC>(params + f->hop_param[i][1], d, lane);
+          if (!PREW) {
+            W0[i] = vload<NC>(params + f->hop_param[i][0], d, lane);
+            W1[i] = (nh > 1) ? vload<NC>(params + f->hop_param[i][1], d, lane) : W0[i];
+          }
+          const Vec<NC>& w0 = W0[i];
+          const Vec<NC>& w1 = W1[i];
           Vec<NC> gw0 = vzero<NC>(), gw1 = vzero<NC>();
 #pragma unroll
           for (int rr = 0; rr < RPW; ++rr) {
@@ -1098,8 +1369,11 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
     }
   }
   GQE_STAMP(7);
+  GQE_WSTAMP(8);
   if (BWD && DEC != DEC_BILINEAR) vecgrads_commit<NC>(e, smem, reinterpret_cast<long long*>(s_idx), vg);
+  GQE_WSTAMP(9);
   if (BWD) push_links(e, olds);
+  GQE_WSTAMP(10);
   if (BWD) {
     // mean hinge loss of the batch (model.py:124-126) and the weighted iteration loss: reduce the waves in
     // LDS (thousands of same-address device atomics serialise at ~12 ns each) and park one partial per tile.
@@ -1115,19 +1389,20 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   }
   GQE_STAMP(8);
 #undef GQE_STAMP
+#undef GQE_WSTAMP
 }
 
 // ------------------------------------------------------------------------------------------
 // per-(DEC, MLP) launcher, instantiated once per translation unit (gqe_fused_inst.hip)
 // ------------------------------------------------------------------------------------------
-inline size_t gqe_fused_lds_bytes_impl(int d) {
+inline size_t gqe_fused_lds_bytes_impl(int d, bool stage) {
   const int DP = d + 4;
-  return (size_t)(8 * GQE_TQ * DP + GQE_FW * d + 5 * GQE_TQ) * sizeof(float);
+  return (size_t)(8 * GQE_TQ * DP + GQE_FW * d + 5 * GQE_TQ + (stage ? d * DP : 0)) * sizeof(float);
 }
 
 template <int DEC, bool MLP, int NC, bool FULL>
 static hipError_t launch_fused_v(const GqeFusedArgs& a) {
-  const size_t lds = gqe_fused_lds_bytes_impl(a.d);
+  const size_t lds = gqe_fused_lds_bytes_impl(a.d, MLP && DEC != DEC_BILINEAR && FULL && NC <= 2 && GQE_FW == 16);
   if (a.bwd)
     hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true, GQE_FW>), dim3(a.plan.tiles), dim3(GQE_FWT), lds, a.stream, a.plan,
                        a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags, a.link_contrib, a.link_counter,

@@ -453,15 +453,15 @@ int formula_of(gqe_ctx* ctx, const gqe_batch& s, int bi, int* out_id) {
   int nslot = 0, njob = 0;
   auto add_job = [&](int64_t param, int Lslot, int Rslot) {
     f.job_param[njob] = param;
-    f.job_L[njob] = (int8_t)Lslot;
-    f.job_R[njob] = (int8_t)Rslot;
+    f.job_L[njob] = Lslot;
+    f.job_R[njob] = Rslot;
     ++njob;
   };
   if (chain && bil) {
     for (int sde = 0; sde < 2; ++sde)
       for (int h = 0; h < f.n_hops[0]; ++h) {
-        f.slot_act[sde][h] = (int8_t)nslot++;
-        f.slot_gact[sde][h] = (int8_t)nslot++;
+        f.slot_act[sde][h] = nslot++;
+        f.slot_gact[sde][h] = nslot++;
         add_job(f.hop_param[0][h], f.slot_act[sde][h], f.slot_gact[sde][h]);  // act_{h+1} = act_h M_h => dM_h += act_h^T g_{h+1}
       }
   }
@@ -469,24 +469,24 @@ int formula_of(gqe_ctx* ctx, const gqe_batch& s, int bi, int* out_id) {
     if (bil) {
       for (int i = 0; i < na; ++i)
         for (int h = 0; h < f.n_hops[i]; ++h) {
-          f.slot_x[i][h] = (int8_t)nslot++;
-          f.slot_gy[i][h] = (int8_t)nslot++;
+          f.slot_x[i][h] = nslot++;
+          f.slot_gy[i][h] = nslot++;
           add_job(f.hop_param[i][h], f.slot_gy[i][h], f.slot_x[i][h]);  // y = M x  =>  dM += g_y x^T
         }
       if (f.n_final) {
-        f.slot_fx = (int8_t)nslot++;
-        f.slot_fg = (int8_t)nslot++;
+        f.slot_fx = nslot++;
+        f.slot_fg = nslot++;
         add_job(f.final_param, f.slot_fg, f.slot_fx);
       }
     }
     if (mlp) {
       for (int i = 0; i < na; ++i) {
-        f.slot_e[i] = (int8_t)nslot++;
-        f.slot_gz[i] = (int8_t)nslot++;
+        f.slot_e[i] = nslot++;
+        f.slot_gz[i] = nslot++;
         add_job(f.pre_param, f.slot_gz[i], f.slot_e[i]);  // z = Pre e  => dPre += g_z e^T
       }
-      f.slot_hh = (int8_t)nslot++;
-      f.slot_gq = (int8_t)nslot++;
+      f.slot_hh = nslot++;
+      f.slot_gq = nslot++;
       add_job(f.post_param, f.slot_gq, f.slot_hh);        // q = Post h => dPost += g_q h^T
     }
   }

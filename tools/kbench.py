@@ -71,12 +71,12 @@ def phase_profile(mix, B, label):
     descs, idx, _ = pack_margin_batches(its)
     ps = eng.prepare_margin(descs, torch.from_numpy(idx).cuda())
     tiles = sum((B + 15) // 16 for _ in mix)
-    stamps = torch.zeros(tiles * 16, dtype=torch.int64, device="cuda")
+    stamps = torch.zeros(tiles * 64, dtype=torch.int64, device="cuda")
     eng.run_margin(ps); eng.materialize(); torch.cuda.synchronize()
     eng._check(eng.lib.gqe_debug_profile(eng.ctx, stamps.data_ptr()))
     eng.run_margin(ps); eng.materialize(); torch.cuda.synchronize()
     eng._check(eng.lib.gqe_debug_profile(eng.ctx, None))
-    st = stamps.cpu().numpy().reshape(tiles, 16).astype(np.float64)
+    st = stamps.cpu().numpy().reshape(tiles, 64).astype(np.float64)
     t0 = st[:, 0].min()
     names = ["start", "idx", "rows", "branches", "post/final", "score", "postT", "branches_bwd", "loss"]
     print("== phase profile %s B=%d (us since first block start; per batch type: median over its tiles)" % (label, B))
@@ -100,4 +100,19 @@ def phase_profile(mix, B, label):
             col = rel[:, k][blk[:, k] > 0]
             cells.append("%s=%6.1f" % (names[k], np.median(col)) if len(col) else "%s=   n/a" % names[k])
         print("%-14s %s  end(max)=%6.1f" % (qt + ("*" if hard else ""), " ".join(cells), rel[:, 8].max()))
+        extra = []
+        for k, nm in ((9, "norm"), (10, "vec+bar"), (11, "pre_mfma"), (12, "gz+bar"), (13, "preT_mfma"), (14, "bar")):
+            col = rel[:, k][blk[:, k] > 0]
+            if len(col):
+                extra.append("%s=%6.1f" % (nm, np.median(col)))
+        if extra:
+            print("%-14s   detail: %s" % ("", " ".join(extra)))
+        wn = ["score_end", "gq_parked", "postT_go", "postT_done", "bar", "commit", "preT_go", "preT_done", "hops_done", "vg_done", "links"]
+        for pidx, nm in enumerate(wn):
+            vals = []
+            for k in range(4):
+                col = rel[:, 16 + pidx * 4 + k][blk[:, 16 + pidx * 4 + k] > 0]
+                vals.append("%6.1f" % np.median(col) if len(col) else "   n/a")
+            if any(v.strip() != "n/a" for v in vals) and qt == "3-inter" and not hard:
+                print("%-14s   waves 0/4/8/12 %-10s %s" % ("", nm, " ".join(vals)))
 phase_profile(list(synth.FULL_MIX), 512, "full mix")
