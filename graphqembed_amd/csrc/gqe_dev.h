@@ -67,7 +67,9 @@ struct GqeDynBatch {
   int32_t loss_index;    // where this batch's loss goes in the caller's losses[]
   int32_t n_candidates;  // > 0: evaluation against candidate lists (forward only): scratch_base = this batch's query
                          // records, unit_begin = its first block of the candidate-scoring kernel
-  int32_t pad[2];
+  int32_t n_anchors;     // copy of the formula's anchor count: the tile's index load needs it, and as a kernel argument
+                         // it does not wait for the descriptor's first scalar load
+  int32_t pad;
 };
 
 // Bag modes (Reddit posts: nn.EmbeddingBag mean over word rows, reddit/data_utils_new.py:155,162-169):

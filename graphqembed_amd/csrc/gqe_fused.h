@@ -102,7 +102,7 @@ __device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 a
 // The A slab of an output row block is fetched in groups of <= KG k-blocks (KG float4 per lane in flight): all of it
 // at d <= 128, two / three / four rounds beyond — a 16-float4 slab (d = 256) next to the rows a wave keeps in registers
 // would spill.
-#define GQE_KG 8
+#define GQE_KG (GQE_FW == 8 && NC >= 3 ? (NC >= 4 ? 2 : 4) : 8)  // the 8-wave d > 128 kernels carry two rows per role: 4 keeps them off the spill cliff
 
 // ---- matrices staged in LDS (the intersection's Pre / Post at d <= 128) -----------------------------------------
 // A d x d matrix every tile of a batch contracts with sits in L2, ~1 us away, and a contraction phase cannot start
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   const int DP = e.DP, lane = e.lane, wave = e.wave;
   const int B = b.B;
   const bool has_neg = b.has_neg != 0;
-  const int n = f->n_anchors;
+  const int n = b.n_anchors;  // == f->n_anchors, without the descriptor round trip in front of the index load
   // evaluation against candidate lists (forward only): index layout anchors[n][B] | cand_ptr[B+1] | cand_rows[..];
   // every query is scored against its own list, the query side being computed once (the reference re-encodes
   // and re-projects the anchors for every candidate, utils.py:50-60,78-88)
@@ -725,8 +725,28 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   constexpr bool STAGE = MLP && DEC != DEC_BILINEAR && FULL && NC <= 2 && FW == 16;
   constexpr int MR = STAGE ? NC * NC : 1;
   float* mbuf = reinterpret_cast<float*>(s_idx + 5 * GQE_TQ);  // [d][DP], only carved for STAGE kernels
-  const bool stage = STAGE && f->qtype > 2;
   MatRegs<MR> mr;
+  // The descriptor fields the gathers need — requested here, pinned (GQE_PIN) behind the index load below, so that
+  // their scalar round trip runs next to that load instead of after the barrier (left alone, the compiler sinks every
+  // descriptor read to its first use: one more dependent trip to L2 per phase).
+  // 16-wave tiles only: the 8-wave kernels of the guarded d in (128, 256) variants sit at 256 VGPRs with spills, and
+  // there the early copies changed the allocation into one that loses lanes >= 16 of a relation gradient
+  // (tests/test_gpu_parity.py::test_eight_wave_workgroups_vs_oracle d = 144) — they keep reading the fields where used.
+#define GQE_PIN(x) asm volatile("" : "+s"(x))
+#define GQE_DSC(early, field) (FW == 16 ? (early) : (field))
+  int qtype = f->qtype;
+  int64_t t_table = 0;
+  int tbag = f->target_bag;
+  int64_t a_table[GQE_MAX_BRANCH] = {0, 0, 0};
+  int a_bag[GQE_MAX_BRANCH] = {-1, -1, -1};
+  if (FW == 16) {
+    t_table = f->target_table;
+#pragma unroll
+    for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
+      a_table[i] = f->anchor_table[i];
+      a_bag[i] = f->anchor_bag[i];
+    }
+  }
 
   // ---- the tile's table rows: one coalesced read, then every gather is issued at once ----
   if (threadIdx.x < 5 * GQE_TQ) {
@@ -740,6 +760,18 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
     }
     s_idx[threadIdx.x] = v;
   }
+  if (FW == 16) {
+    GQE_PIN(qtype);
+    GQE_PIN(t_table);
+    GQE_PIN(tbag);
+#pragma unroll
+    for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
+      GQE_PIN(a_table[i]);
+      GQE_PIN(a_bag[i]);
+    }
+  }
+#undef GQE_PIN
+  const bool stage = STAGE && qtype > 2;
   __syncthreads();
   GQE_STAMP(1);
   // the relation vectors of an intersection tile (<= 2 per branch + the final projection): requested here, in front of
@@ -747,7 +779,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   // (16-wave tiles; the 8-wave tiles keep two rows per role in registers and load the vectors where they use them)
   constexpr bool PREW = FW == 16;
   Vec<NC> W0[GQE_MAX_BRANCH], W1[GQE_MAX_BRANCH], WF;
-  if (PREW && DEC != DEC_BILINEAR && f->qtype > 2) {
+  if (PREW && DEC != DEC_BILINEAR && qtype > 2) {
 #pragma unroll
     for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
       if (i < n) {
@@ -758,22 +790,21 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
     if (f->n_final) WF = vload<NC>(params + f->final_param, d, lane);
   }
   RowSet<NC> RA[GQE_MAX_BRANCH], RT, RN;
-  const int tbag = f->target_bag;
   if (tbag < 0) {
-    rows_issue<NC>(RT, e, f->target_table, s_idx);
-    if (has_neg) rows_issue<NC>(RN, e, f->target_table, s_idx + GQE_TQ);
+    rows_issue<NC>(RT, e, GQE_DSC(t_table, f->target_table), s_idx);
+    if (has_neg) rows_issue<NC>(RN, e, GQE_DSC(t_table, f->target_table), s_idx + GQE_TQ);
   } else {
-    rows_issue_bag<NC>(RT, e, f->target_table, s_idx, bags.ptr[tbag], bags.ids[tbag]);
-    if (has_neg) rows_issue_bag<NC>(RN, e, f->target_table, s_idx + GQE_TQ, bags.ptr[tbag], bags.ids[tbag]);
+    rows_issue_bag<NC>(RT, e, GQE_DSC(t_table, f->target_table), s_idx, bags.ptr[tbag], bags.ids[tbag]);
+    if (has_neg) rows_issue_bag<NC>(RN, e, GQE_DSC(t_table, f->target_table), s_idx + GQE_TQ, bags.ptr[tbag], bags.ids[tbag]);
   }
 #pragma unroll
   for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
     if (i < n) {
-      const int ab = f->anchor_bag[i];
+      const int ab = GQE_DSC(a_bag[i], f->anchor_bag[i]);
       if (ab < 0)
-        rows_issue<NC>(RA[i], e, f->anchor_table[i], s_idx + (2 + i) * GQE_TQ);
+        rows_issue<NC>(RA[i], e, GQE_DSC(a_table[i], f->anchor_table[i]), s_idx + (2 + i) * GQE_TQ);
       else
-        rows_issue_bag<NC>(RA[i], e, f->anchor_table[i], s_idx + (2 + i) * GQE_TQ, bags.ptr[ab], bags.ids[ab]);
+        rows_issue_bag<NC>(RA[i], e, GQE_DSC(a_table[i], f->anchor_table[i]), s_idx + (2 + i) * GQE_TQ, bags.ptr[ab], bags.ids[ab]);
     }
   }
   rows_finish<NC>(RT);
@@ -795,7 +826,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   // gathers delayed those by ~1.5 us); it lands while the branch vectors are built
   if (stage) mat_issue<MR>(mr, params + f->pre_param);
   GQE_STAMP(9);
-  const bool is_chain = f->qtype <= 2;
+  const bool is_chain = qtype <= 2;
   const float gscale = b.grad_scale;  // loss_weight / B
   float loss_part = 0.f;
   VecGrads<NC> vg;  // relation-vector gradient partials of this wave (DEC != bilinear)

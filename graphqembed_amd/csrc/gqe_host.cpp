@@ -831,6 +831,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       b.grad_scale = s.loss_weight / (float)s.n_queries;
       b.loss_index = b0 + k;
       b.n_candidates = s.n_candidates;
+      b.n_anchors = f.n_anchors;
       tiles_of[k] = b.Bpad / GQE_TQ;
       units_of[k] = 0;
       // relative length of one tile's dependent chain: contraction phases dominate (intersections: Pre / Post and
