@@ -113,6 +113,10 @@ struct GqeActSeg {
 
 struct GqeOptActive {
   uint8_t group[GQE_MAX_SEGS];  // per universe entry: 0xFF = not stepped, else index into GqeStepCoef
+  // chunk prefix of the pass over the universe (inactive tensors own no chunks), computed by the host: a workgroup used
+  // to rebuild it — a global load of every tensor's chunk count, then one thread adding them up, ~3 us before its first
+  // useful load, and at the start of the launch every resident workgroup did so at once
+  int32_t begin[GQE_MAX_SEGS + 1];
 };
 
 #define GQE_MAX_STEP_GROUPS 32

@@ -1054,6 +1054,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
   const bool table_form = nu > GQE_MAX_SEGS || distinct.size() > GQE_MAX_STEP_GROUPS;
   std::vector<GqeActSeg> staging;
   const GqeActSeg* act_dev = reinterpret_cast<const GqeActSeg*>(ctx->ws + ctx->lay.act_off);
+  bool prefix_overflow = false;  // the kernel-argument prefix counts chunks in 32 bits (2^31 chunks = 2 T parameters)
   auto emit = [&](auto keep, GqeOptActive& active, GqeStepCoef& coef, const GqeActSeg** act, int* n_act) -> long long {
     long long chunks = 0;
     memset(active.group, 0xFF, sizeof active.group);
@@ -1062,7 +1063,10 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     *n_act = 0;
     if (!table_form) {
       int group_step[GQE_MAX_STEP_GROUPS], n_groups = 0;
+      for (size_t ui = 0; ui <= nu; ++ui) active.begin[ui] = 0;
       for (size_t ui = 0; ui < nu; ++ui) {
+        active.begin[ui] = (int32_t)chunks;
+        active.begin[ui + 1] = (int32_t)chunks;
         if (!ustep[ui] || !keep(ui)) continue;
         int gi = 0;
         while (gi < n_groups && group_step[gi] != ustep[ui]) ++gi;
@@ -1073,7 +1077,9 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
         }
         active.group[ui] = (uint8_t)gi;
         chunks += ctx->universe[ui].n_chunks;
+        active.begin[ui + 1] = (int32_t)chunks;
       }
+      prefix_overflow = prefix_overflow || chunks > 0x7fffffffll;
     } else {
       const size_t first = staging.size();
       for (size_t ui = 0; ui < nu; ++ui) {
@@ -1212,6 +1218,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       ra.dsegs = oa.segs;
       ra.n_dsegs = oa.n_segs;
       ra.dense_chunks = emit(dense_only, ra.dactive, ra.dcoef, &ra.dact, &ra.n_dact);
+      if (prefix_overflow) return fail(ctx, GQE_ERR_ARG, "optimiser pass over more than 2^31 chunks");
       rc = upload_staging();
       if (rc != GQE_OK) return rc;
       rc = timing_begin(ctx, 2, st);
@@ -1286,6 +1293,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
         oa.lz.t.eager[t] = lazy_table_ok(ctx, (int)t) ? 0 : 1;
       }
       oa.total_chunks = emit(everything, oa.active, oa.coef, &oa.act, &oa.n_act);
+      if (prefix_overflow) return fail(ctx, GQE_ERR_ARG, "optimiser pass over more than 2^31 chunks");
       rc = upload_staging();
       if (rc != GQE_OK) return rc;
       if (timed) {
@@ -1307,6 +1315,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     if (flush) return GQE_OK;
   } else {
     oa.total_chunks = emit(everything, oa.active, oa.coef, &oa.act, &oa.n_act);
+    if (prefix_overflow) return fail(ctx, GQE_ERR_ARG, "optimiser pass over more than 2^31 chunks");
     rc = upload_staging();
     if (rc != GQE_OK) return rc;
     if (timed) {

@@ -281,19 +281,9 @@ __device__ __forceinline__ void opt_body(const long long first_chunk, const long
                                                              const GqeActSeg* __restrict__ act, int n_act, const GqeLazyArgs& lazy) {
   // Which tensor owns chunk ch, and its Adam coefficients.  Kernel-argument form (act == NULL): a prefix over the
   // <= GQE_MAX_SEGS universe entries in LDS.  Table form: a binary search in the uploaded list of active tensors.
-  __shared__ long long s_begin[GQE_MAX_SEGS + 1];  // chunk prefix over the universe; inactive tensors get 0 chunks
-  __shared__ long long s_cnt[GQE_MAX_SEGS];
+  __shared__ int32_t s_begin[GQE_MAX_SEGS + 1];  // chunk prefix over the universe (from the host); inactive tensors own 0 chunks
   if (!act) {
-    if ((int)threadIdx.x < n_segs) s_cnt[threadIdx.x] = (active.group[threadIdx.x] != 0xFF) ? segs[threadIdx.x].n_chunks : 0;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      long long run = 0;
-      for (int i = 0; i < n_segs; ++i) {
-        s_begin[i] = run;
-        run += s_cnt[i];
-      }
-      s_begin[n_segs] = run;
-    }
+    if ((int)threadIdx.x <= n_segs) s_begin[threadIdx.x] = active.begin[threadIdx.x];
     __syncthreads();
   }
   const int tpr = d >> 2;               // threads per table row
