@@ -15,7 +15,13 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
                                                                    const float* __restrict__ ws,
                                                                    float* __restrict__ grads, int d,
                                                                    const float* __restrict__ tile_loss,
-                                                                   float* __restrict__ losses) {
+                                                                   float* __restrict__ losses, long long* __restrict__ prof) {
+  // debug profile (gqe_debug_profile): this launch's workgroups stamp behind the fused kernel's tiles
+#define GQE_GSTAMP(k)                                                                                                          \
+  do {                                                                                                                        \
+    if (prof && threadIdx.x == 0) prof[((size_t)plan.tiles + blockIdx.x) * GQE_PROF_SLOTS + (k)] = (long long)wall_clock64(); \
+  } while (0)
+  GQE_GSTAMP(0);
   if (blockIdx.x == 0) {
     // finalize block (first, so that it is not queued behind the GEMM units): per-batch mean hinge loss (model.py:124-126) and the weighted iteration loss from the
     // per-tile partials of the fused kernel — plain stores, nothing to zero, no atomics.
@@ -67,6 +73,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
   const size_t slot_floats = (size_t)b.Bpad * d;
   const float* L = ws + b.scratch_base + (size_t)f->job_L[job] * slot_floats;
   const float* R = ws + b.scratch_base + (size_t)f->job_R[job] * slot_floats;
+  GQE_GSTAMP(1);
   const int ib0 = (wave >> 1) * 2, jb0 = (wave & 1) * 2;
   f32x4 acc[2][2];
 #pragma unroll
@@ -95,6 +102,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
     if (!(okm >> (2 * q) & 1u)) vl[q] = zero4;
     if (!(okm >> (2 * q) & 2u)) vr[q] = zero4;
   }
+  GQE_GSTAMP(2);
 #pragma unroll
   for (int h = 0; h < GQE_GEMM_KCHUNK / KS; ++h) {
     if (h) __syncthreads();  // the previous half is consumed
@@ -105,6 +113,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
       *reinterpret_cast<float4*>(sR + row * STR + c4) = vr[h * 4 + q];
     }
     __syncthreads();
+    GQE_GSTAMP(3 + 2 * h);
     if (ib0 < nib && jb0 < njb) {
 #pragma unroll 4
       for (int s = 0; s < KS / 4; ++s) {
@@ -118,6 +127,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
         acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
       }
     }
+    GQE_GSTAMP(4 + 2 * h);
   }
 #pragma unroll
   for (int x = 0; x < 2; ++x)
@@ -128,6 +138,8 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
 #pragma unroll
       for (int r = 0; r < 4; ++r) unsafeAtomicAdd(out + (size_t)r * d, acc[x][y][r]);
     }
+  GQE_GSTAMP(7);
+#undef GQE_GSTAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -481,7 +493,7 @@ hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a) {
 hipError_t gqe_launch_pair_gemm(const GqeFusedArgs& a, float* losses) {
   const int blocks = a.plan.units + 1;  // + the finalize block
   hipLaunchKernelGGL(gqe_pair_gemm_kernel, dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.plan, a.formulas, a.ws, a.grads, a.d,
-                     a.tile_loss, losses);
+                     a.tile_loss, losses, a.prof);
   return hipGetLastError();
 }
 

@@ -71,12 +71,14 @@ def phase_profile(mix, B, label):
     descs, idx, _ = pack_margin_batches(its)
     ps = eng.prepare_margin(descs, torch.from_numpy(idx).cuda())
     tiles = sum((B + 15) // 16 for _ in mix)
-    stamps = torch.zeros(tiles * 64, dtype=torch.int64, device="cuda")
+    GEMM_WGS = 2048   # the pair-GEMM launch stamps behind the tiles (one row per workgroup; unused rows stay 0)
+    stamps = torch.zeros((tiles + GEMM_WGS) * 64, dtype=torch.int64, device="cuda")
     eng.run_margin(ps); eng.materialize(); torch.cuda.synchronize()
     eng._check(eng.lib.gqe_debug_profile(eng.ctx, stamps.data_ptr()))
     eng.run_margin(ps); eng.materialize(); torch.cuda.synchronize()
     eng._check(eng.lib.gqe_debug_profile(eng.ctx, None))
-    st = stamps.cpu().numpy().reshape(tiles, 64).astype(np.float64)
+    allst = stamps.cpu().numpy().reshape(tiles + GEMM_WGS, 64).astype(np.float64)
+    st = allst[:tiles]
     t0 = st[:, 0].min()
     names = ["start", "idx", "rows", "branches", "post/final", "score", "postT", "branches_bwd", "loss"]
     print("== phase profile %s B=%d (us since first block start; per batch type: median over its tiles)" % (label, B))
@@ -115,4 +117,17 @@ def phase_profile(mix, B, label):
                 vals.append("%6.1f" % np.median(col) if len(col) else "   n/a")
             if any(v.strip() != "n/a" for v in vals) and qt == "3-inter" and not hard:
                 print("%-14s   waves 0/4/8/12 %-10s %s" % ("", nm, " ".join(vals)))
+    # ---- the pair-GEMM launch ----
+    gs = allst[tiles:]
+    gs = gs[gs[:, 0] > 0]
+    if len(gs):
+        g0 = gs[:, 0].min()
+        fused_end = st[:, 8].max()
+        names_g = ["start", "decoded", "panels_in", "lds0", "mfma0", "lds1", "mfma1", "atomics_issued"]
+        units = gs[gs[:, 7] > 0]
+        print("== pair GEMM: %d workgroups stamped (%d units); first start %.1f us after the last fused tile ended" % (len(gs), len(units), (g0 - fused_end) / 100.0))
+        print("   median over units, us since the launch's first start: " + " ".join("%s=%.1f" % (names_g[k], np.median((units[:, k] - g0) / 100.0)) for k in range(8)))
+        print("   max   over units:                                     " + " ".join("%s=%.1f" % (names_g[k], np.max((units[:, k] - g0) / 100.0)) for k in range(8)))
+        fin = gs[gs[:, 7] == 0]
+        if len(fin): print("   finalize block start=%.1f" % ((fin[0, 0] - g0) / 100.0))
 phase_profile(list(synth.FULL_MIX), 512, "full mix")
