@@ -51,6 +51,14 @@ __device__ __forceinline__ void vstore(float* p, const Vec<NC>& x, int d, int la
   }
 }
 
+// Wave-uniform scalar math of the fused kernel (norms, cosines): gfx950 has no scalar float ALU, so every sqrtf / division
+// of a per-query scalar is a VALU sequence issued for the whole wave — 16 instructions for an IEEE sqrtf, 11 for a
+// division, ~125 of the ~400 VALU instructions of an intersection tile's scoring phase, and with four waves per SIMD the
+// vector phases are issue-bound.  v_sqrt_f32 / v_rcp_f32 are accurate to 1 ulp, far inside the parity tolerances
+// (scores 1e-5 absolute against the fp64 oracle).
+__device__ __forceinline__ float gqe_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float gqe_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 template <int NC>
 __device__ __forceinline__ void vatomic_add(float* p, const Vec<NC>& x, int d, int lane) {
 #pragma unroll

@@ -471,7 +471,7 @@ __device__ __forceinline__ void rows_issue_bag(RowSet<NC>& rs, const TileEnv& e,
             if (k0 + u < m) VEC_OP(acc, acc.v[c] + v[u].v[c]);
         }
       }
-      const float inv = 1.f / (float)len;
+      const float inv = gqe_rcp((float)len);
       VEC_OP(acc, acc.v[c] * inv);
     }
     rs.x[rr] = acc;
@@ -503,9 +503,9 @@ __device__ __forceinline__ void rows_finish(RowSet<NC>& rs) {
       rs.x[rr] = vzero<NC>();
       rs.nrm[rr] = 1.f;
     } else {
-      const float n = sqrtf(vdot<NC>(rs.x[rr], rs.x[rr]));
+      const float n = gqe_sqrt(vdot<NC>(rs.x[rr], rs.x[rr]));
       rs.nrm[rr] = n;
-      const float inv = 1.f / n;
+      const float inv = gqe_rcp(n);
       VEC_OP(rs.x[rr], rs.x[rr].v[c] * inv);
     }
   }
@@ -520,7 +520,7 @@ template <int NC>
 __device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_base, int role, int r, int row,
                                                  const Vec<NC>& xhat, float nrm, const Vec<NC>& g, int& old_head) {
   const float pg = vdot<NC>(xhat, g);
-  const float inv = 1.f / nrm;
+  const float inv = gqe_rcp(nrm);
   Vec<NC> gx;
   VEC_OP(gx, (g.v[c] - xhat.v[c] * pg) * inv);
   const int64_t entry = e.sharded ? (int64_t)row : e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
@@ -542,7 +542,7 @@ __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t h
                                                      int bag_index) {
   const int p0 = ptr[bag_index], len = ptr[bag_index + 1] - p0;  // re-read (L2 hit) rather than carried in registers
   const float pg = vdot<NC>(xhat, g);
-  const float inv = 1.f / (nrm * (float)len);
+  const float inv = gqe_rcp(nrm * (float)len);
   Vec<NC> gx;
   VEC_OP(gx, (g.v[c] - xhat.v[c] * pg) * inv);
   const int64_t entry = e.bag_shift + e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
@@ -885,12 +885,12 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
           // decoders.py:200-205: u = t + sum w ; score = cos(a, u)
           VEC_OP(up, tp.v[c] + wcomb.v[c]);
           VEC_OP(un, tn.v[c] + wcomb.v[c]);
-          nap = fmaxf(sqrtf(vdot<NC>(a, a)), COS_EPS);
-          nup = fmaxf(sqrtf(vdot<NC>(up, up)), COS_EPS);
-          sp = vdot<NC>(a, up) / (nap * nup);
+          nap = fmaxf(gqe_sqrt(vdot<NC>(a, a)), COS_EPS);
+          nup = fmaxf(gqe_sqrt(vdot<NC>(up, up)), COS_EPS);
+          sp = vdot<NC>(a, up) * gqe_rcp(nap * nup);
           if (has_neg) {
-            nun = fmaxf(sqrtf(vdot<NC>(un, un)), COS_EPS);
-            sn = vdot<NC>(a, un) / (nap * nun);
+            nun = fmaxf(gqe_sqrt(vdot<NC>(un, un)), COS_EPS);
+            sn = vdot<NC>(a, un) * gqe_rcp(nap * nun);
           }
         }
         if (eval_mode) {  // the query side of this row, for the candidate-scoring kernel
@@ -919,8 +919,8 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
             VEC_OP(gw_acc, gw_acc.v[c] + tmix.v[c] * a.v[c]);
           } else {
             // d cos(a,u)/da = u/(na nu) - s a/na^2 ; d/du = a/(na nu) - s u/nu^2
-            const float ipp = 1.f / (nap * nup), ipn = 1.f / (nap * nun);
-            const float iup = sp / (nup * nup), iun = sn / (nun * nun), iaa = 1.f / (nap * nap);
+            const float ipp = gqe_rcp(nap * nup), ipn = gqe_rcp(nap * nun);
+            const float iup = sp * gqe_rcp(nup * nup), iun = sn * gqe_rcp(nun * nun), iaa = gqe_rcp(nap * nap);
             VEC_OP(gtp, cp * (a.v[c] * ipp - up.v[c] * iup));
             VEC_OP(gtn, cn * (a.v[c] * ipn - un.v[c] * iun));
             VEC_OP(ga, cp * (up.v[c] * ipp - sp * a.v[c] * iaa) + cn * (un.v[c] * ipn - sn * a.v[c] * iaa));
@@ -986,15 +986,15 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
         const int r = wave * RPW + rr;
         const int q = e.q0 + r;
         const Vec<NC>& a = RA[0].x[rr];
-        const float nac = fmaxf(sqrtf(vdot<NC>(a, a)), COS_EPS);
+        const float nac = fmaxf(gqe_sqrt(vdot<NC>(a, a)), COS_EPS);
         Vec<NC> u[2];
         float su[2] = {0.f, 0.f}, nu[2] = {1.f, 1.f};
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           if (s < nside) {
             u[s] = vload<NC>(cur[s] + r * DP, d, lane);
-            nu[s] = fmaxf(sqrtf(vdot<NC>(u[s], u[s])), COS_EPS);
-            su[s] = vdot<NC>(u[s], a) / (nu[s] * nac);
+            nu[s] = fmaxf(gqe_sqrt(vdot<NC>(u[s], u[s])), COS_EPS);
+            su[s] = vdot<NC>(u[s], a) * gqe_rcp(nu[s] * nac);
           } else {
             u[s] = vzero<NC>();
           }
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
         Vec<NC> ga = vzero<NC>();
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const float iun = 1.f / (nu[s] * nac), iuu = su[s] / (nu[s] * nu[s]), iaa = su[s] / (nac * nac);
+          const float iun = gqe_rcp(nu[s] * nac), iuu = su[s] * gqe_rcp(nu[s] * nu[s]), iaa = su[s] * gqe_rcp(nac * nac);
           Vec<NC> gu;
           VEC_OP(gu, cf[s] * (a.v[c] * iun - u[s].v[c] * iuu));
           VEC_OP(ga, ga.v[c] + cf[s] * (u[s].v[c] * iun - a.v[c] * iaa));
@@ -1186,17 +1186,17 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
       const int r = wave * RPW + rr;
       const int q = e.q0 + r;
       Vec<NC> qv = vload<NC>(tqq + r * DP, d, lane);
-      const float nq = fmaxf(sqrtf(vdot<NC>(qv, qv)), COS_EPS);
+      const float nq = fmaxf(gqe_sqrt(vdot<NC>(qv, qv)), COS_EPS);
       if (eval_mode) {
         if (q < B) store_query_record<NC>(e, r, qv, nq, 0.f, 0.f);
         continue;
       }
       const Vec<NC>& tp = RT.x[rr];
       const Vec<NC>& tn = RN.x[rr];
-      const float ncp = fmaxf(sqrtf(vdot<NC>(tp, tp)), COS_EPS);
-      const float ncn = fmaxf(sqrtf(vdot<NC>(tn, tn)), COS_EPS);
-      const float sp = vdot<NC>(tp, qv) / (ncp * nq);
-      const float sn = has_neg ? vdot<NC>(tn, qv) / (ncn * nq) : 0.f;
+      const float ncp = fmaxf(gqe_sqrt(vdot<NC>(tp, tp)), COS_EPS);
+      const float ncn = fmaxf(gqe_sqrt(vdot<NC>(tn, tn)), COS_EPS);
+      const float sp = vdot<NC>(tp, qv) * gqe_rcp(ncp * nq);
+      const float sn = has_neg ? vdot<NC>(tn, qv) * gqe_rcp(ncn * nq) : 0.f;
       if (q < B && lane == 0) {
         if (pos_out) pos_out[b.out_offset + q] = sp;
         if (neg_out && has_neg) neg_out[b.out_offset + q] = sn;
@@ -1206,12 +1206,12 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
       const bool act = (q < B) && hinge > 0.f;
       if (act) loss_part += hinge;
       const float cp = act ? -gscale : 0.f, cn = act ? gscale : 0.f;
-      const float ipq = 1.f / (ncp * nq), inq = 1.f / (ncn * nq), iqq = 1.f / (nq * nq);
+      const float ipq = gqe_rcp(ncp * nq), inq = gqe_rcp(ncn * nq), iqq = gqe_rcp(nq * nq);
       Vec<NC> gq, gtp, gtn;
       VEC_OP(gq, cp * (tp.v[c] * ipq - sp * qv.v[c] * iqq) + cn * (tn.v[c] * inq - sn * qv.v[c] * iqq));
       vstore<NC>(tg + r * DP, gq, d, lane);
       if (act) {
-        const float ipp = sp / (ncp * ncp), inn = sn / (ncn * ncn);
+        const float ipp = sp * gqe_rcp(ncp * ncp), inn = sn * gqe_rcp(ncn * ncn);
         VEC_OP(gtp, cp * (qv.v[c] * ipq - tp.v[c] * ipp));
         VEC_OP(gtn, cn * (qv.v[c] * inq - tn.v[c] * inn));
         scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0]);

@@ -820,17 +820,17 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_eval_score_kernel(const GqeDy
         const int ci = c + u * RW + g;
         const float xx = group_sum<LPR>(dot4(x[u], x[u]));
         const float xv = group_sum<LPR>(dot4(x[u], v4));
-        const float inv = 1.f / sqrtf(xx);                       // encoders.py:41-43: t = x / |x|
+        const float inv = __builtin_amdgcn_rsqf(xx);             // encoders.py:41-43: t = x / |x|  (1-ulp instructions, see gqe_sqrt)
         float sc;
         if (kind == 1) {
           sc = xv * inv;
         } else if (kind == 0) {
-          const float nt = fmaxf(sqrtf(xx * inv * inv), COS_EPS);  // |t|, 1 up to rounding
-          sc = xv * inv / (nt * s0);
+          const float nt = fmaxf(gqe_sqrt(xx * inv * inv), COS_EPS);  // |t|, 1 up to rounding
+          sc = xv * inv * gqe_rcp(nt * s0);
         } else {
           const float xw = group_sum<LPR>(dot4(x[u], w4));
-          const float nu = fmaxf(sqrtf(fmaf(2.f * xw, inv, xx * inv * inv) + s2), COS_EPS);   // |t + w|
-          sc = fmaf(xv, inv, s1) / (s0 * nu);
+          const float nu = fmaxf(gqe_sqrt(fmaf(2.f * xw, inv, xx * inv * inv) + s2), COS_EPS);   // |t + w|
+          sc = fmaf(xv, inv, s1) * gqe_rcp(s0 * nu);
         }
         if (writer && ci < seg_end) out[b.out_offset + ci] = sc;
       }
