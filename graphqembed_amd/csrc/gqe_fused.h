@@ -102,7 +102,7 @@ __device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 a
 // The A slab of an output row block is fetched in groups of <= KG k-blocks (KG float4 per lane in flight): all of it
 // at d <= 128, two / three / four rounds beyond — a 16-float4 slab (d = 256) next to the rows a wave keeps in registers
 // would spill.
-#define GQE_KG (GQE_FW == 8 && NC >= 3 ? (NC >= 4 ? 2 : 4) : 8)  // the 8-wave d > 128 kernels carry two rows per role: 4 keeps them off the spill cliff
+#define GQE_KG ((GQE_FW == 8 && NC >= 3) ? (NC >= 4 ? 2 : 4) : ((GQE_DEC == DEC_BILINEAR && NC >= 4) ? 4 : 8))  // 8-wave d > 128 kernels (two rows per role) and the full-Bilinear d = 256 kernel: smaller groups keep them off the spill cliff
 
 // ---- matrices staged in LDS (the intersection's Pre / Post at d <= 128) -----------------------------------------
 // A d x d matrix every tile of a batch contracts with sits in L2, ~1 us away, and a contraction phase cannot start
@@ -733,13 +733,14 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   // there the early copies changed the allocation into one that loses lanes >= 16 of a relation gradient
   // (tests/test_gpu_parity.py::test_eight_wave_workgroups_vs_oracle d = 144) — they keep reading the fields where used.
 #define GQE_PIN(x) asm volatile("" : "+s"(x))
-#define GQE_DSC(early, field) (FW == 16 ? (early) : (field))
+  constexpr bool EARLY = FW == 16 && NC <= 2;  // (d = 256 kernels sit at the 128-VGPR limit: a few more live SGPRs spill there)
+#define GQE_DSC(early, field) (EARLY ? (early) : (field))
   int qtype = f->qtype;
   int64_t t_table = 0;
   int tbag = f->target_bag;
   int64_t a_table[GQE_MAX_BRANCH] = {0, 0, 0};
   int a_bag[GQE_MAX_BRANCH] = {-1, -1, -1};
-  if (FW == 16) {
+  if (EARLY) {
     t_table = f->target_table;
 #pragma unroll
     for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
     }
     s_idx[threadIdx.x] = v;
   }
-  if (FW == 16) {
+  if (EARLY) {
     GQE_PIN(qtype);
     GQE_PIN(t_table);
     GQE_PIN(tbag);
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   // the relation vectors of an intersection tile (<= 2 per branch + the final projection): requested here, in front of
   // the rows, instead of one dependent L2 round trip per branch in the forward and again in the backward
   // (16-wave tiles; the 8-wave tiles keep two rows per role in registers and load the vectors where they use them)
-  constexpr bool PREW = FW == 16;
+  constexpr bool PREW = FW == 16 && NC <= 2;  // d = 256: the vectors would cost 28 VGPRs of a kernel that sits at the 128-VGPR limit
   Vec<NC> W0[GQE_MAX_BRANCH], W1[GQE_MAX_BRANCH], WF;
   if (PREW && DEC != DEC_BILINEAR && qtype > 2) {
 #pragma unroll
