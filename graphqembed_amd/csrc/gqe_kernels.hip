@@ -738,6 +738,14 @@ __device__ __forceinline__ float group_sum(float x) {
   return x;
 }
 
+// `cond ? *p : zero` on float4 lvalues selects between two ADDRESSES — the zero then lives in scratch and every use is a
+// scratch load; this keeps the choice in registers
+__device__ __forceinline__ float4 load4_if(bool cond, const float* p) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cond) v = *reinterpret_cast<const float4*>(p);
+  return v;
+}
+
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
   return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
@@ -800,7 +808,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_eval_score_kernel(const GqeDy
       continue;
     }
     const float* __restrict__ rec = ws + b.scratch_base + (size_t)q * (d + 4);
-    const float4 v4 = act ? *reinterpret_cast<const float4*>(rec + c4) : zero4;
+    const float4 v4 = load4_if(act, rec + c4);
     const float s0 = rec[d], s1 = rec[d + 1], s2 = rec[d + 2];
     for (; c < seg_end; c += RW * GQE_EVAL_U) {
       float4 x[GQE_EVAL_U];
@@ -812,11 +820,18 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_eval_score_kernel(const GqeDy
           row[u] = cand_rows[ci < seg_end ? ci : c];
         }
 #pragma unroll
-        for (int u = 0; u < GQE_EVAL_U; ++u) x[u] = act ? *reinterpret_cast<const float4*>(table + (size_t)row[u] * d + c4) : zero4;
+        for (int u = 0; u < GQE_EVAL_U; ++u) x[u] = load4_if(act, table + (size_t)row[u] * d + c4);
       } else {
         // bag mode (Reddit posts): a candidate's raw vector is the mean of its word rows
-        const int32_t* __restrict__ bptr = bags.ptr[tbag];
-        const int32_t* __restrict__ bids = bags.ids[tbag];
+        // (a select chain: indexing the by-value argument with a runtime index would put the table in scratch)
+        const int32_t* __restrict__ bptr = bags.ptr[0];
+        const int32_t* __restrict__ bids = bags.ids[0];
+#pragma unroll
+        for (int t = 1; t < GQE_MAX_BAGS; ++t)
+          if (t == tbag) {
+            bptr = bags.ptr[t];
+            bids = bags.ids[t];
+          }
 #pragma unroll
         for (int u = 0; u < GQE_EVAL_U; ++u) {
           const int ci = c + u * RW + g;
@@ -824,7 +839,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_eval_score_kernel(const GqeDy
           const int p0 = bptr[bag], len = bptr[bag + 1] - p0;
           float4 acc = zero4;
           for (int k = 0; k < len; ++k) {
-            const float4 t = act ? *reinterpret_cast<const float4*>(table + (size_t)bids[p0 + k] * d + c4) : zero4;
+            const float4 t = load4_if(act, table + (size_t)bids[p0 + k] * d + c4);
             acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
           }
           const float il = 1.f / (float)len;
