@@ -663,6 +663,10 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
                                                                 long long* __restrict__ prof) {
   static_assert(FW == GQE_FW, "FW only distinguishes the kernels of the per-GQE_FW translation units");
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // Debug profile (gqe_debug_profile; tools/kbench.py reads it): GQE_PROF_SLOTS wall_clock64 stamps per workgroup.
+  // Slots 0 .. 15: thread 0 at the phase boundaries (0 start, 1 indices, 2 rows, 3 Pre, 4 Post / final, 5 scores, 6 Post^T,
+  // 7 hops + scatter, 8 end, 9 .. 14 inside the intersection phases); slots 16 + 4 p + k: lane 0 of waves 0 / 4 / 8 / 12 at
+  // point p of the backward (how far apart the waves of a tile finish a vector phase).  prof == NULL: a uniform branch.
 #define GQE_STAMP(k)                                                                                              \
   do {                                                                                                            \
     if (prof && threadIdx.x == 0) prof[(size_t)blockIdx.x * GQE_PROF_SLOTS + (k)] = (long long)wall_clock64(); \
@@ -1422,6 +1426,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   GQE_STAMP(8);
 #undef GQE_STAMP
 #undef GQE_WSTAMP
+#undef GQE_DSC
 }
 
 // ------------------------------------------------------------------------------------------
