@@ -219,7 +219,8 @@ def test_adam_kernel_matches_formula():
 
 
 CONFIGS = [("bilinear-diag", "min"), ("bilinear-diag", "mean-simple"), ("transe", "mean"),
-           ("transe", "min-simple"), ("bilinear", "min"), ("bilinear", "mean-simple")]
+           ("transe", "min-simple"), ("bilinear", "min"), ("bilinear", "mean-simple"),
+           ("bilinear-diag", "mean"), ("transe", "min")]   # the staged-matrix path (d = 64 / 128) with both aggregations per decoder
 
 
 @pytest.mark.parametrize("d", [16, 64, 128, 192, 256])
