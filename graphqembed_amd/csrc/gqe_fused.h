@@ -615,26 +615,30 @@ __device__ __forceinline__ void vecgrads_init(VecGrads<NC>& vg) {
 
 template <int NC>
 __device__ __forceinline__ void vecgrads_commit(const TileEnv& e, float* lds /* >= SLOTS*8*d floats */, long long* s_param,
-                                                const VecGrads<NC>& vg) {
+                                                const VecGrads<NC>& vg, float* red, float loss_part,
+                                                const int (&olds)[RPW][2 + GQE_MAX_BRANCH]) {
   __syncthreads();  // every wave is done with the tiles this staging area overlays
 #pragma unroll
   for (int k = 0; k < GQE_VG_SLOTS; ++k) {
     if (vg.param[k] >= 0) vstore<NC>(lds + (size_t)(k * GQE_FW + e.wave) * e.d, vg.g[k], e.d, e.lane);
     if (threadIdx.x == 0) s_param[k] = vg.param[k];
   }
+  if (e.lane == 0) red[e.wave] = loss_part;  // the hinge partials ride on the same two barriers (red lies behind the staging area)
   __syncthreads();
-  if (e.wave < GQE_VG_SLOTS) {
-    const long long param = s_param[e.wave];
-    if (param >= 0) {
-      Vec<NC> s = vload<NC>(lds + (size_t)(e.wave * GQE_FW) * e.d, e.d, e.lane);
+  const long long param = e.wave < GQE_VG_SLOTS ? s_param[e.wave] : -1;
+  Vec<NC> s = vzero<NC>();
+  if (param >= 0) {
+    s = vload<NC>(lds + (size_t)(e.wave * GQE_FW) * e.d, e.d, e.lane);
 #pragma unroll
-      for (int w = 1; w < GQE_FW; ++w) {
-        Vec<NC> t = vload<NC>(lds + (size_t)(e.wave * GQE_FW + w) * e.d, e.d, e.lane);
-        VEC_OP(s, s.v[c] + t.v[c]);
-      }
-      vatomic_add<NC>(e.grads + param, s, e.d, e.lane);
+    for (int w = 1; w < GQE_FW; ++w) {
+      Vec<NC> t = vload<NC>(lds + (size_t)(e.wave * GQE_FW + w) * e.d, e.d, e.lane);
+      VEC_OP(s, s.v[c] + t.v[c]);
     }
   }
+  // the list links (they wait for the heads the scatter's exchanges returned) go out BEFORE this wave's atomic row: behind
+  // it their wait would also cover the atomics' own round trip (0.8 us on the waves that flush a vector)
+  push_links(e, olds);
+  if (param >= 0) vatomic_add<NC>(e.grads + param, s, e.d, e.lane);
 }
 
 template <int NC>
@@ -1406,16 +1410,18 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   }
   GQE_STAMP(7);
   GQE_WSTAMP(8);
-  if (BWD && DEC != DEC_BILINEAR) vecgrads_commit<NC>(e, smem, reinterpret_cast<long long*>(s_idx), vg);
-  GQE_WSTAMP(9);
-  if (BWD) push_links(e, olds);
-  GQE_WSTAMP(10);
   if (BWD) {
     // mean hinge loss of the batch (model.py:124-126) and the weighted iteration loss: reduce the waves in
     // LDS (thousands of same-address device atomics serialise at ~12 ns each) and park one partial per tile.
-    __syncthreads();
-    if (lane == 0) red[wave] = loss_part;
-    __syncthreads();
+    if (DEC != DEC_BILINEAR) {
+      vecgrads_commit<NC>(e, smem, reinterpret_cast<long long*>(s_idx), vg, red, loss_part, olds);
+    } else {
+      __syncthreads();
+      if (lane == 0) red[wave] = loss_part;
+      __syncthreads();
+      push_links(e, olds);
+    }
+    GQE_WSTAMP(10);
     if (threadIdx.x == 0) {
       float l = 0.f;
 #pragma unroll

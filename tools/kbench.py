@@ -109,7 +109,7 @@ def phase_profile(mix, B, label):
                 extra.append("%s=%6.1f" % (nm, np.median(col)))
         if extra:
             print("%-14s   detail: %s" % ("", " ".join(extra)))
-        wn = ["score_end", "gq_parked", "postT_go", "postT_done", "bar", "commit", "preT_go", "preT_done", "hops_done", "vg_done", "links"]
+        wn = ["score_end", "gq_parked", "postT_go", "postT_done", "bar", "commit", "preT_go", "preT_done", "hops_done", "(unused)", "vg+links"]
         for pidx, nm in enumerate(wn):
             vals = []
             for k in range(4):
