@@ -741,7 +741,8 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   // there the early copies changed the allocation into one that loses lanes >= 16 of a relation gradient
   // (tests/test_gpu_parity.py::test_eight_wave_workgroups_vs_oracle d = 144) — they keep reading the fields where used.
 #define GQE_PIN(x) asm volatile("" : "+s"(x))
-  constexpr bool EARLY = FW == 16 && NC <= 2;  // (d = 256 kernels sit at the 128-VGPR limit: a few more live SGPRs spill there)
+  constexpr bool EARLY = FW == 16 && NC <= 2 && FULL;  // (the d = 256 and the guarded d % 64 != 0 kernels sit at the 128-VGPR limit:
+                                                       // a few more live registers spill there — and a spilling d = 96 kernel faulted)
 #define GQE_DSC(early, field) (EARLY ? (early) : (field))
   int qtype = f->qtype;
   int64_t t_table = 0;
@@ -786,7 +787,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   // the relation vectors of an intersection tile (<= 2 per branch + the final projection): requested here, in front of
   // the rows, instead of one dependent L2 round trip per branch in the forward and again in the backward
   // (16-wave tiles; the 8-wave tiles keep two rows per role in registers and load the vectors where they use them)
-  constexpr bool PREW = FW == 16 && NC <= 2;  // d = 256: the vectors would cost 28 VGPRs of a kernel that sits at the 128-VGPR limit
+  constexpr bool PREW = FW == 16 && NC <= 2 && FULL;  // d = 256 / guarded d: the vectors would cost registers a kernel at the 128-VGPR limit does not have
   Vec<NC> W0[GQE_MAX_BRANCH], W1[GQE_MAX_BRANCH], WF;
   if (PREW && DEC != DEC_BILINEAR && qtype > 2) {
 #pragma unroll
@@ -1464,13 +1465,14 @@ static hipError_t launch_fused_dm(const GqeFusedArgs& a) {
 #if GQE_FW == 16
   switch (nc) {  // d <= 128 and d = 256 (straight-line code, 125 VGPRs, no scratch)
     case 1: return full ? launch_fused_v<DEC, MLP, 1, true>(a) : launch_fused_v<DEC, MLP, 1, false>(a);
-    case 2: return full ? launch_fused_v<DEC, MLP, 2, true>(a) : launch_fused_v<DEC, MLP, 2, false>(a);
+    case 2: return full ? launch_fused_v<DEC, MLP, 2, true>(a) : hipErrorInvalidValue;  // guarded d in (64, 128): the 8-wave shape
     case 4: return full ? launch_fused_v<DEC, MLP, 4, true>(a) : hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
 #else
-  switch (nc) {  // d = 128 with many tiles (two workgroups per CU) and the guarded d in (128, 256) variants
-    case 2: return full ? launch_fused_v<DEC, MLP, 2, true>(a) : hipErrorInvalidValue;
+  switch (nc) {  // d = 128 with many tiles (two workgroups per CU) and every guarded d > 64 (256 VGPRs per lane: the guarded
+                 // 16-wave kernels spilled at their 128-VGPR limit, and a spilling d = 96 kernel faulted)
+    case 2: return full ? launch_fused_v<DEC, MLP, 2, true>(a) : launch_fused_v<DEC, MLP, 2, false>(a);
     case 3: return launch_fused_v<DEC, MLP, 3, false>(a);
     case 4: return full ? hipErrorInvalidValue : launch_fused_v<DEC, MLP, 4, false>(a);
     default: return hipErrorInvalidValue;

@@ -480,6 +480,7 @@ GQE_DECL(0, 0) GQE_DECL(0, 1) GQE_DECL(1, 0) GQE_DECL(1, 1) GQE_DECL(2, 0) GQE_D
 int gqe_fused_waves(int d, int tiles) {
   if (d == 256) return 16;  // FULL variant: fits 128 VGPRs without scratch; every wave owns an MFMA row block
   if (d > 128) return 8;    // guarded variants
+  if (d > 64 && (d % 64) != 0) return 8;  // guarded d in (64, 128): 256 VGPRs per lane instead of spilling at 128
   if (d == 128 && tiles > GQE_FW8_MIN_TILES) return 8;
   return 16;
 }

@@ -223,7 +223,7 @@ CONFIGS = [("bilinear-diag", "min"), ("bilinear-diag", "mean-simple"), ("transe"
            ("bilinear-diag", "mean"), ("transe", "min")]   # the staged-matrix path (d = 64 / 128) with both aggregations per decoder
 
 
-@pytest.mark.parametrize("d", [16, 64, 128, 192, 256])
+@pytest.mark.parametrize("d", [16, 64, 96, 128, 192, 256])
 @pytest.mark.parametrize("dec,inter", CONFIGS)
 def test_random_schema_vs_oracle(dec, inter, d):
     """Every query type, ragged / tiny / hub-heavy batches, all in ONE grouped launch, against
@@ -269,7 +269,8 @@ def test_random_schema_vs_oracle(dec, inter, d):
 
 
 @pytest.mark.parametrize("dec,inter,d,B", [("bilinear-diag", "min", 128, 1200), ("bilinear", "mean", 128, 1200), ("transe", "min-simple", 128, 1200),
-                                           ("bilinear-diag", "mean", 144, 40), ("bilinear", "min", 208, 40)])
+                                           ("bilinear-diag", "mean", 144, 40), ("bilinear", "min", 208, 40),
+                                           ("bilinear-diag", "min", 208, 40), ("transe", "mean", 240, 40), ("transe", "min", 112, 40)])
 def test_eight_wave_workgroups_vs_oracle(dec, inter, d, B):
     """The 8-wave shape of the fused kernel (two query rows per wave; csrc/gqe_fused.h): d = 128 launches with more than
     512 tiles (two workgroups per CU; here 7 x 1200 queries = 525 tiles, ragged last tiles) and the guarded d in (128, 256)
