@@ -52,7 +52,7 @@ def test_guarded_diag_and_transe_kernels_do_not_spill(kernels):
     """bilinear-diag / TransE at any d <= 192 the dispatcher can select (d % 64 != 0: the 8-wave kernels with 256 VGPRs per
     lane above d = 64, the 16-wave ones below): spilling variants of these once corrupted a relation gradient (d = 144)
     and faulted (d = 96).  The d in (192, 256) and the full-Bilinear guarded kernels still spill a few registers; the
-    parity matrix runs them (tests/test_gpu_parity.py: d = 96, 112, 144, 192, 208, 240)."""
+    parity matrix runs them (tests/test_gpu_parity.py::test_random_schema_vs_oracle: every multiple of 16 up to 256)."""
     from kernel_meta import fused_variant
     checked = 0
     for k in kernels:
