@@ -328,8 +328,9 @@ int gqe_feeder_run(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations,
  * 4 = lazy mode: catch-up launch before a read.  Returns the average milliseconds over the recorded launches and
  * their count, then clears the record. */
 int gqe_timing_enable(gqe_ctx* ctx, int32_t stride);   /* record every stride-th launch; 0 = off */
-/* Debug: when `stamps` (device, 16 int64 per workgroup of the next fused launches) is non-NULL the fused
- * kernel records wall_clock64() (100 MHz) at its phase boundaries; NULL switches it off. */
+/* Debug: when `stamps` (device, 64 int64 per workgroup: the tiles of the next fused launch, then the workgroups of
+ * its pair-GEMM launch) is non-NULL the kernels record wall_clock64() (100 MHz) at their phase boundaries
+ * (tools/kbench.py decodes them); NULL switches it off. */
 int gqe_debug_profile(gqe_ctx* ctx, long long* stamps);
 int gqe_timing_read(gqe_ctx* ctx, int32_t kernel, float* avg_ms, int32_t* count);
 
