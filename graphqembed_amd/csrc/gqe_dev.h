@@ -108,11 +108,12 @@ struct GqeActSeg {
   long long chunk_begin;  // first chunk of this tensor in the pass
   int32_t seg;            // universe index
   float step_size, bc2_sqrt;
-  int32_t pad;
+  int32_t pad;            // != 0: a table whose dense gradient is live (read it, and re-zero it) next to its lists
 };
 
+#define GQE_GROUP_DENSE 0x40    // flag in GqeOptActive::group / GqeActSeg::dense: the table's dense gradient is live too
 struct GqeOptActive {
-  uint8_t group[GQE_MAX_SEGS];  // per universe entry: 0xFF = not stepped, else index into GqeStepCoef
+  uint8_t group[GQE_MAX_SEGS];  // per universe entry: 0xFF = not stepped, else index into GqeStepCoef (| GQE_GROUP_DENSE)
   // chunk prefix of the pass over the universe (inactive tensors own no chunks), computed by the host: a workgroup used
   // to rebuild it — a global load of every tensor's chunk count, then one thread adding them up, ~3 us before its first
   // useful load, and at the start of the launch every resident workgroup did so at once
@@ -184,7 +185,7 @@ struct GqeOptArgs {
   int mode;
   bool lists;         // some table has pending gradient lists
   bool sorted;        // sum each list in ascending node id (bit-identical across data-parallel replicas)
-  bool dense_tables;  // the dense gradient of the tables has to be read (and re-zeroed) too
+  bool dense_tables;  // the dense gradient of SOME stepped table has to be read (and re-zeroed) too: the per-table flags say which
   const GqeDevSeg* segs;
   int n_segs;
   long long total_chunks;

@@ -47,6 +47,8 @@ struct TimedLaunch {
 struct Table {
   int64_t offset, rows, head_base;
   bool pending;  // has un-consumed gradient lists
+  bool dense = false;  // its dense gradient may be non-zero (materialised lists, or a caller that writes gradients itself):
+                       // the next optimiser pass reads (and re-zeroes) it next to the lists
   // lazy Adam (gqe_set_lazy_adam): lstep = Adam steps applied to the table so far (rows are current for <= lstep),
   // since_full = steps since every row was brought to lstep (bounded by the coefficient ring), dirty = some rows lag
   int lstep = 0, since_full = 0;
@@ -99,6 +101,8 @@ struct gqe_ctx {
   int64_t next_n_idx = 0;
   const int32_t* caught_idx = nullptr;   // feed whose rows the last optimiser step already brought up to date
   int64_t caught_n_idx = 0;
+  uint64_t next_sig = 0, caught_sig = 0; // ... and what it was declared to hold (feed_signature): pointer identity alone would
+                                         // accept a recycled buffer that now carries another batch layout
   float lz_lr = 0.f, lz_b1 = 0.f, lz_b2 = 0.f, lz_eps = 0.f;  // hyper-parameters the coefficient ring was written with
   bool lz_hyper = false;
   int rank = 0, world = 1;     // gqe_set_exchange: data-parallel replica id / count
@@ -114,7 +118,6 @@ struct gqe_ctx {
   bool shard_on = false;  // gqe_set_shard was called (world = 1 is the degenerate case: this rank owns every row)
   bool shard_sent = false;   // a margin call's contributions sit in the send buffer (not yet linked by their owners)
   std::vector<int> shard_tables;  // tables that margin call named (every rank runs the same formulas: these receive lists)
-  bool dense_dirty = false;  // the dense gradient of some table may be non-zero (after materialize)
   RingSlot ring[kRing];
   int ring_next = 0;
   // formula descriptor cache: static per-formula data lives on the device, per-call data travels as kernel
@@ -517,6 +520,12 @@ int formula_of(gqe_ctx* ctx, const gqe_batch& s, int bi, int* out_id) {
   return GQE_OK;
 }
 
+bool any_dense(const gqe_ctx* ctx) {
+  for (const Table& t : ctx->tables)
+    if (t.dense) return true;
+  return false;
+}
+
 bool is_bag_table(const gqe_ctx* ctx, int t) {
   for (const Bag& bg : ctx->bags)
     if (bg.table == t) return true;
@@ -600,6 +609,30 @@ void lazy_rows_args(const gqe_ctx* ctx, GqeRowsArgs& ra, hipStream_t st) {
   ra.with_grad = false;
   ra.sorted = false;
   ra.stream = st;
+}
+
+// what a device-resident feed was declared to hold: every field of the batch descriptors that decides which index names a
+// row of which table (FNV-1a)
+uint64_t feed_signature(const gqe_batch* batches, int n_batches, bool with_negatives) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](int64_t v) {
+    for (int k = 0; k < 8; ++k) {
+      h ^= (uint64_t)(v >> (8 * k)) & 0xffu;
+      h *= 1099511628211ull;
+    }
+  };
+  mix(n_batches);
+  mix(with_negatives ? 1 : 0);
+  for (int bi = 0; bi < n_batches; ++bi) {
+    const gqe_batch& s = batches[bi];
+    mix(s.qtype);
+    mix(s.n_queries);
+    mix(s.idx_offset);
+    mix(s.n_candidates);
+    mix(s.target_table);
+    for (int i = 0; i < GQE_MAX_BRANCH; ++i) mix(i < s.n_anchors ? s.anchor_table[i] : -1);
+  }
+  return h;
 }
 
 bool lazy_any_dirty(const gqe_ctx* ctx) {
@@ -727,7 +760,8 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     const bool dirty = lazy_any_dirty(ctx);
     if (dirty || bwd) build_feed(ctx, batches, n_batches, bwd, fid, feed);
     // (gqe_lazy_prefetch: the previous optimiser step already brought this very feed's rows up to date)
-    const bool caught = idx_on_device && ctx->caught_idx == idx && ctx->caught_n_idx == n_idx;
+    const bool caught = idx_on_device && ctx->caught_idx == idx && ctx->caught_n_idx == n_idx &&
+                        ctx->caught_sig == feed_signature(batches, n_batches, bwd);
     ctx->caught_idx = nullptr;
     if (dirty && !caught) {
       GqeRowsArgs ra;
@@ -995,9 +1029,13 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
         any = true;
       }
     }
-    if (!any) {  // nothing (of what was asked for) pending: the dense gradient simply becomes authoritative
+    for (size_t t = 0; t < ctx->tables.size(); ++t) {   // the dense gradient of these tables becomes authoritative
+      bool wanted = n_segs == 0;
+      for (int i = 0; i < n_segs; ++i) wanted = wanted || segs[i].offset == ctx->tables[t].offset;
+      if (wanted) ctx->tables[t].dense = true;
+    }
+    if (!any) {  // nothing (of what was asked for) pending
       if (n_segs == 0) ctx->entries_used = 0;
-      ctx->dense_dirty = true;
       return GQE_OK;
     }
   } else {
@@ -1051,6 +1089,15 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
   // The pass is described to the kernels either in their arguments (<= GQE_MAX_SEGS tensors known to the ctx and
   // <= GQE_MAX_STEP_GROUPS distinct step counts: nothing is uploaded) or as a list of the active tensors that is
   // uploaded with the step (large schemas: dozens of relation types whose step counters diverge).
+  // the FLUSH pass only replays deferred steps: it must neither read nor re-zero a materialised dense gradient
+  // that is still waiting for its optimiser step
+  oa.dense_tables = !flush && (any_dense(ctx) || mode == GQE_OPT_ZERO);
+  // which tables: per universe entry (gqe_materialize_tables folds the replicated bag tables only — the owned shards of a
+  // row-sharded run keep streaming 24 B per parameter)
+  auto seg_dense = [&](size_t ui) {
+    const GqeDevSeg& u = ctx->universe[ui];
+    return u.is_table && oa.dense_tables && mode != GQE_OPT_MATERIALIZE && (mode == GQE_OPT_ZERO || ctx->tables[(size_t)u.table_index].dense);
+  };
   const bool table_form = nu > GQE_MAX_SEGS || distinct.size() > GQE_MAX_STEP_GROUPS;
   std::vector<GqeActSeg> staging;
   const GqeActSeg* act_dev = reinterpret_cast<const GqeActSeg*>(ctx->ws + ctx->lay.act_off);
@@ -1075,7 +1122,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
           coef.step_size[gi] = uss[ui];
           coef.bc2_sqrt[gi] = ubc[ui];
         }
-        active.group[ui] = (uint8_t)gi;
+        active.group[ui] = (uint8_t)(gi | (seg_dense(ui) ? GQE_GROUP_DENSE : 0));
         chunks += ctx->universe[ui].n_chunks;
         active.begin[ui + 1] = (int32_t)chunks;
       }
@@ -1089,7 +1136,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
         a.seg = (int32_t)ui;
         a.step_size = uss[ui];
         a.bc2_sqrt = ubc[ui];
-        a.pad = 0;
+        a.pad = seg_dense(ui) ? 1 : 0;
         staging.push_back(a);
         chunks += ctx->universe[ui].n_chunks;
       }
@@ -1120,9 +1167,6 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
   }
   oa.lists = lists;
   oa.sorted = ctx->world > 1 || ctx->shard_on;  // replicas / reruns must sum a row's contributions in the same order
-  // the FLUSH pass only replays deferred steps: it must neither read nor re-zero a materialised dense gradient
-  // that is still waiting for its optimiser step
-  oa.dense_tables = !flush && (ctx->dense_dirty || mode == GQE_OPT_ZERO);
   oa.segs = reinterpret_cast<const GqeDevSeg*>(ctx->ws + ctx->lay.seg_off);
   oa.n_segs = (int)nu;
   oa.p = ctx->params;
@@ -1167,7 +1211,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       ctx->lz_b2 = b2;
       ctx->lz_eps = eps;
       ctx->lz_hyper = true;
-      sparse = lists && ctx->feed_valid && !ctx->dense_dirty && (ctx->world == 1 || ctx->imported) &&
+      sparse = lists && ctx->feed_valid && !any_dense(ctx) && (ctx->world == 1 || ctx->imported) &&
                (int)ctx->tables.size() <= GQE_LAZY_TABLES && (64 % (d / 4)) == 0;
       for (size_t t = 0; t < ctx->tables.size() && sparse; ++t)
         if (seen[t] && lazy_table_ok(ctx, (int)t) && ctx->tables[t].since_full >= GQE_LAZY_PERIOD)
@@ -1244,6 +1288,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
         merged = true;
         ctx->caught_idx = ctx->next_idx;
         ctx->caught_n_idx = ctx->next_n_idx;
+        ctx->caught_sig = ctx->next_sig;
       }
       for (const SavedFeed& sf : feeds) {
         if (merged) break;
@@ -1262,6 +1307,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
         }
         ctx->caught_idx = ctx->next_idx;
         ctx->caught_n_idx = ctx->next_n_idx;
+        ctx->caught_sig = ctx->next_sig;
       }
       rc = timing_end(ctx, 2, st);
       if (rc != GQE_OK) return rc;
@@ -1346,10 +1392,9 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       ctx->links_used = false;
     }
   }
-  if (mode == GQE_OPT_MATERIALIZE)
-    ctx->dense_dirty = true;
-  else if (!any_pending)
-    ctx->dense_dirty = false;
+  if (mode != GQE_OPT_MATERIALIZE)
+    for (size_t t = 0; t < ctx->tables.size(); ++t)
+      if (seen[t]) ctx->tables[t].dense = false;   // read and re-zeroed by this pass
   return GQE_OK;
 }
 
@@ -1505,7 +1550,7 @@ int gqe_set_lazy_adam(gqe_ctx* ctx, int32_t enable) {
   if (!ctx) return GQE_ERR_ARG;
   if (enable) {
     if ((int)ctx->tables.size() > GQE_LAZY_TABLES) return fail(ctx, GQE_ERR_ARG, "lazy Adam supports at most %d tables", GQE_LAZY_TABLES);
-    if (ctx->dense_dirty || ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "gradients pending: step first");
+    if (any_dense(ctx) || ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "gradients pending: step first");
   } else if (lazy_any_dirty(ctx)) {
     return fail(ctx, GQE_ERR_STATE, "rows still owe Adam steps: call gqe_optimizer_sync before leaving lazy mode");
   }
@@ -1534,6 +1579,7 @@ int gqe_lazy_prefetch(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches,
   build_feed(ctx, batches, n_batches, with_negatives != 0, fid, ctx->next_feed);
   ctx->next_idx = idx;
   ctx->next_n_idx = n_idx;
+  ctx->next_sig = feed_signature(batches, n_batches, with_negatives != 0);
   return GQE_OK;
 }
 

@@ -323,6 +323,7 @@ __device__ __forceinline__ void opt_body(const long long first_chunk, const long
   for (long long ch = first_chunk; ch < total_chunks; ch += chunk_stride) {
     long long chunk_begin;
     float step_size, bc2_sqrt;
+    bool seg_dense;  // tables: this table's dense gradient is live (materialised / written by the caller) and has to be read too
     if (act) {
       int lo = 0, hi = n_act - 1;  // last entry whose first chunk is <= ch
       while (lo < hi) {
@@ -334,12 +335,14 @@ __device__ __forceinline__ void opt_body(const long long first_chunk, const long
       chunk_begin = a.chunk_begin;
       step_size = a.step_size;
       bc2_sqrt = a.bc2_sqrt;
+      seg_dense = a.pad != 0;
     } else {
       while (s_begin[si + 1] <= ch) ++si;  // chunks are visited in increasing order
       chunk_begin = s_begin[si];
       const int grp = active.group[si];
-      step_size = coef.step_size[grp];
-      bc2_sqrt = coef.bc2_sqrt[grp];
+      seg_dense = (grp & GQE_GROUP_DENSE) != 0;
+      step_size = coef.step_size[grp & (GQE_GROUP_DENSE - 1)];
+      bc2_sqrt = coef.bc2_sqrt[grp & (GQE_GROUP_DENSE - 1)];
     }
     const GqeDevSeg sg = segs[si];
     if (sg.is_table) {
@@ -347,7 +350,8 @@ __device__ __forceinline__ void opt_body(const long long first_chunk, const long
       if (lr_row >= rpc || row >= sg.rows) continue;
       const long long off = sg.offset + row * d + c4;
       float4 gg = zero4;
-      if (DENSE_T) {
+      const bool dense_here = DENSE_T && seg_dense;
+      if (dense_here) {
         gg = *reinterpret_cast<const float4*>(g + off);
         if (MODE != GQE_OPT_MATERIALIZE) *reinterpret_cast<float4*>(g + off) = zero4;
       }
@@ -366,7 +370,7 @@ __device__ __forceinline__ void opt_body(const long long first_chunk, const long
       if (MODE == GQE_OPT_ZERO) continue;
       if (MODE == GQE_OPT_MATERIALIZE) {
         if (had) {
-          if (!DENSE_T) {
+          if (!dense_here) {
             const float4 old = *reinterpret_cast<const float4*>(g + off);
             gg.x += old.x;
             gg.y += old.y;
@@ -904,16 +908,20 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_rank_kernel(const float* __re
   const int lane = threadIdx.x & 63;
   const int p0 = ptr[q], p1 = ptr[q + 1];
   const float s = scores[p0];
-  float left = 0.f, right = 0.f;   // counts < 2^24: exact in fp32
+  float left = 0.f, right = 0.f, bad = (s != s) ? 1.f : 0.f;   // counts < 2^24: exact in fp32
   for (int i = p0 + 1 + lane; i < p1; i += 64) {
     const float x = scores[i];
     left += (x < s) ? 1.f : 0.f;
     right += (x <= s) ? 1.f : 0.f;
+    bad += (x != x) ? 1.f : 0.f;
   }
   left = wave_sum(left);
   right = wave_sum(right);
+  bad = wave_sum(bad);
   const int n = p1 - p0 - 1;
-  if (lane == 0) percentile[q] = n > 0 ? ((double)left + (double)right + (right > left ? 1.0 : 0.0)) * 50.0 / (double)n : nan("");
+  // a NaN anywhere in the list (or as the target's score) makes the percentile nan, as scipy's percentileofscore
+  // (nan_policy 'propagate') does: the mean over queries must then be nan, not pulled towards 0
+  if (lane == 0) percentile[q] = (n > 0 && bad == 0.f) ? ((double)left + (double)right + (right > left ? 1.0 : 0.0)) * 50.0 / (double)n : nan("");
 }
 
 __global__ __launch_bounds__(GQE_THREADS) void gqe_auc_kernel(const float* __restrict__ pos, long long n_pos, const float* __restrict__ neg,

@@ -25,7 +25,7 @@ INTER_DECODERS = {"min": 0, "mean": 1, "min-simple": 2, "mean-simple": 3}  # uti
 QTYPES = {"1-chain": 0, "2-chain": 1, "3-chain": 2, "2-inter": 3, "3-inter": 4,
           "3-inter_chain": 5, "3-chain_inter": 6}
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgqe.so")
+LIB_PATH = os.environ.get("GQE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgqe.so")   # GQE_LIB: a probe build (tools/spill_probe.py)
 
 
 class GqeLibraryError(RuntimeError):

@@ -79,7 +79,7 @@ def _percentile_of_score(a, score):
     """scipy.stats.percentileofscore(a, score) with the default kind='rank'."""
     a = np.asarray(a)
     n = len(a)
-    if n == 0:
+    if n == 0 or score != score or np.isnan(a).any():       # nan_policy 'propagate'
         return np.nan
     left = np.count_nonzero(a < score)
     right = np.count_nonzero(a <= score)
@@ -117,6 +117,8 @@ def eval_auc_queries(test_queries, enc_dec, batch_size=1000, hard_negatives=Fals
             f_preds.extend(scores.detach().cpu().tolist())
         if on_device:
             import torch
+            if not f_pos:        # a formula with no queries: the reference's roc_auc_score raises the same ValueError (utils.py:63)
+                raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
             p, n = torch.cat(f_pos), torch.cat(f_neg)
             formula_aucs[formula] = enc_dec.engine.auc(p, n)
             pos_all.append(p)
@@ -127,6 +129,8 @@ def eval_auc_queries(test_queries, enc_dec, batch_size=1000, hard_negatives=Fals
         predictions.extend(f_preds)
     if on_device:
         import torch
+        if not pos_all:
+            raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
         return enc_dec.engine.auc(torch.cat(pos_all), torch.cat(neg_all)), formula_aucs
     return _auc(labels, np.nan_to_num(predictions)), formula_aucs
 

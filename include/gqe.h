@@ -208,8 +208,10 @@ int gqe_materialize_tables(gqe_ctx* ctx, const int64_t* table_offsets, int32_t n
  * gqe_lazy_prefetch(ctx, ..)      optional, between a margin call and its optimiser step: names the DEVICE-resident
  *                               index feed of the NEXT gqe_margin_fwd_bwd / gqe_forward call (same batch layout rules).
  *                               The step's row launch then also brings that feed's rows up to date and the next call — if
- *                               it passes the same device pointer and size — skips its own catch-up launch: one launch
- *                               over rows(t) U rows(t+1) instead of two.  The feed must not change in between; the
+ *                               it passes the same device pointer, size and batch layout (and the same kind of call: with / without
+ *                               negatives) — skips its own catch-up launch: one launch
+ *                               over rows(t) U rows(t+1) instead of two.  The feed's CONTENTS must not change in between (the
+ *                               library cannot see that: a buffer rewritten in place is the caller's responsibility); the
  *                               declaration holds for one optimiser step.  Results are unchanged (bit-identical). */
 int gqe_set_lazy_adam(gqe_ctx* ctx, int32_t enable);
 int gqe_optimizer_sync(gqe_ctx* ctx, void* stream);

@@ -274,3 +274,28 @@ def test_allreduce_grads_entry_point_over_rccl():
     comm.close()
     a.close()
     b.close()
+
+
+def test_rank_candidates_against_scipy_including_nan():
+    """gqe_rank_candidates == scipy.stats.percentileofscore(kind 'rank') list by list — ties, single-candidate lists, and NaN:
+    a NaN target score or a NaN among the candidates gives nan (scipy's nan_policy 'propagate'), not a percentile of 0 that
+    would silently lower the mean (utils.py:26-33, 91)."""
+    import torch
+    from scipy import stats
+    from gpu_utils import TOY_KINDS, TOY_SIZES, engine_from_params, random_params
+    from graphqembed_amd.utils import _percentile_of_score
+    rng = np.random.RandomState(5)
+    eng = engine_from_params(random_params(rng, 16, "bilinear-diag", "min", TOY_SIZES, TOY_KINDS), 16, "bilinear-diag", "min")
+    lists = [np.round(rng.randn(rng.randint(2, 200)), 1).astype(np.float32) for _ in range(40)]     # rounded: ties
+    lists[3][0] = np.nan                   # the target's score
+    lists[7][5 % len(lists[7])] = np.nan   # a candidate's score
+    lists[9] = lists[9][:2]
+    ptr = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int32)
+    got = eng.rank_candidates(torch.from_numpy(np.concatenate(lists)).cuda(), ptr).cpu().numpy()
+    for i, l in enumerate(lists):
+        want = stats.percentileofscore(l[1:], l[0])
+        assert (np.isnan(want) and np.isnan(got[i])) or abs(got[i] - want) < 1e-9, (i, got[i], want)
+        mine = _percentile_of_score(l[1:], l[0])
+        assert (np.isnan(want) and np.isnan(mine)) or abs(mine - want) < 1e-9, (i, mine, want)
+    assert np.isnan(got[3]) and np.isnan(got[7]) and not np.isnan(got[9])
+    eng.close()

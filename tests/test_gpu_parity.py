@@ -70,11 +70,21 @@ def test_golden_scores_loss_grads(path, dec, inter, d):
 
 @pytest.mark.parametrize("path,dec,inter,d", model_files(32), ids=_ids)
 def test_golden_adam_three_steps(path, dec, inter, d):
+    """Three margin + Adam steps against the trajectory the reference recorded (torch.optim.Adam, lr 0.01).
+    Step 1 is pinned tightly elsewhere (test_one_adam_step_from_the_golden_gradient).  After it, Adam's sign-like first
+    steps (dp = lr g / (|g| + 1e-8)) turn gradients that are rounding noise around an exact 0 into lr-sized moves in the
+    reference itself, so the comparison is made where it is well defined: on the SIGNAL elements — those whose gradient
+    in every step is either exactly 0 or above 1e-4 of the tensor's largest (classified with the fp64 oracle run on the
+    same batches) — at rtol 1e-3 (+ 2e-6), whenever the three losses show that no discrete decision (arg-min / relu /
+    hinge) flipped on the way (loss of steps 2-3 within 1e-4 of the reference's).  A trajectory that did flip — the fp32
+    numpy oracle does so on 2 of the 132 recorded cases — is held to the loose bound only, and at most 3 cases per model
+    may take that route."""
     from gpu_utils import engine_from_params, load_params as put, plan_for, read_arena
     from graphqembed_amd.tensorize import pack_margin_batches
     z = np.load(path)
     p0 = load_params(z, d)
     eng = engine_from_params(p0, d, dec, inter)
+    diverged, tight = [], 0
     for case in case_names(z):
         c = load_case(z, case)
         if "adam_neg" not in c:
@@ -83,20 +93,40 @@ def test_golden_adam_three_steps(path, dec, inter, d):
         eng.grads.zero_(); eng.exp_avg.zero_(); eng.exp_avg_sq.zero_()
         eng.steps = {k: 0 for k in eng.steps}
         plan = plan_for(eng, c["type"], c["rels"])
+        oplan = O.make_plan(c["type"], c["rels"])
+        oparams, ostate = {k: v.astype(np.float64) for k, v in p0.items()}, {}
+        signal = {k: np.ones(p0[k].shape, dtype=bool) for k in plan.touched}
+        loss_err = 0.0
         for step in range(3):
             descs, idx, n = pack_margin_batches([(plan, c["target"], c["adam_neg"][step], c["anchors"], 1.0, c["margin"])])
             losses, _, _ = eng.margin_fwd_bwd(descs, idx, n)
-            np.testing.assert_allclose(losses.cpu().numpy()[0], c["adam_loss"][step],
-                                       rtol=LOSS_RTOL if step == 0 else 6e-2, err_msg=case)
+            got_loss = float(losses.cpu().numpy()[0])
+            np.testing.assert_allclose(got_loss, c["adam_loss"][step], rtol=LOSS_RTOL if step == 0 else 6e-2, err_msg=case)
+            loss_err = max(loss_err, abs(got_loss - c["adam_loss"][step]) / max(abs(c["adam_loss"][step]), 1e-12))
             eng.adam_step(plan.touched)
+            _, _, _, og = O.margin_fwd_bwd(oparams, oplan, dec, inter, c["target"], c["adam_neg"][step], c["anchors"], margin=c["margin"])
+            for k in plan.touched:
+                g = np.abs(og[k])
+                signal[k] &= (g == 0) | (g > 1e-4 * g.max())
+            O.adam_step(oparams, og, ostate, plan.touched)
         got = read_arena(eng, eng.params)
         assert float(eng.grads.abs().max()) == 0.0
+        flipped = loss_err > 1e-4
         for k, delta in c["adam_delta"].items():
             diff = np.abs(got[k].astype(np.float64) - p0[k] - delta)
-            # see tests/test_oracle_golden.py: Adam amplifies rounding noise on ~zero gradients
+            # the loose bound every trajectory has to meet (tests/test_oracle_golden.py: Adam amplifies rounding noise on ~zero gradients)
             assert diff.max() < 4e-2 and np.median(diff) < 5e-4, (case, k, diff.max(), np.median(diff))
+            if not flipped and signal[k].any():
+                sg = signal[k]
+                good = diff[sg] <= 1e-3 * np.abs(delta[sg]) + 2e-6
+                assert good.mean() >= 0.995, (case, k, float(good.mean()), float(diff[sg].max()))
+        if flipped:
+            diverged.append(case)
+        else:
+            tight += 1
         for k in set(got) - set(c["adam_delta"]):
             assert np.array_equal(got[k], p0[k]), (case, k)
+    assert len(diverged) <= 3 and tight >= 6, (diverged, tight)
     eng.close()
 
 
@@ -845,21 +875,20 @@ def test_lazy_adam_with_a_bag_mode():
         e.close()
 
 
-def test_reddit_synth_config5_full_size():
-    """BASELINE config 5 at its real size: reddit-synth (500 k users / 400 k posts / 2 k communities, the 12 directed
-    relations of reddit/data_utils_new.py:193-197, posts = EmbeddingBag mean over 5..30 of 50 k words), d=256, the full
-    9 x 512 mix in ONE grouped launch with the index feed resident in HBM.
-      * scores and losses against the fp64 oracle (the oracle only gathers the rows a batch names);
-      * gradients against the oracle on every row the iteration touches (and nothing elsewhere);
-      * linearity (weights x 2), and a fused Adam step that leaves no gradient behind and moves every row that had one,
-        including the rows of the word table, which are reached only through bags."""
+def _full_size_vs_oracle(workload, d, dec, inter, min_params, n_relations):
+    """One full-mix iteration (9 x 512 queries, ONE grouped launch, index feed resident in HBM) of a BASELINE workload at its
+    REAL table sizes against the fp64 oracle (the oracle only gathers the rows a batch names, so it stays cheap):
+      * scores and losses;
+      * gradients on every row the iteration touches (and nothing elsewhere), relation / Pre / Post gradients in full;
+      * linearity (weights x 2), and a fused Adam step that leaves no gradient behind and moves every row that had one
+        (including, for bag modes, the rows of the word table, which are reached only through bags)."""
     import torch
     import bench
     from graphqembed_amd import synth
     from graphqembed_amd.tensorize import FormulaPlan, pack_margin_batches, table_key
-    d, B = 256, 512
-    wl = bench.Workload("reddit-synth", d, "bilinear-diag", "min", synth.FULL_MIX, B, n_distinct=1)
-    assert wl.layout.total > 141 * 10 ** 6 and sum(len(v) for v in wl.g.relations.values()) == 12
+    B = 512
+    wl = bench.Workload(workload, d, dec, inter, synth.FULL_MIX, B, n_distinct=1)
+    assert wl.layout.total >= min_params and sum(len(v) for v in wl.g.relations.values()) == n_relations
     eng = wl.engine()
     items = wl.item_sets[0]
     host = eng.params.cpu().numpy()
@@ -869,8 +898,8 @@ def test_reddit_synth_config5_full_size():
     grads[O.BAGS_KEY] = params[O.BAGS_KEY]
     packed, want_l, want_p, want_n = [], [], [], []
     for (f, t, ng, a, w, m) in items:
-        packed.append((FormulaPlan(f, eng.layout, "min"), t, ng, a, w, m))
-        l, sp, sn, _ = O.margin_fwd_bwd(params, O.make_plan(f.query_type, f.rels), "bilinear-diag", "min", t, ng, a, margin=m, weight=w, grads=grads)
+        packed.append((FormulaPlan(f, eng.layout, inter), t, ng, a, w, m))
+        l, sp, sn, _ = O.margin_fwd_bwd(params, O.make_plan(f.query_type, f.rels), dec, inter, t, ng, a, margin=m, weight=w, grads=grads)
         want_l.append(l)
         want_p.append(sp)
         want_n.append(sn)
@@ -922,3 +951,16 @@ def test_reddit_synth_config5_full_size():
         assert not bad, (k, bad, [float(gmax[r]) for r in bad], float(gmax.max()))
     assert bool(torch.isfinite(eng.params).all())
     eng.close()
+
+
+def test_reddit_synth_config5_full_size():
+    """BASELINE config 5 at its real size: reddit-synth (500 k users / 400 k posts / 2 k communities, the 12 directed
+    relations of reddit/data_utils_new.py:193-197, posts = EmbeddingBag mean over 5..30 of 50 k words), d=256."""
+    _full_size_vs_oracle("reddit-synth", 256, "bilinear-diag", "min", 141 * 10 ** 6, 12)
+
+
+@pytest.mark.parametrize("dec,inter,P", [("bilinear-diag", "min", 12582912), ("bilinear", "mean", 12810496)])
+def test_bio_synth_configs_full_size(dec, inter, P):
+    """BASELINE configs 2-4 at their real size: bio-synth (97 000 nodes in 5 modes, 14 directed relations), d=128,
+    P = 12 582 912 (bilinear-diag + SetIntersection) / 12 810 496 (full Bilinear) parameters — the workload bench.py times."""
+    _full_size_vs_oracle("bio-synth", 128, dec, inter, P, 14)
