@@ -181,8 +181,8 @@ class Workload(object):
                     plans[f] = FormulaPlan(f, eng.layout, self.inter)
                 packed.append((plans[f], t, ng, a, w, m))
             descs, idx, _ = pack_margin_batches(packed)
-            if eng.sharded:                                        # sort the feed by owner, tell the owners (once per pre-sampled iteration)
-                ps = parallel.shard_prepare(eng, dist, descs, idx)
+            if eng.sharded:                                        # host feed of GLOBAL rows: planned (owner sort + publication) per step, inside the timed loop
+                ps = eng.prepare_shard(descs, idx, set().union(*[p[0].touched for p in packed]))
             else:
                 ps = eng.prepare_margin(descs, torch.from_numpy(idx).to(eng.device))
             ps["adam"] = eng.prepare_adam(set().union(*[p[0].touched for p in packed]))
@@ -285,7 +285,7 @@ class Loop(object):
         for i in range(warmup):
             step(i)
         self.fence()
-        for k in range(5):
+        for k in range(7):
             eng.timing_read(k)
         times, i = [], warmup
         while True:
@@ -339,37 +339,33 @@ def make_step(eng, prepared, dist, exchange, n_distinct, ex_events=None):
                 ex_events.append((e0, e1))
         eng.run_adam(ps["adam"])
 
-    def sharded_step(i):                                           # row-sharded: the rows of the batch are fetched first
-        ps = prepared[i % n_distinct]
-        rec = ex_events is not None and (i % 4) == 0
-        if rec:
-            import torch
-            e0, e1, e2, e3 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            e0.record()
-        parallel.shard_fetch(eng, dist, ps)
-        if rec:
-            e1.record()
-        eng.run_margin(ps)
-        if rec:
-            e2.record()
-        parallel.shard_exchange(eng, dist, ps)
-        if rec:
-            e3.record()
-            ex_events.append((e0, e1, e2, e3))
-        eng.run_adam(ps["adam"])
+    posted = {"next": None}
+
+    def sharded_step(i):
+        """Row-sharded: step i + 1 is PLANNED here, inside the timed loop (gqe_shard_post: owner sort of its host feed,
+        publication on the shared-memory plan board), then gqe_shard_step runs step i: serve -> all-to-all of rows -> fused
+        forward / backward + pair GEMM -> all-to-all of contributions -> link -> all-reduce of the small gradients -> Adam
+        on the own shards, one library call."""
+        if posted["next"] != i:
+            eng.shard_post(prepared[i % n_distinct])
+        eng.shard_post(prepared[(i + 1) % n_distinct])
+        posted["next"] = i + 1
+        eng.shard_step(prepared[i % n_distinct])
     return sharded_step if exchange == "sharded" and dist is not None else step
 
 
 def measure(wl, args, dist, rank, world, exchange="sparse", lazy=False, steps=None, warmup=None, min_seconds=0.5, check_replicas=False):
     """One full measurement of a workload on this process group: returns the result dict (valid on every rank)."""
     import torch
+    from graphqembed_amd import parallel
     steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
     sparse = world > 1 and exchange == "sparse"
     sharded = world > 1 and exchange == "sharded"
     eng = wl.engine(rank=rank if sparse else 0, world=world if sparse else 1, lazy=lazy, shard=(rank, world) if sharded else None)
     prepared = wl.prepare(eng, dist)
-    ex_events = [] if dist is not None else None
+    session = parallel.shard_session(eng, dist, rank, world) if sharded else None
+    ex_events = [] if (dist is not None and not sharded) else None
     step = make_step(eng, prepared, dist, exchange, wl.n_distinct, ex_events)
     loop = Loop(eng, dist, world)
     times = loop.run(step, warmup, steps, min_seconds=min_seconds)
@@ -383,15 +379,18 @@ def measure(wl, args, dist, rank, world, exchange="sparse", lazy=False, steps=No
     if not np.isfinite(loss):
         raise SystemExit("non-finite loss")
     out["final_loss"] = round(loss, 6)
+    if sharded:                                                    # hipEvents of the library around the two exchange phases (every 16th step)
+        ms_rows, _ = eng.timing_read(5)
+        ms_contrib, _ = eng.timing_read(6)
+        out["exchange_ms_per_step"] = round(ms_rows + ms_contrib, 4)
+        out["exchange_parts_ms"] = {"serve_and_fetch_rows": round(ms_rows, 4), "contributions_link_and_small_tensors": round(ms_contrib, 4)}
+        out["planning"] = "inside the timed region: every step plans the next one on the host (gqe_shard_post)"
+        if getattr(session, "error", None) is not None:
+            raise session.error
     if ex_events:
         torch.cuda.synchronize()
         ev = ex_events[len(ex_events) // 5:]
-        if sharded:                                                # rows in (before the fused kernel) + contributions out (after it)
-            out["exchange_ms_per_step"] = round(float(np.mean([e[0].elapsed_time(e[1]) + e[2].elapsed_time(e[3]) for e in ev])), 4)
-            out["exchange_parts_ms"] = {"fetch_rows": round(float(np.mean([e[0].elapsed_time(e[1]) for e in ev])), 4),
-                                        "contributions_and_small_tensors": round(float(np.mean([e[2].elapsed_time(e[3]) for e in ev])), 4)}
-        else:
-            out["exchange_ms_per_step"] = round(float(np.mean([a.elapsed_time(b) for a, b in ev])), 4)
+        out["exchange_ms_per_step"] = round(float(np.mean([a.elapsed_time(b) for a, b in ev])), 4)
     if dist is not None:
         ones = torch.ones(1, device=eng.device)
         dist.all_reduce(ones)
@@ -601,10 +600,12 @@ def main():
                    "backend": None if world == 1 else backend,
                    "optimizer": "lazy (deferred, bit-exact) Adam — NON-DEFAULT mode" if args.lazy_adam else "eager dense Adam",
                    "gradient_exchange": "none" if world == 1 else
-                   ("row-sharded tables (rank k owns rows r %% %d == k and their Adam moments): per step one all-to-all of the %d "
-                    "rows the batch reads (%d floats each), one all-to-all of their gradient contributions back to the owners, one "
-                    "all-reduce of the relation/Pre/Post gradients; the fused Adam pass streams 1/%d of the tables per rank"
-                    % (world, prepared[0]["n_entries"], d, world)) if sharded else
+                   ("row-sharded tables (rank k owns rows r %% %d == k and their Adam moments), one library call per step "
+                    "(gqe_shard_step over RCCL): all-to-all of the %d rows the batch reads (%d floats each), all-to-all of their "
+                    "gradient contributions back to the owners, all-reduce of the relation/Pre/Post gradients; the fused Adam pass "
+                    "streams 1/%d of the tables per rank.  INSIDE the timed region: the host planning of every step (owner sort of "
+                    "its index feed + publication on the shared-memory plan board, gqe_shard_post), the serve / link kernels, all "
+                    "three collectives, the optimiser" % (world, prepared[0]["n_entries"], d, world)) if sharded else
                    ("one all-gather per step of per-rank slabs: %d contribution entries x (%d floats + row id) + the dense "
                     "relation/Pre/Post gradients" % (prepared[0]["n_entries"], d)) if sparse else
                    "all-reduce of the %d-float gradient arena" % wl.layout.total},
@@ -613,7 +614,7 @@ def main():
     }
     if backend_note:
         out["config"]["backend_note"] = backend_note
-    for key in ("exchange_ms_per_step", "exchange_parts_ms", "ranks_seen", "replicas_identical"):
+    for key in ("exchange_ms_per_step", "exchange_parts_ms", "planning", "ranks_seen", "replicas_identical"):
         if key in res:
             out[key] = res[key]
     short = dict(steps=max(20, min(args.steps, 100)), warmup=min(args.warmup, 10), min_seconds=0.25)

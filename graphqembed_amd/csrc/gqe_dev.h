@@ -80,6 +80,8 @@ struct GqeDynBatch {
 struct GqeBagTable {
   const int32_t* ptr[GQE_MAX_BAGS];
   const int32_t* ids[GQE_MAX_BAGS];
+  int32_t max_len;   // longest bag of any bag table: the link nodes of contribution entry e are e * max_len + (word position)
+  int32_t pad;
 };
 
 struct GqeDynPlan {
@@ -234,6 +236,8 @@ struct GqeFusedArgs {
 };
 
 hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a);
+int gqe_config_supported(int dec, int inter, int d);   // gqe_kernels.hip, next to the dispatcher
+void gqe_fused_variant(int dec, int d, int tiles, int* nc, int* full, int* fw);
 hipError_t gqe_launch_pair_gemm(const GqeFusedArgs& a, float* losses);
 #define GQE_EVAL_BLOCK 512   // candidates one workgroup of the scoring kernel covers (= GQE_EVAL_UB in gqe_kernels.hip)
 hipError_t gqe_launch_eval_score(const GqeFusedArgs& a, int dec, float* scores);   // plan.unit_begin / units = candidate blocks

@@ -438,39 +438,65 @@ __device__ __forceinline__ void rows_issue(RowSet<NC>& rs, const TileEnv& e, int
   }
 }
 
-// bag mode: raw vector = mean of the bag's word rows (nn.EmbeddingBag, mode 'mean'), then normalised like any
-// other row by rows_finish.  Lanes fetch the word ids together, the row loads are then issued back to back.
+// bag mode: raw vector = mean of the bag's word rows (nn.EmbeddingBag, mode 'mean'), then normalised like any other row
+// by rows_finish.  A tile may gather up to five bag roles (target, negative, three anchors); done role after role each
+// would put its own chain  s_idx -> ptr[row] -> ids[..] -> word rows  (three dependent trips to memory before the first row
+// arrives, then one per group of rows) on the tile's critical path.  So the gather runs in three PHASES over all bag roles:
+// (1) the spans (ptr[row], ptr[row + 1]) of every role — scalar loads: the row is wave-uniform; (2) the word ids of every
+// role (one coalesced load each); (3) the word rows, BU at a time (all loads of a group in flight before the first add).
+// The rows of the non-bag roles are requested between (1) and (2).  At the start of the kernel nothing else is live yet,
+// so sixteen rows in flight (64 VGPRs at d = 256) do not raise the kernel's register peak.
+struct BagSpan {
+  int p0, len;   // wave-uniform
+};
+
 template <int NC>
-__device__ __forceinline__ void rows_issue_bag(RowSet<NC>& rs, const TileEnv& e, int64_t table, const int* s_rows,
-                                               const int32_t* __restrict__ ptr, const int32_t* __restrict__ ids) {
+__device__ __forceinline__ void bag_spans(BagSpan (&sp)[RPW], RowSet<NC>& rs, const TileEnv& e, const int* s_rows,
+                                          const int32_t* __restrict__ ptr) {
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr) {
-    const int row = s_rows[e.wave * RPW + rr];
+    const int row = __builtin_amdgcn_readfirstlane(s_rows[e.wave * RPW + rr]);
     rs.row[rr] = row;
-    Vec<NC> acc = vzero<NC>();
-    int p0 = 0, len = 0;
+    sp[rr].p0 = 0;
+    sp[rr].len = 0;
     if (row >= 0) {
-      p0 = ptr[row];
-      len = ptr[row + 1] - p0;
-      // the word rows are requested BU at a time (all loads of a group in flight before the first add; the adds keep
-      // the word order, so the sum is the same as a one-by-one loop's): a post has 5-30 words, one dependent HBM round
-      // trip per word would put ~17 of them on the tile's critical path
-      constexpr int BU = NC <= 2 ? 8 : 4;
-      for (int c0 = 0; c0 < len; c0 += 64) {
-        const int m = min(64, len - c0);
-        const int wid = (e.lane < m) ? ids[p0 + c0 + e.lane] : 0;
-        for (int k0 = 0; k0 < m; k0 += BU) {
-          Vec<NC> v[BU];
+      sp[rr].p0 = ptr[row];
+      sp[rr].len = ptr[row + 1] - sp[rr].p0;
+    }
+  }
+}
+
+__device__ __forceinline__ void bag_ids(int (&wid)[RPW], const BagSpan (&sp)[RPW], const TileEnv& e, const int32_t* __restrict__ ids) {
 #pragma unroll
-          for (int u = 0; u < BU; ++u) {
-            const int w = __builtin_amdgcn_readlane(wid, min(k0 + u, m - 1));
-            v[u] = vload<NC>(e.params + table + (size_t)w * e.d, e.d, e.lane);
-          }
+  for (int rr = 0; rr < RPW; ++rr) wid[rr] = (e.lane < min(sp[rr].len, 64)) ? ids[sp[rr].p0 + e.lane] : 0;
+}
+
+template <int NC>
+__device__ __forceinline__ void bag_rows(RowSet<NC>& rs, const BagSpan (&sp)[RPW], const int (&wid0)[RPW], const TileEnv& e, int64_t table,
+                                         const int32_t* __restrict__ ids) {
+  // word rows in flight per wave (the adds keep the word order: the sum equals a one-by-one loop's); the full-Bilinear d = 256
+  // kernel sits at its 128-VGPR limit: eight there
+  constexpr int BU = (GQE_DEC == DEC_BILINEAR && NC >= 4) ? 8 : 16;
 #pragma unroll
-          for (int u = 0; u < BU; ++u)
-            if (k0 + u < m) VEC_OP(acc, acc.v[c] + v[u].v[c]);
+  for (int rr = 0; rr < RPW; ++rr) {
+    Vec<NC> acc = vzero<NC>();
+    const int p0 = sp[rr].p0, len = sp[rr].len;
+    for (int c0 = 0; c0 < len; c0 += 64) {
+      const int m = min(64, len - c0);
+      const int wid = (c0 == 0) ? wid0[rr] : ((e.lane < m) ? ids[p0 + c0 + e.lane] : 0);
+      for (int k0 = 0; k0 < m; k0 += BU) {
+        Vec<NC> v[BU];
+#pragma unroll
+        for (int u = 0; u < BU; ++u) {
+          const int w = __builtin_amdgcn_readlane(wid, min(k0 + u, m - 1));
+          v[u] = vload<NC>(e.params + table + (size_t)w * e.d, e.d, e.lane);
         }
+#pragma unroll
+        for (int u = 0; u < BU; ++u)
+          if (k0 + u < m) VEC_OP(acc, acc.v[c] + v[u].v[c]);
       }
+    }
+    if (len > 0) {
       const float inv = gqe_rcp((float)len);
       VEC_OP(acc, acc.v[c] * inv);
     }
@@ -534,34 +560,39 @@ __device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_
 }
 
 // bag mode: one contribution (already divided by the bag length: EmbeddingBag mean backward) shared by every
-// word row of the bag through link nodes: node -> (contribution entry, next).  Nodes come from a bump allocator.
+// word row of the bag through link nodes: node -> (contribution entry, next).  The nodes of entry e are e * max_len + k
+// (k = position of the word in the bag): no allocator, no counter to reset.  As for plain rows, the previous list heads
+// the exchanges return are only needed for next[node]; those stores are deferred to the end of the kernel (push_bag_links)
+// for the first 64 words of a bag, so that the wave does not stall on the atomics' round trip once per bag role.
 template <int NC>
 __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t head_base, int role, int r,
                                                      const int32_t* __restrict__ ptr, const int32_t* __restrict__ ids,
                                                      const Vec<NC>& xhat, float nrm, const Vec<NC>& g, int bag_slot,
-                                                     int bag_index) {
-  const int p0 = ptr[bag_index], len = ptr[bag_index + 1] - p0;  // re-read (L2 hit) rather than carried in registers
+                                                     int bag_index, int max_len, int& old_head, int& bag_len) {
+  const int bi = __builtin_amdgcn_readfirstlane(bag_index);   // wave-uniform: the span comes from scalar loads and stays in SGPRs
+  const int p0 = ptr[bi], len = ptr[bi + 1] - p0;             // re-read (cache hit) rather than carried in registers
+  constexpr bool DEFER = !(GQE_DEC == DEC_BILINEAR && NC >= 4);   // (not in the full-Bilinear d = 256 kernel: no register to spare)
+  bag_len = DEFER ? min(len, 64) : 0;   // lanes whose link push_links still owes
   const float pg = vdot<NC>(xhat, g);
   const float inv = gqe_rcp(nrm * (float)len);
   Vec<NC> gx;
   VEC_OP(gx, (g.v[c] - xhat.v[c] * pg) * inv);
   const int64_t entry = e.bag_shift + e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
   vstore<NC>(e.contrib_bag + entry * e.d, gx, e.d, e.lane);
-  int base = 0;
-  if (e.lane == 0) {
-    base = __hip_atomic_fetch_add(e.link_counter, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // entry -> "bag b of bag table s", for the data-parallel exchange: the importer re-expands the bag itself
-    e.next[entry - e.max_entries] = GQE_BAG_CODE(bag_slot, bag_index);
-  }
-  base = __builtin_amdgcn_readfirstlane(base);
+  // entry -> "bag b of bag table s", for the data-parallel exchange: the importer re-expands the bag itself
+  if (e.lane == 0) e.next[entry - e.max_entries] = GQE_BAG_CODE(bag_slot, bi);
+  const int base = (int)entry * max_len;
   for (int c0 = 0; c0 < len; c0 += 64) {
     const int k = c0 + e.lane;
     if (k < len) {
       const int node = base + k;
       const int w = ids[p0 + k];
-      const int old = __hip_atomic_exchange(e.head + head_base + w, e.max_entries + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      e.next[e.max_entries + node] = old;
       e.link_contrib[node] = (int)entry;
+      const int old = __hip_atomic_exchange(e.head + head_base + w, e.max_entries + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (DEFER && c0 == 0)
+        old_head = old;   // lane k keeps word k's previous head until push_links
+      else
+        e.next[e.max_entries + node] = old;
     }
   }
 }
@@ -575,22 +606,28 @@ __device__ __forceinline__ void sharded_zero(const TileEnv& e, int bag, int row)
 
 template <int NC>
 __device__ __forceinline__ void scatter_row(const TileEnv& e, const GqeBagTable& bags, int bag, int64_t head_base, int role, int r,
-                                            const RowSet<NC>& rs, int rr, const Vec<NC>& g, int& old_head) {
+                                            const RowSet<NC>& rs, int rr, const Vec<NC>& g, int& old_head, int& bag_len) {
   if (bag < 0)
     scatter_norm_bwd<NC>(e, head_base, role, r, rs.row[rr], rs.x[rr], rs.nrm[rr], g, old_head);
   else
-    scatter_norm_bwd_bag<NC>(e, head_base, role, r, bags.ptr[bag], bags.ids[bag], rs.x[rr], rs.nrm[rr], g, bag, rs.row[rr]);
+    scatter_norm_bwd_bag<NC>(e, head_base, role, r, bags.ptr[bag], bags.ids[bag], rs.x[rr], rs.nrm[rr], g, bag, rs.row[rr], bags.max_len, old_head, bag_len);
 }
 
-// next[entry] = previous head, for every contribution this wave pushed
-__device__ __forceinline__ void push_links(const TileEnv& e, const int (&olds)[RPW][2 + GQE_MAX_BRANCH]) {
-  if (e.lane != 0) return;
+// next[entry] = previous head, for every contribution this wave pushed; bag roles: lane k holds the previous head of the
+// bag's k-th word row (node = entry * max_len + k)
+__device__ __forceinline__ void push_links(const TileEnv& e, const int (&olds)[RPW][2 + GQE_MAX_BRANCH], const int (&blens)[RPW][2 + GQE_MAX_BRANCH],
+                                           int max_len) {
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-    for (int role = 0; role < 2 + GQE_MAX_BRANCH; ++role)
-      if (olds[rr][role] != GQE_NO_PUSH)
-        e.next[e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + e.wave * RPW + rr)] = olds[rr][role];
+    for (int role = 0; role < 2 + GQE_MAX_BRANCH; ++role) {
+      const int64_t q = e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + e.wave * RPW + rr);
+      if (blens[rr][role] > 0) {
+        if (e.lane < blens[rr][role]) e.next[e.max_entries + (int)(e.bag_shift + q) * max_len + e.lane] = olds[rr][role];
+      } else if (e.lane == 0 && olds[rr][role] != GQE_NO_PUSH) {
+        e.next[q] = olds[rr][role];
+      }
+    }
 }
 
 // Relation-vector gradients (bilinear-diag / TransE): every wave keeps its partial sums in registers
@@ -616,7 +653,7 @@ __device__ __forceinline__ void vecgrads_init(VecGrads<NC>& vg) {
 template <int NC>
 __device__ __forceinline__ void vecgrads_commit(const TileEnv& e, float* lds /* >= SLOTS*8*d floats */, long long* s_param,
                                                 const VecGrads<NC>& vg, float* red, float loss_part,
-                                                const int (&olds)[RPW][2 + GQE_MAX_BRANCH]) {
+                                                const int (&olds)[RPW][2 + GQE_MAX_BRANCH], const int (&blens)[RPW][2 + GQE_MAX_BRANCH], int max_len) {
   __syncthreads();  // every wave is done with the tiles this staging area overlays
 #pragma unroll
   for (int k = 0; k < GQE_VG_SLOTS; ++k) {
@@ -637,7 +674,7 @@ __device__ __forceinline__ void vecgrads_commit(const TileEnv& e, float* lds /* 
   }
   // the list links (they wait for the heads the scatter's exchanges returned) go out BEFORE this wave's atomic row: behind
   // it their wait would also cover the atomics' own round trip (0.8 us on the waves that flush a vector)
-  push_links(e, olds);
+  push_links(e, olds, blens, max_len);
   if (param >= 0) vatomic_add<NC>(e.grads + param, s, e.d, e.lane);
 }
 
@@ -800,22 +837,63 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
     if (f->n_final) WF = vload<NC>(params + f->final_param, d, lane);
   }
   RowSet<NC> RA[GQE_MAX_BRANCH], RT, RN;
-  if (tbag < 0) {
-    rows_issue<NC>(RT, e, GQE_DSC(t_table, f->target_table), s_idx);
-    if (has_neg) rows_issue<NC>(RN, e, GQE_DSC(t_table, f->target_table), s_idx + GQE_TQ);
-  } else {
-    rows_issue_bag<NC>(RT, e, GQE_DSC(t_table, f->target_table), s_idx, bags.ptr[tbag], bags.ids[tbag]);
-    if (has_neg) rows_issue_bag<NC>(RN, e, GQE_DSC(t_table, f->target_table), s_idx + GQE_TQ, bags.ptr[tbag], bags.ids[tbag]);
-  }
-#pragma unroll
-  for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
-    if (i < n) {
-      const int ab = GQE_DSC(a_bag[i], f->anchor_bag[i]);
-      if (ab < 0)
-        rows_issue<NC>(RA[i], e, GQE_DSC(a_table[i], f->anchor_table[i]), s_idx + (2 + i) * GQE_TQ);
-      else
-        rows_issue_bag<NC>(RA[i], e, GQE_DSC(a_table[i], f->anchor_table[i]), s_idx + (2 + i) * GQE_TQ, bags.ptr[ab], bags.ids[ab]);
+  // (the full-Bilinear d = 256 kernel has two VGPRs to spare: there the bag roles are gathered one after the other)
+  constexpr bool PHASED = !(DEC == DEC_BILINEAR && NC >= 4);
+  if (PHASED) {
+    // bag roles: spans of all of them, then (after the plain rows are requested) their word ids, then their word rows
+    BagSpan st[RPW], sn[RPW], sa[GQE_MAX_BRANCH][RPW];
+    int wt[RPW], wn[RPW], wa[GQE_MAX_BRANCH][RPW];
+    int abag[GQE_MAX_BRANCH] = {-1, -1, -1};
+    const int64_t tt = GQE_DSC(t_table, f->target_table);
+    if (tbag >= 0) {
+      bag_spans<NC>(st, RT, e, s_idx, bags.ptr[tbag]);
+      if (has_neg) bag_spans<NC>(sn, RN, e, s_idx + GQE_TQ, bags.ptr[tbag]);
     }
+#pragma unroll
+    for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
+      if (i < n) {
+        abag[i] = GQE_DSC(a_bag[i], f->anchor_bag[i]);
+        if (abag[i] >= 0) bag_spans<NC>(sa[i], RA[i], e, s_idx + (2 + i) * GQE_TQ, bags.ptr[abag[i]]);
+      }
+    }
+    if (tbag < 0) {
+      rows_issue<NC>(RT, e, tt, s_idx);
+      if (has_neg) rows_issue<NC>(RN, e, tt, s_idx + GQE_TQ);
+    }
+#pragma unroll
+    for (int i = 0; i < GQE_MAX_BRANCH; ++i)
+      if (i < n && abag[i] < 0) rows_issue<NC>(RA[i], e, GQE_DSC(a_table[i], f->anchor_table[i]), s_idx + (2 + i) * GQE_TQ);
+    if (tbag >= 0) {
+      bag_ids(wt, st, e, bags.ids[tbag]);
+      if (has_neg) bag_ids(wn, sn, e, bags.ids[tbag]);
+    }
+#pragma unroll
+    for (int i = 0; i < GQE_MAX_BRANCH; ++i)
+      if (i < n && abag[i] >= 0) bag_ids(wa[i], sa[i], e, bags.ids[abag[i]]);
+    if (tbag >= 0) {
+      bag_rows<NC>(RT, st, wt, e, tt, bags.ids[tbag]);
+      if (has_neg) bag_rows<NC>(RN, sn, wn, e, tt, bags.ids[tbag]);
+    }
+#pragma unroll
+    for (int i = 0; i < GQE_MAX_BRANCH; ++i)
+      if (i < n && abag[i] >= 0) bag_rows<NC>(RA[i], sa[i], wa[i], e, GQE_DSC(a_table[i], f->anchor_table[i]), bags.ids[abag[i]]);
+  } else {
+    auto gather = [&](RowSet<NC>& rs, int64_t table, const int* s_rows, int bag) {
+      if (bag < 0) {
+        rows_issue<NC>(rs, e, table, s_rows);
+      } else {
+        BagSpan sp[RPW];
+        int wid[RPW];
+        bag_spans<NC>(sp, rs, e, s_rows, bags.ptr[bag]);
+        bag_ids(wid, sp, e, bags.ids[bag]);
+        bag_rows<NC>(rs, sp, wid, e, table, bags.ids[bag]);
+      }
+    };
+    gather(RT, GQE_DSC(t_table, f->target_table), s_idx, tbag);
+    if (has_neg) gather(RN, GQE_DSC(t_table, f->target_table), s_idx + GQE_TQ, tbag);
+#pragma unroll
+    for (int i = 0; i < GQE_MAX_BRANCH; ++i)
+      if (i < n) gather(RA[i], GQE_DSC(a_table[i], f->anchor_table[i]), s_idx + (2 + i) * GQE_TQ, GQE_DSC(a_bag[i], f->anchor_bag[i]));
   }
   rows_finish<NC>(RT);
   if (has_neg) {
@@ -842,10 +920,14 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   VecGrads<NC> vg;  // relation-vector gradient partials of this wave (DEC != bilinear)
   vecgrads_init<NC>(vg);
   int olds[RPW][2 + GQE_MAX_BRANCH];  // previous list heads returned by this wave's pushes
+  int blens[RPW][2 + GQE_MAX_BRANCH]; // bag roles: lanes that hold one (the bag's first <= 64 words); 0: a plain row
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-    for (int role = 0; role < 2 + GQE_MAX_BRANCH; ++role) olds[rr][role] = GQE_NO_PUSH;
+    for (int role = 0; role < 2 + GQE_MAX_BRANCH; ++role) {
+      olds[rr][role] = GQE_NO_PUSH;
+      blens[rr][role] = 0;
+    }
   GQE_STAMP(2);
 
   if (is_chain) {
@@ -936,9 +1018,9 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
             VEC_OP(ga, cp * (up.v[c] * ipp - sp * a.v[c] * iaa) + cn * (un.v[c] * ipn - sn * a.v[c] * iaa));
             VEC_OP(gw_acc, gw_acc.v[c] + gtp.v[c] + gtn.v[c]);
           }
-          scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0]);
-          scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1]);
-          scatter_row<NC>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2]);
+          scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0], blens[rr][0]);
+          scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1], blens[rr][1]);
+          scatter_row<NC>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2], blens[rr][2]);
         } else {
           sharded_zero<NC>(e, f->target_bag, RT.row[rr]);
           sharded_zero<NC>(e, f->target_bag, RN.row[rr]);
@@ -1027,7 +1109,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
           VEC_OP(ga, ga.v[c] + cf[s] * (u[s].v[c] * iun - a.v[c] * iaa));
           vstore<NC>(cur[s] + r * DP, gu, d, lane);
         }
-        if (act) scatter_row<NC>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2]);
+        if (act) scatter_row<NC>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2], blens[rr][2]);
         else if (q < B) sharded_zero<NC>(e, f->anchor_bag[0], RA[0].row[rr]);
       }
       if (BWD) {
@@ -1049,8 +1131,8 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
         for (int rr = 0; rr < RPW; ++rr) {
           const int r = wave * RPW + rr;
           if (e.q0 + r >= B) continue;
-          scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, r, RT, rr, vload<NC>(cur[0] + r * DP, d, lane), olds[rr][0]);
-          scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, r, RN, rr, vload<NC>(cur[1] + r * DP, d, lane), olds[rr][1]);
+          scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, r, RT, rr, vload<NC>(cur[0] + r * DP, d, lane), olds[rr][0], blens[rr][0]);
+          scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, r, RN, rr, vload<NC>(cur[1] + r * DP, d, lane), olds[rr][1], blens[rr][1]);
         }
       }
     }
@@ -1224,8 +1306,8 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
         const float ipp = sp * gqe_rcp(ncp * ncp), inn = sn * gqe_rcp(ncn * ncn);
         VEC_OP(gtp, cp * (qv.v[c] * ipq - tp.v[c] * ipp));
         VEC_OP(gtn, cn * (qv.v[c] * inq - tn.v[c] * inn));
-        scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0]);
-        scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1]);
+        scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0], blens[rr][0]);
+        scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1], blens[rr][1]);
       } else if (q < B) {
         sharded_zero<NC>(e, f->target_bag, RT.row[rr]);
         sharded_zero<NC>(e, f->target_bag, RN.row[rr]);
@@ -1360,7 +1442,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
             const int r = wave * RPW + rr;
             if (e.q0 + r >= B) continue;
             scatter_row<NC>(e, bags, f->anchor_bag[i], f->anchor_head[i], 2 + i, r, RA[i], rr, vload<NC>(tcur + r * DP, d, lane),
-                            olds[rr][2 + i]);
+                            olds[rr][2 + i], blens[rr][2 + i]);
           }
           __syncthreads();  // tt / tq are rewritten by the next branch
         } else {
@@ -1397,7 +1479,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
             } else {
               VEC_OP(gw0, gw0.v[c] + g.v[c]);
             }
-            scatter_row<NC>(e, bags, f->anchor_bag[i], f->anchor_head[i], 2 + i, r, RA[i], rr, g, olds[rr][2 + i]);
+            scatter_row<NC>(e, bags, f->anchor_bag[i], f->anchor_head[i], 2 + i, r, RA[i], rr, g, olds[rr][2 + i], blens[rr][2 + i]);
           }
           vg.g[2 * i] = gw0;
           vg.param[2 * i] = f->hop_param[i][0];
@@ -1415,12 +1497,12 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
     // mean hinge loss of the batch (model.py:124-126) and the weighted iteration loss: reduce the waves in
     // LDS (thousands of same-address device atomics serialise at ~12 ns each) and park one partial per tile.
     if (DEC != DEC_BILINEAR) {
-      vecgrads_commit<NC>(e, smem, reinterpret_cast<long long*>(s_idx), vg, red, loss_part, olds);
+      vecgrads_commit<NC>(e, smem, reinterpret_cast<long long*>(s_idx), vg, red, loss_part, olds, blens, bags.max_len);
     } else {
       __syncthreads();
       if (lane == 0) red[wave] = loss_part;
       __syncthreads();
-      push_links(e, olds);
+      push_links(e, olds, blens, bags.max_len);
     }
     GQE_WSTAMP(10);
     if (threadIdx.x == 0) {
@@ -1463,15 +1545,21 @@ static hipError_t launch_fused_dm(const GqeFusedArgs& a) {
   const int nc = (a.d + 63) / 64;
   const bool full = (a.d % 64) == 0;
 #if GQE_FW == 16
-  switch (nc) {  // d <= 128 and d = 256 (straight-line code, 125 VGPRs, no scratch)
-    case 1: return full ? launch_fused_v<DEC, MLP, 1, true>(a) : launch_fused_v<DEC, MLP, 1, false>(a);
+  switch (nc) {  // d <= 128 and d = 256 (straight-line code, <= 125 VGPRs, no scratch)
+    case 1:
+      if (full) return launch_fused_v<DEC, MLP, 1, true>(a);
+      if constexpr (DEC != DEC_BILINEAR) return launch_fused_v<DEC, MLP, 1, false>(a);   // (full Bilinear at d < 64: the 8-wave shape)
+      return hipErrorInvalidValue;
     case 2: return full ? launch_fused_v<DEC, MLP, 2, true>(a) : hipErrorInvalidValue;  // guarded d in (64, 128): the 8-wave shape
     case 4: return full ? launch_fused_v<DEC, MLP, 4, true>(a) : hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
 #else
   switch (nc) {  // d = 128 with many tiles (two workgroups per CU) and every guarded d > 64 (256 VGPRs per lane: the guarded
-                 // 16-wave kernels spilled at their 128-VGPR limit, and a spilling d = 96 kernel faulted)
+                 // 16-wave kernels spilled at their 128-VGPR limit); full Bilinear at d < 64 (171 VGPRs, no scratch)
+    case 1:
+      if constexpr (DEC == DEC_BILINEAR) return full ? hipErrorInvalidValue : launch_fused_v<DEC, MLP, 1, false>(a);
+      return hipErrorInvalidValue;
     case 2: return full ? launch_fused_v<DEC, MLP, 2, true>(a) : launch_fused_v<DEC, MLP, 2, false>(a);
     case 3: return launch_fused_v<DEC, MLP, 3, false>(a);
     case 4: return full ? hipErrorInvalidValue : launch_fused_v<DEC, MLP, 4, false>(a);

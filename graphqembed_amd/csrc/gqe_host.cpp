@@ -28,6 +28,8 @@
 namespace {
 
 constexpr int kRing = 4;
+constexpr int kFeedGroup = 4;      // feeder, copy mode: iterations whose feeds are uploaded with one copy / one event pair
+constexpr int kStageBufs = 2 + 2 * kFeedGroup;   // staged index buffers in the workspace: 2 for host feeds of single calls, 2 groups for the feeder
 constexpr int kMaxSlots = 20;      // upper bound of pair-scratch slots any batch can use
 constexpr int kRolesPerQuery = 5;  // target, negative, <= 3 anchors
 
@@ -67,14 +69,18 @@ struct Bag {
 };
 
 struct Layout {  // byte offsets inside the bound workspace
-  size_t idx_cap, tloss_off, scratch_off, scratch_cap;  // [staged indices x2 | tile losses | pair scratch]
+  size_t idx_cap, tloss_off, scratch_off, scratch_cap;  // [staged indices x kStageBufs | tile losses | pair scratch]
   size_t shard_req_send, shard_req_recv, shard_fetch, shard_csend;  // row-sharded mode (0 otherwise)
   int64_t shard_cap_send, shard_cap_recv;                          // entries
   size_t seg_off, act_off, formula_off, head_off, rows_off, next_off, contrib_off, linkc_off, counter_off, last_off, ring_off, total;
   int64_t max_entries, max_links;  // max_entries = per-rank capacity x world (the exchange gathers every rank's entries)
 };
 
+constexpr int kTimingKinds = 7;
+
 }  // namespace
+
+struct ShardSession;  // gqe_shard_step.h: plan board, transport and plan slots of the one-call row-sharded step
 
 struct gqe_ctx {
   gqe_config cfg{};
@@ -143,9 +149,13 @@ struct gqe_ctx {
   std::vector<GqeDevSeg> universe;             // every tensor ever stepped (device copy at lay.seg_off)
   size_t universe_uploaded = 0;                // entries of `universe` the device table already holds
   int timing = 0;                              // record every `timing`-th launch of each kernel (0 = off)
-  long long timing_calls[5] = {0, 0, 0, 0, 0};
-  bool timing_open[5] = {false, false, false, false, false};
-  std::vector<TimedLaunch> timed[5];  // 0 fused, 1 pair GEMM, 2 optimiser (tables), 3 lazy: small tensors, 4 lazy: catch-up before a read
+  long long timing_calls[kTimingKinds] = {0, 0, 0, 0, 0, 0, 0};
+  bool timing_open[kTimingKinds] = {false, false, false, false, false, false, false};
+  // 0 fused, 1 pair GEMM, 2 optimiser (tables), 3 lazy: small tensors, 4 lazy: catch-up before a read,
+  // 5 row-sharded step: serve + exchange of rows, 6 row-sharded step: exchange of contributions + link + all-reduces
+  std::vector<TimedLaunch> timed[kTimingKinds];
+  ShardSession* shard_sess = nullptr;   // gqe_shard_open
+  bool shard_internal = false;          // gqe_shard_step is driving the phase entry points
   std::vector<TimedLaunch> event_pool;  // recycled hipEvent pairs (creation is not free)
 };
 
@@ -166,6 +176,7 @@ struct FeederPool {
 struct gqe_feeder {
   gqe_ctx* ctx;
   uint64_t rng[2];
+  uint64_t neg_rng[2];   // row-sharded runs: 1-chain negatives are drawn from a per-rank stream
   int32_t batch_size;
   float path_weight, inter_weight;
   std::vector<FeederPool> pools;
@@ -175,6 +186,22 @@ struct gqe_feeder {
   std::vector<int32_t> idx;
   std::vector<gqe_batch> batches;
   std::vector<gqe_segment> segs;
+  // prepared iterations (a ring of 2 * kFeedGroup): the batches / touched tensors of an iteration, where its feed starts in
+  // the group buffer, its length
+  struct Prepared {
+    int64_t it = -1;
+    std::vector<gqe_batch> batches;
+    std::vector<gqe_segment> segs;
+    std::vector<int32_t> host_idx;     // row-sharded mode: the host feed gqe_shard_post takes
+    const int32_t* dev_idx = nullptr;  // where the kernels read the feed (device buffer or pinned host slot)
+    int64_t n_idx = 0;
+  };
+  Prepared prep[2 * kFeedGroup];
+  // copy mode: two pinned group buffers (kFeedGroup feeds each) -> two groups of staged buffers in the workspace
+  int32_t* grp_pin[2] = {nullptr, nullptr};
+  size_t grp_cap = 0;                  // int32 entries per feed slot of a group buffer
+  hipEvent_t grp_ready[2] = {nullptr, nullptr}, grp_free[2] = {nullptr, nullptr};
+  bool grp_free_set[2] = {false, false};
   // Index feed of an iteration, two ways (gqe_feeder_set_feed):
   //   0  pinned staging + hipMemcpyAsync on the library's upload stream (what gqe_margin_fwd_bwd does for host feeds)
   //   1  the kernels read the feed straight from pinned host memory (default): no copy, no cross-stream dependency and
@@ -258,8 +285,8 @@ int64_t slab_entries(const gqe_ctx* ctx, int64_t n, int64_t dense_floats) {
 Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches) {
   Layout L;
   const int64_t rows = max_queries + (int64_t)GQE_TQ * max_batches;  // queries incl. tile padding
-  L.idx_cap = align_up((size_t)rows * kRolesPerQuery * sizeof(int32_t), 256);  // exists twice (double-buffered uploads)
-  L.tloss_off = 2 * L.idx_cap;
+  L.idx_cap = align_up((size_t)rows * kRolesPerQuery * sizeof(int32_t), 256);  // exists kStageBufs times (double-buffered uploads + feeder groups)
+  L.tloss_off = (size_t)kStageBufs * L.idx_cap;
   L.scratch_off = L.tloss_off + align_up(sizeof(float) * (size_t)(rows / GQE_TQ + GQE_MAX_BATCHES + 1), 256);
   L.scratch_cap = align_up((size_t)rows * kMaxSlots * ctx->cfg.dim * sizeof(float), 256);
   L.seg_off = L.scratch_off + L.scratch_cap;
@@ -693,7 +720,6 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   const bool shard = ctx->shard_on;
   if (shard) {
     if (!idx_on_device) return fail(ctx, GQE_ERR_ARG, "row-sharded mode: the index feed is the device-resident position feed of gqe_shard_plan");
-    if (ctx->lazy) return fail(ctx, GQE_ERR_STATE, "row-sharded mode and lazy Adam are mutually exclusive");
     if (n_idx > L.shard_cap_send) return fail(ctx, GQE_ERR_WORKSPACE, "row-sharded mode: %lld indices exceed the fetched-row buffer (%lld rows)", (long long)n_idx, (long long)L.shard_cap_send);
     for (int bi = 0; bi < n_batches; ++bi)
       if (batches[bi].n_candidates > 0) return fail(ctx, GQE_ERR_ARG, "row-sharded mode: candidate lists are not supported (expand the candidates)");
@@ -754,7 +780,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     d_idx = reinterpret_cast<const int32_t*>(dev);
   }
 
-  if (ctx->lazy) {
+  if (ctx->lazy && !shard) {   // (row-sharded: the owners bring the rows up to date before they serve them, gqe_shard_step)
     // rows this call reads must be current: replay their deferred zero-gradient Adam steps first
     std::vector<SavedFeed> feed;
     const bool dirty = lazy_any_dirty(ctx);
@@ -808,6 +834,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   for (size_t k = 0; k < ctx->bags.size(); ++k) {
     fa.bags.ptr[k] = ctx->bags[k].ptr;
     fa.bags.ids[k] = ctx->bags[k].ids;
+    fa.bags.max_len = std::max(fa.bags.max_len, ctx->bags[k].max_len);
   }
   fa.link_contrib = reinterpret_cast<int32_t*>(ctx->ws + L.linkc_off);
   fa.link_counter = reinterpret_cast<int32_t*>(ctx->ws + L.counter_off);
@@ -1387,10 +1414,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
   }
   if (!any_pending) {
     ctx->entries_used = 0;
-    if (ctx->links_used) {  // recycle the link nodes of the bag modes
-      HIP_TRY(ctx, hipMemsetAsync(ctx->ws + ctx->lay.counter_off, 0, sizeof(int32_t), st));
-      ctx->links_used = false;
-    }
+    ctx->links_used = false;   // (link nodes are numbered by their entry: nothing to recycle)
   }
   if (mode != GQE_OPT_MATERIALIZE)
     for (size_t t = 0; t < ctx->tables.size(); ++t)
@@ -1404,6 +1428,14 @@ extern "C" {
 
 int gqe_abi_version(void) { return GQE_ABI_VERSION; }
 
+int gqe_dim_supported(int32_t decoder, int32_t inter, int32_t dim) { return gqe_config_supported(decoder, inter, dim); }
+
+int gqe_debug_fused_variant(int32_t decoder, int32_t dim, int32_t tiles, int32_t* nc_full_fw) {
+  if (!nc_full_fw) return GQE_ERR_ARG;
+  gqe_fused_variant(decoder, dim, tiles, &nc_full_fw[0], &nc_full_fw[1], &nc_full_fw[2]);
+  return GQE_OK;
+}
+
 const char* gqe_last_error(const gqe_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int gqe_create(const gqe_config* cfg, gqe_ctx** out) {
@@ -1412,6 +1444,10 @@ int gqe_create(const gqe_config* cfg, gqe_ctx** out) {
   if (cfg->dim < 16 || cfg->dim > GQE_MAX_DIM || cfg->dim % 16) return fail(nullptr, GQE_ERR_ARG, "dim must be a multiple of 16 in [16,%d], got %d", GQE_MAX_DIM, cfg->dim);
   if (cfg->decoder < 0 || cfg->decoder > 2) return fail(nullptr, GQE_ERR_ARG, "Metapath decoder not recognized.");
   if (cfg->inter < 0 || cfg->inter > 3) return fail(nullptr, GQE_ERR_ARG, "Intersection decoder not recognized.");
+  if (!gqe_config_supported(cfg->decoder, cfg->inter, cfg->dim))
+    return fail(nullptr, GQE_ERR_ARG, "dim %d is not supported with this decoder / intersection decoder: its fused kernel spills registers on gfx950 "
+                "and spilling variants are not vouched for (gqe_dim_supported; full Bilinear: 16, 32, 48, 64, 128, 256; SetIntersection "
+                "min / mean: not in (192, 256))", cfg->dim);
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev < 1) return fail(nullptr, GQE_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(e));
@@ -1424,8 +1460,11 @@ int gqe_create(const gqe_config* cfg, gqe_ctx** out) {
   return GQE_OK;
 }
 
+void shard_session_free_fwd(gqe_ctx* ctx);
+
 int gqe_destroy(gqe_ctx* ctx) {
   if (!ctx) return GQE_OK;
+  shard_session_free_fwd(ctx);
   for (auto& s : ctx->ring) {
     if (s.in_flight) (void)hipEventSynchronize(s.done);
     if (s.done) (void)hipEventDestroy(s.done);
@@ -1467,6 +1506,7 @@ int gqe_set_tables(gqe_ctx* ctx, const int64_t* offsets, const int64_t* rows, in
   if (!ctx) return GQE_ERR_ARG;
   if (!offsets || !rows || n_tables < 1 || n_tables > ctx->cap_tensors) return fail(ctx, GQE_ERR_ARG, "bad table list");
   if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "gradients pending; step or materialize before changing the tables");
+  if (ctx->shard_on && n_tables > GQE_LAZY_TABLES) return fail(ctx, GQE_ERR_ARG, "row-sharded mode supports at most %d tables", GQE_LAZY_TABLES);
   ctx->tables.clear();
   ctx->bags.clear();
   ctx->total_rows = 0;
@@ -1510,6 +1550,7 @@ int gqe_set_bag(gqe_ctx* ctx, int64_t table_offset, const int32_t* bag_ptr, cons
 
 int64_t gqe_workspace_bytes(gqe_ctx* ctx, int64_t max_queries, int32_t max_batches) {
   if (!ctx || max_queries < 1 || max_batches < 1 || max_batches > GQE_MAX_BATCHES) return GQE_ERR_ARG;
+  if (ctx->shard_on && (int)ctx->tables.size() > GQE_LAZY_TABLES) return fail(ctx, GQE_ERR_ARG, "row-sharded mode supports at most %d tables", GQE_LAZY_TABLES);
   ctx->cap_queries = max_queries;
   ctx->cap_batches = max_batches;
   return (int64_t)make_layout(ctx, max_queries, max_batches).total;
@@ -1522,6 +1563,7 @@ int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* strea
   if (ctx->cap_queries < 1) return fail(ctx, GQE_ERR_STATE, "call gqe_workspace_bytes first");
   if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "gradients pending; step or materialize before re-binding the workspace");
   if (lazy_any_dirty(ctx)) return fail(ctx, GQE_ERR_STATE, "lazy Adam: call gqe_optimizer_sync before re-binding the workspace");
+  if (ctx->shard_on && (int)ctx->tables.size() > GQE_LAZY_TABLES) return fail(ctx, GQE_ERR_ARG, "row-sharded mode supports at most %d tables", GQE_LAZY_TABLES);
   const Layout L = make_layout(ctx, ctx->cap_queries, ctx->cap_batches);
   if ((int64_t)L.total > bytes) return fail(ctx, GQE_ERR_WORKSPACE, "workspace has %lld bytes, %zu needed", (long long)bytes, L.total);
   ctx->ws = static_cast<char*>(workspace);
@@ -1647,6 +1689,7 @@ int gqe_shard_plan(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
                    int32_t* positions, int32_t* requests, int64_t* send_counts) {
   if (!ctx) return GQE_ERR_ARG;
   if (!ctx->shard_on) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard has not been called");
+  if ((int)ctx->tables.size() > GQE_LAZY_TABLES) return fail(ctx, GQE_ERR_STATE, "row-sharded mode supports at most %d tables", GQE_LAZY_TABLES);
   if (!batches || n_batches < 1 || n_batches > GQE_MAX_BATCHES || !idx || n_idx < 1 || !positions || !requests || !send_counts)
     return fail(ctx, GQE_ERR_ARG, "gqe_shard_plan: bad arguments");
   const int W = ctx->shard_world;
@@ -1707,6 +1750,9 @@ int gqe_shard_serve(gqe_ctx* ctx, const int32_t* requests, int64_t n, float* row
   if (!ctx->ws || !ctx->params) return fail(ctx, GQE_ERR_STATE, "arena / workspace not bound");
   if (!ctx->shard_on) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard has not been called");
   if (n < 0 || n > ctx->lay.shard_cap_recv || (n > 0 && (!requests || !rows_out))) return fail(ctx, GQE_ERR_ARG, "gqe_shard_serve: bad arguments");
+  if ((int)ctx->tables.size() > GQE_LAZY_TABLES) return fail(ctx, GQE_ERR_STATE, "row-sharded mode supports at most %d tables", GQE_LAZY_TABLES);
+  if (ctx->lazy && !ctx->shard_internal)
+    return fail(ctx, GQE_ERR_STATE, "row-sharded mode with lazy Adam runs through gqe_shard_step (the owner has to bring the rows it serves up to date)");
   if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "row-sharded mode: received contributions are still pending (step first)");
   GqeShardTabs t;
   memset(&t, 0, sizeof t);
@@ -1776,6 +1822,7 @@ int gqe_import_entries(gqe_ctx* ctx, int64_t slab, void* stream) {
   for (size_t k = 0; k < ctx->bags.size(); ++k) {
     ib.csr.ptr[k] = ctx->bags[k].ptr;
     ib.csr.ids[k] = ctx->bags[k].ids;
+    ib.csr.max_len = std::max(ib.csr.max_len, ctx->bags[k].max_len);
     ib.head_base[k] = ctx->tables[ctx->bags[k].table].head_base;
   }
   ib.link_contrib = reinterpret_cast<int32_t*>(ctx->ws + L.linkc_off);
@@ -1883,6 +1930,16 @@ static inline uint64_t feeder_next(gqe_feeder* f) {  // xoroshiro128+
   return r;
 }
 
+static inline uint64_t feeder_next_neg(gqe_feeder* f) {  // the same generator on the per-rank state
+  const uint64_t s0 = f->neg_rng[0];
+  uint64_t s1 = f->neg_rng[1];
+  const uint64_t r = s0 + s1;
+  s1 ^= s0;
+  f->neg_rng[0] = ((s0 << 24) | (s0 >> 40)) ^ s1 ^ (s1 << 16);
+  f->neg_rng[1] = (s1 << 37) | (s1 >> 27);
+  return r;
+}
+
 int gqe_feeder_create(gqe_ctx* ctx, uint64_t seed, int32_t batch_size, float path_weight, float inter_weight, gqe_feeder** out) {
   if (!ctx || !out) return GQE_ERR_ARG;
   if (batch_size < 1) return fail(ctx, GQE_ERR_ARG, "batch_size must be >= 1");
@@ -1895,6 +1952,14 @@ int gqe_feeder_create(gqe_ctx* ctx, uint64_t seed, int32_t batch_size, float pat
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     f->rng[k] = x ^ (x >> 31);
+  }
+  z += 0x9E3779B97F4A7C15ull * (uint64_t)(1 + (ctx->shard_on ? ctx->shard_rank : 0));
+  for (int k = 0; k < 2; ++k) {
+    z += 0x9E3779B97F4A7C15ull;
+    uint64_t x = z;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    f->neg_rng[k] = x ^ (x >> 31);
   }
   f->batch_size = batch_size;
   f->path_weight = path_weight;
@@ -1912,6 +1977,17 @@ int gqe_feeder_destroy(gqe_feeder* f) {
     }
   for (int k = 0; k < 8; ++k)
     if (f->pin[k]) (void)hipHostFree(f->pin[k]);
+  for (int k = 0; k < 2; ++k) {
+    if (f->grp_ready[k]) {
+      (void)hipEventSynchronize(f->grp_ready[k]);
+      (void)hipEventDestroy(f->grp_ready[k]);
+    }
+    if (f->grp_free[k]) {
+      if (f->grp_free_set[k]) (void)hipEventSynchronize(f->grp_free[k]);
+      (void)hipEventDestroy(f->grp_free[k]);
+    }
+    if (f->grp_pin[k]) (void)hipHostFree(f->grp_pin[k]);
+  }
   delete f;
   return GQE_OK;
 }
@@ -1971,10 +2047,26 @@ static int feeder_batch(gqe_feeder* f, int qtype, int64_t it, float weight, bool
   const FeederPool& p = f->pools[cand[pick]];
   if (hard && p.hard.empty()) return fail(ctx, GQE_ERR_ARG, "pool of query type %d has no hard negatives", qtype);
   const int64_t n = p.n, B = f->batch_size;
-  const int64_t start = (it * B) % n;
-  int64_t end = std::min(((it + 1) * B) % n, n);
-  if (end <= start) end = n;
+  // row-sharded data parallelism: the W ranks of iteration `it` train the W consecutive slices it * W + rank of the same
+  // formula draw (the reference's wrap-around rule, train_helpers.py:102-105) and weight their mean losses by n_rank / n_all
+  const int W = ctx->shard_on ? ctx->shard_world : 1, rk = ctx->shard_on ? ctx->shard_rank : 0;
+  auto slice = [&](int64_t i, int64_t* a, int64_t* e) {
+    *a = (i * B) % n;
+    *e = std::min(((i + 1) * B) % n, n);
+    if (*e <= *a) *e = n;
+  };
+  int64_t start, end;
+  slice(it * W + rk, &start, &end);
   const int64_t m = end - start;
+  if (W > 1) {
+    int64_t n_all = 0;
+    for (int r = 0; r < W; ++r) {
+      int64_t a, e;
+      slice(it * W + r, &a, &e);
+      n_all += e - a;
+    }
+    weight *= (float)((double)m / (double)n_all);
+  }
   gqe_batch b = p.proto;
   b.n_queries = (int32_t)m;
   b.idx_offset = (int32_t)f->idx.size();
@@ -1987,7 +2079,8 @@ static int feeder_batch(gqe_feeder* f, int qtype, int64_t it, float weight, bool
     auto it_rows = f->mode_rows.find(p.proto.target_table);
     if (it_rows == f->mode_rows.end()) return fail(ctx, GQE_ERR_STATE, "gqe_feeder_set_mode_rows missing for the 1-chain target table");
     const std::vector<int32_t>& rows = it_rows->second;
-    for (int64_t k = 0; k < m; ++k) f->idx.push_back(rows[feeder_next(f) % rows.size()]);
+    // (several ranks: the negatives come from a per-rank stream, the formula draws stay on the shared one)
+    for (int64_t k = 0; k < m; ++k) f->idx.push_back(rows[(W > 1 ? feeder_next_neg(f) : feeder_next(f)) % rows.size()]);
   } else {
     const std::vector<int32_t>& src = hard ? p.hard : p.neg;
     f->idx.insert(f->idx.end(), src.begin() + start, src.begin() + end);
@@ -2010,86 +2103,198 @@ static void feeder_touch(gqe_feeder* f, int64_t offset, int64_t numel) {
   f->segs.push_back(s);
 }
 
+// sample + pack iteration `it` into f->batches / f->idx / f->segs: the reference's schedule (train_helpers.py:50-72): 1-chain
+// always; after burn-in every other type, chains once (path_weight), intersections with regular and with hard negatives
+// (inter_weight each)
+static int feeder_build(gqe_feeder* f, int64_t it, int32_t burn_in) {
+  gqe_ctx* ctx = f->ctx;
+  const int d = ctx->cfg.dim;
+  const bool bil = ctx->cfg.decoder == GQE_DEC_BILINEAR;
+  const int64_t vec = bil ? (int64_t)d * d : d;
+  f->batches.clear();
+  f->idx.clear();
+  f->segs.clear();
+  int rc = feeder_batch(f, GQE_Q_1CHAIN, it, 1.f, false);
+  if (rc != GQE_OK) return rc;
+  if (it >= burn_in) {
+    for (int t = GQE_Q_2CHAIN; t <= GQE_Q_3CHAIN_INTER; ++t) {
+      if (f->by_type[t].empty()) continue;
+      const bool inter = t >= GQE_Q_2INTER;
+      rc = feeder_batch(f, t, it, inter ? f->inter_weight : f->path_weight, false);
+      if (rc != GQE_OK) return rc;
+      if (inter) {
+        rc = feeder_batch(f, t, it, f->inter_weight, true);
+        if (rc != GQE_OK) return rc;
+      }
+    }
+  }
+  if (f->batches.empty()) return fail(ctx, GQE_ERR_STATE, "feeder has no 1-chain pool");
+  for (const gqe_batch& b : f->batches) {
+    const int tt = table_of(ctx, b.target_table);
+    feeder_touch(f, b.target_table, ctx->tables[tt].rows * d);
+    const bool chain = b.qtype <= GQE_Q_3CHAIN;
+    for (int a = 0; a < b.n_anchors; ++a) feeder_touch(f, b.anchor_table[a], ctx->tables[table_of(ctx, b.anchor_table[a])].rows * d);
+    for (int i = 0; i < (chain ? 1 : b.n_anchors); ++i)
+      for (int h = 0; h < b.n_hops[i]; ++h) feeder_touch(f, b.hop_param[i][h], vec);
+    if (!chain) {
+      if (b.n_final) feeder_touch(f, b.final_param, vec);
+      if (is_mlp(ctx)) {
+        feeder_touch(f, b.pre_param, (int64_t)d * d);
+        feeder_touch(f, b.post_param, (int64_t)d * d);
+      }
+    }
+  }
+  return GQE_OK;
+}
+
+int shard_plans_ahead(gqe_ctx* ctx);   // gqe_shard_step.h: plans posted but not yet run
+
+// make iteration `it` ready: sampled, packed, and its index feed where the kernels will read it.
+//   zero-copy (feed mode 1): one of 8 pinned host slots (two groups of four; an event per group guards their re-use);
+//   copy (feed mode 0): the iterations of a GROUP of four are sampled together and travel with ONE hipMemcpyAsync on the
+//     library's upload stream into one of two groups of staged buffers in the workspace — two cross-stream event packets
+//     per four iterations instead of per iteration (they sit between kernels that otherwise overlap);
+//   row-sharded: a host feed of global rows for gqe_shard_post.
+static int feeder_ensure(gqe_feeder* f, int64_t it, int32_t burn_in, hipStream_t st) {
+  gqe_ctx* ctx = f->ctx;
+  gqe_feeder::Prepared& P = f->prep[it % (2 * kFeedGroup)];
+  if (P.it == it) return GQE_OK;
+  const Layout& L = ctx->lay;
+  const size_t slot_ints = L.idx_cap / sizeof(int32_t);
+  int rc;
+  auto stash = [&](gqe_feeder::Prepared& Q, int64_t i) {
+    Q.it = i;
+    Q.batches = f->batches;
+    Q.segs = f->segs;
+    Q.n_idx = (int64_t)f->idx.size();
+  };
+  if (ctx->shard_on) {
+    rc = feeder_build(f, it, burn_in);
+    if (rc != GQE_OK) return rc;
+    stash(P, it);
+    P.host_idx = f->idx;
+    P.dev_idx = nullptr;
+    return GQE_OK;
+  }
+  if (f->grp_cap != slot_ints) {   // first use, or the workspace was re-bound with another capacity: nothing may still read the old buffers
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (ctx->up) HIP_TRY(ctx, hipStreamSynchronize(ctx->up));
+    for (int k = 0; k < 8; ++k) {
+      if (f->pin[k]) HIP_TRY(ctx, hipHostFree(f->pin[k]));
+      f->pin[k] = nullptr;
+    }
+    for (int k = 0; k < 2; ++k) {
+      if (f->grp_pin[k]) HIP_TRY(ctx, hipHostFree(f->grp_pin[k]));
+      f->grp_pin[k] = nullptr;
+      if (!f->pin_ev[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&f->pin_ev[k], hipEventDisableTiming));
+      if (!f->grp_ready[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&f->grp_ready[k], hipEventDisableTiming));
+      if (!f->grp_free[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&f->grp_free[k], hipEventDisableTiming));
+      f->pin_ev_set[k] = f->grp_free_set[k] = false;
+    }
+    f->grp_cap = slot_ints;
+    for (auto& q : f->prep) q.it = -1;
+  }
+  if (f->feed_mode == 1) {
+    if (!f->pin[0])
+      for (int k = 0; k < 8; ++k) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&f->pin[k]), L.idx_cap, hipHostMallocDefault));
+    const long long group = it / kFeedGroup;
+    if (f->pin_ev_set[group & 1]) {   // the slots of group - 2 come up for re-use
+      if (hipEventQuery(f->pin_ev[group & 1]) != hipSuccess) HIP_TRY(ctx, hipEventSynchronize(f->pin_ev[group & 1]));
+      f->pin_ev_set[group & 1] = false;
+    }
+    rc = feeder_build(f, it, burn_in);
+    if (rc != GQE_OK) return rc;
+    if (f->idx.size() > slot_ints) return fail(ctx, GQE_ERR_WORKSPACE, "index feed of %zu entries exceeds the bound workspace", f->idx.size());
+    int32_t* slot = f->pin[it % 8];
+    memcpy(slot, f->idx.data(), f->idx.size() * sizeof(int32_t));
+    stash(P, it);
+    P.dev_idx = slot;
+    return GQE_OK;
+  }
+  // ---- copy mode: the rest of this iteration's group in one upload ----
+  if (!ctx->up) {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->up, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->plan_ready[k], hipEventDisableTiming));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->plan_free[k], hipEventDisableTiming));
+    }
+  }
+  const long long group = it / kFeedGroup;
+  const int g = (int)(group & 1);
+  if (!f->grp_pin[g]) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&f->grp_pin[g]), (size_t)kFeedGroup * L.idx_cap, hipHostMallocDefault));
+  HIP_TRY(ctx, hipEventSynchronize(f->grp_ready[g]));   // the previous upload out of this pinned buffer (two groups ago) is long done
+  const int k0 = (int)(it % kFeedGroup);
+  for (int k = k0; k < kFeedGroup; ++k) {
+    const int64_t i = group * kFeedGroup + k;
+    rc = feeder_build(f, i, burn_in);
+    if (rc != GQE_OK) return rc;
+    if (f->idx.size() > slot_ints) return fail(ctx, GQE_ERR_WORKSPACE, "index feed of %zu entries exceeds the bound workspace", f->idx.size());
+    memcpy(f->grp_pin[g] + (size_t)k * slot_ints, f->idx.data(), f->idx.size() * sizeof(int32_t));
+    gqe_feeder::Prepared& Q = f->prep[i % (2 * kFeedGroup)];
+    stash(Q, i);
+    Q.dev_idx = reinterpret_cast<const int32_t*>(ctx->ws + (size_t)(2 + g * kFeedGroup + k) * L.idx_cap);
+  }
+  char* dev = ctx->ws + (size_t)(2 + g * kFeedGroup + k0) * L.idx_cap;
+  if (f->grp_free_set[g]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->up, f->grp_free[g], 0));   // the kernels of group - 2 have read the buffers
+  HIP_TRY(ctx, hipMemcpyAsync(dev, f->grp_pin[g] + (size_t)k0 * slot_ints, (size_t)(kFeedGroup - k0) * L.idx_cap, hipMemcpyHostToDevice, ctx->up));
+  HIP_TRY(ctx, hipEventRecord(f->grp_ready[g], ctx->up));
+  HIP_TRY(ctx, hipStreamWaitEvent(st, f->grp_ready[g], 0));
+  return GQE_OK;
+}
+
 int gqe_feeder_run(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations, int32_t burn_in, float lr, float beta1,
                    float beta2, float eps, float* losses, void* stream) {
   if (!f) return GQE_ERR_ARG;
   gqe_ctx* ctx = f->ctx;
   if (n_iterations < 1 || !losses) return fail(ctx, GQE_ERR_ARG, "bad arguments");
-  const int d = ctx->cfg.dim;
-  const bool bil = ctx->cfg.decoder == GQE_DEC_BILINEAR;
-  const int64_t vec = bil ? (int64_t)d * d : d;
-  for (int64_t it = first_iteration; it < first_iteration + n_iterations; ++it) {
-    f->batches.clear();
-    f->idx.clear();
-    f->segs.clear();
-    // the reference's schedule (train_helpers.py:50-72): 1-chain always; after burn-in every other type,
-    // chains once (path_weight), intersections with regular and with hard negatives (inter_weight each)
-    int rc = feeder_batch(f, GQE_Q_1CHAIN, it, 1.f, false);
+  if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
+  const bool shard = ctx->shard_on;
+  if (shard && !ctx->shard_sess) return fail(ctx, GQE_ERR_STATE, "row-sharded ctx: gqe_shard_open comes before gqe_feeder_run");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t end = first_iteration + n_iterations;
+  for (int64_t it = first_iteration; it < end; ++it) {
+    int rc = feeder_ensure(f, it, burn_in, st);
     if (rc != GQE_OK) return rc;
-    if (it >= burn_in) {
-      for (int t = GQE_Q_2CHAIN; t <= GQE_Q_3CHAIN_INTER; ++t) {
-        if (f->by_type[t].empty()) continue;
-        const bool inter = t >= GQE_Q_2INTER;
-        rc = feeder_batch(f, t, it, inter ? f->inter_weight : f->path_weight, false);
+    // one iteration of look-ahead where it pays: lazy Adam (the step's row launch also brings the next feed's rows up to
+    // date: one launch instead of two) and row-sharded runs (the next plan is posted before this step runs)
+    const bool ahead = (ctx->lazy || shard) && it + 1 < end;
+    if (ahead) {
+      rc = feeder_ensure(f, it + 1, burn_in, st);
+      if (rc != GQE_OK) return rc;
+    }
+    gqe_feeder::Prepared& P = f->prep[it % (2 * kFeedGroup)];
+    gqe_feeder::Prepared& N = f->prep[(it + 1) % (2 * kFeedGroup)];
+    if (shard) {
+      if (shard_plans_ahead(ctx) == 0) {
+        rc = gqe_shard_post(ctx, P.batches.data(), (int32_t)P.batches.size(), P.host_idx.data(), P.n_idx, 1, P.segs.data(), (int32_t)P.segs.size());
         if (rc != GQE_OK) return rc;
-        if (inter) {
-          rc = feeder_batch(f, t, it, f->inter_weight, true);
-          if (rc != GQE_OK) return rc;
-        }
       }
+      if (ahead) {
+        rc = gqe_shard_post(ctx, N.batches.data(), (int32_t)N.batches.size(), N.host_idx.data(), N.n_idx, 1, N.segs.data(), (int32_t)N.segs.size());
+        if (rc != GQE_OK) return rc;
+      }
+      rc = gqe_shard_step(ctx, lr, beta1, beta2, eps, losses, nullptr, nullptr, stream);
+      if (rc != GQE_OK) return rc;
+      continue;
     }
-    if (f->batches.empty()) return fail(ctx, GQE_ERR_STATE, "feeder has no 1-chain pool");
-    bool record_group = false;
-    if (f->feed_mode == 1) {
-      const size_t bytes = f->idx.size() * sizeof(int32_t);
-      if (bytes > f->pin_cap) {   // (re)allocate the pinned slots: nothing may still be reading the old ones
-        HIP_TRY(ctx, hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
-        for (int k = 0; k < 8; ++k) {
-          if (f->pin[k]) HIP_TRY(ctx, hipHostFree(f->pin[k]));
-          f->pin[k] = nullptr;
-        }
-        f->pin_cap = align_up(bytes * 2, 4096);
-        for (int k = 0; k < 8; ++k) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&f->pin[k]), f->pin_cap, hipHostMallocDefault));
-        for (int k = 0; k < 2; ++k)
-          if (!f->pin_ev[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&f->pin_ev[k], hipEventDisableTiming));
-        f->pin_ev_set[0] = f->pin_ev_set[1] = false;
-      }
-      const long long group = f->pin_it / 4;
-      if (f->pin_it % 4 == 0 && f->pin_ev_set[group & 1]) {   // slots of group - 2 come up for re-use
-        if (hipEventQuery(f->pin_ev[group & 1]) != hipSuccess) HIP_TRY(ctx, hipEventSynchronize(f->pin_ev[group & 1]));
-      }
-      int32_t* slot = f->pin[f->pin_it % 8];
-      memcpy(slot, f->idx.data(), bytes);
-      rc = run_queries(ctx, f->batches.data(), (int32_t)f->batches.size(), slot, (int64_t)f->idx.size(), 1, true, losses, nullptr, nullptr,
-                       stream);
-      record_group = f->pin_it % 4 == 3;
-      ++f->pin_it;
-    } else {
-      rc = run_queries(ctx, f->batches.data(), (int32_t)f->batches.size(), f->idx.data(), (int64_t)f->idx.size(), 0, true, losses,
-                       nullptr, nullptr, stream);
-    }
+    rc = run_queries(ctx, P.batches.data(), (int32_t)P.batches.size(), P.dev_idx, P.n_idx, 1, true, losses, nullptr, nullptr, stream);
     if (rc != GQE_OK) return rc;
-    for (const gqe_batch& b : f->batches) {
-      const int tt = table_of(ctx, b.target_table);
-      feeder_touch(f, b.target_table, ctx->tables[tt].rows * d);
-      const bool chain = b.qtype <= GQE_Q_3CHAIN;
-      for (int a = 0; a < b.n_anchors; ++a) feeder_touch(f, b.anchor_table[a], ctx->tables[table_of(ctx, b.anchor_table[a])].rows * d);
-      for (int i = 0; i < (chain ? 1 : b.n_anchors); ++i)
-        for (int h = 0; h < b.n_hops[i]; ++h) feeder_touch(f, b.hop_param[i][h], vec);
-      if (!chain) {
-        if (b.n_final) feeder_touch(f, b.final_param, vec);
-        if (is_mlp(ctx)) {
-          feeder_touch(f, b.pre_param, (int64_t)d * d);
-          feeder_touch(f, b.post_param, (int64_t)d * d);
-        }
-      }
+    if (ctx->lazy && ahead) {
+      rc = gqe_lazy_prefetch(ctx, N.batches.data(), (int32_t)N.batches.size(), N.dev_idx, N.n_idx, 1);
+      if (rc != GQE_OK) return rc;
     }
-    rc = run_opt(ctx, GQE_OPT_ADAM, f->segs.data(), (int32_t)f->segs.size(), lr, beta1, beta2, eps, stream);
+    rc = run_opt(ctx, GQE_OPT_ADAM, P.segs.data(), (int32_t)P.segs.size(), lr, beta1, beta2, eps, stream);
     if (rc != GQE_OK) return rc;
-    if (record_group) {   // everything that reads the last four feeds (fused kernel, lazy row launches) is enqueued
-      const long long group = (f->pin_it - 1) / 4;
-      HIP_TRY(ctx, hipEventRecord(f->pin_ev[group & 1], reinterpret_cast<hipStream_t>(stream)));
-      f->pin_ev_set[group & 1] = true;
+    // everything that reads the feeds of this group (fused kernel, lazy row launches) is enqueued
+    const bool group_done = (it % kFeedGroup) == kFeedGroup - 1 || it == end - 1;
+    const int g = (int)((it / kFeedGroup) & 1);
+    if (group_done && f->feed_mode == 1 && (it % kFeedGroup) == kFeedGroup - 1) {
+      HIP_TRY(ctx, hipEventRecord(f->pin_ev[g], st));
+      f->pin_ev_set[g] = true;
+    }
+    if (group_done && f->feed_mode == 0) {
+      HIP_TRY(ctx, hipEventRecord(f->grp_free[g], st));
+      f->grp_free_set[g] = true;
     }
   }
   return GQE_OK;
@@ -2104,12 +2309,12 @@ int gqe_debug_profile(gqe_ctx* ctx, long long* stamps) {
 int gqe_timing_enable(gqe_ctx* ctx, int32_t stride) {
   if (!ctx) return GQE_ERR_ARG;
   ctx->timing = stride > 0 ? stride : 0;
-  for (int k = 0; k < 5; ++k) ctx->timing_calls[k] = 0;
+  for (int k = 0; k < kTimingKinds; ++k) ctx->timing_calls[k] = 0;
   return GQE_OK;
 }
 
 int gqe_timing_read(gqe_ctx* ctx, int32_t kernel, float* avg_ms, int32_t* count) {
-  if (!ctx || kernel < 0 || kernel > 4 || !avg_ms || !count) return GQE_ERR_ARG;
+  if (!ctx || kernel < 0 || kernel >= kTimingKinds || !avg_ms || !count) return GQE_ERR_ARG;
   double total = 0;
   int n = 0;
   for (auto& t : ctx->timed[kernel]) {
@@ -2127,3 +2332,5 @@ int gqe_timing_read(gqe_ctx* ctx, int32_t kernel, float* avg_ms, int32_t* count)
 }
 
 }  // extern "C"
+
+#include "gqe_shard_step.h"   // gqe_shard_open / post / step / forward / close: the row-sharded step as one call

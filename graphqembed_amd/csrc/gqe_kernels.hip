@@ -481,17 +481,41 @@ GQE_DECL(0, 0) GQE_DECL(0, 1) GQE_DECL(1, 0) GQE_DECL(1, 1) GQE_DECL(2, 0) GQE_D
 // 8 waves (two rows per wave, 256 VGPRs) for the guarded d in (128, 256) variants, and at d = 128 when the launch has
 // so many tiles that two co-resident workgroups per CU (2 x 74 KB of LDS, 2 x 8 waves at <= 128 VGPRs) beat the shorter
 // per-tile chain of the 16-wave shape.
-int gqe_fused_waves(int d, int tiles) {
+int gqe_fused_waves(int dec, int d, int tiles) {
   if (d == 256) return 16;  // FULL variant: fits 128 VGPRs without scratch; every wave owns an MFMA row block
   if (d > 128) return 8;    // guarded variants
   if (d > 64 && (d % 64) != 0) return 8;  // guarded d in (64, 128): 256 VGPRs per lane instead of spilling at 128
+  if (dec == DEC_BILINEAR && d < 64) return 8;  // full Bilinear, guarded d < 64: 171 VGPRs (the 16-wave form spilled at 128)
   if (d == 128 && tiles > GQE_FW8_MIN_TILES) return 8;
   return 16;
 }
 
+// Which (decoder, intersection, dim) the library vouches for.  Every kernel the dispatcher can select for a supported
+// configuration is free of register spills and of the allocator's "spill / copy ahead of the EXEC restore" placement
+// (the root cause of the corrupted gradients / memory faults of two spilling guarded kernels in round 2);
+// tests/test_build_meta.py checks that against the code objects and the assembly of the built library.  What is refused:
+// full Bilinear at d % 64 != 0 above 64 and at d = 192 (its guarded 8-wave kernels spill up to 476 registers), and the
+// SetIntersection (min / mean) decoders at d in (192, 256) (3-24 spilled registers; one of those kernels carries the
+// bad placement).
+int gqe_config_supported(int dec, int inter, int d) {
+  if (d < 16 || d > GQE_MAX_DIM || d % 16) return 0;
+  if (dec == DEC_BILINEAR) return d <= 64 || d == 128 || d == 256;
+  const bool mlp = inter == GQE_INTER_MIN || inter == GQE_INTER_MEAN;
+  if (mlp && d > 192 && d < 256) return 0;
+  return 1;
+}
+
+// the template arguments (NC, FULL, FW) of the kernel gqe_launch_fused runs for (decoder, d) in a launch of `tiles` tiles
+// (mirrors launch_fused_dm in gqe_fused.h; tests/test_build_meta.py looks the variant up in the built library)
+void gqe_fused_variant(int dec, int d, int tiles, int* nc, int* full, int* fw) {
+  *nc = (d + 63) / 64;
+  *full = ((d % 64) == 0 && d != 192) ? 1 : 0;   // (d = 192 runs the guarded NC = 3 kernel)
+  *fw = gqe_fused_waves(dec, d, tiles);
+}
+
 hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a) {
   const int key = dec * 2 + (mlp ? 1 : 0);
-  if (gqe_fused_waves(a.d, a.plan.tiles) == 8) {
+  if (gqe_fused_waves(dec, a.d, a.plan.tiles) == 8) {
     switch (key) {
       case 0: return gqe_launch_fused_0_0_w8(a);
       case 1: return gqe_launch_fused_0_1_w8(a);
@@ -702,7 +726,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_import_kernel(int32_t* __rest
       // a bag contribution: one link node per word row of the bag, exactly what the producer's fused kernel did
       const int code = -h - 2, slot = code >> 27, bag = code & ((1 << 27) - 1);
       const int p0 = bags.csr.ptr[slot][bag], len = bags.csr.ptr[slot][bag + 1] - p0;
-      const int base = __hip_atomic_fetch_add(bags.link_counter, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int base = e * bags.csr.max_len;   // the entry's own block of link nodes (as the producer's fused kernel numbers them)
       for (int j = 0; j < len; ++j) {
         const int node = base + j;
         const int w = bags.csr.ids[slot][p0 + j];

@@ -63,10 +63,20 @@ class gqe_segment(C.Structure):
     _fields_ = [("offset", C.c_int64), ("numel", C.c_int64), ("step", C.c_int32), ("reserved", C.c_int32)]
 
 
+# gqe_transport (include/gqe.h): the two collectives of the row-sharded step as callbacks
+A2A_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class gqe_transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_to_all", A2A_FN), ("all_reduce_sum_f32", ALLREDUCE_FN)]
+
+
 # every symbol include/gqe.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = OrderedDict([
     ("gqe_abi_version", (C.c_int, [])),
+    ("gqe_dim_supported", (C.c_int, [C.c_int32, C.c_int32, C.c_int32])),
     ("gqe_last_error", (C.c_char_p, [_P])),
     ("gqe_create", (C.c_int, [C.POINTER(gqe_config), C.POINTER(_P)])),
     ("gqe_destroy", (C.c_int, [_P])),
@@ -90,6 +100,11 @@ SYMBOLS = OrderedDict([
     ("gqe_shard_plan", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P, _P])),
     ("gqe_shard_serve", (C.c_int, [_P, _P, C.c_int64, _P, _P])),
     ("gqe_shard_link", (C.c_int, [_P, _P, C.c_int64, _P])),
+    ("gqe_shard_open", (C.c_int, [_P, C.c_char_p, _P, C.POINTER(gqe_transport)])),
+    ("gqe_shard_close", (C.c_int, [_P])),
+    ("gqe_shard_post", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, C.POINTER(gqe_segment), C.c_int32])),
+    ("gqe_shard_step", (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P])),
+    ("gqe_shard_forward", (C.c_int, [_P, _P, _P])),
     ("gqe_rank_candidates", (C.c_int, [_P, _P, _P, C.c_int32, _P, _P])),
     ("gqe_auc_pair_counts", (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, _P])),
     ("gqe_forward", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P])),
@@ -106,6 +121,7 @@ SYMBOLS = OrderedDict([
     ("gqe_feeder_run", (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P])),
     ("gqe_timing_enable", (C.c_int, [_P, C.c_int32])),
     ("gqe_debug_profile", (C.c_int, [_P, _P])),
+    ("gqe_debug_fused_variant", (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)])),
     ("gqe_timing_read", (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)])),
 ])
 
@@ -319,6 +335,61 @@ class Engine(object):
                                             1 if with_negatives else 0, C.c_void_p(pos.ctypes.data), C.c_void_p(req.ctypes.data),
                                             C.c_void_p(counts.ctypes.data)))
         return pos, req, counts
+
+    # -- the row-sharded step as one call (include/gqe.h: gqe_shard_open / post / step / forward) ----------------
+    def shard_open(self, session=None, nccl_comm=None, transport=None):
+        """Join the node's plan board "/gqe_<session>" (the same name on every rank; None for world = 1) and name the
+        transport: an ncclComm_t of RCCL (``nccl_comm``: integer handle, e.g. parallel.RcclComm.handle) or a
+        ``gqe_transport`` of callbacks (parallel.TorchTransport)."""
+        self._shard_transport = transport          # keep the callbacks alive
+        self._check(self.lib.gqe_shard_open(self.ctx, None if session is None else session.encode(),
+                                            None if nccl_comm is None else C.c_void_p(int(nccl_comm)),
+                                            None if transport is None else C.byref(transport)))
+
+    def shard_close(self):
+        if getattr(self, "ctx", None):
+            self._check(self.lib.gqe_shard_close(self.ctx))
+
+    def prepare_shard(self, descs, idx, keys=None, with_negatives=True):
+        """Freeze one step for gqe_shard_post: ctypes descriptors, the HOST index feed of GLOBAL rows (numpy int32) and,
+        for a margin step, the parameter tensors its batches touch."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        total = sum(dsc["n"] for dsc in descs)
+        self.reserve(total, len(descs))
+        t = self.torch
+        ps = {"arr": self.make_batches(descs), "n": len(descs), "idx": idx, "idx_ptr": C.c_void_p(idx.ctypes.data), "n_idx": int(idx.size),
+              "queries": total, "with_negatives": 1 if with_negatives else 0,
+              "losses": t.zeros(len(descs) + 1, dtype=t.float32, device=self.device), "segs": None, "n_segs": 0}
+        if with_negatives:
+            keys = [k for k in self.layout.entries if k in set(keys)]
+            ps["keys"], ps["segs"], ps["n_segs"] = keys, self._segments(keys, False), len(keys)
+        return ps
+
+    def shard_post(self, ps):
+        """gqe_shard_post: plan the step on the host (owner sort) and publish it to the other ranks; never blocks on a GPU."""
+        self._check(self.lib.gqe_shard_post(self.ctx, ps["arr"], ps["n"], ps["idx_ptr"], ps["n_idx"], ps["with_negatives"],
+                                            ps["segs"], ps["n_segs"]))
+
+    def shard_step(self, ps, lr=0.01, betas=(0.9, 0.999), eps=1e-8, pos=None, neg=None):
+        """gqe_shard_step: run the oldest posted plan (must be ``ps``'s): rows in, fused forward / backward, contributions
+        out, Adam on the own shards — one library call; returns ps["losses"]."""
+        self._check(self.lib.gqe_shard_step(self.ctx, lr, betas[0], betas[1], eps, ps["losses"].data_ptr(),
+                                            None if pos is None else pos.data_ptr(), None if neg is None else neg.data_ptr(), self._stream()))
+        return ps["losses"]
+
+    def shard_forward(self, n_scores, out=None):
+        scores = out if out is not None else self.torch.empty(n_scores, dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.gqe_shard_forward(self.ctx, scores.data_ptr(), self._stream()))
+        return scores
+
+    def view_bytes(self, ptr, nbytes):
+        """uint8 view of ``nbytes`` at device address ``ptr`` inside one of the tensors the ctx borrows (transport callbacks)."""
+        t = self.torch
+        for base in (self.workspace, self.grads, self._params):
+            off = int(ptr) - base.data_ptr()
+            if 0 <= off and off + nbytes <= base.numel() * base.element_size():
+                return base.view(-1).view(t.uint8)[off:off + nbytes]
+        raise ValueError("address %#x (+%d) is outside the workspace and the arenas" % (int(ptr), nbytes))
 
     def shard_serve(self, requests, n, rows_out):
         self._check(self.lib.gqe_shard_serve(self.ctx, C.c_void_p(requests.data_ptr()), int(n), C.c_void_p(rows_out.data_ptr()), self._stream()))

@@ -184,6 +184,67 @@ def _all_to_all(dist, out, inp, out_splits, in_splits):
         dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits)
 
 
+class TorchTransport(object):
+    """gqe_transport over ``torch.distributed`` (include/gqe.h): the two collectives gqe_shard_step needs, as callbacks.
+    With the gloo backend device buffers are staged through the host (several ranks sharing one GPU: the tests); a nccl
+    process group moves them in place — but there the library's own RCCL path (Engine.shard_open(nccl_comm=...)) is the
+    one to use.  The callbacks run on the calling thread inside gqe_shard_step; the stream is torch's current stream."""
+
+    def __init__(self, engine, dist):
+        import torch
+        from .engine import A2A_FN, ALLREDUCE_FN, gqe_transport
+        self.engine, self.dist, self.error = engine, dist, None
+        world = dist.get_world_size()
+
+        def a2a(user, send, scounts, recv, rcounts, elem_bytes, stream):
+            try:
+                sc = [int(scounts[i]) for i in range(world)]
+                rc = [int(rcounts[i]) for i in range(world)]
+                cols = int(elem_bytes) // 4
+                src = engine.view_bytes(send, sum(sc) * elem_bytes).view(torch.float32).view(sum(sc), cols)
+                dst = engine.view_bytes(recv, sum(rc) * elem_bytes).view(torch.float32).view(sum(rc), cols)
+                _all_to_all(dist, dst, src, rc, sc)
+                return 0
+            except Exception as e:                      # noqa: an exception must not unwind through the C frames
+                self.error = e
+                return 1
+
+        def allreduce(user, buf, n, stream):
+            try:
+                t = engine.view_bytes(buf, int(n) * 4).view(torch.float32)
+                if t.is_cuda and dist.get_backend() == "gloo":
+                    h = t.cpu()
+                    dist.all_reduce(h)
+                    t.copy_(h)
+                else:
+                    dist.all_reduce(t)
+                return 0
+            except Exception as e:                      # noqa
+                self.error = e
+                return 1
+        self._a2a, self._ar = A2A_FN(a2a), ALLREDUCE_FN(allreduce)     # keep the thunks alive
+        self.struct = gqe_transport(None, self._a2a, self._ar)
+
+
+def shard_session(engine, dist, rank=0, world=1):
+    """Open the row-sharded session of ``engine`` (gqe_shard_open): agree on a plan-board name, pick the transport — the
+    library's own RCCL calls on a nccl process group (a communicator of its own: RcclComm), callbacks over
+    torch.distributed otherwise (gloo), nothing for a single rank.  Returns the object that keeps the transport alive."""
+    if dist is None or world == 1:
+        engine.shard_open(None)
+        return None
+    import uuid
+    name = [uuid.uuid4().hex[:16] if rank == 0 else None]
+    dist.broadcast_object_list(name, src=0)
+    if dist.get_backend() == "nccl":
+        comm = RcclComm(rank, world, dist, device=engine.device)
+        engine.shard_open(name[0], nccl_comm=comm.handle)
+        return comm
+    tr = TorchTransport(engine, dist)
+    engine.shard_open(name[0], transport=tr.struct)
+    return tr
+
+
 def shard_prepare(engine, dist, descs, idx, with_negatives=True):
     """Plan one call in row-sharded mode: sort its index feed (numpy int32, GLOBAL rows) by owner, tell every owner
     which of its rows this rank will request (one all-to-all of counts, one of row ids) and freeze the launch

@@ -79,6 +79,7 @@ class TensorizedTrainer(object):
         self.ema_loss = None
         self.iterations = 0
         self.queries_seen = 0
+        self._session, self._session_open, self._posted = None, False, None   # row-sharded: transport keep-alive, the plan posted ahead
 
     def _batch(self, qtype, it, weight, hard=False):
         """formula drawn in proportion to its number of queries, slice by the reference's wrap-around rule."""
@@ -127,30 +128,50 @@ class TensorizedTrainer(object):
         self.queries_seen += sum(len(x[1]) for x in items)
         return losses
 
-    def _sharded_step(self, items):
-        """Row-sharded tables: plan the iteration (sort its index feed by owner, tell the owners), fetch the rows, one
-        grouped fused launch on the fetched rows, contributions back to the owners, Adam on the own shards."""
+    def _shard_ps(self, items):
         packed = [(self.plan_of(f), t, ng, a, w, m) for (f, t, ng, a, w, m) in items]
         descs, idx, _ = pack_margin_batches(packed)
-        ps = parallel.shard_prepare(self.engine, self.dist, descs, idx)
-        parallel.shard_fetch(self.engine, self.dist, ps)
-        self.engine.run_margin(ps)
-        parallel.shard_exchange(self.engine, self.dist, ps)
-        if hasattr(self.model, "_mark_touched"):
-            for p in packed:
-                self.model._mark_touched(p[0].touched)
+        ps = self.engine.prepare_shard(descs, idx, set().union(*[p[0].touched for p in packed]))
+        ps["n_queries"] = sum(len(x[1]) for x in items)
+        return ps
+
+    def _sharded_step(self, items, next_items=None):
+        """Row-sharded tables (include/gqe.h, gqe_shard_post / gqe_shard_step): the iteration is planned on the host (its
+        index feed sorted by owner, the plan published to the other ranks through shared memory), then ONE library call
+        fetches the rows, runs the fused launch on them, routes the contributions to their owners and steps the own shards
+        (torch.optim.Adam semantics with the optimiser's lr / betas / eps; the step counters are the library's).
+        ``next_items``: the following iteration, posted BEFORE this one runs so that no rank waits for a peer's plan."""
+        eng = self.engine
+        if not self._session_open:
+            self._session = parallel.shard_session(eng, self.dist, self.rank, self.world)
+            self._session_open = True
+        if self._posted is None:
+            ps = self._shard_ps(items)
+            eng.shard_post(ps)
         else:
-            self.model.touched = getattr(self.model, "touched", set()) | set().union(*[p[0].touched for p in packed])
-        self.opt.step()
+            ps = self._posted
+        self._posted = None
+        if next_items is not None:
+            self._posted = self._shard_ps(next_items)
+            eng.shard_post(self._posted)
+        losses = eng.shard_step(ps, getattr(self.opt, "lr", 0.01), getattr(self.opt, "betas", (0.9, 0.999)), getattr(self.opt, "eps", 1e-8))
+        err = getattr(self._session, "error", None)
+        if err is not None:
+            raise err
         self.iterations += 1
-        self.queries_seen += sum(len(x[1]) for x in items)
-        return ps["losses"]
+        self.queries_seen += ps["n_queries"]
+        return losses
 
     def run(self, max_iter, burn_in=0, log_every=100, logger=None):
         t0 = time.time()
         losses = None
+        nxt = self.items(0, 0 >= burn_in) if self.sharded and max_iter > 0 else None
         for it in range(max_iter):
-            losses = self.step(it, edge_conv=it >= burn_in)
+            if self.sharded:          # one iteration of look-ahead: iteration it + 1 is planned and posted before it runs
+                cur, nxt = nxt, (self.items(it + 1, it + 1 >= burn_in) if it + 1 < max_iter else None)
+                losses = self._sharded_step(cur, nxt)
+            else:
+                losses = self.step(it, edge_conv=it >= burn_in)
             if log_every and it % log_every == 0:
                 val = float(losses[-1].item())        # the only host sync of the loop
                 self.ema_loss = val if self.ema_loss is None else 0.99 * self.ema_loss + 0.01 * val

@@ -116,6 +116,11 @@ typedef struct {
 } gqe_segment;
 
 int gqe_abi_version(void);
+/* 1 if gqe_create accepts (decoder, inter, dim): dim a multiple of 16 in [16, GQE_MAX_DIM], except the combinations whose
+ * fused kernel the compiler can only build with register spills (full Bilinear: only 16, 32, 48, 64, 128, 256; SetIntersection
+ * min / mean: not 208, 224, 240) — spilling variants corrupted results once (a register-allocator placement bug)
+ * and are refused rather than trusted.  No GPU needed. */
+int gqe_dim_supported(int32_t decoder, int32_t inter, int32_t dim);
 const char* gqe_last_error(const gqe_ctx* ctx);   /* ctx may be NULL: last create error */
 
 /* replaces: QueryEncoderDecoder.__init__ + enc_dec.cuda() (model.py:62-68, bio/train.py:56-57) */
@@ -269,7 +274,9 @@ int gqe_import_entries(gqe_ctx* ctx, int64_t slab_entries, void* stream);
  * it is a bag id that gqe_shard_plan passes through, its rows are gathered from the local replica and its gradient is
  * linked onto the local lists; before the optimiser step the host folds those lists into the dense gradient
  * (gqe_materialize_tables), all-reduces that table's span of the gradient arena and steps it like the other replicated
- * tensors.  Candidate lists and lazy Adam are not available in this mode. */
+ * tensors.  Candidate lists are not available in this mode; lazy Adam only through gqe_shard_step (below).
+ * Driving these phases by hand, EVERY RANK MUST RUN THE SAME FORMULAS in a step: gqe_shard_link marks as pending the tables
+ * this rank's own margin call named, so a contribution a peer sends for another table would not be consumed. */
 typedef struct {
   int64_t req_send, req_recv;         /* byte offsets in the workspace: int32 requests I send / receive            */
   int64_t rows_send, fetched;         /* float rows I serve / rows I fetched (dim floats each)                      */
@@ -285,6 +292,48 @@ int gqe_shard_plan(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
                    int32_t* positions, int32_t* requests, int64_t* send_counts);
 int gqe_shard_serve(gqe_ctx* ctx, const int32_t* requests, int64_t n, float* rows_out, void* stream);   /* device pointers */
 int gqe_shard_link(gqe_ctx* ctx, const int32_t* requests, int64_t n, void* stream);
+
+/* ---- the row-sharded step as ONE call (what a trainer uses; the phase entry points above are its building blocks) ----------
+ * gqe_shard_plan / serve / link driven by hand require every rank to run the SAME formulas in a step (an owner marks as
+ * pending only the tables its own batches name) and leave planning and transport to the caller.  The session entry points
+ * below take both over:
+ *   - planning stays on the host cores and uses no collective: each rank sorts its feed by owner and POSTS the counts, the
+ *     request lists and the parameter tensors its batches touch on a plan board in POSIX shared memory ("/gqe_<session>",
+ *     the ranks of ONE node); owners read their requests from the board; the kernels read the position feed and the
+ *     received requests from pinned host memory (no staging copy, no side stream);
+ *   - data moves on the caller's stream over RCCL (ncclSend / ncclRecv groups and ncclAllReduce of librccl, bound at run
+ *     time; `nccl_comm` is an ncclComm_t created by the caller) or over the gqe_transport callbacks; world = 1 needs neither;
+ *   - the optimiser steps the UNION of the tensors the ranks' batches touch (library-kept per-tensor Adam step counts), so
+ *     the replicated relation / Pre / Post tensors stay bit-identical whatever formulas the ranks drew;
+ *   - lazy Adam (gqe_set_lazy_adam) works: an owner replays the deferred steps of the rows it is asked for before it serves
+ *     them and steps only the rows it received contributions for (a full pass over its shard every 32 steps).
+ * Two plans may be posted ahead: a trainer posts step t + 1 before it runs step t, so the only host-side wait of a step
+ * (until every peer has posted that step) is hidden behind the previous step.
+ *
+ *   gqe_shard_open(ctx, session, comm, NULL)                once, after gqe_bind_workspace (every rank: same capacities)
+ *   gqe_shard_post(ctx, batches, n, idx, n_idx, 1, segs, n_segs)   plan a margin step: idx = HOST feed of GLOBAL rows,
+ *                                                           segs = the tensors its batches touch (gqe_segment.step unused)
+ *   gqe_shard_step(ctx, lr, b1, b2, eps, losses, pos, neg, stream) run the oldest posted plan: serve -> all-to-all of rows ->
+ *                                                           fused forward / backward + pair GEMM -> all-to-all of contributions ->
+ *                                                           link -> all-reduce of the small gradients -> Adam on the own shards
+ *   gqe_shard_post(.., 0, NULL, 0) + gqe_shard_forward(ctx, scores, stream)   the same for gqe_forward (no candidate lists)
+ *   gqe_shard_close(ctx)                                    (gqe_destroy closes an open session)
+ * Every rank must issue the same sequence of post / step / forward calls. */
+typedef struct {
+  void* user;
+  /* blocks of send_counts[p] / recv_counts[p] elements of elem_bytes, contiguous in peer order on both sides (device pointers),
+   * stream-ordered on `stream`; return 0 on success */
+  int (*all_to_all)(void* user, const void* send, const int64_t* send_counts, void* recv, const int64_t* recv_counts,
+                    int64_t elem_bytes, void* stream);
+  int (*all_reduce_sum_f32)(void* user, float* buf, int64_t n, void* stream);
+} gqe_transport;
+int gqe_shard_open(gqe_ctx* ctx, const char* session, void* nccl_comm, const gqe_transport* transport);
+int gqe_shard_close(gqe_ctx* ctx);
+int gqe_shard_post(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx, int32_t with_negatives,
+                   const gqe_segment* segs, int32_t n_segs);
+int gqe_shard_step(gqe_ctx* ctx, float lr, float beta1, float beta2, float eps, float* losses, float* pos_scores, float* neg_scores,
+                   void* stream);
+int gqe_shard_forward(gqe_ctx* ctx, float* scores, void* stream);
 
 /* The dense exchange named by the north star, as one call: fold the row-gradient lists into the dense gradient arena
  * (gqe_materialize_grads) and sum the arena over the ranks of `nccl_comm` (an ncclComm_t of RCCL, created by the caller:
@@ -328,12 +377,16 @@ int gqe_feeder_run(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations,
  * torch.cuda.Event cannot see a raw hipStream).  kernel: 0 = fused fwd/bwd, 1 = param-grad
  * GEMM, 2 = optimiser (table pass, or the sparse row launch in lazy mode), 3 = lazy mode: small dense tensors,
  * 4 = lazy mode: catch-up launch before a read.  Returns the average milliseconds over the recorded launches and
- * their count, then clears the record. */
+ * their count, then clears the record.  Row-sharded step (gqe_shard_step): 5 = serve + exchange of rows, 6 = exchange of
+ * contributions + link + all-reduces of the replicated gradients. */
 int gqe_timing_enable(gqe_ctx* ctx, int32_t stride);   /* record every stride-th launch; 0 = off */
 /* Debug: when `stamps` (device, 64 int64 per workgroup: the tiles of the next fused launch, then the workgroups of
  * its pair-GEMM launch) is non-NULL the kernels record wall_clock64() (100 MHz) at their phase boundaries
  * (tools/kbench.py decodes them); NULL switches it off. */
 int gqe_debug_profile(gqe_ctx* ctx, long long* stamps);
+/* Debug: which instantiation gqe_fused_kernel<DEC, MLP, NC, FULL, BWD, FW> a launch of `tiles` tiles runs for (decoder, dim):
+ * nc_full_fw[3] = {NC, FULL, FW}.  tests/test_build_meta.py checks every selectable instantiation of the built library. */
+int gqe_debug_fused_variant(int32_t decoder, int32_t dim, int32_t tiles, int32_t* nc_full_fw);
 int gqe_timing_read(gqe_ctx* ctx, int32_t kernel, float* avg_ms, int32_t* count);
 
 #ifdef __cplusplus

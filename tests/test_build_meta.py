@@ -1,7 +1,15 @@
 """What the built library contains (no GPU needed): the code objects inside graphqembed_amd/libgqe.so carry the registers
-and scratch of every kernel.  The hot kernels must not use scratch — a fused tile that spills (the d = 256 kernels sit
-at the 128-VGPR limit of a 16-wave workgroup) loses the registers-for-the-whole-kernel design, and a spilling guarded
-variant once lost lanes of a gradient."""
+and scratch of every kernel, and the build keeps the compiler's device assembly (csrc/obj/*/*.s).
+
+Round 2 saw two fused-kernel variants that spill registers corrupt results (d = 144: lanes >= 16 of a gradient lost; d = 96
+/ 80: a memory fault).  Round 3 found the cause with rocgdb on the faulting wave: the register allocator
+placed a live-range-split copy and spill stores at the top of the JOIN block of a guarded store, ahead of the
+`s_or_b64 exec` that ends the guarded region, so they ran with lanes >= 16 masked off.  Hence two rules, checked here for
+EVERY instantiation the dispatcher can select for a configuration gqe_create accepts:
+  * no spilled VGPRs;
+  * no allocator-inserted instruction ahead of an EXEC restore (tools/exec_check.py on the kept assembly).
+Configurations that would need a spilling kernel are refused by gqe_create (gqe_dim_supported)."""
+import ctypes
 import os
 import sys
 
@@ -10,6 +18,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 LIB = os.path.join(ROOT, "graphqembed_amd", "libgqe.so")
+DIMS = list(range(16, 257, 16))
+INTERS = {"min": 0, "mean": 1, "min-simple": 2, "mean-simple": 3}
 
 
 @pytest.fixture(scope="module")
@@ -23,8 +33,61 @@ def kernels():
     return ks
 
 
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        import __graft_entry__ as g
+        g.build()
+    from graphqembed_amd.engine import load_library
+    return load_library()
+
+
+def selectable(lib):
+    """{(DEC, MLP, NC, FULL, BWD, FW)} the dispatcher can run for the configurations gqe_create accepts, with the
+    (decoder, inter, d) that reach each."""
+    out = {}
+    for dec in (0, 1, 2):
+        for name, inter in INTERS.items():
+            for d in DIMS:
+                if not lib.gqe_dim_supported(dec, inter, d):
+                    continue
+                for tiles in (1, 100000):                   # few tiles / more tiles than GQE_FW8_MIN_TILES
+                    v = (ctypes.c_int32 * 3)()
+                    assert lib.gqe_debug_fused_variant(dec, d, tiles, v) == 0
+                    for bwd in (0, 1):
+                        out.setdefault((dec, 1 if inter < 2 else 0, v[0], v[1], bwd, v[2]), []).append((dec, name, d))
+    return out
+
+
+def test_supported_configurations(lib):
+    """BASELINE's dims (128, 256) and the golden fixtures' (32) with every decoder; what is refused is exactly the list
+    include/gqe.h states."""
+    for dec in (0, 1, 2):
+        for inter in INTERS.values():
+            for d in (32, 64, 128, 256):
+                assert lib.gqe_dim_supported(dec, inter, d), (dec, inter, d)
+    refused = sorted((dec, inter, d) for dec in (0, 1, 2) for inter in INTERS.values() for d in DIMS if not lib.gqe_dim_supported(dec, inter, d))
+    want = sorted([(2, i, d) for i in INTERS.values() for d in DIMS if d not in (16, 32, 48, 64, 128, 256)] +
+                  [(dec, i, d) for dec in (0, 1) for i in (0, 1) for d in (208, 224, 240)])
+    assert refused == want
+    assert not lib.gqe_dim_supported(0, 0, 24) and not lib.gqe_dim_supported(0, 0, 272) and not lib.gqe_dim_supported(1, 2, 0)
+
+
+def test_every_selectable_fused_kernel_is_free_of_spills(kernels, lib):
+    from kernel_meta import fused_variant
+    built = {fused_variant(k["name"]): k for k in kernels if fused_variant(k["name"])}
+    sel = selectable(lib)
+    assert len(sel) >= 60, len(sel)
+    for v, cfgs in sorted(sel.items()):
+        assert v in built, "the dispatcher selects %r (%r) but the library does not contain it" % (v, cfgs[0])
+        k = built[v]
+        assert k["vgpr_spill"] == 0, "gqe_fused_kernel<DEC=%d, MLP=%d, NC=%d, FULL=%d, BWD=%d, FW=%d> spills %d VGPRs; reached by %r" % (v + (k["vgpr_spill"], cfgs[0]))
+        assert k["vgpr"] <= (128 if v[5] == 16 else 256), (v, k["vgpr"])
+
+
 def test_sixteen_wave_full_kernels_use_no_scratch(kernels):
-    """d = 64 / 128 / 256 (FULL) tiles of 16 waves, forward and backward, every decoder and both intersection kinds."""
+    """d = 64 / 128 / 256 (FULL) tiles of 16 waves — BASELINE's kernels — forward and backward, every decoder and both
+    intersection kinds: no scratch at all (a dynamically indexed local array would show here too)."""
     from kernel_meta import fused_variant
     seen = 0
     for k in kernels:
@@ -48,21 +111,44 @@ def test_streaming_and_gemm_kernels_use_no_scratch(kernels):
             assert k["vgpr"] <= 64, (n[:60], k["vgpr"])
 
 
-def test_guarded_diag_and_transe_kernels_do_not_spill(kernels):
-    """bilinear-diag / TransE at any d <= 192 the dispatcher can select (d % 64 != 0: the 8-wave kernels with 256 VGPRs per
-    lane above d = 64, the 16-wave ones below): spilling variants of these once corrupted a relation gradient (d = 144)
-    and faulted (d = 96).  The d in (192, 256) and the full-Bilinear guarded kernels still spill a few registers; the
-    parity matrix runs them (tests/test_gpu_parity.py::test_random_schema_vs_oracle: every multiple of 16 up to 256)."""
-    from kernel_meta import fused_variant
-    checked = 0
-    for k in kernels:
-        v = fused_variant(k["name"])
-        if not v:
-            continue
-        dec, mlp, nc, full, bwd, fw = v
-        if dec in (0, 1) and ((fw == 16 and nc == 1) or (fw == 8 and nc in (2, 3))):
-            checked += 1
-            assert k["vgpr_spill"] == 0, (k["name"][:60], k["vgpr_spill"])
-    assert checked >= 2 * 2 * 2 * 4, checked
-    # the shapes that are no longer built: guarded d in (64, 128) on 16 waves
-    assert not any(fused_variant(k["name"]) and fused_variant(k["name"])[2:4] == (2, 0) and fused_variant(k["name"])[5] == 16 for k in kernels)
+def test_no_allocator_code_ahead_of_an_exec_restore(lib):
+    """tools/exec_check.py on the assembly the build kept: the placement that corrupted the round-2 variants must not occur in
+    any kernel the dispatcher can select (it may in instantiations that are compiled but unreachable — they are listed)."""
+    import exec_check
+    files = exec_check.default_files()
+    assert len(files) >= 13, "the build keeps one device assembly file per translation unit under csrc/obj/ (found %d)" % len(files)
+    found = exec_check.check_files(files)
+    sel = selectable(lib)
+    names = {"gqe_fused_kernel<DEC=%d, MLP=%d, NC=%d, FULL=%d, BWD=%d, FW=%d>" % v for v in sel}
+    bad = sorted(set(k for _, k, _, _, _ in found if k in names or not k.startswith("gqe_fused_kernel<")))
+    assert not bad, "allocator-inserted code runs before EXEC is restored in: %r" % bad
+
+
+def test_the_check_recognises_the_round_two_miscompile():
+    """The block rocgdb stopped in (d = 80, gqe_fused_kernel<0, 1, 2, FULL=0, BWD=1, FW=16> of commit 8dea5d1^), verbatim."""
+    import exec_check
+    asm = """
+_Z16gqe_fused_kernelILi0ELb1ELi2ELb0ELb1ELi16EEvX:
+.LBB6_688:
+	s_or_b64 exec, exec, s[0:1]
+	scratch_store_dwordx2 off, v[82:83], off offset:140 ; 8-byte Folded Spill
+	s_and_saveexec_b64 s[0:1], s[4:5]
+	s_cbranch_execz .LBB6_690
+; %bb.689:
+	global_store_dword v[2:3], v0, off offset:256
+.LBB6_690:                              ; %_Z15tile_to_scratchILi2EEvRK7TileEnviPKf.exit1503
+	v_writelane_b32 v127, s50, 38
+	v_mov_b32_e32 v124, v52
+	s_mov_b64 s[12:13], s[94:95]
+	scratch_store_dwordx2 off, v[20:21], off offset:220 ; 8-byte Folded Spill
+	s_waitcnt vmcnt(4)
+	scratch_store_dword off, v9, off offset:152 ; 4-byte Folded Spill
+	s_or_b64 exec, exec, s[0:1]
+	v_mov_b32_e32 v0, 0
+"""
+    found = exec_check.check_text(asm)
+    assert [f[2] for f in found] == ["v_mov_b32_e32 v124, v52", "scratch_store_dwordx2 off, v[20:21], off offset:220", "scratch_store_dword off, v9, off offset:152"]
+    # the same region with the restore where it belongs is clean, and so is a guarded BODY that ends in its own restore
+    good = asm.replace("\tv_writelane_b32 v127, s50, 38\n", "\ts_or_b64 exec, exec, s[0:1]\n\tv_writelane_b32 v127, s50, 38\n", 1)
+    good = good.replace("\ts_or_b64 exec, exec, s[0:1]\n\tv_mov_b32_e32 v0, 0\n", "\tv_mov_b32_e32 v0, 0\n")
+    assert exec_check.check_text(good) == []

@@ -62,6 +62,44 @@ def _worker(rank, port, out_dir):
     sf = parallel.shard_forward(eng, dist, psf, n_f)
     descs_r, idx_r, _ = pack_forward_batches([(plan_for(ref, "3-inter", TOY_FORMULAS["3-inter"]), t, a)])
     assert torch.allclose(sf, ref.forward(descs_r, idx_r, n_f), rtol=1e-5, atol=1e-6)
+    # ---- the same protocol as ONE library call over the library's own RCCL binding (gqe_shard_open / post / step / forward):
+    # ncclSend / ncclRecv groups to self + ncclAllReduce, planning on the host every step; three steps against the plain engine
+    one = engine_from_params(params, d, dec, inter, shard=(0, 1))
+    plain = engine_from_params(params, d, dec, inter)
+    comm = parallel.RcclComm(0, 1)
+    one.shard_open(None, nccl_comm=comm.handle)
+    srng = np.random.RandomState(9)
+    steps = [[(q,) + toy_batch(srng, q, 64 + 8 * k) + (wgt,) for q, wgt in mix] for k in range(3)]
+    pss = []
+    for bt in steps:
+        packed = [(plan_for(one, q, TOY_FORMULAS[q]), t, g, a, wgt, 1.0) for (q, t, g, a, wgt) in bt]
+        dsc, ix, _ = pack_margin_batches(packed)
+        pss.append(one.prepare_shard(dsc, ix, set().union(*[p[0].touched for p in packed])))
+    one.shard_post(pss[0])
+    for k, bt in enumerate(steps):
+        if k + 1 < len(steps):
+            one.shard_post(pss[k + 1])                 # the next step is planned before this one runs
+        losses = one.shard_step(pss[k], 0.01)
+        packed = [(plan_for(plain, q, TOY_FORMULAS[q]), t, g, a, wgt, 1.0) for (q, t, g, a, wgt) in bt]
+        dsc, ix, nsc = pack_margin_batches(packed)
+        want_l, _, _ = plain.margin_fwd_bwd(dsc, ix, nsc)
+        plain.adam_step(set().union(*[p[0].touched for p in packed]), 0.01)
+        if k == 0:
+            assert torch.allclose(losses, want_l, rtol=1e-6, atol=1e-7)
+    torch.cuda.synchronize()
+    diff = (one.params - plain.params).abs()
+    assert float(diff.max()) < 0.04 and float((diff > 1e-4).float().mean()) < 0.02, (float(diff.max()),)   # Adam amplifies list-order noise
+    psf = one.prepare_shard(descs_f, idx_f, with_negatives=False)
+    one.shard_post(psf)
+    sf1 = one.shard_forward(n_f)
+    plain.params.copy_(one.params)
+    descs_p, idx_p, _ = pack_forward_batches([(plan_for(plain, "3-inter", TOY_FORMULAS["3-inter"]), t, a)])
+    assert torch.equal(sf1, plain.forward(descs_p, idx_p, n_f))
+    with pytest.raises(Exception):                    # nothing posted
+        one.shard_step(pss[0], 0.01)
+    one.close()
+    plain.close()
+    comm.close()
     # ---- replicated tables: the slab all-gather (in place, on a view of the workspace) needs exchange mode with world > 1 to
     # exist at all, so with one rank what is exercised is the dense form: lists -> arena -> RCCL all-reduce of the arena
     eng = engines["dense"]

@@ -249,6 +249,23 @@ def _trainer_worker(rank, world, port, out_dir):
     dist.broadcast(ref, 0)
     assert torch.equal(mine, ref), "replicated tensors diverged"
     assert np.isfinite(last) and last < 0.9 * first, (first, last)
+    # ---- the native feeder on the same row-sharded engine (gqe_feeder_run: sampling, packing, gqe_shard_post one iteration
+    # ahead and gqe_shard_step from C++): per-rank slices it * W + rank of shared formula draws, loss weights n_rank / n_all
+    from graphqembed_amd.tensorize import table_key
+    plist = [(shim.plan(p.formula), p) for t in types for p in pools[t]]
+    rows_by_key = {table_key(m): np.arange(1, g.mode_sizes[m] + 1, dtype=np.int32) for m in g.modes}
+    feeder = eng.make_feeder(plist, rows_by_key, batch_size=B, seed=3)
+    n_b = 1 + sum(2 if "inter" in t else 1 for t in types if t != "1-chain")
+    l0 = global_loss(eng.feeder_run(feeder, 0, 5)[:n_b + 1])
+    l1 = global_loss(eng.feeder_run(feeder, 5, 120)[:n_b + 1])
+    torch.cuda.synchronize()
+    assert getattr(tr._session, "error", None) is None, tr._session.error
+    mine = torch.cat([eng.params[o:o + n] for o, n in eng.dense_spans()]).cpu()
+    ref = mine.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(mine, ref), "replicated tensors diverged under the native feeder"
+    assert np.isfinite(l1) and l1 < l0, (l0, l1)
+    eng.feeder_destroy(feeder)
     with open(os.path.join(out_dir, "tr_ok%d" % rank), "w") as f:
         f.write("%r %r" % (first, last))
     dist.barrier()
@@ -260,3 +277,140 @@ def test_row_sharded_trainer_two_ranks(tmp_path):
     port = 29250 + os.getpid() % 40
     mp.spawn(_trainer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "tr_ok0") and os.path.exists(tmp_path / "tr_ok1")
+
+
+def _session_worker(rank, world, port, out_dir, dec, inter, d):
+    """gqe_shard_open / post / step (the row-sharded step as one library call, planning through the shared-memory plan board)
+    on 2 gloo ranks sharing cuda:0, the transport being callbacks over torch.distributed:
+      * == the phases driven by hand (plan / serve / link + Python collectives) BIT FOR BIT on shards, moments and the
+        replicated tensors after three steps with unequal slices (same kernels, order-independent list sums);
+      * lazy Adam on sharded tables == eager, bit for bit, once synchronised (rows owe deferred steps in between);
+      * ranks that run DIFFERENT formulas in a step: the touched-tensor sets travel with the plans, the optimiser steps the
+        union, the replicated tensors stay bit-identical, and the result matches a single-rank engine on the union batch;
+      * forward through the session == the single-rank forward bit for bit."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from graphqembed_amd import parallel
+    from graphqembed_amd.engine import ArenaLayout, Engine
+    from graphqembed_amd.tensorize import pack_forward_batches, pack_margin_batches
+    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, read_arena, toy_batch
+    r, w, _, dist = parallel.init_from_env("gloo")
+    rng = np.random.RandomState(33)
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
+    tables = [k for k in params if k.startswith("enc.")]
+
+    def sharded_engine(lazy=False):
+        layout = ArenaLayout()
+        for k, v in params.items():
+            layout.add(k, (parallel.shard_rows(v.shape[0], w), d) if k in tables else v.shape)
+        eng = Engine(d, dec, inter, layout, shard=(r, w), max_queries=1024, max_batches=8, lazy_adam=lazy)
+        for k, v in params.items():
+            src = parallel.shard_of(v, r, w) if k in tables else v
+            layout.view(eng._params, k).copy_(torch.from_numpy(np.ascontiguousarray(src)))
+        return eng
+
+    def gather_full(eng):
+        out = {}
+        for k in params:
+            mine = eng.layout.view(eng.params, k).cpu()
+            if k in tables:
+                parts = [torch.zeros_like(mine) for _ in range(w)]
+                dist.all_gather(parts, mine)
+                full_t = torch.zeros(params[k].shape[0], d)
+                for rr in range(w):
+                    full_t[rr::w] = parts[rr][:len(full_t[rr::w])]
+                out[k] = full_t.numpy()
+            else:
+                out[k] = mine.numpy().copy()
+        return out
+
+    by_hand, session, lazy = sharded_engine(), sharded_engine(), sharded_engine(lazy=True)
+    keep = [parallel.shard_session(session, dist, r, w), parallel.shard_session(lazy, dist, r, w)]
+    # One query type per step and <= 16 queries per rank (one tile): every floating-point reduction is then order-free (two
+    # branch gradients into Pre, two ranks into the all-reduce, row lists summed order-independently) and two engines agree
+    # BIT FOR BIT — or differ because of the protocol.  No 3-inter: its three branches add into the Pre gradient in atomic order.
+    types = ["1-chain", "2-inter", "2-chain", "3-inter_chain", "3-chain", "3-chain_inter", "2-inter", "1-chain", "3-inter_chain"]
+    sizes = [12, 9]                                                    # unequal slices
+    for step, qtype in enumerate(types):
+        t, g, a = toy_batch(rng, qtype, sum(sizes), hub=(step == 1))   # hub rows: long lists at one owner
+        hi = 25 + 12 * step                                            # most rows untouched at first: they lag in lazy mode
+        t[:], g[:] = np.minimum(t, hi), np.minimum(g, hi)
+        s0 = sum(sizes[:r])
+        sl = slice(s0, s0 + sizes[r])
+        items = [(qtype, t[sl], g[sl], a[:, sl], sizes[r] / float(sum(sizes)))]
+        # the phases by hand
+        packed = [(plan_for(by_hand, q, TOY_FORMULAS[q]), tt, gg, aa, wgt, 1.0) for (q, tt, gg, aa, wgt) in items]
+        descs, idx, _ = pack_margin_batches(packed)
+        keys = set().union(*[p[0].touched for p in packed])
+        ps = parallel.shard_prepare(by_hand, dist, descs, idx)
+        parallel.shard_margin_step(by_hand, dist, ps, adam=by_hand.prepare_adam(keys), lr=0.01)
+        # one call (eager and lazy)
+        for eng in (session, lazy):
+            packed = [(plan_for(eng, q, TOY_FORMULAS[q]), tt, gg, aa, wgt, 1.0) for (q, tt, gg, aa, wgt) in items]
+            descs, idx, _ = pack_margin_batches(packed)
+            p1 = eng.prepare_shard(descs, idx, keys)
+            eng.shard_post(p1)
+            losses = eng.shard_step(p1, 0.01)
+            assert torch.equal(losses, ps["losses"]), (step, eng is lazy)
+        for k in keep:
+            assert getattr(k, "error", None) is None, k.error
+    torch.cuda.synchronize()
+    assert not torch.equal(lazy._params, session._params)       # rows of the lazy engine do owe steps ...
+    for name in ("params", "exp_avg", "exp_avg_sq"):            # ... and agree bit for bit once settled (the property syncs)
+        assert torch.equal(getattr(session, name), getattr(by_hand, name)), "one call != phases: " + name
+        assert torch.equal(getattr(lazy, name), getattr(session, name)), "lazy != eager: " + name
+    # ---- different formulas on the two ranks (fresh engines: first Adam step on both sides) ----
+    het = sharded_engine()
+    keep.append(parallel.shard_session(het, dist, r, w))
+    single = engine_from_params(params, d, dec, inter)
+    per_rank = [[(q,) + toy_batch(np.random.RandomState(100 + 10 * rr + j), q, 40) + (wgt,) for j, (q, wgt) in enumerate(lst)]
+                for rr, lst in enumerate(([("2-chain", 0.5), ("1-chain", 1.0)], [("3-inter", 0.5), ("1-chain", 1.0)]))]
+    packed = [(plan_for(het, q, TOY_FORMULAS[q]), t, g, a, wgt, 1.0) for (q, t, g, a, wgt) in per_rank[r]]
+    descs, idx, _ = pack_margin_batches(packed)
+    p1 = het.prepare_shard(descs, idx, set().union(*[p[0].touched for p in packed]))
+    het.shard_post(p1)
+    het.shard_step(p1, 0.01)
+    union = [x for lst in per_rank for x in lst]
+    packed = [(plan_for(single, q, TOY_FORMULAS[q]), t, g, a, wgt, 1.0) for (q, t, g, a, wgt) in union]
+    descs, idx, n_sc = pack_margin_batches(packed)
+    single.margin_fwd_bwd(descs, idx, n_sc)
+    single.adam_step(set().union(*[p[0].touched for p in packed]), 0.01)
+    torch.cuda.synchronize()
+    rep = torch.cat([het.params[o:o + n] for o, n in het.dense_spans()]).cpu()
+    ref = rep.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(rep, ref), "replicated tensors diverged when the ranks ran different formulas"
+    got, want = gather_full(het), read_arena(single, single.params)
+    changed = 0
+    for k in params:
+        diff = np.abs(got[k] - want[k])
+        assert float(diff.max()) < 0.04 and float((diff > 1e-4).mean()) < 0.02, (k, float(diff.max()), float((diff > 1e-4).mean()))
+        changed += int((np.abs(want[k] - params[k]) > 1e-3).sum())
+    assert changed > 1000                              # the step did move the model: the comparison is not vacuous
+    het.close()
+    got = gather_full(session)
+    # ---- forward through the session ----
+    for k, v in got.items():
+        single.layout.view(single.params, k).copy_(torch.from_numpy(v))
+    for qtype in ("2-chain", "3-inter"):
+        t, g, a = toy_batch(rng, qtype, 30 + 5 * r)
+        descs, idx, n = pack_forward_batches([(plan_for(session, qtype, TOY_FORMULAS[qtype]), t, a)])
+        pf = session.prepare_shard(descs, idx, with_negatives=False)
+        session.shard_post(pf)
+        sc = session.shard_forward(n)
+        descs, idx, n = pack_forward_batches([(plan_for(single, qtype, TOY_FORMULAS[qtype]), t, a)])
+        assert torch.equal(sc, single.forward(descs, idx, n)), qtype
+    with open(os.path.join(out_dir, "s_ok%d" % rank), "w") as f:
+        f.write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+    for e in (by_hand, session, lazy, single):
+        e.close()
+
+
+@pytest.mark.parametrize("dec,inter,d", [("bilinear-diag", "min", 32), ("bilinear", "mean", 32), ("transe", "min-simple", 64)])
+def test_shard_step_session_two_ranks(tmp_path, dec, inter, d):
+    port = 29300 + os.getpid() % 90
+    mp.spawn(_session_worker, args=(2, port, str(tmp_path), dec, inter, d), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "s_ok0") and os.path.exists(tmp_path / "s_ok1")

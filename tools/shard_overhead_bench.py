@@ -17,17 +17,41 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 wl = bench.Workload("bio-synth", 128, "bilinear-diag", "min", synth.FULL_MIX, 512)
-for label, shard in (("plain", None), ("row-sharded protocol, 1 rank over RCCL", (0, 1))):
+from graphqembed_amd.tensorize import FormulaPlan, pack_margin_batches
+for label, shard in (("plain", None), ("phases driven from Python (torch.distributed collectives), planned ONCE", (0, 1)),
+                     ("gqe_shard_step over RCCL, planned EVERY step", (0, 1))):
     eng = wl.engine(shard=shard)
-    prepared = wl.prepare(eng, dist)
+    one_call = label.startswith("gqe_shard_step")
+    prepared = wl.prepare(eng, dist)                  # sharded: host feeds for gqe_shard_post
+    if shard and not one_call:                        # the round-2 form: requests exchanged once per pre-sampled iteration, outside the loop
+        legacy = []
+        for items in wl.item_sets:
+            packed = [(FormulaPlan(f, eng.layout, wl.inter), t, ng, a, w, m) for (f, t, ng, a, w, m) in items]
+            descs, idx, _ = pack_margin_batches(packed)
+            ps = parallel.shard_prepare(eng, dist, descs, idx)
+            ps["adam"] = eng.prepare_adam(set().union(*[p[0].touched for p in packed]))
+            legacy.append(ps)
+    if one_call:
+        comm = parallel.RcclComm(0, 1)                # the library's own RCCL calls: self send / recv groups + all-reduce
+        eng.shard_open(None, nccl_comm=comm.handle)
+        state = {"next": None}
 
     def step(i):
-        ps = prepared[i % wl.n_distinct]
+        if one_call:
+            if state["next"] != i:
+                eng.shard_post(prepared[i % wl.n_distinct])
+            eng.shard_post(prepared[(i + 1) % wl.n_distinct])     # host planning of the next step
+            state["next"] = i + 1
+            eng.shard_step(prepared[i % wl.n_distinct])
+            return
         if shard:
+            ps = legacy[i % wl.n_distinct]
             parallel.shard_fetch(eng, dist, ps)
-        eng.run_margin(ps)
-        if shard:
+            eng.run_margin(ps)
             parallel.shard_exchange(eng, dist, ps)
+        else:
+            ps = prepared[i % wl.n_distinct]
+            eng.run_margin(ps)
         eng.run_adam(ps["adam"])
     for i in range(50):
         step(i)
@@ -40,10 +64,10 @@ for label, shard in (("plain", None), ("row-sharded protocol, 1 rank over RCCL",
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t0) / 100)
     t0 = time.perf_counter()                                  # host time alone: enqueue without waiting
-    for i in range(200):
+    for i in range(2050, 2250):
         step(i)
     host = (time.perf_counter() - t0) / 200
     torch.cuda.synchronize()
-    print("%-42s %7.1f us/step (median of 20 x 100 steps), host enqueue %6.1f us/step" % (label, np.median(times) * 1e6, host * 1e6), flush=True)
+    print("%-74s %7.1f us/step (median of 20 x 100 steps), host enqueue %6.1f us/step" % (label, np.median(times) * 1e6, host * 1e6), flush=True)
     eng.close()
 dist.destroy_process_group()
