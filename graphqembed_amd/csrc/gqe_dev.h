@@ -69,7 +69,11 @@ struct GqeDynBatch {
                          // records, unit_begin = its first block of the candidate-scoring kernel
   int32_t n_anchors;     // copy of the formula's anchor count: the tile's index load needs it, and as a kernel argument
                          // it does not wait for the descriptor's first scalar load
-  int32_t pad;
+  int32_t expand;        // != 0: candidate lists of a full-Bilinear CHAIN batch.  The projection t^T M_r1 .. M_rk runs on the
+                         // candidate side (decoders.py:142-147), so there is no per-query vector to score candidates against:
+                         // the tiles of this batch cover its CANDIDATES, 16 per tile ([16 x d] . [d x d] on the matrix cores per
+                         // hop), target row = the candidate, anchor row = the anchor of the candidate's query; the int32 query of
+                         // every candidate sits at ws + scratch_base (gqe_expand_ptr_kernel writes it from cand_ptr)
 };
 
 // Bag modes (Reddit posts: nn.EmbeddingBag mean over word rows, reddit/data_utils_new.py:155,162-169):
@@ -241,6 +245,7 @@ void gqe_fused_variant(int dec, int d, int tiles, int* nc, int* full, int* fw);
 hipError_t gqe_launch_pair_gemm(const GqeFusedArgs& a, float* losses);
 #define GQE_EVAL_BLOCK 512   // candidates one workgroup of the scoring kernel covers (= GQE_EVAL_UB in gqe_kernels.hip)
 hipError_t gqe_launch_eval_score(const GqeFusedArgs& a, int dec, float* scores);   // plan.unit_begin / units = candidate blocks
+hipError_t gqe_launch_expand_ptr(const int32_t* cand_ptr, int n_queries, int n_candidates, int32_t* query_of, hipStream_t stream);
 hipError_t gqe_launch_rank(const float* scores, const int32_t* ptr, int nq, double* percentile, hipStream_t stream);
 hipError_t gqe_launch_auc(const float* pos, long long n_pos, const float* neg, long long n_neg, unsigned long long* count2, hipStream_t stream);
 hipError_t gqe_launch_opt(const GqeOptArgs& a);

@@ -753,6 +753,9 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   // every query is scored against its own list, the query side being computed once (the reference re-encodes
   // and re-projects the anchors for every candidate, utils.py:50-60,78-88)
   const bool eval_mode = !BWD && b.n_candidates > 0;
+  // ... except for full-Bilinear chains: t^T M_r1 .. M_rk is a projection of the CANDIDATE (decoders.py:142-147), so this
+  // batch's tiles cover its candidates — row r of the tile is candidate q0 + r, whose anchor is its query's
+  const bool expand = !BWD && DEC == DEC_BILINEAR && b.expand != 0;
 
   // ---- LDS carve: 7 float tiles [16][DP] + meta tile + red[8][d] + index block ----
   float* te[GQE_MAX_BRANCH];
@@ -800,8 +803,13 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
     const int role = threadIdx.x / GQE_TQ, r = threadIdx.x % GQE_TQ;
     const int q = e.q0 + r;
     int v = -1;
-    const bool used = (role == 0 && !eval_mode) || (role == 1 && has_neg) || (role >= 2 && role - 2 < n);
-    if (used && q < B) {
+    const bool used = (role == 0 && (!eval_mode || expand)) || (role == 1 && has_neg) || (role >= 2 && role - 2 < n);
+    if (expand) {
+      if (used && q < b.n_candidates) {
+        const int32_t* __restrict__ lists = idx + b.idx_offset + (size_t)n * B;   // cand_ptr[B + 1] | cand_rows[n_candidates]
+        v = role == 0 ? lists[B + 1 + q] : idx[b.idx_offset + reinterpret_cast<const int32_t*>(ws)[b.scratch_base + q]];
+      }
+    } else if (used && q < B) {
       const int src = (role == 0) ? 0 : (role == 1) ? 1 : (has_neg ? role : (eval_mode ? role - 2 : role - 1));
       v = idx[b.idx_offset + (size_t)src * B + q];
     }
@@ -1091,7 +1099,7 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
             u[s] = vzero<NC>();
           }
         }
-        if (q < B && lane == 0) {
+        if (q < (expand ? b.n_candidates : B) && lane == 0) {
           if (pos_out) pos_out[b.out_offset + q] = su[0];
           if (neg_out && has_neg) neg_out[b.out_offset + q] = su[1];
         }

@@ -156,6 +156,7 @@ struct gqe_ctx {
   std::vector<TimedLaunch> timed[kTimingKinds];
   ShardSession* shard_sess = nullptr;   // gqe_shard_open
   bool shard_internal = false;          // gqe_shard_step is driving the phase entry points
+  bool ordered_sums = false;            // gqe_set_ordered_sums
   std::vector<TimedLaunch> event_pool;  // recycled hipEvent pairs (creation is not free)
 };
 
@@ -694,8 +695,6 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     if (rc != GQE_OK) return rc;
     const int na = ctx->formulas[fid[bi]].n_anchors;
     if (s.n_candidates < 0 || (bwd && s.n_candidates != 0)) return fail(ctx, GQE_ERR_ARG, "batch %d: candidate lists are for gqe_forward only", bi);
-    if (s.n_candidates > 0 && ctx->cfg.decoder == GQE_DEC_BILINEAR && s.qtype <= GQE_Q_3CHAIN)
-      return fail(ctx, GQE_ERR_ARG, "batch %d: candidate lists are not available for Bilinear chain queries (expand the candidates)", bi);
     const int64_t need_idx = s.n_candidates > 0
         ? (int64_t)s.idx_offset + (int64_t)na * s.n_queries + s.n_queries + 1 + s.n_candidates
         : (int64_t)s.idx_offset + (int64_t)(na + (bwd ? 2 : 1)) * s.n_queries;
@@ -906,6 +905,15 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
         entry += (int64_t)(2 + f.n_anchors) * s.n_queries;
         scratch += (int64_t)f.n_slots * b.Bpad * d;
         units_of[k] = f.n_jobs * ((b.Bpad + GQE_GEMM_KCHUNK - 1) / GQE_GEMM_KCHUNK) * macros_sq;
+      } else if (s.n_candidates > 0 && bil && chain) {
+        // candidate lists of a full-Bilinear chain: the projection runs on the candidate side, so the batch's tiles cover its
+        // candidates (16 per tile, one [16 x d] . [d x d] contraction per hop on the matrix cores); the query of every
+        // candidate goes to the scratch region first
+        b.expand = 1;
+        tiles_of[k] = (s.n_candidates + GQE_TQ - 1) / GQE_TQ;
+        HIP_TRY(ctx, gqe_launch_expand_ptr(d_idx + s.idx_offset + (int64_t)f.n_anchors * s.n_queries, s.n_queries, s.n_candidates,
+                                           reinterpret_cast<int32_t*>(ctx->ws) + scratch, st));
+        scratch += (int64_t)align_up((size_t)s.n_candidates, 64);
       } else if (s.n_candidates > 0) {
         // evaluation against candidate lists: the fused kernel leaves one record (d + 4 floats) per query in the
         // scratch region, the scoring kernel covers the batch's candidates in blocks
@@ -1193,7 +1201,9 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     oa.nt = mode == GQE_OPT_ADAM && stream > GQE_NT_STREAM_BYTES;
   }
   oa.lists = lists;
-  oa.sorted = ctx->world > 1 || ctx->shard_on;  // replicas / reruns must sum a row's contributions in the same order
+  // replicas must sum a row's contributions in the same order (exchange mode); elsewhere — a row-sharded row has ONE owner —
+  // order-independent sums only buy run-to-run reproducibility and are the caller's choice (gqe_set_ordered_sums)
+  oa.sorted = ctx->world > 1 || ctx->ordered_sums;
   oa.segs = reinterpret_cast<const GqeDevSeg*>(ctx->ws + ctx->lay.seg_off);
   oa.n_segs = (int)nu;
   oa.p = ctx->params;
@@ -1657,6 +1667,12 @@ int gqe_set_limits(gqe_ctx* ctx, int32_t max_tensors, int32_t max_formulas) {
   return GQE_OK;
 }
 
+int gqe_set_ordered_sums(gqe_ctx* ctx, int32_t enable) {
+  if (!ctx) return GQE_ERR_ARG;
+  ctx->ordered_sums = enable != 0;
+  return GQE_OK;
+}
+
 int gqe_set_shard(gqe_ctx* ctx, int32_t rank, int32_t world) {
   if (!ctx) return GQE_ERR_ARG;
   if (world < 1 || world > 1024 || rank < 0 || rank >= world) return fail(ctx, GQE_ERR_ARG, "need 0 <= rank < world <= 1024, got rank %d world %d", rank, world);
@@ -1685,64 +1701,117 @@ int gqe_shard_layout(gqe_ctx* ctx, gqe_shard_buffers* out) {
   return GQE_OK;
 }
 
-int gqe_shard_plan(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx, int32_t with_negatives,
-                   int32_t* positions, int32_t* requests, int64_t* send_counts) {
-  if (!ctx) return GQE_ERR_ARG;
-  if (!ctx->shard_on) return fail(ctx, GQE_ERR_STATE, "gqe_set_shard has not been called");
-  if ((int)ctx->tables.size() > GQE_LAZY_TABLES) return fail(ctx, GQE_ERR_STATE, "row-sharded mode supports at most %d tables", GQE_LAZY_TABLES);
+// The owner sort of gqe_shard_plan.  Reads the ctx only (tables, bags, shard geometry) and reports errors through `err`,
+// so the session's planning thread can run it next to the caller's thread (gqe_shard_step.h).
+int shard_plan_impl(const gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx, int32_t with_negatives,
+                    int32_t* positions, int32_t* requests, int64_t* send_counts, char* err, size_t err_len) {
+  auto bad = [&](int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err, err_len, fmt, ap);
+    va_end(ap);
+    return code;
+  };
+  if (!ctx->shard_on) return bad(GQE_ERR_STATE, "gqe_set_shard has not been called");
+  if ((int)ctx->tables.size() > GQE_LAZY_TABLES) return bad(GQE_ERR_STATE, "row-sharded mode supports at most %d tables", GQE_LAZY_TABLES);
   if (!batches || n_batches < 1 || n_batches > GQE_MAX_BATCHES || !idx || n_idx < 1 || !positions || !requests || !send_counts)
-    return fail(ctx, GQE_ERR_ARG, "gqe_shard_plan: bad arguments");
+    return bad(GQE_ERR_ARG, "gqe_shard_plan: bad arguments");
   const int W = ctx->shard_world;
-  // which table every index of the feed names (the layout of gqe_batch's index block)
-  std::vector<int8_t> table_of_idx((size_t)n_idx, -1);
+  // the runs of the feed that name rows of one table (the layout of gqe_batch's index block), in feed order
+  struct Run { int64_t off, n; int table; };
+  Run runs[GQE_MAX_BATCHES * (1 + GQE_MAX_BRANCH)];
+  int n_runs = 0;
   for (int bi = 0; bi < n_batches; ++bi) {
     const gqe_batch& s = batches[bi];
     const int na = anchors_of(s.qtype);
-    if (na < 0 || s.n_anchors != na || s.n_queries < 1) return fail(ctx, GQE_ERR_ARG, "batch %d: bad query type / anchors / size", bi);
-    if (s.n_candidates != 0) return fail(ctx, GQE_ERR_ARG, "batch %d: candidate lists are not supported in row-sharded mode", bi);
+    if (na < 0 || s.n_anchors != na || s.n_queries < 1) return bad(GQE_ERR_ARG, "batch %d: bad query type / anchors / size", bi);
+    if (s.n_candidates != 0) return bad(GQE_ERR_ARG, "batch %d: candidate lists are not supported in row-sharded mode", bi);
     const int lead = with_negatives ? 2 : 1;
     const int64_t B = s.n_queries, o = s.idx_offset;
-    if (o < 0 || o + (lead + na) * B > n_idx) return fail(ctx, GQE_ERR_ARG, "batch %d: index range exceeds the %lld indices given", bi, (long long)n_idx);
+    if (o < 0 || o + (lead + na) * B > n_idx) return bad(GQE_ERR_ARG, "batch %d: index range exceeds the %lld indices given", bi, (long long)n_idx);
     const int tt = table_of(ctx, s.target_table);
-    if (tt < 0) return fail(ctx, GQE_ERR_STATE, "batch %d: target_table is not a registered table", bi);
-    for (int64_t k = 0; k < lead * B; ++k) table_of_idx[(size_t)(o + k)] = (int8_t)tt;
+    if (tt < 0) return bad(GQE_ERR_STATE, "batch %d: target_table is not a registered table", bi);
+    runs[n_runs++] = Run{o, lead * B, tt};
     for (int i = 0; i < na; ++i) {
       const int ta = table_of(ctx, s.anchor_table[i]);
-      if (ta < 0) return fail(ctx, GQE_ERR_STATE, "batch %d: anchor_table[%d] is not a registered table", bi, i);
-      for (int64_t k = 0; k < B; ++k) table_of_idx[(size_t)(o + (lead + i) * B + k)] = (int8_t)ta;
+      if (ta < 0) return bad(GQE_ERR_STATE, "batch %d: anchor_table[%d] is not a registered table", bi, i);
+      runs[n_runs++] = Run{o + (lead + i) * B, B, ta};
     }
   }
-  // counting sort of the feed by owner: request = list-head index of the row in the owner's shard, position = where
-  // the fetched row (and later its gradient contribution) sits in the owner-grouped buffers
-  std::vector<int64_t> count((size_t)W, 0), at((size_t)W, 0);
-  std::vector<char> bag_table(ctx->tables.size(), 0);   // bag tables are replicated: their indices (bag ids) pass through
-  for (const Bag& bg : ctx->bags) bag_table[(size_t)bg.table] = 1;
-  for (int64_t e = 0; e < n_idx; ++e) {
-    if (table_of_idx[(size_t)e] < 0) return fail(ctx, GQE_ERR_ARG, "index %lld of the feed belongs to no batch", (long long)e);
-    if (idx[e] < 0) return fail(ctx, GQE_ERR_ARG, "index %lld of the feed is negative", (long long)e);
-    if (!bag_table[(size_t)table_of_idx[(size_t)e]]) ++count[(size_t)(idx[e] % W)];
+  std::sort(runs, runs + n_runs, [](const Run& a, const Run& b) { return a.off < b.off; });
+  int64_t covered = 0;
+  for (int k = 0; k < n_runs; ++k) {   // the batches must tile the feed: every index belongs to exactly one of them
+    if (runs[k].off != covered) return bad(GQE_ERR_ARG, "index %lld of the feed belongs to %s", (long long)std::min(covered, runs[k].off), runs[k].off > covered ? "no batch" : "two batches");
+    covered += runs[k].n;
+  }
+  if (covered != n_idx) return bad(GQE_ERR_ARG, "index %lld of the feed belongs to no batch", (long long)covered);
+  bool bag_table[GQE_LAZY_TABLES] = {false, false, false, false, false, false, false, false};   // replicated: their indices (bag ids) pass through
+  for (const Bag& bg : ctx->bags) bag_table[bg.table] = true;
+  // counting sort of the feed by owner (row % W): request = list-head index of the row in the owner's shard, position =
+  // where the fetched row (and later its gradient contribution) sits in the owner-grouped buffers
+  int64_t at[1024];
+  for (int o = 0; o < W; ++o) at[o] = 0;
+  const bool pow2 = (W & (W - 1)) == 0;
+  const int mask = W - 1;
+  int shift = 0;
+  while ((1 << shift) < W) ++shift;
+  for (int k = 0; k < n_runs; ++k) {
+    if (bag_table[runs[k].table]) continue;
+    const int32_t* p = idx + runs[k].off;
+    int32_t neg = 0;
+    if (pow2)
+      for (int64_t j = 0; j < runs[k].n; ++j) {
+        neg |= p[j];
+        ++at[p[j] & mask];
+      }
+    else
+      for (int64_t j = 0; j < runs[k].n; ++j) {
+        neg |= p[j];
+        ++at[p[j] < 0 ? 0 : p[j] % W];
+      }
+    if (neg < 0) return bad(GQE_ERR_ARG, "the feed holds a negative index (batch run at %lld)", (long long)runs[k].off);
   }
   int64_t run = 0;
   for (int o = 0; o < W; ++o) {
-    at[(size_t)o] = run;
-    run += count[(size_t)o];
-    send_counts[o] = count[(size_t)o];
+    const int64_t c = at[o];
+    send_counts[o] = c;
+    at[o] = run;
+    run += c;
   }
-  for (int64_t e = 0; e < n_idx; ++e) {
-    const int64_t r = idx[e];
-    if (bag_table[(size_t)table_of_idx[(size_t)e]]) {
-      positions[e] = (int32_t)r;
+  for (int k = 0; k < n_runs; ++k) {
+    const int32_t* p = idx + runs[k].off;
+    int32_t* out = positions + runs[k].off;
+    if (bag_table[runs[k].table]) {
+      for (int64_t j = 0; j < runs[k].n; ++j) {
+        if (p[j] < 0) return bad(GQE_ERR_ARG, "index %lld of the feed is negative", (long long)(runs[k].off + j));
+        out[j] = p[j];
+      }
       continue;
     }
-    const int o = (int)(r % W);
-    const Table& tb = ctx->tables[(size_t)table_of_idx[(size_t)e]];
-    const int64_t local = r / W;
-    if (local >= tb.rows) return fail(ctx, GQE_ERR_ARG, "index %lld: global row %lld is outside the table (%lld local rows x %d ranks)", (long long)e, (long long)r, (long long)tb.rows, W);
-    const int64_t pos = at[(size_t)o]++;
-    positions[e] = (int32_t)pos;
-    requests[pos] = (int32_t)(tb.head_base + local);
+    const Table& tb = ctx->tables[(size_t)runs[k].table];
+    const int64_t rows = tb.rows, hb = tb.head_base;
+    int64_t worst = 0;
+    for (int64_t j = 0; j < runs[k].n; ++j) {
+      const int64_t r = p[j];
+      const int o = pow2 ? (int)(r & mask) : (int)(r % W);
+      const int64_t local = pow2 ? (r >> shift) : (r / W);
+      worst = std::max(worst, local);
+      const int64_t pos = at[o]++;
+      out[j] = (int32_t)pos;
+      requests[pos] = (int32_t)(hb + local);
+    }
+    if (worst >= rows)
+      return bad(GQE_ERR_ARG, "a global row of the batch run at %lld is outside its table (%lld local rows x %d ranks)", (long long)runs[k].off, (long long)rows, W);
   }
   return GQE_OK;
+}
+
+int gqe_shard_plan(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx, int32_t with_negatives,
+                   int32_t* positions, int32_t* requests, int64_t* send_counts) {
+  if (!ctx) return GQE_ERR_ARG;
+  char err[256] = "";
+  const int rc = shard_plan_impl(ctx, batches, n_batches, idx, n_idx, with_negatives, positions, requests, send_counts, err, sizeof err);
+  return rc == GQE_OK ? GQE_OK : fail(ctx, rc, "%s", err);
 }
 
 int gqe_shard_serve(gqe_ctx* ctx, const int32_t* requests, int64_t n, float* rows_out, void* stream) {

@@ -900,6 +900,26 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_eval_score_kernel(const GqeDy
   }
 }
 
+// query of every candidate of a batch (largest q with cand_ptr[q] <= c): the fused kernel's candidate tiles of a
+// full-Bilinear chain batch look their anchor up through it
+__global__ __launch_bounds__(GQE_THREADS) void gqe_expand_ptr_kernel(const int32_t* __restrict__ ptr, int nq, int nc, int32_t* __restrict__ query_of) {
+  const int c = (int)blockIdx.x * GQE_THREADS + threadIdx.x;
+  if (c >= nc) return;
+  int lo = 0, hi = nq;   // invariant: ptr[lo] <= c < ptr[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (ptr[mid] <= c) lo = mid; else hi = mid;
+  }
+  query_of[c] = lo;
+}
+
+hipError_t gqe_launch_expand_ptr(const int32_t* cand_ptr, int n_queries, int n_candidates, int32_t* query_of, hipStream_t stream) {
+  if (n_candidates < 1) return hipSuccess;
+  hipLaunchKernelGGL(gqe_expand_ptr_kernel, dim3((unsigned)((n_candidates + GQE_THREADS - 1) / GQE_THREADS)), dim3(GQE_THREADS), 0, stream, cand_ptr,
+                     n_queries, n_candidates, query_of);
+  return hipGetLastError();
+}
+
 hipError_t gqe_launch_eval_score(const GqeFusedArgs& a, int dec, float* scores) {
   if (a.plan.units < 1) return hipSuccess;
   const float* rows_base = a.fetched ? a.fetched : a.params;
@@ -993,22 +1013,33 @@ hipError_t gqe_launch_auc(const float* pos, long long n_pos, const float* neg, l
 // row-sharded data parallelism ("owner computes", gqe_set_shard).  A request names a row of a local shard by its list
 // head index (head_base of the local table + local row), which is also where its gradient contribution is linked.
 // ------------------------------------------------------------------------------------------
+// d/4 lanes per row, four rows per lane group in flight (the requests and the four row loads are all issued before the first
+// store: a 512-byte row per 32 lanes with one load in flight measured 1.8 TB/s on 9 MB)
+#define GQE_SERVE_U 4
 __global__ __launch_bounds__(GQE_THREADS) void gqe_shard_serve_kernel(const float* __restrict__ p, const int32_t* __restrict__ req,
                                                                      long long n, float* __restrict__ out, int d, const GqeShardTabs t) {
   const int tpr = d >> 2;
-  const long long g = (long long)blockIdx.x * GQE_THREADS + threadIdx.x;
-  const long long j = g / tpr;
-  if (j >= n) return;
-  const int c4 = (int)(g - j * tpr) * 4;
-  const int h = req[j];
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (h >= 0) {
-    int k = 0;
+  const int gpb = GQE_THREADS / tpr;                     // lane groups per workgroup
+  const int g = threadIdx.x / tpr, c4 = (threadIdx.x - g * tpr) * 4;
+  if (g >= gpb) return;
+  const long long j0 = ((long long)blockIdx.x * gpb + g) * GQE_SERVE_U;
+  int h[GQE_SERVE_U];
 #pragma unroll
-    for (int i = 1; i < GQE_LAZY_TABLES; ++i) k += (i < t.n && h >= t.head_base[i]) ? 1 : 0;
-    v = *reinterpret_cast<const float4*>(p + t.offset[k] + (long long)(h - t.head_base[k]) * d + c4);
+  for (int u = 0; u < GQE_SERVE_U; ++u) h[u] = j0 + u < n ? req[j0 + u] : -1;
+  float4 v[GQE_SERVE_U];
+#pragma unroll
+  for (int u = 0; u < GQE_SERVE_U; ++u) {
+    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h[u] >= 0) {
+      int k = 0;
+#pragma unroll
+      for (int i = 1; i < GQE_LAZY_TABLES; ++i) k += (i < t.n && h[u] >= t.head_base[i]) ? 1 : 0;
+      v[u] = *reinterpret_cast<const float4*>(p + t.offset[k] + (long long)(h[u] - t.head_base[k]) * d + c4);
+    }
   }
-  *reinterpret_cast<float4*>(out + j * d + c4) = v;
+#pragma unroll
+  for (int u = 0; u < GQE_SERVE_U; ++u)
+    if (j0 + u < n) *reinterpret_cast<float4*>(out + (j0 + u) * d + c4) = v[u];
 }
 
 __global__ __launch_bounds__(GQE_THREADS) void gqe_shard_link_kernel(int32_t* __restrict__ head, int32_t* __restrict__ next,
@@ -1022,8 +1053,8 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_shard_link_kernel(int32_t* __
 hipError_t gqe_launch_shard_serve(const float* params, const int32_t* req, long long n, float* out, int d, const GqeShardTabs& t,
                                   hipStream_t stream) {
   if (n < 1) return hipSuccess;
-  const long long threads = n * (d >> 2);
-  hipLaunchKernelGGL(gqe_shard_serve_kernel, dim3((unsigned)((threads + GQE_THREADS - 1) / GQE_THREADS)), dim3(GQE_THREADS), 0, stream,
+  const long long rows_per_block = (long long)(GQE_THREADS / (d >> 2)) * GQE_SERVE_U;
+  hipLaunchKernelGGL(gqe_shard_serve_kernel, dim3((unsigned)((n + rows_per_block - 1) / rows_per_block)), dim3(GQE_THREADS), 0, stream,
                      params, req, n, out, d, t);
   return hipGetLastError();
 }

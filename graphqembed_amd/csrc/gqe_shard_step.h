@@ -28,6 +28,9 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 #define GQE_SHARD_MAX_WORLD 64
 #define GQE_SHARD_MAX_SEGS 512
@@ -68,6 +71,12 @@ struct ShardPlanSlot {
   int64_t send_counts[GQE_SHARD_MAX_WORLD];
   int64_t n_send = 0;
   int pin = 0;                  // which pinned buffer set holds this plan's feeds
+  // the owner sort runs on the session's planning thread: gqe_shard_post hands it over and returns
+  const int32_t* idx = nullptr; // the caller's host feed (has to stay valid until the plan is run)
+  bool with_neg = false;
+  std::atomic<int> planned{0};  // 0: queued / being planned, 1: posted on the board (or failed: rc below)
+  int plan_rc = 0;
+  char plan_err[256] = "";
 };
 
 struct ShardPins {
@@ -101,6 +110,13 @@ struct ShardSession {
   ShardPlanSlot slot[GQE_SHARD_SLOTS];
   ShardPins pins[GQE_SHARD_PINS];
   uint64_t next_post = 0, next_run = 0;
+  // planning thread (one per session): takes the step numbers gqe_shard_post queues
+  gqe_ctx* ctx = nullptr;
+  std::thread planner;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<uint64_t> queue;
+  bool stop = false;
   ShardPost* post(int r, int s) const { return reinterpret_cast<ShardPost*>(base + sizeof(ShardBoardHeader) + ((size_t)r * GQE_SHARD_SLOTS + s) * post_bytes); }
   int32_t* requests(int r, int s) const { return reinterpret_cast<int32_t*>(reinterpret_cast<char*>(post(r, s)) + sizeof(ShardPost)); }
   std::atomic<uint64_t>* ack(int reader, int writer, int s) const {
@@ -145,6 +161,14 @@ bool shard_wait(Pred ready) {
 
 void shard_session_free(ShardSession* S) {
   if (!S) return;
+  if (S->planner.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(S->mu);
+      S->stop = true;
+    }
+    S->cv.notify_all();
+    S->planner.join();
+  }
   if (S->profile && S->host_n > 0) {
     double tot = 0;
     for (double v : S->host_us) tot += v;
@@ -168,6 +192,60 @@ void shard_session_free(ShardSession* S) {
     }
   }
   delete S;
+}
+
+// ---- planning thread ----------------------------------------------------------------------------------------
+// One step's plan: wait until every peer has read the board slot's previous post, sort the feed by owner straight into the
+// pinned position buffer and the board's request area, publish.  Runs next to the caller's thread, which meanwhile
+// enqueues the previous step; touches only the slot, the board and read-only parts of the ctx.
+void shard_plan_job(ShardSession* S, uint64_t t) {
+  const int s = (int)(t % GQE_SHARD_SLOTS), W = S->world, me = S->rank;
+  ShardPlanSlot& sl = S->slot[s];
+  ShardPins& pn = S->pins[sl.pin];
+  ShardClock clk(S);
+  int rc = GQE_OK;
+  if (t >= GQE_SHARD_SLOTS) {
+    for (int j = 0; j < W && rc == GQE_OK; ++j)
+      if (!shard_wait([&] { return S->ack(j, me, s)->load(std::memory_order_acquire) >= t + 1 - GQE_SHARD_SLOTS; })) {
+        snprintf(sl.plan_err, sizeof sl.plan_err, "row-sharded post %llu: rank %d has not consumed step %llu within %.0f s", (unsigned long long)t, j,
+                 (unsigned long long)(t - GQE_SHARD_SLOTS), GQE_SHARD_WAIT_SECONDS);
+        rc = GQE_ERR_STATE;
+      }
+  }
+  ShardPost* P = S->post(me, s);
+  if (rc == GQE_OK)
+    rc = shard_plan_impl(S->ctx, sl.batches.data(), (int32_t)sl.batches.size(), sl.idx, sl.n_idx, sl.with_neg ? 1 : 0, pn.pos, S->requests(me, s),
+                         sl.send_counts, sl.plan_err, sizeof sl.plan_err);
+  clk.mark(0);
+  sl.n_send = 0;
+  for (int o = 0; o < W; ++o) {
+    P->counts[o] = rc == GQE_OK ? sl.send_counts[o] : 0;
+    sl.n_send += P->counts[o];
+  }
+  P->kind = rc == GQE_OK ? (sl.with_neg ? 1 : 0) : -1;   // a failed plan is published too: the peers must not wait for it forever
+  P->n_segs = sl.with_neg && rc == GQE_OK ? (int32_t)sl.segs.size() : 0;
+  for (int k = 0; k < P->n_segs; ++k) {
+    P->seg_off[k] = sl.segs[(size_t)k].offset;
+    P->seg_numel[k] = sl.segs[(size_t)k].numel;
+  }
+  P->seq.store(t + 1, std::memory_order_release);
+  sl.plan_rc = rc;
+  clk.mark(1);
+  sl.planned.store(1, std::memory_order_release);
+}
+
+void shard_planner_main(ShardSession* S) {
+  for (;;) {
+    uint64_t t;
+    {
+      std::unique_lock<std::mutex> lk(S->mu);
+      S->cv.wait(lk, [&] { return S->stop || !S->queue.empty(); });
+      if (S->queue.empty()) return;   // stop requested and nothing left
+      t = S->queue.front();
+      S->queue.erase(S->queue.begin());
+    }
+    shard_plan_job(S, t);
+  }
 }
 
 // ---- transports -------------------------------------------------------------------------------------------
@@ -233,6 +311,7 @@ int shard_collect(gqe_ctx* ctx, ShardSession* S, uint64_t t, int s, int kind, Sh
     ShardPost* P = S->post(j, s);
     if (!shard_wait([&] { return P->seq.load(std::memory_order_acquire) >= t + 1; }))
       return fail(ctx, GQE_ERR_STATE, "row-sharded step %llu: rank %d did not post its plan within %.0f s", (unsigned long long)t, j, GQE_SHARD_WAIT_SECONDS);
+    if (P->kind == -1) return fail(ctx, GQE_ERR_STATE, "row-sharded step %llu: rank %d could not plan its step", (unsigned long long)t, j);
     if (P->seq.load(std::memory_order_acquire) != t + 1 || P->kind != kind)
       return fail(ctx, GQE_ERR_STATE, "row-sharded step %llu: rank %d posted step %llu of kind %d (ranks must run the same sequence of forward / margin steps)",
                   (unsigned long long)t, j, (unsigned long long)P->seq.load() - 1, P->kind);
@@ -274,6 +353,13 @@ int shard_run(gqe_ctx* ctx, int kind, float lr, float b1, float b2, float eps, f
   ShardCollected col;
   memset(col.recv_counts, 0, sizeof col.recv_counts);
   ShardClock clk(S);
+  // the planning thread has (normally long) finished this step's owner sort
+  if (!shard_wait([&] { return sl.planned.load(std::memory_order_acquire) == 1; })) return fail(ctx, GQE_ERR_STATE, "the planning thread did not finish");
+  if (sl.plan_rc != GQE_OK) {
+    ++S->next_run;
+    sl.posted = false;
+    return fail(ctx, sl.plan_rc, "%s", sl.plan_err);
+  }
   int rc = shard_collect(ctx, S, t, s, kind, col);
   if (rc != GQE_OK) return rc;
   clk.mark(2);
@@ -483,6 +569,8 @@ int gqe_shard_open(gqe_ctx* ctx, const char* session, void* nccl_comm, const gqe
       return fail(ctx, GQE_ERR_STATE, "the plan board was created for another world size / workspace capacity (every rank must bind the same capacities)");
     }
   }
+  S->ctx = ctx;
+  S->planner = std::thread(shard_planner_main, S);
   ctx->shard_sess = S;
   return GQE_OK;
 }
@@ -517,42 +605,32 @@ int gqe_shard_post(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
     if (hipEventQuery(pn.done) != hipSuccess) HIP_TRY(ctx, hipEventSynchronize(pn.done));
     pn.done_set = false;
   }
-  if (t >= GQE_SHARD_SLOTS) {
-    for (int j = 0; j < W; ++j)
-      if (!shard_wait([&] { return S->ack(j, me, s)->load(std::memory_order_acquire) >= t + 1 - GQE_SHARD_SLOTS; }))
-        return fail(ctx, GQE_ERR_STATE, "row-sharded post %llu: rank %d has not consumed step %llu within %.0f s", (unsigned long long)t, j,
-                    (unsigned long long)(t - GQE_SHARD_SLOTS), GQE_SHARD_WAIT_SECONDS);
-  }
   if (!pn.pos) {
     HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&pn.pos), sizeof(int32_t) * (size_t)std::max<int64_t>(S->cap_req, 1), hipHostMallocDefault));
     HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&pn.req), sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->lay.shard_cap_recv, 1), hipHostMallocDefault));
   }
-  ShardPost* P = S->post(me, s);
-  ShardClock clk(S);
-  int rc = gqe_shard_plan(ctx, batches, n_batches, idx, n_idx, with_negatives, pn.pos, S->requests(me, s), sl.send_counts);
-  if (rc != GQE_OK) return rc;
-  clk.mark(0);
-  sl.n_send = 0;
-  for (int o = 0; o < W; ++o) {
-    P->counts[o] = sl.send_counts[o];
-    sl.n_send += sl.send_counts[o];
-  }
-  P->kind = with_negatives ? 1 : 0;
-  P->n_segs = with_negatives ? n_segs : 0;
-  for (int k = 0; k < P->n_segs; ++k) {
+  for (int k = 0; k < n_segs && with_negatives; ++k)
     if (segs[k].offset < 0 || segs[k].numel < 1 || segs[k].offset + segs[k].numel > ctx->n_arena)
       return fail(ctx, GQE_ERR_ARG, "gqe_shard_post: segment %d outside the arena", k);
-    P->seg_off[k] = segs[k].offset;
-    P->seg_numel[k] = segs[k].numel;
-  }
-  P->seq.store(t + 1, std::memory_order_release);
   sl.posted = true;
   sl.step = t;
   sl.kind = with_negatives ? 1 : 0;
+  sl.with_neg = with_negatives != 0;
   sl.batches.assign(batches, batches + n_batches);
+  sl.segs.assign(segs, segs + (with_negatives ? n_segs : 0));
+  sl.idx = idx;
   sl.n_idx = n_idx;
+  sl.plan_rc = GQE_OK;
+  sl.plan_err[0] = 0;
+  sl.planned.store(0, std::memory_order_release);
   ++S->next_post;
-  clk.mark(1);
+  {
+    std::lock_guard<std::mutex> lk(S->mu);
+    S->queue.push_back(t);
+  }
+  S->cv.notify_one();
+  (void)me;
+  (void)W;
   return GQE_OK;
 }
 

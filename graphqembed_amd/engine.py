@@ -96,6 +96,7 @@ SYMBOLS = OrderedDict([
     ("gqe_export_entries", (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P])),
     ("gqe_import_entries", (C.c_int, [_P, C.c_int64, _P])),
     ("gqe_set_shard", (C.c_int, [_P, C.c_int32, C.c_int32])),
+    ("gqe_set_ordered_sums", (C.c_int, [_P, C.c_int32])),
     ("gqe_shard_layout", (C.c_int, [_P, C.POINTER(gqe_shard_buffers)])),
     ("gqe_shard_plan", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P, _P])),
     ("gqe_shard_serve", (C.c_int, [_P, _P, C.c_int64, _P, _P])),
@@ -188,7 +189,7 @@ class Engine(object):
     """One gqe_ctx + the tensors it borrows."""
 
     def __init__(self, dim, decoder, inter_decoder, layout, device=None, max_queries=8192, max_batches=16, bags=None,
-                 rank=0, world=1, lazy_adam=False, max_formulas=0, shard=None):
+                 rank=0, world=1, lazy_adam=False, max_formulas=0, shard=None, ordered_sums=False):
         """``bags``: {table key: (ptr int32[n+1], ids int32[nnz])} for modes whose feature is an
         nn.EmbeddingBag (mean over table rows) — an index into such a mode is a bag index.
         ``world`` > 1 (and no bags): size the gradient-entry space for the data-parallel exchange
@@ -247,6 +248,8 @@ class Engine(object):
         if self.sharded:
             self._check(self.lib.gqe_set_shard(self.ctx, self.shard_rank, self.shard_world))
         self._shard_views = None
+        if ordered_sums:             # bit-reproducible list sums (include/gqe.h, gqe_set_ordered_sums)
+            self._check(self.lib.gqe_set_ordered_sums(self.ctx, 1))
         if lazy_adam:
             self._check(self.lib.gqe_set_lazy_adam(self.ctx, 1))
             self.lazy_adam = True

@@ -176,9 +176,6 @@ class QueryEncoderDecoder(nn.Module):
         ptr = np.zeros(len(queries) + 1, dtype=np.int32)
         ptr[1:] = np.cumsum(lens)
         flat = [x for c in candidate_nodes for x in c]
-        if self.path_dec.kind == "bilinear" and formula.query_type.endswith("chain") and "inter" not in formula.query_type:
-            rep = [q for q, k in zip(queries, lens) for _ in range(k)]       # act = t^T M.. is per candidate anyway
-            return self.forward(formula, rep, flat), ptr
         rows = self.enc.rows(flat, formula.target_mode)
         anchors = np.stack([self.enc.rows([q.anchor_nodes[i] for q in queries], m)
                             for i, m in enumerate(formula.anchor_modes)])

@@ -100,9 +100,10 @@ typedef struct {
                                                      against candidate lists: the index layout is
                                                      anchor_0[B] | .. | cand_ptr[B+1] | cand_rows[n_candidates]
                                                      and scores[out_offset + c] is the score of candidate c
-                                                     (cand_ptr[q] <= c < cand_ptr[q+1]) as the target of query q;
-                                                     not available for the full-Bilinear decoder on chain
-                                                     queries (GQE_ERR_ARG: expand the candidates instead)      */
+                                                     (cand_ptr[q] <= c < cand_ptr[q+1]) as the target of query q.
+                                                     Full-Bilinear chain queries project the CANDIDATE
+                                                     (decoders.py:142-147): their tiles cover 16 candidates each
+                                                     and contract [16 x d] . [d x d] per hop on the matrix cores  */
 } gqe_batch;
 
 /* One parameter tensor for the optimiser (torch.optim semantics: a tensor with no gradient
@@ -284,6 +285,11 @@ typedef struct {
   int64_t cap_send, cap_recv;         /* capacities in entries (rows): one rank's feed / what one owner can receive */
 } gqe_shard_buffers;
 int gqe_set_shard(gqe_ctx* ctx, int32_t rank, int32_t world);   /* before gqe_workspace_bytes; world = 1: every row is this rank's */
+/* Sum every row's gradient list order-independently (integer accumulation for lists longer than two entries): results no
+ * longer depend on the order in which atomics linked the contributions, i.e. runs are bit-reproducible.  Always on in
+ * gqe_set_exchange mode (replicas must round identically); optional elsewhere — a row-sharded row has one owner, so ranks
+ * agree without it — and off by default: it costs the optimiser pass ~14 % (53.9 vs 47.1 us on bio-synth). */
+int gqe_set_ordered_sums(gqe_ctx* ctx, int32_t enable);
 int gqe_shard_layout(gqe_ctx* ctx, gqe_shard_buffers* out);     /* after gqe_bind_workspace */
 /* idx: HOST index feed of GLOBAL table rows laid out as gqe_batch describes (with_negatives: margin layout).  Outputs
  * (host): positions[n_idx] — the feed to hand to gqe_margin_fwd_bwd / gqe_forward (device copy); requests[n_idx] — grouped
@@ -311,7 +317,9 @@ int gqe_shard_link(gqe_ctx* ctx, const int32_t* requests, int64_t n, void* strea
  * (until every peer has posted that step) is hidden behind the previous step.
  *
  *   gqe_shard_open(ctx, session, comm, NULL)                once, after gqe_bind_workspace (every rank: same capacities)
- *   gqe_shard_post(ctx, batches, n, idx, n_idx, 1, segs, n_segs)   plan a margin step: idx = HOST feed of GLOBAL rows,
+ *   gqe_shard_post(ctx, batches, n, idx, n_idx, 1, segs, n_segs)   plan a margin step: idx = HOST feed of GLOBAL rows (it has
+ *                                                           to stay valid until the step has run: the owner sort happens on
+ *                                                           the session's planning thread, next to the caller's thread),
  *                                                           segs = the tensors its batches touch (gqe_segment.step unused)
  *   gqe_shard_step(ctx, lr, b1, b2, eps, losses, pos, neg, stream) run the oldest posted plan: serve -> all-to-all of rows ->
  *                                                           fused forward / backward + pair GEMM -> all-to-all of contributions ->

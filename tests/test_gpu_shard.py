@@ -304,7 +304,8 @@ def _session_worker(rank, world, port, out_dir, dec, inter, d):
         layout = ArenaLayout()
         for k, v in params.items():
             layout.add(k, (parallel.shard_rows(v.shape[0], w), d) if k in tables else v.shape)
-        eng = Engine(d, dec, inter, layout, shard=(r, w), max_queries=1024, max_batches=8, lazy_adam=lazy)
+        eng = Engine(d, dec, inter, layout, shard=(r, w), max_queries=1024, max_batches=8, lazy_adam=lazy,
+                     ordered_sums=True)       # bit-reproducible list sums: the engines below are compared bit for bit
         for k, v in params.items():
             src = parallel.shard_of(v, r, w) if k in tables else v
             layout.view(eng._params, k).copy_(torch.from_numpy(np.ascontiguousarray(src)))
