@@ -432,7 +432,7 @@ template <int NC>
 __device__ __forceinline__ void rows_issue(RowSet<NC>& rs, const TileEnv& e, int64_t table, const int* s_rows) {
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr) {
-    const int row = s_rows[e.wave * RPW + rr];
+    const int row = __builtin_amdgcn_readfirstlane(s_rows[e.wave * RPW + rr]);   // wave-uniform: scalar address arithmetic
     rs.row[rr] = row;
     rs.x[rr] = vload<NC>(e.rows + (e.sharded ? 0 : table) + (size_t)(row < 0 ? 0 : row) * e.d, e.d, e.lane);
   }
@@ -742,7 +742,10 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   e.max_entries = max_entries;
   e.d = d;
   e.DP = d + 4;
-  e.wave = threadIdx.x >> 6;
+  // the wave index as an SGPR: everything derived from it (the rows a wave owns, their bounds checks, row base addresses) is then
+  // scalar arithmetic and scalar branches instead of 64-bit VALU address math and EXEC masks issued for all 64 lanes
+  // (not in the full-Bilinear d = 256 kernel: the extra SGPRs spill into VGPR lanes it does not have)
+  e.wave = (DEC == DEC_BILINEAR && NC >= 4) ? (int)(threadIdx.x >> 6) : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   e.lane = threadIdx.x & 63;
   e.q0 = ((int)blockIdx.x - b.tile_begin) * GQE_TQ;
   const int DP = e.DP, lane = e.lane, wave = e.wave;

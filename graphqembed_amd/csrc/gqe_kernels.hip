@@ -53,7 +53,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
   if (unit >= plan.units) return;
   constexpr int MT = GQE_GEMM_MT, KS = 64, STR = MT + 16;
   __shared__ float sL[KS * STR], sR[KS * STR];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lq = lane & 15, lk = lane >> 4;
   int bi = 0;
 #pragma unroll
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_eval_score_kernel(const GqeDy
                                                                     const float* __restrict__ ws, const int32_t* __restrict__ idx,
                                                                     float* __restrict__ out, int d, int dec, const GqeBagTable bags) {
   constexpr int RW = 64 / LPR;  // rows per wave-wide load
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int bi = 0;
 #pragma unroll
   for (int k = 1; k < GQE_LAUNCH_BATCHES; ++k) bi += ((int)blockIdx.x >= plan.unit_begin[k]) ? 1 : 0;
