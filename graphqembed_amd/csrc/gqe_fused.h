@@ -617,6 +617,21 @@ __device__ __forceinline__ void scatter_row(const TileEnv& e, const GqeBagTable&
 // bag's k-th word row (node = entry * max_len + k)
 __device__ __forceinline__ void push_links(const TileEnv& e, const int (&olds)[RPW][2 + GQE_MAX_BRANCH], const int (&blens)[RPW][2 + GQE_MAX_BRANCH],
                                            int max_len) {
+  int any_bag = 0;   // wave-uniform
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+    for (int role = 0; role < 2 + GQE_MAX_BRANCH; ++role) any_bag |= blens[rr][role];
+  if (any_bag == 0) {   // no bag role (every workload without EmbeddingBag modes): lane 0 alone, one EXEC region for all roles
+    if (e.lane != 0) return;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+      for (int role = 0; role < 2 + GQE_MAX_BRANCH; ++role)
+        if (olds[rr][role] != GQE_NO_PUSH)
+          e.next[e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + e.wave * RPW + rr)] = olds[rr][role];
+    return;
+  }
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
