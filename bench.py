@@ -447,7 +447,7 @@ def host_fed(wl, args):
                            "reference's wrap-around rule, draws 1-chain negatives and packs the index feed into a pinned slot")
         elif feed == "copy":
             res["note"] = ("pinned staging + hipMemcpyAsync on the library's upload stream (the transport north_star names): the feeds of "
-                           "FOUR iterations travel per copy / per pair of cross-stream events")
+                           "EIGHT iterations travel per copy / per pair of cross-stream events")
             out["pinned_hipMemcpyAsync"] = res
         else:
             res["note"] = ("lazy (deferred, bit-exact) Adam driven by the native feeder: every step names the next iteration's feed "

@@ -28,7 +28,7 @@
 namespace {
 
 constexpr int kRing = 4;
-constexpr int kFeedGroup = 4;      // feeder, copy mode: iterations whose feeds are uploaded with one copy / one event pair
+constexpr int kFeedGroup = 8;      // feeder: iterations whose feeds share one upload / one pair of cross-stream events (copy mode), one guard event (zero-copy)
 constexpr int kStageBufs = 2 + 2 * kFeedGroup;   // staged index buffers in the workspace: 2 for host feeds of single calls, 2 groups for the feeder
 constexpr int kMaxSlots = 20;      // upper bound of pair-scratch slots any batch can use
 constexpr int kRolesPerQuery = 5;  // target, negative, <= 3 anchors
@@ -207,9 +207,9 @@ struct gqe_feeder {
   //   0  pinned staging + hipMemcpyAsync on the library's upload stream (what gqe_margin_fwd_bwd does for host feeds)
   //   1  the kernels read the feed straight from pinned host memory (default): no copy, no cross-stream dependency and
   //      no marker packet between the iteration's kernels — the upload's two event packets cost ~10 us of a 88 us
-  //      iteration, a 70 KB feed read over PCIe ~2 us.  8 pinned slots; an event every 4 iterations guards their re-use.
+  //      iteration, a 70 KB feed read over PCIe ~2 us.  16 pinned slots; an event every 8 iterations guards their re-use.
   int feed_mode = 1;
-  int32_t* pin[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int32_t* pin[2 * kFeedGroup] = {};
   size_t pin_cap = 0;
   hipEvent_t pin_ev[2] = {nullptr, nullptr};
   bool pin_ev_set[2] = {false, false};
@@ -2044,7 +2044,7 @@ int gqe_feeder_destroy(gqe_feeder* f) {
       if (f->pin_ev_set[k]) (void)hipEventSynchronize(f->pin_ev[k]);
       (void)hipEventDestroy(f->pin_ev[k]);
     }
-  for (int k = 0; k < 8; ++k)
+  for (int k = 0; k < 2 * kFeedGroup; ++k)
     if (f->pin[k]) (void)hipHostFree(f->pin[k]);
   for (int k = 0; k < 2; ++k) {
     if (f->grp_ready[k]) {
@@ -2219,10 +2219,10 @@ static int feeder_build(gqe_feeder* f, int64_t it, int32_t burn_in) {
 int shard_plans_ahead(gqe_ctx* ctx);   // gqe_shard_step.h: plans posted but not yet run
 
 // make iteration `it` ready: sampled, packed, and its index feed where the kernels will read it.
-//   zero-copy (feed mode 1): one of 8 pinned host slots (two groups of four; an event per group guards their re-use);
-//   copy (feed mode 0): the iterations of a GROUP of four are sampled together and travel with ONE hipMemcpyAsync on the
+//   zero-copy (feed mode 1): one of 16 pinned host slots (two groups of eight; an event per group guards their re-use);
+//   copy (feed mode 0): the iterations of a GROUP of eight are sampled together and travel with ONE hipMemcpyAsync on the
 //     library's upload stream into one of two groups of staged buffers in the workspace — two cross-stream event packets
-//     per four iterations instead of per iteration (they sit between kernels that otherwise overlap);
+//     per eight iterations instead of per iteration (they sit between kernels that otherwise overlap);
 //   row-sharded: a host feed of global rows for gqe_shard_post.
 static int feeder_ensure(gqe_feeder* f, int64_t it, int32_t burn_in, hipStream_t st) {
   gqe_ctx* ctx = f->ctx;
@@ -2248,7 +2248,7 @@ static int feeder_ensure(gqe_feeder* f, int64_t it, int32_t burn_in, hipStream_t
   if (f->grp_cap != slot_ints) {   // first use, or the workspace was re-bound with another capacity: nothing may still read the old buffers
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (ctx->up) HIP_TRY(ctx, hipStreamSynchronize(ctx->up));
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 2 * kFeedGroup; ++k) {
       if (f->pin[k]) HIP_TRY(ctx, hipHostFree(f->pin[k]));
       f->pin[k] = nullptr;
     }
@@ -2265,7 +2265,7 @@ static int feeder_ensure(gqe_feeder* f, int64_t it, int32_t burn_in, hipStream_t
   }
   if (f->feed_mode == 1) {
     if (!f->pin[0])
-      for (int k = 0; k < 8; ++k) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&f->pin[k]), L.idx_cap, hipHostMallocDefault));
+      for (int k = 0; k < 2 * kFeedGroup; ++k) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&f->pin[k]), L.idx_cap, hipHostMallocDefault));
     const long long group = it / kFeedGroup;
     if (f->pin_ev_set[group & 1]) {   // the slots of group - 2 come up for re-use
       if (hipEventQuery(f->pin_ev[group & 1]) != hipSuccess) HIP_TRY(ctx, hipEventSynchronize(f->pin_ev[group & 1]));
@@ -2274,7 +2274,7 @@ static int feeder_ensure(gqe_feeder* f, int64_t it, int32_t burn_in, hipStream_t
     rc = feeder_build(f, it, burn_in);
     if (rc != GQE_OK) return rc;
     if (f->idx.size() > slot_ints) return fail(ctx, GQE_ERR_WORKSPACE, "index feed of %zu entries exceeds the bound workspace", f->idx.size());
-    int32_t* slot = f->pin[it % 8];
+    int32_t* slot = f->pin[it % (2 * kFeedGroup)];
     memcpy(slot, f->idx.data(), f->idx.size() * sizeof(int32_t));
     stash(P, it);
     P.dev_idx = slot;

@@ -91,6 +91,7 @@ struct ShardPins {
 struct ShardSession {
   // host time per phase, accumulated when GQE_SHARD_PROFILE is set (printed by gqe_shard_close)
   bool profile = false;
+  bool self_rccl = false;   // GQE_SHARD_SELF_VIA_RCCL: send this rank's own block through RCCL too (measuring / testing the transport with one rank)
   double host_us[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long host_n = 0;
   int world = 1, rank = 0;
@@ -264,17 +265,29 @@ int shard_all_to_all(gqe_ctx* ctx, const void* send, const int64_t* send_counts,
     return GQE_OK;
   }
   const int nccl_float32 = 7;   // ncclDataType_t (rccl.h); every block is rows of floats
-  int nr = S->group_start();
-  int64_t so = 0, ro = 0;
+  // this rank's own block never leaves the device: a plain copy on the stream (1 / world of the rows, and everything
+  // when world = 1); the other blocks travel as one ncclSend / ncclRecv group
+  int64_t so = 0, ro = 0, others = 0;
+  for (int p = 0; p < S->world; ++p)
+    if (p != S->rank || S->self_rccl) others += send_counts[p] + recv_counts[p];
+  int nr = 0, ne = 0;
+  if (others > 0) nr = S->group_start();
   for (int p = 0; p < S->world && nr == 0; ++p) {
-    if (send_counts[p] > 0)
-      nr = S->send(const_cast<char*>(static_cast<const char*>(send)) + so * elem_bytes, (size_t)(send_counts[p] * elem_bytes / 4), nccl_float32, p, S->comm, st);
-    if (nr == 0 && recv_counts[p] > 0)
-      nr = S->recv(static_cast<char*>(recv) + ro * elem_bytes, (size_t)(recv_counts[p] * elem_bytes / 4), nccl_float32, p, S->comm, st);
+    if (p == S->rank && !S->self_rccl) {
+      if (send_counts[p] != recv_counts[p]) return fail(ctx, GQE_ERR_STATE, "row-sharded exchange: this rank's own block has two sizes");
+      if (send_counts[p] > 0)
+        HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(recv) + ro * elem_bytes, static_cast<const char*>(send) + so * elem_bytes,
+                                    (size_t)(send_counts[p] * elem_bytes), hipMemcpyDeviceToDevice, st));
+    } else {
+      if (send_counts[p] > 0)
+        nr = S->send(const_cast<char*>(static_cast<const char*>(send)) + so * elem_bytes, (size_t)(send_counts[p] * elem_bytes / 4), nccl_float32, p, S->comm, st);
+      if (nr == 0 && recv_counts[p] > 0)
+        nr = S->recv(static_cast<char*>(recv) + ro * elem_bytes, (size_t)(recv_counts[p] * elem_bytes / 4), nccl_float32, p, S->comm, st);
+    }
     so += send_counts[p];
     ro += recv_counts[p];
   }
-  const int ne = S->group_end();
+  if (others > 0) ne = S->group_end();
   if (nr != 0 || ne != 0) return fail(ctx, GQE_ERR_HIP, "ncclSend / ncclRecv group failed with ncclResult_t %d / %d", nr, ne);
   return GQE_OK;
 }
@@ -483,6 +496,7 @@ int gqe_shard_open(gqe_ctx* ctx, const char* session, void* nccl_comm, const gqe
   S->world = W;
   S->rank = ctx->shard_rank;
   S->profile = getenv("GQE_SHARD_PROFILE") != nullptr;
+  S->self_rccl = getenv("GQE_SHARD_SELF_VIA_RCCL") != nullptr;
   S->cap_req = ctx->lay.shard_cap_send;
   if (transport) {
     S->tr = *transport;

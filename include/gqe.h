@@ -375,7 +375,8 @@ int gqe_feeder_add_pool(gqe_feeder* f, const gqe_batch* formula, int64_t n, cons
 int gqe_feeder_set_mode_rows(gqe_feeder* f, int64_t table_offset, const int32_t* rows, int64_t n);
 /* How an iteration's index feed reaches the kernels: 0 = pinned staging ring + hipMemcpyAsync on the library's upload
  * stream (as gqe_margin_fwd_bwd does for any host feed); 1 (default) = the kernels read the feed straight from pinned host
- * memory (8 slots, an event every 4 iterations guards their re-use). */
+ * memory (16 slots, an event every 8 iterations guards their re-use).  In mode 0 the feeds of eight iterations are sampled together
+ * and travel with ONE copy and one pair of cross-stream events. */
 int gqe_feeder_set_feed(gqe_feeder* f, int32_t mode);
 int gqe_feeder_run(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations, int32_t burn_in, float lr, float beta1,
                    float beta2, float eps, float* losses, void* stream);

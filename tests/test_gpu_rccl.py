@@ -67,7 +67,9 @@ def _worker(rank, port, out_dir):
     one = engine_from_params(params, d, dec, inter, shard=(0, 1))
     plain = engine_from_params(params, d, dec, inter)
     comm = parallel.RcclComm(0, 1)
+    os.environ["GQE_SHARD_SELF_VIA_RCCL"] = "1"      # (by default a rank copies its own block locally: here it goes through RCCL too)
     one.shard_open(None, nccl_comm=comm.handle)
+    del os.environ["GQE_SHARD_SELF_VIA_RCCL"]
     srng = np.random.RandomState(9)
     steps = [[(q,) + toy_batch(srng, q, 64 + 8 * k) + (wgt,) for q, wgt in mix] for k in range(3)]
     pss = []

@@ -19,9 +19,14 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 wl = bench.Workload("bio-synth", 128, "bilinear-diag", "min", synth.FULL_MIX, 512)
 from graphqembed_amd.tensorize import FormulaPlan, pack_margin_batches
 for label, shard in (("plain", None), ("phases driven from Python (torch.distributed collectives), planned ONCE", (0, 1)),
-                     ("gqe_shard_step over RCCL, planned EVERY step", (0, 1))):
-    eng = wl.engine(shard=shard)
+                     ("gqe_shard_step, planned EVERY step, every block through RCCL", (0, 1)),
+                     ("gqe_shard_step, planned EVERY step, own block copied locally (default)", (0, 1))):
     one_call = label.startswith("gqe_shard_step")
+    if "through RCCL" in label:
+        os.environ["GQE_SHARD_SELF_VIA_RCCL"] = "1"       # read by gqe_shard_open
+    else:
+        os.environ.pop("GQE_SHARD_SELF_VIA_RCCL", None)
+    eng = wl.engine(shard=shard)
     prepared = wl.prepare(eng, dist)                  # sharded: host feeds for gqe_shard_post
     if shard and not one_call:                        # the round-2 form: requests exchanged once per pre-sampled iteration, outside the loop
         legacy = []
