@@ -407,6 +407,31 @@ def measure(wl, args, dist, rank, world, exchange="sparse", lazy=False, steps=No
     return out, eng, prepared
 
 
+def measure_or_fall_back(wl, args, dist, rank, world, exchange, **kw):
+    """measure(); when the row-sharded session cannot be brought up on this node (plan board, the library's own RCCL
+    communicator) every rank agrees on it and the replicated sparse exchange is measured instead — the line then says so
+    (`fell_back`).  Only clean errors can be agreed on: a rank that fails makes the others' plan wait time out first."""
+    if world == 1 or exchange != "sharded":
+        return measure(wl, args, dist, rank, world, exchange=exchange, **kw) + (None,)
+    import torch
+    err, got = None, None
+    try:
+        got = measure(wl, args, dist, rank, world, exchange=exchange, **kw)
+    except Exception as e:                                          # noqa: BLE001 - reported in the line
+        err = "%s: %s" % (type(e).__name__, e)
+    ok = torch.tensor([0 if err else 1], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        return got + (None,)
+    if got is not None:
+        got[1].close()
+    errs = [None] * world
+    dist.all_gather_object(errs, err)
+    why = next((e for e in errs if e), "unknown")
+    sys.stderr.write("bench.py: row-sharded step unavailable (%s): measuring the sparse exchange\n" % why)
+    return measure(wl, args, dist, rank, world, exchange="sparse", **kw) + (why[:300],)
+
+
 def host_fed(wl, args):
     """The same schedule driven by the native feeder (gqe_feeder_run): formula draw, wrap-around slice, negative draw and
     packing on a host core, launches and the Adam step from C++ — everything inside the timed region (SURVEY.md §8f-3,
@@ -588,8 +613,10 @@ def main():
     d = args.dim or (256 if reddit else 128)
     B = args.batch_size
     wl = Workload(args.workload, d, args.decoder, args.inter_decoder, synth.FULL_MIX, B, rank=rank, world=world)
-    res, eng, prepared = measure(wl, args, dist, rank, world, exchange=args.exchange, lazy=args.lazy_adam, check_replicas=world > 1,
-                                 min_seconds=args.min_seconds)
+    res, eng, prepared, fell_back = measure_or_fall_back(wl, args, dist, rank, world, exchange=args.exchange, lazy=args.lazy_adam,
+                                                         check_replicas=world > 1, min_seconds=args.min_seconds)
+    if fell_back:
+        args.exchange = "sparse"
     sparse = world > 1 and args.exchange == "sparse"
     sharded = world > 1 and args.exchange == "sharded"
     res["roofline"]["traffic"] = None if (world > 1 or args.lazy_adam or (d, B, args.decoder, args.inter_decoder) != ((256 if reddit else 128), 512, "bilinear-diag", "min")) \
@@ -621,6 +648,8 @@ def main():
     }
     if backend_note:
         out["config"]["backend_note"] = backend_note
+    if fell_back:
+        out["config"]["fell_back"] = "row-sharded step unavailable on this node (%s): replicated tables + sparse exchange measured" % fell_back
     for key in ("exchange_ms_per_step", "exchange_parts_ms", "planning", "ranks_seen", "replicas_identical"):
         if key in res:
             out[key] = res[key]
@@ -630,7 +659,7 @@ def main():
         eng.close()
         forms = {args.exchange: res}
         for other in ("sharded", "sparse", "dense"):
-            if other == args.exchange:
+            if other == args.exchange or (fell_back and other == "sharded"):
                 continue
             r2, e2, _ = measure(wl, args, dist, rank, world, exchange=other, lazy=False, check_replicas=True, **short)
             e2.close()

@@ -720,8 +720,6 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   if (shard) {
     if (!idx_on_device) return fail(ctx, GQE_ERR_ARG, "row-sharded mode: the index feed is the device-resident position feed of gqe_shard_plan");
     if (n_idx > L.shard_cap_send) return fail(ctx, GQE_ERR_WORKSPACE, "row-sharded mode: %lld indices exceed the fetched-row buffer (%lld rows)", (long long)n_idx, (long long)L.shard_cap_send);
-    for (int bi = 0; bi < n_batches; ++bi)
-      if (batches[bi].n_candidates > 0) return fail(ctx, GQE_ERR_ARG, "row-sharded mode: candidate lists are not supported (expand the candidates)");
   }
   if (bwd && !shard && ctx->entries_used + entries > L.max_entries)
     return fail(ctx, GQE_ERR_WORKSPACE, "gradient contribution buffer full (%lld + %lld > %lld entries): step or "
@@ -1719,23 +1717,30 @@ int shard_plan_impl(const gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batc
   const int W = ctx->shard_world;
   // the runs of the feed that name rows of one table (the layout of gqe_batch's index block), in feed order
   struct Run { int64_t off, n; int table; };
-  Run runs[GQE_MAX_BATCHES * (1 + GQE_MAX_BRANCH)];
+  Run runs[GQE_MAX_BATCHES * (3 + GQE_MAX_BRANCH)];   // table < 0: a run of list offsets (not rows)
   int n_runs = 0;
   for (int bi = 0; bi < n_batches; ++bi) {
     const gqe_batch& s = batches[bi];
     const int na = anchors_of(s.qtype);
     if (na < 0 || s.n_anchors != na || s.n_queries < 1) return bad(GQE_ERR_ARG, "batch %d: bad query type / anchors / size", bi);
-    if (s.n_candidates != 0) return bad(GQE_ERR_ARG, "batch %d: candidate lists are not supported in row-sharded mode", bi);
-    const int lead = with_negatives ? 2 : 1;
+    if (s.n_candidates < 0 || (s.n_candidates > 0 && with_negatives)) return bad(GQE_ERR_ARG, "batch %d: candidate lists are for gqe_forward only", bi);
+    const int lead = s.n_candidates > 0 ? 0 : (with_negatives ? 2 : 1);
     const int64_t B = s.n_queries, o = s.idx_offset;
-    if (o < 0 || o + (lead + na) * B > n_idx) return bad(GQE_ERR_ARG, "batch %d: index range exceeds the %lld indices given", bi, (long long)n_idx);
+    const int64_t tail = s.n_candidates > 0 ? B + 1 + (int64_t)s.n_candidates : 0;   // cand_ptr[B + 1] | cand_rows[n_candidates]
+    if (o < 0 || o + (lead + na) * B + tail > n_idx) return bad(GQE_ERR_ARG, "batch %d: index range exceeds the %lld indices given", bi, (long long)n_idx);
     const int tt = table_of(ctx, s.target_table);
     if (tt < 0) return bad(GQE_ERR_STATE, "batch %d: target_table is not a registered table", bi);
-    runs[n_runs++] = Run{o, lead * B, tt};
+    if (lead) runs[n_runs++] = Run{o, lead * B, tt};
     for (int i = 0; i < na; ++i) {
       const int ta = table_of(ctx, s.anchor_table[i]);
       if (ta < 0) return bad(GQE_ERR_STATE, "batch %d: anchor_table[%d] is not a registered table", bi, i);
       runs[n_runs++] = Run{o + (lead + i) * B, B, ta};
+    }
+    if (s.n_candidates > 0) {
+      // evaluation against candidate lists: the list offsets pass through, the candidates are rows of the target table
+      // (fetched like any other row — a candidate named by several queries is fetched once per naming)
+      runs[n_runs++] = Run{o + na * B, B + 1, -1};
+      runs[n_runs++] = Run{o + na * B + B + 1, (int64_t)s.n_candidates, tt};
     }
   }
   std::sort(runs, runs + n_runs, [](const Run& a, const Run& b) { return a.off < b.off; });
@@ -1756,7 +1761,7 @@ int shard_plan_impl(const gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batc
   int shift = 0;
   while ((1 << shift) < W) ++shift;
   for (int k = 0; k < n_runs; ++k) {
-    if (bag_table[runs[k].table]) continue;
+    if (runs[k].table < 0 || bag_table[runs[k].table]) continue;
     const int32_t* p = idx + runs[k].off;
     int32_t neg = 0;
     if (pow2)
@@ -1781,6 +1786,10 @@ int shard_plan_impl(const gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batc
   for (int k = 0; k < n_runs; ++k) {
     const int32_t* p = idx + runs[k].off;
     int32_t* out = positions + runs[k].off;
+    if (runs[k].table < 0) {
+      memcpy(out, p, sizeof(int32_t) * (size_t)runs[k].n);
+      continue;
+    }
     if (bag_table[runs[k].table]) {
       for (int64_t j = 0; j < runs[k].n; ++j) {
         if (p[j] < 0) return bad(GQE_ERR_ARG, "index %lld of the feed is negative", (long long)(runs[k].off + j));

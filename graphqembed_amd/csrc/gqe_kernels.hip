@@ -829,7 +829,9 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_eval_score_kernel(const GqeDy
   }
   int q = lo;
   const int tbag = f->target_bag;
-  const float* __restrict__ table = rows_base + f->target_table;
+  // row-sharded mode: a candidate index is a position in the fetched-row buffer, whatever its table; bag tables stay
+  // replicated (their word rows come from the local arena)
+  const float* __restrict__ table = (rows_base != params && tbag < 0) ? rows_base : params + f->target_table;
   while (c < c_end) {
     const int seg_end = min(cand_ptr[q + 1], c_end);
     if (seg_end <= c) {  // (empty candidate list)

@@ -358,7 +358,7 @@ class Engine(object):
         for a margin step, the parameter tensors its batches touch."""
         idx = np.ascontiguousarray(idx, dtype=np.int32)
         total = sum(dsc["n"] for dsc in descs)
-        self.reserve(total, len(descs))
+        self.reserve(max(total, (int(idx.size) + 4) // 5), len(descs))   # candidate lists: every index is a fetched row
         t = self.torch
         ps = {"arr": self.make_batches(descs), "n": len(descs), "idx": idx, "idx_ptr": C.c_void_p(idx.ctypes.data), "n_idx": int(idx.size),
               "queries": total, "with_negatives": 1 if with_negatives else 0,

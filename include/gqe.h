@@ -324,7 +324,11 @@ int gqe_shard_link(gqe_ctx* ctx, const int32_t* requests, int64_t n, void* strea
  *   gqe_shard_step(ctx, lr, b1, b2, eps, losses, pos, neg, stream) run the oldest posted plan: serve -> all-to-all of rows ->
  *                                                           fused forward / backward + pair GEMM -> all-to-all of contributions ->
  *                                                           link -> all-reduce of the small gradients -> Adam on the own shards
- *   gqe_shard_post(.., 0, NULL, 0) + gqe_shard_forward(ctx, scores, stream)   the same for gqe_forward (no candidate lists)
+ *   gqe_shard_post(.., 0, NULL, 0) + gqe_shard_forward(ctx, scores, stream)   the same for gqe_forward, candidate lists included:
+ *                                                           the list offsets pass through the plan, every candidate is fetched from
+ *                                                           its owner like any other row (once per naming: the whole index feed of
+ *                                                           a call has to fit the fetched-row buffer, i.e. size the workspace with
+ *                                                           max_queries >= n_idx / 5)
  *   gqe_shard_close(ctx)                                    (gqe_destroy closes an open session)
  * Every rank must issue the same sequence of post / step / forward calls. */
 typedef struct {

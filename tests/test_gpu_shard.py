@@ -402,6 +402,26 @@ def _session_worker(rank, world, port, out_dir, dec, inter, d):
         sc = session.shard_forward(n)
         descs, idx, n = pack_forward_batches([(plan_for(single, qtype, TOY_FORMULAS[qtype]), t, a)])
         assert torch.equal(sc, single.forward(descs, idx, n)), qtype
+    # ---- candidate lists through the session (fused evaluation on row-sharded tables): the candidates are fetched from
+    # their owners like any other row; ragged lists (one of them empty), a different number of queries per rank ----
+    from graphqembed_amd.tensorize import pack_candidate_batches
+    from gpu_utils import TOY_SIZES as SIZES
+    import oracle.netquery_numpy as O
+    for qtype in ("1-chain", "3-chain", "2-inter", "3-inter_chain"):
+        nq = 9 + 4 * r
+        t, g, a = toy_batch(rng, qtype, nq)
+        mode = O.make_plan(qtype, TOY_FORMULAS[qtype])["target_mode"]
+        lens = rng.randint(1, 40, nq)
+        lens[nq // 2] = 0
+        ptr = np.zeros(nq + 1, dtype=np.int32)
+        ptr[1:] = np.cumsum(lens)
+        rows = rng.randint(1, SIZES[mode] + 1, int(ptr[-1])).astype(np.int32)
+        descs, idx, n = pack_candidate_batches([(plan_for(session, qtype, TOY_FORMULAS[qtype]), a, ptr, rows)])
+        pf = session.prepare_shard(descs, idx, with_negatives=False)
+        session.shard_post(pf)
+        sc = session.shard_forward(n)
+        descs, idx, n = pack_candidate_batches([(plan_for(single, qtype, TOY_FORMULAS[qtype]), a, ptr, rows)])
+        assert torch.equal(sc, single.forward(descs, idx, n)), "candidate lists, " + qtype
     with open(os.path.join(out_dir, "s_ok%d" % rank), "w") as f:
         f.write("ok")
     dist.barrier()

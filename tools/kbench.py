@@ -16,8 +16,15 @@ ap.add_argument("--dim", type=int, default=128)
 ap.add_argument("--decoder", default="bilinear-diag")
 ap.add_argument("--inter", default="min")
 ap.add_argument("--reps", type=int, default=50)
+ap.add_argument("--workload", default="bio-synth", help="--durations: bio-synth | reddit-synth")
+ap.add_argument("--durations", type=int, default=0, help="only the per-tile phase DURATIONS of the full mix at this batch size (many tiles per CU)")
 args = ap.parse_args()
 d = args.dim
+if args.durations and args.workload != "bio-synth":
+    from bench import Workload
+    wl = Workload(args.workload, d, args.decoder, args.inter, synth.FULL_MIX, args.durations, n_distinct=2)
+    weng = wl.engine()
+    wps = wl.prepare(weng)[0]
 g = synth.bio_synth(seed=0)
 layout = build_layout(g, d, args.decoder, args.inter)
 eng = Engine(d, args.decoder, args.inter, layout, max_queries=9 * 4096, max_batches=16)
@@ -53,6 +60,53 @@ def time_forward(mix, B, label):
     for r in range(args.reps): eng.forward(descs, didx, n, out=out)
     torch.cuda.synchronize(); f, nf = eng.timing_read(0); eng.timing_enable(0)
     print("%-38s B=%5d forward-only %8.2f us" % (label, B, f * 1e3), flush=True)
+def phase_durations(mix, B, eng=eng, ps=None):
+    """Per tile: time between consecutive phase stamps (median / 90th percentile over the tiles of a batch type)."""
+    import ctypes as C
+    if ps is None:
+        its = items_for(mix, B)
+        descs, idx, _ = pack_margin_batches(its)
+        ps = eng.prepare_margin(descs, torch.from_numpy(idx).cuda())
+    tiles = sum((B + 15) // 16 for _ in mix)
+    stamps = torch.zeros((tiles + 16384) * 64, dtype=torch.int64, device="cuda")
+    eng.run_margin(ps); eng.materialize(); torch.cuda.synchronize()
+    eng._check(eng.lib.gqe_debug_profile(eng.ctx, stamps.data_ptr()))
+    eng.run_margin(ps); eng.materialize(); torch.cuda.synchronize()
+    eng._check(eng.lib.gqe_debug_profile(eng.ctx, None))
+    st = stamps.cpu().numpy().reshape(tiles + 16384, 64).astype(np.float64)[:tiles]
+    print("== per-tile phase durations, full mix B=%d (%d tiles); launch span %.1f us" % (B, tiles, (st[:, 8].max() - st[:, 0].min()) / 100.0))
+    seq = [(0, "start"), (1, "idx"), (9, "rows+norm"), (2, "init"), (10, "vec+bar"), (11, "pre_mfma"), (3, "pre_bar"), (4, "post/final"),
+           (5, "score"), (6, "postT"), (12, "gz+bar"), (13, "preT_mfma"), (14, "bar"), (7, "hops+scatter"), (8, "commit")]
+    n_anchor = {"1-chain": 1, "2-chain": 1, "3-chain": 1, "2-inter": 2, "3-inter": 3, "3-inter_chain": 2, "3-chain_inter": 2}
+    hops = {"1-chain": 1, "2-chain": 2, "3-chain": 3, "2-inter": 2, "3-inter": 3, "3-inter_chain": 3, "3-chain_inter": 3}
+    mlp = not args.inter.endswith("simple")
+    bil = args.decoder == "bilinear"
+    def cost(qt):
+        na, chain = n_anchor[qt], qt.endswith("chain") and "inter" not in qt
+        extra = (4 * hops[qt] if bil else 0) if chain else ((6 + 2 * na) if mlp else 2) + (2 * hops[qt] if bil else 0)
+        return 2 + na + extra
+    order = sorted(range(len(mix)), key=lambda k: -cost(mix[k][0]))
+    off = 0
+    for (qt, w, hard) in [mix[k] for k in order]:
+        nt = (B + 15) // 16
+        blk = st[off:off + nt]; off += nt
+        cells, prev = [], 0
+        for (k, nm) in seq[1:]:
+            ok = (blk[:, k] > 0) & (blk[:, prev] > 0)
+            if not ok.any():
+                continue
+            dur = (blk[ok, k] - blk[ok, prev]) / 100.0
+            cells.append("%s %.1f/%.1f" % (nm, np.median(dur), np.percentile(dur, 90)))
+            prev = k
+        tot = (blk[:, 8] - blk[:, 0]) / 100.0
+        print("%-15s tile %.1f/%.1f us | %s" % (qt + ("*" if hard else ""), np.median(tot), np.percentile(tot, 90), "  ".join(cells)))
+if args.durations and args.workload != "bio-synth":
+    phase_durations(list(synth.FULL_MIX), args.durations, weng, wps)
+    sys.exit(0)
+if args.durations:
+    time_margin(list(synth.FULL_MIX), args.durations, "full mix")
+    phase_durations(list(synth.FULL_MIX), args.durations)
+    sys.exit(0)
 for qt in types:
     hard = "inter" in qt
     time_margin([(qt, 0.01, hard)] * 9, 512, "9x " + qt)
