@@ -156,6 +156,10 @@ struct gqe_ctx {
   std::vector<TimedLaunch> timed[kTimingKinds];
   ShardSession* shard_sess = nullptr;   // gqe_shard_open
   bool shard_internal = false;          // gqe_shard_step is driving the phase entry points
+  // ... which keeps this rank's OWN block in place (no copy through the send / receive buffers): requests
+  // [own_lo, own_lo + own_n) of the received list are its own, their rows are served into the fetched buffer at row own_fetch
+  // and their contributions are linked as entries own_entry + k (the send region is part of the entry space)
+  int64_t own_lo = 0, own_n = 0, own_fetch = 0, own_entry = 0;
   bool ordered_sums = false;            // gqe_set_ordered_sums
   std::vector<TimedLaunch> event_pool;  // recycled hipEvent pairs (creation is not free)
 };
@@ -306,8 +310,10 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
     // the buffer the served rows are gathered into (rows are served before the fused kernel, contributions arrive after)
     L.shard_cap_send = L.max_entries;
     L.shard_cap_recv = L.max_entries * ctx->shard_world;
-    // + one block behind the received entries for the contributions of bag (replicated) tables, which are linked locally
-    L.max_entries = L.shard_cap_recv + (ctx->bags.empty() ? 0 : L.shard_cap_send);
+    // behind the received entries: the block this rank's fused kernel writes its contributions to (the SEND buffer is part
+    // of the entry space, so the contributions to rows this rank owns itself are linked where they are), and one more
+    // block for the contributions of bag (replicated) tables, which are linked locally
+    L.max_entries = L.shard_cap_recv + L.shard_cap_send + (ctx->bags.empty() ? 0 : L.shard_cap_send);
   }
   // entry -> list head it was pushed on (-1: not pushed); sits exactly max_entries ints below next[], so the
   // kernels address it as next[entry - max_entries]
@@ -327,8 +333,8 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
     L.shard_req_send = L.total;
     L.shard_req_recv = L.shard_req_send + align_up(sizeof(int32_t) * (size_t)L.shard_cap_send, 256);
     L.shard_fetch = L.shard_req_recv + align_up(sizeof(int32_t) * (size_t)L.shard_cap_recv, 256);
-    L.shard_csend = L.shard_fetch + align_up(sizeof(float) * (size_t)L.shard_cap_send * ctx->cfg.dim, 256);
-    L.total = L.shard_csend + align_up(sizeof(float) * (size_t)L.shard_cap_send * ctx->cfg.dim, 256);
+    L.shard_csend = L.contrib_off + sizeof(float) * (size_t)L.shard_cap_recv * ctx->cfg.dim;   // entries [cap_recv, cap_recv + cap_send)
+    L.total = L.shard_fetch + align_up(sizeof(float) * (size_t)L.shard_cap_send * ctx->cfg.dim, 256);
   }
   return L;
 }
@@ -826,7 +832,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   fa.contrib = reinterpret_cast<float*>(ctx->ws + (shard ? L.shard_csend : L.contrib_off));
   fa.fetched = shard ? reinterpret_cast<const float*>(ctx->ws + L.shard_fetch) : nullptr;
   fa.contrib_bag = reinterpret_cast<float*>(ctx->ws + L.contrib_off);
-  fa.bag_shift = shard ? L.shard_cap_recv : 0;
+  fa.bag_shift = shard ? L.shard_cap_recv + L.shard_cap_send : 0;
   memset(&fa.bags, 0, sizeof fa.bags);
   for (size_t k = 0; k < ctx->bags.size(); ++k) {
     fa.bags.ptr[k] = ctx->bags[k].ptr;
@@ -1839,7 +1845,10 @@ int gqe_shard_serve(gqe_ctx* ctx, const int32_t* requests, int64_t n, float* row
     t.offset[k] = ctx->tables[k].offset;
     t.head_base[k] = ctx->tables[k].head_base;
   }
-  HIP_TRY(ctx, gqe_launch_shard_serve(ctx->params, requests, n, rows_out, ctx->cfg.dim, t, reinterpret_cast<hipStream_t>(stream)));
+  const bool own = ctx->shard_internal && ctx->own_n > 0;
+  float* fetched = reinterpret_cast<float*>(ctx->ws + ctx->lay.shard_fetch);
+  HIP_TRY(ctx, gqe_launch_shard_serve(ctx->params, requests, n, rows_out, ctx->cfg.dim, t, own ? ctx->own_lo : 0, own ? ctx->own_n : 0,
+                                      own ? fetched + ctx->own_fetch * ctx->cfg.dim : nullptr, reinterpret_cast<hipStream_t>(stream)));
   return GQE_OK;
 }
 
@@ -1850,8 +1859,9 @@ int gqe_shard_link(gqe_ctx* ctx, const int32_t* requests, int64_t n, void* strea
   if (n < 0 || n > ctx->lay.shard_cap_recv || (n > 0 && !requests)) return fail(ctx, GQE_ERR_ARG, "gqe_shard_link: bad arguments");
   if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "row-sharded mode: the previous step's contributions are still linked (step first)");
   const Layout& L = ctx->lay;
+  const bool own = ctx->shard_internal && ctx->own_n > 0;
   HIP_TRY(ctx, gqe_launch_shard_link(reinterpret_cast<int32_t*>(ctx->ws + L.head_off), reinterpret_cast<int32_t*>(ctx->ws + L.next_off), requests, n,
-                                     reinterpret_cast<hipStream_t>(stream)));
+                                     own ? ctx->own_lo : 0, own ? ctx->own_n : 0, own ? ctx->own_entry : 0, reinterpret_cast<hipStream_t>(stream)));
   ctx->shard_sent = false;
   if (n > 0) {
     ctx->entries_used = n;

@@ -1018,8 +1018,11 @@ hipError_t gqe_launch_auc(const float* pos, long long n_pos, const float* neg, l
 // d/4 lanes per row, four rows per lane group in flight (the requests and the four row loads are all issued before the first
 // store: a 512-byte row per 32 lanes with one load in flight measured 1.8 TB/s on 9 MB)
 #define GQE_SERVE_U 4
+// Requests [own_lo, own_lo + own_n) are this rank's own: their rows go straight to where the fused kernel reads them
+// (own_out, the own block of the fetched-row buffer) instead of through the send buffer and a copy.
 __global__ __launch_bounds__(GQE_THREADS) void gqe_shard_serve_kernel(const float* __restrict__ p, const int32_t* __restrict__ req,
-                                                                     long long n, float* __restrict__ out, int d, const GqeShardTabs t) {
+                                                                     long long n, float* __restrict__ out, int d, const GqeShardTabs t,
+                                                                     long long own_lo, long long own_n, float* __restrict__ own_out) {
   const int tpr = d >> 2;
   const int gpb = GQE_THREADS / tpr;                     // lane groups per workgroup
   const int g = threadIdx.x / tpr, c4 = (threadIdx.x - g * tpr) * 4;
@@ -1040,31 +1043,39 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_shard_serve_kernel(const floa
     }
   }
 #pragma unroll
-  for (int u = 0; u < GQE_SERVE_U; ++u)
-    if (j0 + u < n) *reinterpret_cast<float4*>(out + (j0 + u) * d + c4) = v[u];
+  for (int u = 0; u < GQE_SERVE_U; ++u) {
+    const long long j = j0 + u, k = j - own_lo;
+    if (j < n) *reinterpret_cast<float4*>((k >= 0 && k < own_n ? own_out + k * d : out + j * d) + c4) = v[u];
+  }
 }
 
+// Contribution j answers request j: entry j of the receive buffer — except this rank's own block [own_lo, own_lo + own_n),
+// whose contributions stayed where the fused kernel wrote them: entries own_entry + (j - own_lo).
 __global__ __launch_bounds__(GQE_THREADS) void gqe_shard_link_kernel(int32_t* __restrict__ head, int32_t* __restrict__ next,
-                                                                    const int32_t* __restrict__ req, long long n) {
+                                                                    const int32_t* __restrict__ req, long long n, long long own_lo,
+                                                                    long long own_n, long long own_entry) {
   const long long j = (long long)blockIdx.x * GQE_THREADS + threadIdx.x;
   if (j >= n) return;
   const int h = req[j];
-  if (h >= 0) next[j] = __hip_atomic_exchange(head + h, (int)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const long long k = j - own_lo;
+  const int e = (int)(k >= 0 && k < own_n ? own_entry + k : j);
+  if (h >= 0) next[e] = __hip_atomic_exchange(head + h, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 hipError_t gqe_launch_shard_serve(const float* params, const int32_t* req, long long n, float* out, int d, const GqeShardTabs& t,
-                                  hipStream_t stream) {
+                                  long long own_lo, long long own_n, float* own_out, hipStream_t stream) {
   if (n < 1) return hipSuccess;
   const long long rows_per_block = (long long)(GQE_THREADS / (d >> 2)) * GQE_SERVE_U;
   hipLaunchKernelGGL(gqe_shard_serve_kernel, dim3((unsigned)((n + rows_per_block - 1) / rows_per_block)), dim3(GQE_THREADS), 0, stream,
-                     params, req, n, out, d, t);
+                     params, req, n, out, d, t, own_lo, own_n, own_out);
   return hipGetLastError();
 }
 
-hipError_t gqe_launch_shard_link(int32_t* head, int32_t* next, const int32_t* req, long long n, hipStream_t stream) {
+hipError_t gqe_launch_shard_link(int32_t* head, int32_t* next, const int32_t* req, long long n, long long own_lo, long long own_n,
+                                 long long own_entry, hipStream_t stream) {
   if (n < 1) return hipSuccess;
   hipLaunchKernelGGL(gqe_shard_link_kernel, dim3((unsigned)((n + GQE_THREADS - 1) / GQE_THREADS)), dim3(GQE_THREADS), 0, stream, head,
-                     next, req, n);
+                     next, req, n, own_lo, own_n, own_entry);
   return hipGetLastError();
 }
 

@@ -251,8 +251,9 @@ void shard_planner_main(ShardSession* S) {
 
 // ---- transports -------------------------------------------------------------------------------------------
 // all-to-all of variable blocks (elem_bytes each), blocks contiguous in peer order on both sides
+// own_in_place: this rank's own block is not moved (the caller arranged for producer and consumer to meet in place)
 int shard_all_to_all(gqe_ctx* ctx, const void* send, const int64_t* send_counts, void* recv, const int64_t* recv_counts, int64_t elem_bytes,
-                     hipStream_t st) {
+                     bool own_in_place, hipStream_t st) {
   ShardSession* S = ctx->shard_sess;
   if (S->custom) {
     const int rc = S->tr.all_to_all(S->tr.user, send, send_counts, recv, recv_counts, elem_bytes, st);
@@ -260,7 +261,7 @@ int shard_all_to_all(gqe_ctx* ctx, const void* send, const int64_t* send_counts,
     return GQE_OK;
   }
   if (!S->comm) {  // world = 1 without a communicator: the block goes from the send to the receive buffer
-    if (send_counts[0] > 0)
+    if (send_counts[0] > 0 && !own_in_place)
       HIP_TRY(ctx, hipMemcpyAsync(recv, send, (size_t)(send_counts[0] * elem_bytes), hipMemcpyDeviceToDevice, st));
     return GQE_OK;
   }
@@ -275,7 +276,7 @@ int shard_all_to_all(gqe_ctx* ctx, const void* send, const int64_t* send_counts,
   for (int p = 0; p < S->world && nr == 0; ++p) {
     if (p == S->rank && !S->self_rccl) {
       if (send_counts[p] != recv_counts[p]) return fail(ctx, GQE_ERR_STATE, "row-sharded exchange: this rank's own block has two sizes");
-      if (send_counts[p] > 0)
+      if (send_counts[p] > 0 && !own_in_place)
         HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(recv) + ro * elem_bytes, static_cast<const char*>(send) + so * elem_bytes,
                                     (size_t)(send_counts[p] * elem_bytes), hipMemcpyDeviceToDevice, st));
     } else {
@@ -402,10 +403,24 @@ int shard_run(gqe_ctx* ctx, int kind, float lr, float b1, float b2, float eps, f
     ra.segs = rsegs;
     HIP_TRY(ctx, gqe_launch_rows(ra));
   }
+  // this rank's own block stays in place (unless a caller-supplied transport moves every block — gqe_transport.skips_own_block
+  // = 0 — or the debug switch sends it through RCCL): its rows are served straight into the fetched buffer, its contributions are linked where the fused
+  // kernel writes them
+  const bool in_place = S->custom ? S->tr.skips_own_block != 0 : !S->self_rccl;
+  ctx->own_lo = ctx->own_n = ctx->own_fetch = ctx->own_entry = 0;
+  if (in_place) {
+    for (int j = 0; j < S->rank; ++j) {
+      ctx->own_lo += col.recv_counts[j];
+      ctx->own_fetch += sl.send_counts[j];
+    }
+    ctx->own_n = col.recv_counts[S->rank];
+    ctx->own_entry = L.shard_cap_recv + ctx->own_fetch;
+    if (ctx->own_n != sl.send_counts[S->rank]) return fail(ctx, GQE_ERR_STATE, "row-sharded exchange: this rank's own block has two sizes");
+  }
   rc = gqe_shard_serve(ctx, pn.req, col.n_recv, rows_send, stream);
   if (rc != GQE_OK) return rc;
   clk.mark(3);
-  rc = shard_all_to_all(ctx, rows_send, col.recv_counts, fetched, sl.send_counts, (int64_t)d * 4, st);
+  rc = shard_all_to_all(ctx, rows_send, col.recv_counts, fetched, sl.send_counts, (int64_t)d * 4, in_place, st);
   if (rc != GQE_OK) return rc;
   clk.mark(4);
   rc = timing_end(ctx, 5, st);
@@ -418,7 +433,7 @@ int shard_run(gqe_ctx* ctx, int kind, float lr, float b1, float b2, float eps, f
     // ---- contributions to the owners, the small gradients summed over the ranks, Adam on the own shards ----
     rc = timing_begin(ctx, 6, st);
     if (rc != GQE_OK) return rc;
-    rc = shard_all_to_all(ctx, csend, sl.send_counts, crecv, col.recv_counts, (int64_t)d * 4, st);
+    rc = shard_all_to_all(ctx, csend, sl.send_counts, crecv, col.recv_counts, (int64_t)d * 4, in_place, st);
     if (rc != GQE_OK) return rc;
     clk.mark(6);
     // the tables the UNION of the ranks' batches names may receive lists (whatever this rank's own batches named)

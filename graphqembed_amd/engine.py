@@ -69,7 +69,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_
 
 
 class gqe_transport(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("all_to_all", A2A_FN), ("all_reduce_sum_f32", ALLREDUCE_FN)]
+    _fields_ = [("user", C.c_void_p), ("all_to_all", A2A_FN), ("all_reduce_sum_f32", ALLREDUCE_FN), ("skips_own_block", C.c_int32)]
 
 
 # every symbol include/gqe.h declares: name -> (restype, argtypes)

@@ -190,11 +190,13 @@ class TorchTransport(object):
     process group moves them in place — but there the library's own RCCL path (Engine.shard_open(nccl_comm=...)) is the
     one to use.  The callbacks run on the calling thread inside gqe_shard_step; the stream is torch's current stream."""
 
-    def __init__(self, engine, dist):
+    def __init__(self, engine, dist, skip_own=True):
+        """``skip_own``: the all-to-all leaves this rank's own block alone (gqe_transport.skips_own_block): the library keeps
+        it in place, as on its RCCL path."""
         import torch
         from .engine import A2A_FN, ALLREDUCE_FN, gqe_transport
         self.engine, self.dist, self.error = engine, dist, None
-        world = dist.get_world_size()
+        world, me = dist.get_world_size(), dist.get_rank()
 
         def a2a(user, send, scounts, recv, rcounts, elem_bytes, stream):
             try:
@@ -203,7 +205,17 @@ class TorchTransport(object):
                 cols = int(elem_bytes) // 4
                 src = engine.view_bytes(send, sum(sc) * elem_bytes).view(torch.float32).view(sum(sc), cols)
                 dst = engine.view_bytes(recv, sum(rc) * elem_bytes).view(torch.float32).view(sum(rc), cols)
-                _all_to_all(dist, dst, src, rc, sc)
+                if not skip_own:
+                    _all_to_all(dist, dst, src, rc, sc)
+                    return 0
+                # the own block stays where it is: exchange the other blocks, compacted on both sides
+                so, ro = sum(sc[:me]), sum(rc[:me])
+                inp = torch.cat([src[:so], src[so + sc[me]:]])
+                out = torch.empty((sum(rc) - rc[me], cols), dtype=torch.float32, device=dst.device)
+                sc[me] = rc[me] = 0
+                _all_to_all(dist, out, inp, rc, sc)
+                dst[:ro].copy_(out[:ro])
+                dst[ro + int(rcounts[me]):].copy_(out[ro:])
                 return 0
             except Exception as e:                      # noqa: an exception must not unwind through the C frames
                 self.error = e
@@ -223,10 +235,10 @@ class TorchTransport(object):
                 self.error = e
                 return 1
         self._a2a, self._ar = A2A_FN(a2a), ALLREDUCE_FN(allreduce)     # keep the thunks alive
-        self.struct = gqe_transport(None, self._a2a, self._ar)
+        self.struct = gqe_transport(None, self._a2a, self._ar, 1 if skip_own else 0)
 
 
-def shard_session(engine, dist, rank=0, world=1):
+def shard_session(engine, dist, rank=0, world=1, skip_own=True):
     """Open the row-sharded session of ``engine`` (gqe_shard_open): agree on a plan-board name, pick the transport — the
     library's own RCCL calls on a nccl process group (a communicator of its own: RcclComm), callbacks over
     torch.distributed otherwise (gloo), nothing for a single rank.  Returns the object that keeps the transport alive."""
@@ -240,7 +252,7 @@ def shard_session(engine, dist, rank=0, world=1):
         comm = RcclComm(rank, world, dist, device=engine.device)
         engine.shard_open(name[0], nccl_comm=comm.handle)
         return comm
-    tr = TorchTransport(engine, dist)
+    tr = TorchTransport(engine, dist, skip_own=skip_own)
     engine.shard_open(name[0], transport=tr.struct)
     return tr
 

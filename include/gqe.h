@@ -338,6 +338,10 @@ typedef struct {
   int (*all_to_all)(void* user, const void* send, const int64_t* send_counts, void* recv, const int64_t* recv_counts,
                     int64_t elem_bytes, void* stream);
   int (*all_reduce_sum_f32)(void* user, float* buf, int64_t n, void* stream);
+  /* non-zero: all_to_all leaves the CALLER'S OWN block (block `rank` of both buffers) untouched.  The library then keeps that
+   * block in place — its rows are served straight into the fetched-row buffer, its contributions are linked where the fused
+   * kernel wrote them — as it does on its RCCL path; 0: the transport moves every block, the own one included. */
+  int32_t skips_own_block;
 } gqe_transport;
 int gqe_shard_open(gqe_ctx* ctx, const char* session, void* nccl_comm, const gqe_transport* transport);
 int gqe_shard_close(gqe_ctx* ctx);

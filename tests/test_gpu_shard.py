@@ -327,7 +327,9 @@ def _session_worker(rank, world, port, out_dir, dec, inter, d):
         return out
 
     by_hand, session, lazy = sharded_engine(), sharded_engine(), sharded_engine(lazy=True)
-    keep = [parallel.shard_session(session, dist, r, w), parallel.shard_session(lazy, dist, r, w)]
+    # (session: the transport leaves the own block alone and the library keeps it in place, as on the RCCL path; lazy: the
+    # transport moves every block)
+    keep = [parallel.shard_session(session, dist, r, w), parallel.shard_session(lazy, dist, r, w, skip_own=False)]
     # One query type per step and <= 16 queries per rank (one tile): every floating-point reduction is then order-free (two
     # branch gradients into Pre, two ranks into the all-reduce, row lists summed order-independently) and two engines agree
     # BIT FOR BIT — or differ because of the protocol.  No 3-inter: its three branches add into the Pre gradient in atomic order.

@@ -20,7 +20,7 @@ wl = bench.Workload("bio-synth", 128, "bilinear-diag", "min", synth.FULL_MIX, 51
 from graphqembed_amd.tensorize import FormulaPlan, pack_margin_batches
 for label, shard in (("plain", None), ("phases driven from Python (torch.distributed collectives), planned ONCE", (0, 1)),
                      ("gqe_shard_step, planned EVERY step, every block through RCCL", (0, 1)),
-                     ("gqe_shard_step, planned EVERY step, own block copied locally (default)", (0, 1))):
+                     ("gqe_shard_step, planned EVERY step, own block kept in place (default)", (0, 1))):
     one_call = label.startswith("gqe_shard_step")
     if "through RCCL" in label:
         os.environ["GQE_SHARD_SELF_VIA_RCCL"] = "1"       # read by gqe_shard_open
