@@ -1770,12 +1770,29 @@ int shard_plan_impl(const gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batc
     if (runs[k].table < 0 || bag_table[runs[k].table]) continue;
     const int32_t* p = idx + runs[k].off;
     int32_t neg = 0;
-    if (pow2)
-      for (int64_t j = 0; j < runs[k].n; ++j) {
+    if (W == 1) {
+      for (int64_t j = 0; j < runs[k].n; ++j) neg |= p[j];
+      at[0] += runs[k].n;
+    } else if (pow2) {
+      // four counter sets: consecutive indices with the same owner would otherwise chain through one memory cell
+      int64_t c4[4][8];
+      const bool small = W <= 8;
+      if (small) memset(c4, 0, sizeof c4);
+      int64_t j = 0;
+      for (; small && j + 4 <= runs[k].n; j += 4) {
+        neg |= p[j] | p[j + 1] | p[j + 2] | p[j + 3];
+        ++c4[0][p[j] & mask];
+        ++c4[1][p[j + 1] & mask];
+        ++c4[2][p[j + 2] & mask];
+        ++c4[3][p[j + 3] & mask];
+      }
+      for (; j < runs[k].n; ++j) {
         neg |= p[j];
         ++at[p[j] & mask];
       }
-    else
+      if (small)
+        for (int o = 0; o < W; ++o) at[o] += c4[0][o] + c4[1][o] + c4[2][o] + c4[3][o];
+    } else
       for (int64_t j = 0; j < runs[k].n; ++j) {
         neg |= p[j];
         ++at[p[j] < 0 ? 0 : p[j] % W];
@@ -1806,6 +1823,19 @@ int shard_plan_impl(const gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batc
     const Table& tb = ctx->tables[(size_t)runs[k].table];
     const int64_t rows = tb.rows, hb = tb.head_base;
     int64_t worst = 0;
+    if (W == 1) {   // every row is this rank's: positions are the feed order (no counter chain through memory)
+      const int64_t base = at[0];
+      for (int64_t j = 0; j < runs[k].n; ++j) {
+        const int64_t r = p[j];
+        worst = std::max(worst, r);
+        out[j] = (int32_t)(base + j);
+        requests[base + j] = (int32_t)(hb + r);
+      }
+      at[0] += runs[k].n;
+      if (worst >= rows)
+        return bad(GQE_ERR_ARG, "a global row of the batch run at %lld is outside its table (%lld local rows x %d ranks)", (long long)runs[k].off, (long long)rows, W);
+      continue;
+    }
     for (int64_t j = 0; j < runs[k].n; ++j) {
       const int64_t r = p[j];
       const int o = pow2 ? (int)(r & mask) : (int)(r % W);
