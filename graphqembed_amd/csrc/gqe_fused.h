@@ -326,6 +326,12 @@ __device__ __forceinline__ void pre_intersect(float* __restrict__ th, int* __res
         }
       }
       hv[r] = inter_min ? best : best / (float)NB;
+      // bits 8 + b: branch b receives this element's gradient (see pre_intersect_staged)
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi) {
+        const int on = ((meta >> (4 + bi)) & 1) & (inter_min ? (int)((meta & 3) == bi) : 1);
+        meta |= on << (8 + bi);
+      }
       mv[r] = meta;
     }
     *reinterpret_cast<float4*>(th + lq * DP + i0 + 4 * lk) = make_float4(hv[0], hv[1], hv[2], hv[3]);
@@ -387,7 +393,7 @@ __device__ __forceinline__ void pre_intersect_bwd(float* const (&te)[GQE_MAX_BRA
                                                   int DP, int wave, int lane, int inter_min) {
   constexpr int KB = 4 * NC, KG = KB < GQE_KG ? KB : GQE_KG;
   const int lq = lane & 15, lk = lane >> 4, nkb = d >> 4;
-  const float inv_n = 1.f / (float)NB;
+  const float gsc = inter_min ? 1.f : 1.f / (float)NB;  // mean: every live branch gets g_h / n (mask_gz)
   for (int i0 = wave * 16; i0 < d; i0 += GQE_FW * 16) {
     f32x4 acc[NB];
 #pragma unroll
@@ -399,12 +405,14 @@ __device__ __forceinline__ void pre_intersect_bwd(float* const (&te)[GQE_MAX_BRA
 #pragma unroll
       for (int kb = 0; kb < KG; ++kb) {
         if (g0 + kb < nkb) {
-          const float4 gh = *reinterpret_cast<const float4*>(tgh + lq * DP + (g0 + kb) * 16 + 4 * lk);
+          const float4 g4 = *reinterpret_cast<const float4*>(tgh + lq * DP + (g0 + kb) * 16 + 4 * lk);
+          const float4 gh = make_float4(g4.x * gsc, g4.y * gsc, g4.z * gsc, g4.w * gsc);
           const int4 mt = *reinterpret_cast<const int4*>(tmeta + lq * DP + (g0 + kb) * 16 + 4 * lk);
 #pragma unroll
           for (int bi = 0; bi < NB; ++bi) {
-            const float4 b = make_float4(mask_gz(gh.x, mt.x, bi, inter_min, inv_n, true), mask_gz(gh.y, mt.y, bi, inter_min, inv_n, true),
-                                         mask_gz(gh.z, mt.z, bi, inter_min, inv_n, true), mask_gz(gh.w, mt.w, bi, inter_min, inv_n, true));
+            // bit 8 + b of the meta word (pre_intersect): two VALU ops per element instead of mask_gz's five
+            const float4 b = make_float4(keep_if_bit(gh.x, mt.x, 8 + bi), keep_if_bit(gh.y, mt.y, 8 + bi), keep_if_bit(gh.z, mt.z, 8 + bi),
+                                         keep_if_bit(gh.w, mt.w, 8 + bi));
             acc[bi] = mfma4(a[kb], b, acc[bi]);
           }
         }
