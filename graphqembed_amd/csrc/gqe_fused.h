@@ -102,7 +102,7 @@ __device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 a
 // The A slab of an output row block is fetched in groups of <= KG k-blocks (KG float4 per lane in flight): all of it
 // at d <= 128, two / three / four rounds beyond — a 16-float4 slab (d = 256) next to the rows a wave keeps in registers
 // would spill.
-#define GQE_KG ((GQE_FW == 8 && NC >= 3) ? (NC >= 4 ? 2 : 4) : ((GQE_DEC == DEC_BILINEAR && NC >= 4) ? 4 : 8))  // 8-wave d > 128 kernels (two rows per role) and the full-Bilinear d = 256 kernel: smaller groups keep them off the spill cliff
+#define GQE_KG ((GQE_FW == 8 && NC >= 2) ? (NC >= 4 ? 2 : 4) : ((GQE_DEC == DEC_BILINEAR && NC >= 4) ? 4 : 8))  // 8-wave d > 128 kernels (two rows per role) and the full-Bilinear d = 256 kernel: smaller groups keep them off the spill cliff
 
 // ---- matrices staged in LDS (the intersection's Pre / Post at d <= 128) -----------------------------------------
 // A d x d matrix every tile of a batch contracts with sits in L2, ~1 us away, and a contraction phase cannot start
@@ -254,10 +254,12 @@ __device__ __forceinline__ float keep_if_bit(float g, int meta, int bit) {  // g
 }
 
 // dst[q][i] = sum_k A[i][k] src[q][k]   (one source tile), A streamed from L2
+// (one accumulator: the 8-wave d <= 128 kernels can afford the whole slab in flight here even at their 80-VGPR budget)
+#define GQE_KG1 ((GQE_FW == 8 && NC == 2) ? 8 : GQE_KG)
 template <bool TRANS, int NC>
 __device__ __forceinline__ void tile_matmul(float* __restrict__ dst, const float* __restrict__ M,
                                             const float* __restrict__ src, int d, int DP, int wave, int lane) {
-  constexpr int KB = 4 * NC, KG = KB < GQE_KG ? KB : GQE_KG;
+  constexpr int KB = 4 * NC, KG = KB < GQE_KG1 ? KB : GQE_KG1;
   const int lq = lane & 15, lk = lane >> 4, nkb = d >> 4;
   for (int i0 = wave * 16; i0 < d; i0 += GQE_FW * 16) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -579,7 +581,9 @@ __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t h
                                                      int bag_index, int max_len, int& old_head, int& bag_len) {
   const int bi = __builtin_amdgcn_readfirstlane(bag_index);   // wave-uniform: the span comes from scalar loads and stays in SGPRs
   const int p0 = ptr[bi], len = ptr[bi + 1] - p0;             // re-read (cache hit) rather than carried in registers
-  constexpr bool DEFER = !(GQE_DEC == DEC_BILINEAR && NC >= 4);   // (not in the full-Bilinear d = 256 kernel: no register to spare)
+  // (not in the full-Bilinear d = 256 kernel, nor in the 8-wave d <= 128 kernels that are held to 80 VGPRs for three workgroups
+  // per CU: no register to spare)
+  constexpr bool DEFER = !(GQE_DEC == DEC_BILINEAR && NC >= 4) && !(GQE_FW == 8 && NC == 2);
   bag_len = DEFER ? min(len, 64) : 0;   // lanes whose link push_links still owes
   const float pg = vdot<NC>(xhat, g);
   const float inv = gqe_rcp(nrm * (float)len);
@@ -710,8 +714,17 @@ __device__ __forceinline__ void tile_to_scratch(const TileEnv& e, int slot, cons
   }
 }
 
+// COMPACT: the d = 128 many-tile kernels (8 waves, MLP intersection on element-wise decoders) keep five LDS tiles instead of
+// eight (q and g_q live in branch tiles that are dead by then) and are held to 80 VGPRs: THREE workgroups per CU instead of
+// two — the launch is a throughput problem there (thousands of tiles), and a tile's phases are latency / barrier chains.
+template <int DEC, bool MLP, int NC, bool FULL, int FW>
+struct FusedShape {
+  static constexpr bool COMPACT = FW == 8 && NC == 2 && FULL && MLP && DEC != DEC_BILINEAR;
+  static constexpr int MIN_WAVES_PER_EU = COMPACT ? 6 : FW / 4;   // (FW / 4 is what the workgroup size implies anyway)
+};
+
 template <int DEC, bool MLP, int NC, bool FULL, bool BWD, int FW>
-__global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan plan,
+__global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_WAVES_PER_EU)) void gqe_fused_kernel(const GqeDynPlan plan,
                                                                 const GqeDevFormula* __restrict__ formulas,
                                                                 const float* __restrict__ params,
                                                                 float* __restrict__ grads, float* __restrict__ ws,
@@ -788,13 +801,14 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
   te[0] = smem;
   te[1] = te[0] + GQE_TQ * DP;
   te[2] = te[1] + GQE_TQ * DP;
-  float* tt = te[2] + GQE_TQ * DP;    // temp / ping-pong
-  float* tacc = tt + GQE_TQ * DP;     // h (MLP) or q (simple); later g_h
-  float* tq = tacc + GQE_TQ * DP;     // q
-  float* tg = tq + GQE_TQ * DP;       // g_q
-  int* tmeta = reinterpret_cast<int*>(tg + GQE_TQ * DP);
+  constexpr bool COMPACT = FusedShape<DEC, MLP, NC, FULL, FW>::COMPACT;
+  float* tt = COMPACT ? nullptr : te[2] + GQE_TQ * DP;          // temp / ping-pong (full Bilinear only)
+  float* tacc = (COMPACT ? te[2] : tt) + GQE_TQ * DP;           // h (MLP) or q (simple); later g_h
+  float* tq = COMPACT ? te[1] : tacc + GQE_TQ * DP;             // q     (COMPACT: the branch tiles are dead between Pre and Pre^T;
+  float* tg = COMPACT ? te[2] : tq + GQE_TQ * DP;               // g_q    te[0] stays free for the final projection)
+  int* tmeta = reinterpret_cast<int*>((COMPACT ? tacc : tg) + GQE_TQ * DP);
   float* red = reinterpret_cast<float*>(tmeta + GQE_TQ * DP);
-  int* s_idx = reinterpret_cast<int*>(red + GQE_FW * d);  // [5][16]: target, negative, anchor 0..2
+  int* s_idx = reinterpret_cast<int*>(red + (COMPACT ? 64 : GQE_FW * d));  // [5][16]: target, negative, anchor 0..2
   // staged matrices (see mat_issue): the MLP intersection's Pre / Post, d <= 128, 16-wave tiles
   constexpr bool STAGE = MLP && DEC != DEC_BILINEAR && FULL && NC <= 2 && FW == 16;
   constexpr int MR = STAGE ? NC * NC : 1;
@@ -1401,20 +1415,43 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
         tgh = tacc;
       }
       GQE_STAMP(6);
+      if (COMPACT) {
+        // the heads the target / negative pushes returned (score phase, two contractions ago) are stored now: four registers
+        // less across the Pre^T contraction, where this kernel's 80-VGPR budget is tightest
+        if (lane == 0) {
+#pragma unroll
+          for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+            for (int role = 0; role < 2; ++role)
+              if (olds[rr][role] != GQE_NO_PUSH && blens[rr][role] == 0)
+                e.next[e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + wave * RPW + rr)] = olds[rr][role];
+        }
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+          for (int role = 0; role < 2; ++role)
+            if (blens[rr][role] == 0) olds[rr][role] = GQE_NO_PUSH;
+      }
       // ---- backward of Pre for all branches: g_e_i -> te[i] ----
       if (MLP) {
 #pragma unroll
-        for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
-          if (i >= n) continue;
+        for (int rr = 0; rr < RPW; ++rr) {  // g_z_i rows for the deferred dPre (own rows): g_h and the meta word are read once
+          const int r = wave * RPW + rr;    // for all branches; bit 8 + i of the meta word says whether branch i receives the element
+          const float gsc = inter_min ? 1.f : inv_n;
+          float gh[NC];
+          int mt[NC];
 #pragma unroll
-          for (int rr = 0; rr < RPW; ++rr) {  // g_z_i rows for the deferred dPre (own rows)
-            const int r = wave * RPW + rr;
+          for (int c = 0; c < NC; ++c) {
+            const int j = lane + 64 * c;
+            gh[c] = (j < d) ? tgh[r * DP + j] * gsc : 0.f;
+            mt[c] = (j < d) ? tmeta[r * DP + j] : 0;
+          }
+#pragma unroll
+          for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
+            if (i >= n) continue;
             Vec<NC> gz;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-              const int j = lane + 64 * c;
-              gz.v[c] = (j < d) ? mask_gz(tgh[r * DP + j], tmeta[r * DP + j], i, inter_min, inv_n, true) : 0.f;
-            }
+            for (int c = 0; c < NC; ++c) gz.v[c] = keep_if_bit(gh[c], mt[c], 8 + i);
             vstore<NC>(scratch_row(e, f->slot_gz[i], r), gz, d, lane);
           }
         }
@@ -1555,14 +1592,16 @@ __global__ __launch_bounds__(GQE_FWT) void gqe_fused_kernel(const GqeDynPlan pla
 // ------------------------------------------------------------------------------------------
 // per-(DEC, MLP) launcher, instantiated once per translation unit (gqe_fused_inst.hip)
 // ------------------------------------------------------------------------------------------
-inline size_t gqe_fused_lds_bytes_impl(int d, bool stage) {
+inline size_t gqe_fused_lds_bytes_impl(int d, bool stage, bool compact) {
   const int DP = d + 4;
+  if (compact) return (size_t)(5 * GQE_TQ * DP + 64 + 5 * GQE_TQ) * sizeof(float);
   return (size_t)(8 * GQE_TQ * DP + GQE_FW * d + 5 * GQE_TQ + (stage ? d * DP : 0)) * sizeof(float);
 }
 
 template <int DEC, bool MLP, int NC, bool FULL>
 static hipError_t launch_fused_v(const GqeFusedArgs& a) {
-  const size_t lds = gqe_fused_lds_bytes_impl(a.d, MLP && DEC != DEC_BILINEAR && FULL && NC <= 2 && GQE_FW == 16);
+  const size_t lds = gqe_fused_lds_bytes_impl(a.d, MLP && DEC != DEC_BILINEAR && FULL && NC <= 2 && GQE_FW == 16,
+                                              FusedShape<DEC, MLP, NC, FULL, GQE_FW>::COMPACT);
   if (a.bwd)
     hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true, GQE_FW>), dim3(a.plan.tiles), dim3(GQE_FWT), lds, a.stream, a.plan,
                        a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags, a.link_contrib, a.link_counter,

@@ -1,5 +1,6 @@
 // gqe_kernels.hip — pair-GEMM (deferred matrix gradients), fused optimiser pass and the dispatcher of
 // the fused query kernel (gqe_fused.h, instantiated per decoder variant in gqe_fused_inst.hip).
+#include <cstdlib>
 #include "gqe_common.h"
 #include "gqe_adam.h"
 
@@ -486,7 +487,11 @@ int gqe_fused_waves(int dec, int d, int tiles) {
   if (d > 128) return 8;    // guarded variants
   if (d > 64 && (d % 64) != 0) return 8;  // guarded d in (64, 128): 256 VGPRs per lane instead of spilling at 128
   if (dec == DEC_BILINEAR && d < 64) return 8;  // full Bilinear, guarded d < 64: 171 VGPRs (the 16-wave form spilled at 128)
-  if (d == 128 && tiles > GQE_FW8_MIN_TILES) return 8;
+  static const int min_tiles = [] {   // GQE_DEBUG_FW8_MIN_TILES: tuning runs only
+    const char* e = getenv("GQE_DEBUG_FW8_MIN_TILES");
+    return e ? atoi(e) : GQE_FW8_MIN_TILES;
+  }();
+  if (d == 128 && tiles > min_tiles) return 8;
   return 16;
 }
 
