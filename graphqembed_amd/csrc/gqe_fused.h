@@ -250,7 +250,7 @@ __device__ __forceinline__ void pre_intersect_staged(float* __restrict__ th, int
 }
 
 __device__ __forceinline__ float keep_if_bit(float g, int meta, int bit) {  // g if bit `bit` of meta is set, else +0
-  return __int_as_float(__float_as_int(g) & ((int)((unsigned)meta << (31 - bit)) >> 31));
+  return __int_as_float(__float_as_int(g) & __builtin_amdgcn_sbfe(meta, bit, 1));   // v_bfe_i32 (0 / -1) + v_and
 }
 
 // dst[q][i] = sum_k A[i][k] src[q][k]   (one source tile), A streamed from L2
