@@ -14,7 +14,8 @@
 #define GQE_THREADS 256
 #define GQE_OPT_CHUNK 1024   // floats per optimiser chunk (256 threads x float4)
 #define GQE_MAX_SEGS 96      // tensors the kernel-argument form of an optimiser pass can describe (more: table form)
-#define GQE_GEMM_KCHUNK 128  // queries per pair-GEMM unit
+#define GQE_GEMM_KCHUNK 128  // queries per pair-GEMM chunk (a unit walks 1, 2, 4 or 8 chunks: GqeDynPlan.pad[0])
+#define GQE_GEMM_MIN_UNITS 600  // ... as many as leave the launch this many units (measured: B = 512 -> 1, 2048 -> 2, 4096 -> 4, 8192 -> 8)
 #define GQE_GEMM_MT 64       // edge of the gradient block one pair-GEMM unit produces
 #define GQE_PROF_SLOTS 64     // wall_clock64 stamps per workgroup (debug profile)
 
@@ -90,7 +91,7 @@ struct GqeBagTable {
 
 struct GqeDynPlan {
   int32_t n_batches, tiles, units, first;  // first != 0: this launch starts the weighted total (=), else +=
-  int32_t total_index, pad[3];
+  int32_t total_index, pad[3];             // pad[0]: chunks per pair-GEMM unit
   int32_t tile_begin[GQE_LAUNCH_BATCHES];  // contiguous copies for the "which batch am I" scan (one wide
   int32_t unit_begin[GQE_LAUNCH_BATCHES];  // scalar load); entries >= n_batches hold INT_MAX
   GqeDynBatch b[GQE_LAUNCH_BATCHES];

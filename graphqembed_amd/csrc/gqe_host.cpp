@@ -874,6 +874,21 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     // workgroup per CU at d >= 128) the tiles that start late should be the short chain tiles (~8 us), not the
     // ~30 us three-branch intersection tiles.
     bool any_candidates = false;
+    // pair-GEMM units cover kmul x GQE_GEMM_KCHUNK queries: with thousands of units (large batches) a unit walks several
+    // chunks before its one atomic pass over the 64 x 64 block — the units of a block all add into the same lines
+    int kmul = 1;
+    if (bwd) {
+      long long units1 = 0;
+      for (int k = 0; k < nb; ++k)
+        units1 += (long long)ctx->formulas[fid[b0 + k]].n_jobs * ((align_up(batches[b0 + k].n_queries, GQE_TQ) + GQE_GEMM_KCHUNK - 1) / GQE_GEMM_KCHUNK) * macros_sq;
+      while (kmul < 8 && units1 / (kmul * 2) >= GQE_GEMM_MIN_UNITS) kmul *= 2;   // ... but the launch keeps >= GQE_GEMM_MIN_UNITS units
+      static const int forced = [] {   // GQE_DEBUG_GEMM_KMUL: tuning runs only
+        const char* e = getenv("GQE_DEBUG_GEMM_KMUL");
+        return e ? atoi(e) : 0;
+      }();
+      if (forced == 1 || forced == 2 || forced == 4 || forced == 8) kmul = forced;
+    }
+    P.pad[0] = kmul;
     GqeDynBatch tmp[GQE_LAUNCH_BATCHES];
     int tiles_of[GQE_LAUNCH_BATCHES], units_of[GQE_LAUNCH_BATCHES], cost[GQE_LAUNCH_BATCHES], order[GQE_LAUNCH_BATCHES];
     for (int k = 0; k < nb; ++k) {
@@ -908,7 +923,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       if (bwd) {
         entry += (int64_t)(2 + f.n_anchors) * s.n_queries;
         scratch += (int64_t)f.n_slots * b.Bpad * d;
-        units_of[k] = f.n_jobs * ((b.Bpad + GQE_GEMM_KCHUNK - 1) / GQE_GEMM_KCHUNK) * macros_sq;
+        units_of[k] = f.n_jobs * ((b.Bpad + GQE_GEMM_KCHUNK * kmul - 1) / (GQE_GEMM_KCHUNK * kmul)) * macros_sq;
       } else if (s.n_candidates > 0 && bil && chain) {
         // candidate lists of a full-Bilinear chain: the projection runs on the candidate side, so the batch's tiles cover its
         // candidates (16 per tile, one [16 x d] . [d x d] contraction per hop on the matrix cores); the query of every

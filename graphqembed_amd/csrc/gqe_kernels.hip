@@ -62,7 +62,8 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
   const GqeDynBatch b = plan.b[bi];
   const GqeDevFormula* __restrict__ f = formulas + b.formula;
   const int mper = (d + MT - 1) / MT, macros = mper * mper;
-  const int chunks = (b.Bpad + GQE_GEMM_KCHUNK - 1) / GQE_GEMM_KCHUNK;
+  const int kmul = plan.pad[0];   // chunks of GQE_GEMM_KCHUNK queries this unit walks before its atomic pass
+  const int chunks = (b.Bpad + GQE_GEMM_KCHUNK * kmul - 1) / (GQE_GEMM_KCHUNK * kmul);
   int u = unit - b.unit_begin;
   const int job = u / (chunks * macros);
   u -= job * chunks * macros;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
   const int mt = u - chunk * macros;
   const int i0 = (mt / mper) * MT, j0 = (mt % mper) * MT;
   const int nib = (min(d - i0, MT)) >> 4, njb = (min(d - j0, MT)) >> 4;  // 16-wide tile columns present in this block
-  const int k_begin = chunk * GQE_GEMM_KCHUNK;
+  const int k_first = chunk * GQE_GEMM_KCHUNK * kmul;
   const size_t slot_floats = (size_t)b.Bpad * d;
   const float* L = ws + b.scratch_base + (size_t)f->job_L[job] * slot_floats;
   const float* R = ws + b.scratch_base + (size_t)f->job_R[job] * slot_floats;
@@ -82,6 +83,10 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
 #pragma unroll
     for (int y = 0; y < 2; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int kc = 0; kc < kmul; ++kc) {
+  const int k_begin = k_first + kc * GQE_GEMM_KCHUNK;
+  if (k_begin >= b.Bpad) break;
+  if (kc) __syncthreads();  // the previous chunk's second half is consumed
   // the whole K chunk is requested up front (16 float4 per thread) and fed through the LDS panels half by half.
   // Out-of-range lanes read the panel's first floats (always mapped) and are zeroed afterwards: a predicated load
   // would fence each load behind its own wait.
@@ -146,6 +151,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
     }
     GQE_GSTAMP(4 + 2 * h);
   }
+  }  // chunks of this unit
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll

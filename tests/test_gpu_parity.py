@@ -306,6 +306,8 @@ def test_random_schema_vs_oracle(dec, inter, d):
 
 
 @pytest.mark.parametrize("dec,inter,d,B", [("bilinear-diag", "min", 128, 1200), ("bilinear", "mean", 128, 1200), ("transe", "min-simple", 128, 1200),
+                                           # thousands of pair-GEMM units: a unit walks 2 / 4 chunks of 128 queries (ragged last ones)
+                                           ("bilinear-diag", "mean", 128, 4100), ("bilinear", "min", 128, 4100),
                                            ("bilinear-diag", "mean", 144, 40), ("bilinear", "min", 48, 40),
                                            ("bilinear-diag", "min", 176, 40), ("transe", "mean-simple", 240, 40), ("transe", "min", 112, 40)])
 def test_eight_wave_workgroups_vs_oracle(dec, inter, d, B):
