@@ -1600,8 +1600,12 @@ inline size_t gqe_fused_lds_bytes_impl(int d, bool stage, bool compact) {
 
 template <int DEC, bool MLP, int NC, bool FULL>
 static hipError_t launch_fused_v(const GqeFusedArgs& a) {
+  static const size_t lds_pad = [] {   // GQE_DEBUG_LDS_PAD: occupancy experiments only
+    const char* e = getenv("GQE_DEBUG_LDS_PAD");
+    return e ? (size_t)atol(e) : (size_t)0;
+  }();
   const size_t lds = gqe_fused_lds_bytes_impl(a.d, MLP && DEC != DEC_BILINEAR && FULL && NC <= 2 && GQE_FW == 16,
-                                              FusedShape<DEC, MLP, NC, FULL, GQE_FW>::COMPACT);
+                                              FusedShape<DEC, MLP, NC, FULL, GQE_FW>::COMPACT) + lds_pad;
   if (a.bwd)
     hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true, GQE_FW>), dim3(a.plan.tiles), dim3(GQE_FWT), lds, a.stream, a.plan,
                        a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags, a.link_contrib, a.link_counter,
