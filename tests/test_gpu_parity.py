@@ -343,6 +343,10 @@ def _eight_wave_case(dec, inter, d, B, many_tiles=True):
     np.testing.assert_allclose(neg.cpu().numpy(), np.concatenate(want_n), atol=SCORE_ATOL, rtol=1e-4)
     np.testing.assert_allclose(losses.cpu().numpy()[:-1], want_l, rtol=LOSS_RTOL, atol=1e-6)
     assert_grads_close(read_arena(eng, eng.grads), grads, "%s/%s d=%d B=%d" % (dec, inter, d, B), want32=grads32)
+    # the forward-only kernels of the same shape (their own instantiations, and at d = 128 their own LDS layout)
+    from graphqembed_amd.tensorize import pack_forward_batches
+    descs, idx, n = pack_forward_batches([(it[0], it[1], it[3]) for it in items])
+    np.testing.assert_allclose(eng.forward(descs, idx, n).cpu().numpy(), np.concatenate(want_p), atol=SCORE_ATOL, rtol=1e-4)
     eng.close()
 
 
