@@ -416,6 +416,8 @@ def measure_or_fall_back(wl, args, dist, rank, world, exchange, **kw):
     import torch
     err, got = None, None
     try:
+        if os.environ.get("GQE_BENCH_DEBUG_FAIL_SHARDED") in (str(rank), "all"):   # exercises this path (tests)
+            raise RuntimeError("GQE_BENCH_DEBUG_FAIL_SHARDED")
         got = measure(wl, args, dist, rank, world, exchange=exchange, **kw)
     except Exception as e:                                          # noqa: BLE001 - reported in the line
         err = "%s: %s" % (type(e).__name__, e)

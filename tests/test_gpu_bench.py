@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(argv, timeout):
-    env = dict(os.environ)
+def _run(argv, timeout, **extra_env):
+    env = dict(os.environ, **extra_env)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, cwd=ROOT, env=env, stdout=subprocess.PIPE,
@@ -39,6 +39,15 @@ def test_bench_two_ranks_self_launch():
     assert "row-sharded" in out["config"]["gradient_exchange"]
     assert out["reddit_synth"]["ranks_seen"] == 2 and out["reddit_synth"]["replicas_identical"] is True
     assert out["scaling"] == "weak" and out["cpu_baseline"] is None
+
+
+def test_bench_falls_back_to_the_sparse_exchange_when_the_sharded_session_fails():
+    """A node on which the row-sharded session cannot be brought up (plan board, the library's RCCL communicator): every
+    rank agrees on the failure and the line reports the replicated sparse exchange instead, saying so."""
+    out = _run(["--gpus", "2", "--backend", "gloo", "--steps", "20", "--warmup", "5", "--no-reddit"], 900, GQE_BENCH_DEBUG_FAIL_SHARDED="all")
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["replicas_identical"] is True
+    assert "GQE_BENCH_DEBUG_FAIL_SHARDED" in out["config"]["fell_back"]
+    assert "all-gather" in out["config"]["gradient_exchange"] and set(out["exchange"]) == {"sparse", "dense"}
 
 
 def test_bench_single_gpu_line_has_the_contract_keys():
