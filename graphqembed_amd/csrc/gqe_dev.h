@@ -91,7 +91,7 @@ struct GqeBagTable {
 
 struct GqeDynPlan {
   int32_t n_batches, tiles, units, first;  // first != 0: this launch starts the weighted total (=), else +=
-  int32_t total_index, pad[3];             // pad[0]: chunks per pair-GEMM unit
+  int32_t total_index, pad[3];             // pad[0]: chunks per pair-GEMM unit; pad[1]: write-through stores (vstore_wt)
   int32_t tile_begin[GQE_LAUNCH_BATCHES];  // contiguous copies for the "which batch am I" scan (one wide
   int32_t unit_begin[GQE_LAUNCH_BATCHES];  // scalar load); entries >= n_batches hold INT_MAX
   GqeDynBatch b[GQE_LAUNCH_BATCHES];

@@ -58,7 +58,26 @@ struct TileEnv {
   int32_t* link_counter;
   int32_t max_entries;
   int d, DP, wave, lane, q0;  // q0 = first query of this tile
+  bool wt;                    // write-through stores for what the next kernels read (vstore_wt)
 };
+
+// Rows another kernel (on whatever XCD) reads next — scratch rows for the pair GEMM, contribution entries for the optimiser
+// pass — are WRITTEN THROUGH (sc1) in launches of few tiles: the L2 of an XCD is not coherent with the others', so plain
+// stores sit dirty in it until the write-back at the kernel boundary, and at B = 512 that burst is on the step's critical
+// path (fused 28.7 -> 27.4 us, step 87.0 -> 85.6 us in an A / B / C on one box).  Launches with thousands of tiles keep plain
+// stores: there the boundary is amortised and write-through cost 1.5 % (B = 8192: 227 -> 230.5 us).
+template <int NC>
+__device__ __forceinline__ void vstore_wt(bool wt, float* p, const Vec<NC>& x, int d, int lane) {
+  if (wt) {   // workgroup-uniform
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int j = lane + 64 * c;
+      if (j < d) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p + j), "v"(x.v[c]) : "memory");
+    }
+  } else {
+    vstore<NC>(p, x, d, lane);
+  }
+}
 
 __device__ __forceinline__ float* scratch_row(const TileEnv& e, int slot, int r) {
   return e.ws + e.b.scratch_base + ((size_t)slot * e.b.Bpad + e.q0 + r) * e.d;
@@ -560,7 +579,7 @@ __device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_
   Vec<NC> gx;
   VEC_OP(gx, (g.v[c] - xhat.v[c] * pg) * inv);
   const int64_t entry = e.sharded ? (int64_t)row : e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
-  vstore<NC>(e.contrib + entry * e.d, gx, e.d, e.lane);
+  vstore_wt<NC>(e.wt, e.contrib + entry * e.d, gx, e.d, e.lane);
   // The returned previous head is only needed for next[entry]; that store is deferred to the end of the
   // kernel (push_links) so that the wave never stalls on the atomic's round trip.
   if (e.lane == 0 && !e.sharded) {
@@ -590,7 +609,7 @@ __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t h
   Vec<NC> gx;
   VEC_OP(gx, (g.v[c] - xhat.v[c] * pg) * inv);
   const int64_t entry = e.bag_shift + e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
-  vstore<NC>(e.contrib_bag + entry * e.d, gx, e.d, e.lane);
+  vstore_wt<NC>(e.wt, e.contrib_bag + entry * e.d, gx, e.d, e.lane);
   // entry -> "bag b of bag table s", for the data-parallel exchange: the importer re-expands the bag itself
   if (e.lane == 0) e.next[entry - e.max_entries] = GQE_BAG_CODE(bag_slot, bi);
   const int base = (int)entry * max_len;
@@ -710,7 +729,7 @@ __device__ __forceinline__ void tile_to_scratch(const TileEnv& e, int slot, cons
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr) {
     const int r = e.wave * RPW + rr;
-    vstore<NC>(scratch_row(e, slot, r), vload<NC>(tile + r * e.DP, e.d, e.lane), e.d, e.lane);
+    vstore_wt<NC>(e.wt, scratch_row(e, slot, r), vload<NC>(tile + r * e.DP, e.d, e.lane), e.d, e.lane);
   }
 }
 
@@ -777,6 +796,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
   e.link_counter = link_counter;
   e.max_entries = max_entries;
   e.d = d;
+  e.wt = plan.pad[1] != 0;
   e.DP = d + 4;
   // the wave index as an SGPR: everything derived from it (the rows a wave owns, their bounds checks, row base addresses) is then
   // scalar arithmetic and scalar branches instead of 64-bit VALU address math and EXEC masks issued for all 64 lanes
@@ -1103,8 +1123,8 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
         vstore<NC>(cur[0] + r * DP, RT.x[rr], d, lane);
         if (has_neg) vstore<NC>(cur[1] + r * DP, RN.x[rr], d, lane);
         if (BWD) {
-          vstore<NC>(scratch_row(e, f->slot_act[0][0], r), RT.x[rr], d, lane);
-          vstore<NC>(scratch_row(e, f->slot_act[1][0], r), RN.x[rr], d, lane);
+          vstore_wt<NC>(e.wt, scratch_row(e, f->slot_act[0][0], r), RT.x[rr], d, lane);
+          vstore_wt<NC>(e.wt, scratch_row(e, f->slot_act[1][0], r), RN.x[rr], d, lane);
         }
       }
       for (int h = 0; h < K; ++h) {
@@ -1203,7 +1223,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
         for (int rr = 0; rr < RPW; ++rr) {
           const int r = wave * RPW + rr;
           vstore<NC>(src + r * DP, RA[i].x[rr], d, lane);
-          if (BWD) vstore<NC>(scratch_row(e, f->slot_x[i][0], r), RA[i].x[rr], d, lane);
+          if (BWD) vstore_wt<NC>(e.wt, scratch_row(e, f->slot_x[i][0], r), RA[i].x[rr], d, lane);
         }
         for (int h = 0; h < nh; ++h) {
           __syncthreads();
@@ -1229,7 +1249,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
           VEC_OP(x, (DEC == DEC_DIAG) ? x.v[c] * w0.v[c] : x.v[c] + w0.v[c]);
           if (nh > 1) VEC_OP(x, (DEC == DEC_DIAG) ? x.v[c] * w1.v[c] : x.v[c] + w1.v[c]);
           vstore<NC>(te[i] + r * DP, x, d, lane);
-          if (MLP && BWD) vstore<NC>(scratch_row(e, f->slot_e[i], r), x, d, lane);
+          if (MLP && BWD) vstore_wt<NC>(e.wt, scratch_row(e, f->slot_e[i], r), x, d, lane);
         }
       }
     }
@@ -1452,7 +1472,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
             Vec<NC> gz;
 #pragma unroll
             for (int c = 0; c < NC; ++c) gz.v[c] = keep_if_bit(gh[c], mt[c], 8 + i);
-            vstore<NC>(scratch_row(e, f->slot_gz[i], r), gz, d, lane);
+            vstore_wt<NC>(e.wt, scratch_row(e, f->slot_gz[i], r), gz, d, lane);
           }
         }
         if (STAGE) {

@@ -951,6 +951,8 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       P.tiles += tiles_of[order[pos]];
       P.units += units_of[order[pos]];
     }
+    // few tiles: what the next kernels read is written through (gqe_fused.h, vstore_wt); thousands: plain stores
+    P.pad[1] = (bwd && P.tiles <= GQE_FW8_MIN_TILES) ? 1 : 0;
     if ((size_t)(scratch * (int64_t)sizeof(float)) > L.scratch_off + L.scratch_cap)
       return fail(ctx, GQE_ERR_WORKSPACE, "workspace too small for this call (bound for %lld queries, %d batches)",
                   (long long)ctx->cap_queries, ctx->cap_batches);
