@@ -138,6 +138,13 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise GqeLibraryError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950). There is no CPU fallback." % p)
+    # torch first: it brings its OWN libamdhip64 / libhsa-runtime64 (torch/lib).  Loaded after libgqe.so had bound the
+    # system ROCm's copies, the process would hold two HIP runtimes and the second one to initialise sees no device
+    # ("no ROCm-capable device is detected" from gqe_create, although torch.cuda.is_available())
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = C.CDLL(p)
     except OSError as e:
