@@ -299,3 +299,19 @@ def test_rank_candidates_against_scipy_including_nan():
         assert (np.isnan(want) and np.isnan(mine)) or abs(mine - want) < 1e-9, (i, mine, want)
     assert np.isnan(got[3]) and np.isnan(got[7]) and not np.isnan(got[9])
     eng.close()
+
+
+@pytest.mark.parametrize("env", [{"GQE_DEBUG_GEMM_KMUL": "8"}, {"GQE_DEBUG_GEMM_KMUL": "1"}, {"GQE_DEBUG_FW8_MIN_TILES": "0"},
+                                 {"GQE_DEBUG_FW8_MIN_TILES": "1000000"}])
+def test_tuning_switches_do_not_change_results(env):
+    """The launch-shape heuristics (chunks per pair-GEMM unit, 8- vs 16-wave tiles at d = 128) pick between kernels that must
+    agree: the d = 128 many-tile parity cases run again in a process of their own with the heuristic forced either way
+    (the switches are read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        "-k", "eight_wave and 128 and bilinear-diag"], cwd=root, env=dict(os.environ, **env), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:]
