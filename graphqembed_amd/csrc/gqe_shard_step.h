@@ -111,6 +111,12 @@ struct ShardSession {
   ShardPlanSlot slot[GQE_SHARD_SLOTS];
   ShardPins pins[GQE_SHARD_PINS];
   uint64_t next_post = 0, next_run = 0;
+  // "everything up to step e has run" events, recorded every 4th step (two kept): what a pinned buffer set waits for before it
+  // is re-used GQE_SHARD_PINS steps later — an event per step cost the host 1.6 us of each
+  hipEvent_t ring_ev[2] = {nullptr, nullptr};
+  uint64_t ring_ev_step[2] = {0, 0};
+  bool ring_ev_set[2] = {false, false};
+  std::vector<std::pair<int64_t, int64_t>> uni;   // scratch of shard_collect: union of the touched tensors (no per-step allocation)
   // planning thread (one per session): takes the step numbers gqe_shard_post queues
   gqe_ctx* ctx = nullptr;
   std::thread planner;
@@ -176,6 +182,12 @@ void shard_session_free(ShardSession* S) {
     fprintf(stderr, "[gqe shard profile] rank %d, %lld steps: host time per step %.1f us\n", S->rank, S->host_n, tot / (double)S->host_n);
     for (int k = 0; k < 10; ++k) fprintf(stderr, "[gqe shard profile]   %-34s %7.1f us\n", kShardPhase[k], S->host_us[k] / (double)S->host_n);
   }
+  if (S->next_run > 0) (void)hipDeviceSynchronize();   // steps behind the last recorded event may still read the pinned feeds
+  for (int k = 0; k < 2; ++k)
+    if (S->ring_ev[k]) {
+      if (S->ring_ev_set[k]) (void)hipEventSynchronize(S->ring_ev[k]);
+      (void)hipEventDestroy(S->ring_ev[k]);
+    }
   for (auto& pn : S->pins) {
     if (pn.done) {
       if (pn.done_set) (void)hipEventSynchronize(pn.done);
@@ -318,7 +330,8 @@ struct ShardCollected {
 // of the touched tensors, acknowledge
 int shard_collect(gqe_ctx* ctx, ShardSession* S, uint64_t t, int s, int kind, ShardCollected& out) {
   const int W = S->world, me = S->rank;
-  std::map<int64_t, int64_t> uni;
+  std::vector<std::pair<int64_t, int64_t>>& uni = S->uni;
+  uni.clear();
   int32_t* dst = S->pins[S->slot[s].pin].req;
   const int64_t cap = ctx->lay.shard_cap_recv;
   for (int j = 0; j < W; ++j) {
@@ -337,13 +350,16 @@ int shard_collect(gqe_ctx* ctx, ShardSession* S, uint64_t t, int s, int kind, Sh
     out.recv_counts[j] = n;
     out.n_recv += n;
     for (int k = 0; k < P->n_segs; ++k) {
-      auto it = uni.find(P->seg_off[k]);
-      if (it != uni.end() && it->second != P->seg_numel[k])
+      size_t at = 0;
+      while (at < uni.size() && uni[at].first != P->seg_off[k]) ++at;   // a few dozen tensors: a scan beats a tree
+      if (at < uni.size() && uni[at].second != P->seg_numel[k])
         return fail(ctx, GQE_ERR_ARG, "row-sharded step: ranks disagree about the tensor at offset %lld", (long long)P->seg_off[k]);
-      uni[P->seg_off[k]] = P->seg_numel[k];
+      if (at == uni.size()) uni.emplace_back(P->seg_off[k], P->seg_numel[k]);
     }
     S->ack(me, j, s)->store(t + 1, std::memory_order_release);
   }
+  std::sort(uni.begin(), uni.end());   // arena order
+  out.segs.reserve(uni.size());
   for (auto& kv : uni) out.segs.push_back(gqe_segment{kv.first, kv.second, 0, 0});
   return GQE_OK;
 }
@@ -478,9 +494,13 @@ int shard_run(gqe_ctx* ctx, int kind, float lr, float b1, float b2, float eps, f
     }
     clk.mark(8);
   }
-  if (!pn.done) HIP_TRY(ctx, hipEventCreateWithFlags(&pn.done, hipEventDisableTiming));
-  HIP_TRY(ctx, hipEventRecord(pn.done, st));
-  pn.done_set = true;
+  if ((t & 3) == 3) {   // (steps 3, 7, 11, ...: the buffers of step t are re-used at step t + 8, by when step t | 3 has been enqueued)
+    const int k = (int)((t >> 2) & 1);
+    if (!S->ring_ev[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&S->ring_ev[k], hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(S->ring_ev[k], st));
+    S->ring_ev_step[k] = t;
+    S->ring_ev_set[k] = true;
+  }
   clk.mark(9);
   ++S->host_n;
   return GQE_OK;
@@ -630,9 +650,14 @@ int gqe_shard_post(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
   // board slot's previous post (step t - 2)
   sl.pin = (int)(t % GQE_SHARD_PINS);
   ShardPins& pn = S->pins[sl.pin];
-  if (pn.done_set) {
-    if (hipEventQuery(pn.done) != hipSuccess) HIP_TRY(ctx, hipEventSynchronize(pn.done));
-    pn.done_set = false;
+  if (t >= GQE_SHARD_PINS) {
+    // the step that used these buffers last (t - 8) has run: the OLDER recorded event that covers it, else the newer one
+    const uint64_t need = t - GQE_SHARD_PINS;
+    int pick = -1;
+    for (int k = 0; k < 2; ++k)
+      if (S->ring_ev_set[k] && S->ring_ev_step[k] >= need && (pick < 0 || S->ring_ev_step[k] < S->ring_ev_step[pick])) pick = k;
+    if (pick < 0) return fail(ctx, GQE_ERR_STATE, "row-sharded post %llu: step %llu has not been run", (unsigned long long)t, (unsigned long long)need);
+    if (hipEventQuery(S->ring_ev[pick]) != hipSuccess) HIP_TRY(ctx, hipEventSynchronize(S->ring_ev[pick]));
   }
   if (!pn.pos) {
     HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&pn.pos), sizeof(int32_t) * (size_t)std::max<int64_t>(S->cap_req, 1), hipHostMallocDefault));
