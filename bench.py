@@ -72,6 +72,20 @@ def pmc_traffic(kernel, tag):
     return None
 
 
+def rocprof_ms(kernel, tag):
+    """Average duration (ms) of ``kernel`` in the newest committed rocprofv3 kernel trace of this workload
+    (profiles/r*_pmc_traffic.json carries it as ``rocprof_avg_us``): the figure to compare with ``avg_launch_ms``, whose hipEvent
+    bracket also contains the launch boundary in front of the kernel."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        with open(path) as f:
+            data = json.load(f)
+        entry = data.get(tag, {}).get(kernel)
+        if entry and entry.get("rocprof_avg_us") is not None:
+            return round(entry["rocprof_avg_us"] * 1e-3, 5)
+    return None
+
+
 def build_layout(g, d, decoder, inter, shard_world=1):
     """``shard_world`` > 1: the layout of ONE rank's shards in row-sharded mode (ceil(rows / world) rows per table)."""
     from graphqembed_amd.engine import ArenaLayout
@@ -132,10 +146,12 @@ def mfma_flops(qtype, decoder, inter, d, n):
 class Workload(object):
     """A synthetic graph, its parameter layout, query pools and ``n_distinct`` pre-sampled iterations."""
 
-    def __init__(self, name, d, decoder, inter, mix, B, rank=0, world=1, n_distinct=32, formulas_per_type=6):
+    def __init__(self, name, d, decoder, inter, mix, B, rank=0, world=1, n_distinct=32, formulas_per_type=6, zipf=None):
+        """``zipf`` = exponent: node degrees (and reddit-synth's word frequencies) follow 1 / rank^zipf instead of the uniform
+        draw — hub rows collect hundreds of gradient contributions per step (synth.CsrGraph)."""
         from graphqembed_amd import synth
-        self.name, self.d, self.decoder, self.inter, self.mix, self.B = name, d, decoder, inter, mix, B
-        self.g = synth.reddit_synth(seed=0) if name == "reddit-synth" else synth.bio_synth(seed=0)
+        self.name, self.d, self.decoder, self.inter, self.mix, self.B, self.zipf = name, d, decoder, inter, mix, B, zipf
+        self.g = synth.reddit_synth(seed=0, zipf=zipf) if name == "reddit-synth" else synth.bio_synth(seed=0, zipf=zipf)
         self.layout = build_layout(self.g, d, decoder, inter)
         self.types = sorted(set(m[0] for m in mix))
         self.pools = synth.make_pools(self.g, self.types, formulas_per_type=formulas_per_type, pool_size=max(16 * B, 8192), seed=0)
@@ -148,7 +164,8 @@ class Workload(object):
     def describe(self):
         g = self.g
         n_rel = sum(len(v) for v in g.relations.values())
-        return "%d modes, %d nodes, %d directed relations, seed 0" % (len(g.modes), sum(g.mode_sizes.values()), n_rel)
+        return "%d modes, %d nodes, %d directed relations, seed 0%s" % (len(g.modes), sum(g.mode_sizes.values()), n_rel,
+                                                                       (", Zipf(%.2g) degrees%s" % (self.zipf, " and word frequencies" if g.bags else "")) if self.zipf else "")
 
     def engine(self, rank=0, world=1, lazy=False, shard=None):
         """``shard`` = (rank, world): row-sharded mode — the engine holds this rank's shards of the tables."""
@@ -191,10 +208,19 @@ class Workload(object):
             direct = bagged = links = 0                            # gradient contributions: on table rows / on bags; word links
             aq = 0.0
             ff = gf = 0.0
+            per_row = {}                                           # contributions per table row of the step (the longest gradient list)
             for (f, t, ng, a, w, m) in items:
                 n = len(t)
                 roles = [(f.target_mode, t), (f.target_mode, ng)] + [(am, a[i]) for i, am in enumerate(f.anchor_modes)]
                 for mode, rows in roles:
+                    cnt = per_row.setdefault(mode, np.zeros(self.g.table_rows[mode], dtype=np.int64))
+                    if mode in bag_len:
+                        ptr, ids = self.g.bags[mode]
+                        lens = bag_len[mode][rows]
+                        flat = np.repeat(ptr[rows].astype(np.int64), lens) + (np.arange(int(lens.sum())) - np.repeat(np.cumsum(lens) - lens, lens))
+                        cnt += np.bincount(ids[flat], minlength=len(cnt))
+                    else:
+                        cnt += np.bincount(rows, minlength=len(cnt))
                     if mode in bag_len:                            # a post = the mean of its word rows
                         words = int(bag_len[mode][rows].sum())
                         bagged += n
@@ -211,6 +237,8 @@ class Workload(object):
             p_den = sum(eng.layout.numel(k) for k in keys if not k.startswith("enc."))
             rows_tab = sum(eng.layout.entries[k][1][0] for k in keys if k.startswith("enc."))
             ps["n_entries"], ps["aq_bytes"], ps["fused_flops"], ps["gemm_flops"] = direct + bagged, aq, ff, gf
+            ps["longest_list"] = int(max(int(c.max()) for c in per_row.values()))
+            ps["rows_over_32"] = int(sum(int((c > 32).sum()) for c in per_row.values()))
             ps["p_touched"] = p_tab + p_den
             # the fused Adam pass: p, m, v of every table parameter in and out; p, g, m, v in / p, m, v, g := 0 out for the
             # relation / Pre / Post tensors; one list head per table row; per contribution on a row its vector, its link
@@ -220,8 +248,16 @@ class Workload(object):
         return prepared
 
 
-def kernel_block(eng, prepared, used, ms_per_step, lazy=False, world=1, d=128):
-    """roofline / kernels / step_roofline from the library's hipEvent timings of the timed region."""
+EVENT_NOTE = ("avg_launch_ms = mean time between the two hipEvents the library records around a launch on the launch stream: "
+              "it contains the launch boundary in front of the kernel (1.5-3 us here, MI355X_MICROARCH.md 'boundary'), so the "
+              "three brackets of a step add up to MORE than ms_per_step and every GB/s / TF/s derived from them is a lower bound; "
+              "rocprof_avg_launch_ms = the kernel's own duration in the committed rocprofv3 trace of the same command "
+              "(profiles/, null for configurations that were not profiled)")
+
+
+def kernel_block(eng, prepared, used, ms_per_step, lazy=False, world=1, d=128, tag=None):
+    """roofline / kernels / step_roofline from the library's hipEvent timings of the timed region.  ``tag``: the workload
+    whose committed rocprofv3 trace this configuration corresponds to (None: not profiled)."""
     ms_fused, n_fused = eng.timing_read(0)
     ms_gemm, n_gemm = eng.timing_read(1)
     ms_opt, n_opt = eng.timing_read(2)
@@ -239,16 +275,22 @@ def kernel_block(eng, prepared, used, ms_per_step, lazy=False, world=1, d=128):
 
     def tfs(flops, ms):
         return round(flops / (ms * 1e-3) / 1e12, 2) if ms > 0 and flops > 0 else None
+    rp = (lambda k: rocprof_ms(k, tag)) if (tag and not lazy and world == 1) else (lambda k: None)
+    rp_opt, rp_fused, rp_gemm = rp("gqe_opt_kernel"), rp("gqe_fused_kernel"), rp("gqe_pair_gemm_kernel")
     out = {
         "roofline": {"bound": "hbm", "kernel": opt_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 4),
                      "traffic": None, "algorithmic_bytes_per_launch": a_opt, "survey_bytes_per_launch": survey,
-                     "avg_launch_ms": round(ms_opt, 5), "launches": n_opt},
-        "kernels": {"fused_fwd_bwd": {"avg_launch_ms": round(ms_fused, 5), "launches": n_fused, "algorithmic_bytes_per_launch": a_q,
+                     "avg_launch_ms": round(ms_opt, 5), "launches": n_opt, "rocprof_avg_launch_ms": rp_opt,
+                     "frac_at_rocprof_duration": round(a_opt / (rp_opt * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if rp_opt else None},
+        "kernels": {"timing_note": EVENT_NOTE,
+                    "sum_of_event_brackets_ms": round(ms_fused + ms_gemm + ms_opt, 5),
+                    "sum_of_rocprof_durations_ms": round(rp_opt + rp_fused + rp_gemm, 5) if (rp_opt and rp_fused and rp_gemm) else None,
+                    "fused_fwd_bwd": {"avg_launch_ms": round(ms_fused, 5), "rocprof_avg_launch_ms": rp_fused, "launches": n_fused, "algorithmic_bytes_per_launch": a_q,
                                       "achieved_GBs": round(a_q / (ms_fused * 1e-3) / 1e9, 1) if ms_fused > 0 else None,
                                       "mfma_flop_per_launch": ff, "mfma_TFs": tfs(ff, ms_fused),
                                       "mfma_frac_of_f32_peak": round(ff / (ms_fused * 1e-3) / 1e12 / MFMA_F32_TFS, 4) if ms_fused > 0 and ff else None},
-                    "pair_gemm": {"avg_launch_ms": round(ms_gemm, 5), "launches": n_gemm, "mfma_flop_per_launch": gf,
+                    "pair_gemm": {"avg_launch_ms": round(ms_gemm, 5), "rocprof_avg_launch_ms": rp_gemm, "launches": n_gemm, "mfma_flop_per_launch": gf,
                                   "mfma_TFs": tfs(gf, ms_gemm),
                                   "mfma_frac_of_f32_peak": round(gf / (ms_gemm * 1e-3) / 1e12 / MFMA_F32_TFS, 4) if ms_gemm > 0 and gf else None}},
         "step_roofline": {"algorithmic_bytes_per_step": a_opt + a_q,
@@ -373,7 +415,11 @@ def measure(wl, args, dist, rank, world, exchange="sparse", lazy=False, steps=No
     ms_per_step = med * 1e3 / steps
     used = prepared[:min(steps, wl.n_distinct)]
     out = {"value": round(steps * wl.qpi * world / med, 1), "unit": "queries/s", "ms_per_step": round(ms_per_step, 4), "timing": blocks}
-    out.update(kernel_block(eng, prepared, used, ms_per_step, lazy=lazy, world=world if sparse else 1, d=wl.d))
+    profiled = (wl.d, wl.B, wl.decoder, wl.inter, wl.zipf, len(wl.mix)) == ((256 if wl.name == "reddit-synth" else 128), 512, "bilinear-diag", "min", None, 9)
+    out.update(kernel_block(eng, prepared, used, ms_per_step, lazy=lazy, world=world if sparse else 1, d=wl.d,
+                            tag=wl.name if (profiled and world == 1) else None))
+    out["longest_gradient_list"] = int(max(p["longest_list"] for p in used))
+    out["rows_with_over_32_contributions"] = int(max(p["rows_over_32"] for p in used))
     eng.timing_enable(0)
     loss = float(prepared[loop.last_step % wl.n_distinct]["losses"][-1].item())
     if not np.isfinite(loss):
@@ -496,19 +542,36 @@ def cpu_baseline(eng, decoder, inter, item_sets, budget_s, queries_per_iter):
     port = TorchPort(params, decoder, inter)
     sets = [[(make_plan(f.query_type, f.rels), t, g, a, w, m) for (f, t, g, a, w, m) in items] for items in item_sets]
     default_threads = torch.get_num_threads()
+    try:
+        import psutil
+        physical = int(psutil.cpu_count(logical=False) or default_threads)
+    except Exception:                                              # noqa: BLE001
+        physical = default_threads
     port.train_iteration(sets[0])                                  # warm-up (allocator, Adam state)
+
+    def rate(nt, iters):
+        torch.set_num_threads(nt)
+        port.train_iteration(sets[0])
+        t0 = time.time()
+        for k in range(iters):
+            port.train_iteration(sets[(k + 1) % len(sets)])
+        return (time.time() - t0) / iters
+    # the port at n = 1 and at n = all physical cores, stated next to the best of a short sweep (torch's
+    # default — one thread per hardware thread — is far from its best on a 2 x 64-core host)
+    fixed = {}
+    for nt in sorted(set([1, physical])):
+        dt = rate(nt, 2)
+        fixed[nt] = {"threads": nt, "value": round(queries_per_iter / dt, 1), "unit": "queries/s", "iterations": 2}
     best = (None, 1e30)
     for nt in sorted(set([8, 16, 32, 64, default_threads])):
         if nt > default_threads:
             continue
-        torch.set_num_threads(nt)
-        port.train_iteration(sets[0])
-        t0 = time.time()
-        for k in range(2):
-            port.train_iteration(sets[(k + 1) % len(sets)])
-        dt = (time.time() - t0) / 2
+        dt = rate(nt, 2)
         if dt < best[1]:
             best = (nt, dt)
+    for nt, r in fixed.items():
+        if queries_per_iter / best[1] < r["value"]:
+            best = (nt, queries_per_iter / r["value"])
     torch.set_num_threads(best[0])
     n, t0 = 0, time.time()
     while True:
@@ -520,8 +583,9 @@ def cpu_baseline(eng, decoder, inter, item_sets, budget_s, queries_per_iter):
     torch.set_num_threads(default_threads)
     return {"value": round(n * queries_per_iter / el, 1), "unit": "queries/s", "cores": int(best[0]),
             "kind": "port", "sample": "%d full-mix iterations (9x512 queries, P=%d, dense torch Adam) in %.1f s with %d threads "
-            "(best of a sweep; host exposes %d); oracle/netquery_torch.py, torch %s"
-            % (n, eng.layout.total, el, best[0], default_threads, torch.__version__)}
+            "(best of a sweep over 1 / 8 / 16 / 32 / 64 / %d physical cores / %d hardware threads); oracle/netquery_torch.py, torch %s"
+            % (n, eng.layout.total, el, best[0], physical, default_threads, torch.__version__),
+            "one_thread": fixed[1], "all_physical_cores": fixed[physical], "physical_cores": physical, "hardware_threads": default_threads}
 
 
 def slim(res):
@@ -529,7 +593,8 @@ def slim(res):
     k = res["kernels"]
     out = {"value": res["value"], "unit": "queries/s", "ms_per_step": res["ms_per_step"], "timing": res["timing"],
            "final_loss": res["final_loss"],
-           "kernels_ms": {name: v["avg_launch_ms"] for name, v in k.items()},
+           "kernels_ms": {name: v["avg_launch_ms"] for name, v in k.items() if isinstance(v, dict)},
+           "longest_gradient_list": res.get("longest_gradient_list"),
            "optimiser": {"avg_launch_ms": res["roofline"]["avg_launch_ms"], "achieved_GBs": res["roofline"]["achieved"],
                          "frac": res["roofline"]["frac"], "algorithmic_bytes_per_launch": res["roofline"]["algorithmic_bytes_per_launch"]},
            "fused_mfma_TFs": k["fused_fwd_bwd"]["mfma_TFs"], "pair_gemm_mfma_TFs": k["pair_gemm"]["mfma_TFs"],
@@ -685,8 +750,8 @@ def main():
         cfgs = {}
         M = synth.FULL_MIX
 
-        def run_cfg(name, decoder, mix, Bc, note):
-            w = Workload("bio-synth", d, decoder, args.inter_decoder, mix, Bc, n_distinct=16 if Bc > 512 else 32)
+        def run_cfg(name, decoder, mix, Bc, note, zipf=None):
+            w = Workload("bio-synth", d, decoder, args.inter_decoder, mix, Bc, n_distinct=16 if Bc > 512 else 32, zipf=zipf)
             r, e, _ = measure(w, args, None, 0, 1, **(dict(short, steps=20) if Bc > 512 else short))
             e.close()
             s = slim(r)
@@ -699,6 +764,9 @@ def main():
         run_cfg("C3_scaled_batch_B8192", args.decoder, M, 8192, "full mix, scaled batch (B=512 is launch-latency-bound)")
         run_cfg("C3_plus_3chain_inter", args.decoder, M + (("3-chain_inter", 0.005, False), ("3-chain_inter", 0.005, True)), B,
                 "11-batch mix incl. 3-chain_inter (model.py:99-109)")
+        run_cfg("C3_zipf", args.decoder, M, B, "full mix on a HEAVY-TAILED graph: node degrees ~ 1 / rank (hub proteins: graph.py:108-122 keeps "
+                "the real adjacency; every other line here is on uniform-random graphs)", zipf=1.0)
+        cfgs["C3_zipf"]["optimiser_vs_uniform"] = round(cfgs["C3_zipf"]["optimiser"]["avg_launch_ms"] / res["roofline"]["avg_launch_ms"], 3)
         out["configs"] = cfgs
     if not args.no_reddit and not reddit:
         if eng is not None and world > 1:
@@ -720,6 +788,17 @@ def main():
             rs["lazy_exact_adam"] = {"value": lz["value"], "unit": "queries/s", "ms_per_step": lz["ms_per_step"], "kernels_ms": lz["kernels_ms"],
                                      "note": "NON-DEFAULT mode (see lazy_exact_adam above); full pass every <= 32 steps and the final sync inside the timed region"}
         out["reddit_synth"] = rs
+        if world == 1:
+            # the same workload with Zipfian word frequencies and node degrees (a real vocabulary: reddit/data_utils_new.py:155,162-169)
+            wz = Workload("reddit-synth", 256, args.decoder, args.inter_decoder, synth.FULL_MIX, B, n_distinct=16, zipf=1.0)
+            rz, ez, _ = measure(wz, args, None, 0, 1, **short)
+            ez.close()
+            zs = slim(rz)
+            zs["config"] = "reddit-synth with Zipf(1) word frequencies and node degrees (%s), same mix / d / decoders" % wz.describe()
+            zs["rows_with_over_32_contributions"] = rz["rows_with_over_32_contributions"]
+            zs["optimiser_vs_uniform"] = round(zs["optimiser"]["avg_launch_ms"] / rs["optimiser"]["avg_launch_ms"], 3)
+            zs["fused_vs_uniform"] = round(zs["kernels_ms"]["fused_fwd_bwd"] / rs["kernels_ms"]["fused_fwd_bwd"], 3)
+            out["reddit_synth_zipf"] = zs
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not reddit:
         out["cpu_baseline"] = cpu_baseline(eng, args.decoder, args.inter_decoder, wl.item_sets[:8], args.cpu_seconds, wl.qpi)
     elif rank == 0:

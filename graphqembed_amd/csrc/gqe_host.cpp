@@ -218,6 +218,10 @@ struct gqe_feeder {
   hipEvent_t pin_ev[2] = {nullptr, nullptr};
   bool pin_ev_set[2] = {false, false};
   long long pin_it = 0;  // iterations fed so far
+  // prepared iterations, pinned slots and their guard events are keyed on the iteration number: a run that does not continue
+  // where the previous one ended (or changes burn_in) starts from a clean ring
+  int64_t next_it = -1;
+  int32_t last_burn_in = -1;
 };
 
 namespace {
@@ -1594,6 +1598,9 @@ int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* strea
   if (ctx->cap_queries < 1) return fail(ctx, GQE_ERR_STATE, "call gqe_workspace_bytes first");
   if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "gradients pending; step or materialize before re-binding the workspace");
   if (lazy_any_dirty(ctx)) return fail(ctx, GQE_ERR_STATE, "lazy Adam: call gqe_optimizer_sync before re-binding the workspace");
+  // an open row-sharded session sized its plan board and pinned feeds for the bound capacities, its planning thread may be
+  // sorting a posted feed against them right now, and the peers did not grow with this rank
+  if (ctx->shard_sess) return fail(ctx, GQE_ERR_STATE, "a row-sharded session is open: gqe_shard_close first, bind the same (larger) capacities on every rank, re-open");
   if (ctx->shard_on && (int)ctx->tables.size() > GQE_LAZY_TABLES) return fail(ctx, GQE_ERR_ARG, "row-sharded mode supports at most %d tables", GQE_LAZY_TABLES);
   const Layout L = make_layout(ctx, ctx->cap_queries, ctx->cap_batches);
   if ((int64_t)L.total > bytes) return fail(ctx, GQE_ERR_WORKSPACE, "workspace has %lld bytes, %zu needed", (long long)bytes, L.total);
@@ -2387,6 +2394,16 @@ int gqe_feeder_run(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations,
   if (shard && !ctx->shard_sess) return fail(ctx, GQE_ERR_STATE, "row-sharded ctx: gqe_shard_open comes before gqe_feeder_run");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t end = first_iteration + n_iterations;
+  if (f->next_it >= 0 && (first_iteration != f->next_it || burn_in != f->last_burn_in)) {
+    // re-running a range would silently re-use the cached samples (and ignore another burn_in), and a slot of the ring could
+    // be overwritten while kernels of the old range still read it: its guard event belongs to another group
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (ctx->up) HIP_TRY(ctx, hipStreamSynchronize(ctx->up));
+    for (auto& q : f->prep) q.it = -1;
+    for (int k = 0; k < 2; ++k) f->pin_ev_set[k] = f->grp_free_set[k] = false;
+  }
+  f->next_it = end;
+  f->last_burn_in = burn_in;
   for (int64_t it = first_iteration; it < end; ++it) {
     int rc = feeder_ensure(f, it, burn_in, st);
     if (rc != GQE_OK) return rc;

@@ -111,6 +111,10 @@ struct ShardSession {
   ShardPlanSlot slot[GQE_SHARD_SLOTS];
   ShardPins pins[GQE_SHARD_PINS];
   uint64_t next_post = 0, next_run = 0;
+  // a step failed AFTER its plan was consumed: the plans posted ahead no longer line up with what the caller believes is next
+  // (and the peers may be mid-exchange), so every later post / step is refused until the session is closed and re-opened
+  bool poisoned = false;
+  std::string poison_why;
   // "everything up to step e has run" events, recorded every 4th step (two kept): what a pinned buffer set waits for before it
   // is re-used GQE_SHARD_PINS steps later — an event per step cost the host 1.6 us of each
   hipEvent_t ring_ev[2] = {nullptr, nullptr};
@@ -364,22 +368,27 @@ int shard_collect(gqe_ctx* ctx, ShardSession* S, uint64_t t, int s, int kind, Sh
   return GQE_OK;
 }
 
+int shard_run_consumed(gqe_ctx* ctx, ShardSession* S, uint64_t t, int s, int kind, ShardCollected& col, ShardClock& clk, float lr, float b1,
+                       float b2, float eps, float* losses, float* pos, float* neg, void* stream);
+
+int shard_poisoned(gqe_ctx* ctx, ShardSession* S) {
+  return fail(ctx, GQE_ERR_STATE, "row-sharded session: an earlier step failed after its plan was consumed (%s): gqe_shard_close and re-open it",
+              S->poison_why.c_str());
+}
+
 int shard_run(gqe_ctx* ctx, int kind, float lr, float b1, float b2, float eps, float* losses, float* pos, float* neg, void* stream) {
   if (!ctx) return GQE_ERR_ARG;
   ShardSession* S = ctx->shard_sess;
   if (!S) return fail(ctx, GQE_ERR_STATE, "gqe_shard_open has not been called");
   if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
+  if (S->poisoned) return shard_poisoned(ctx, S);
   if (S->next_run == S->next_post) return fail(ctx, GQE_ERR_STATE, "no posted plan to run (gqe_shard_post first)");
   const uint64_t t = S->next_run;
   const int s = (int)(t % GQE_SHARD_SLOTS);
   ShardPlanSlot& sl = S->slot[s];
-  ShardPins& pn = S->pins[sl.pin];
   if (sl.kind != kind) return fail(ctx, GQE_ERR_STATE, "the oldest posted plan is a %s step", sl.kind ? "margin" : "forward");
   if (kind == 1 && !losses) return fail(ctx, GQE_ERR_ARG, "losses buffer is NULL");
   if (kind == 0 && !pos) return fail(ctx, GQE_ERR_ARG, "scores buffer is NULL");
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const Layout& L = ctx->lay;
-  const int d = ctx->cfg.dim;
   ShardCollected col;
   memset(col.recv_counts, 0, sizeof col.recv_counts);
   ShardClock clk(S);
@@ -395,6 +404,38 @@ int shard_run(gqe_ctx* ctx, int kind, float lr, float b1, float b2, float eps, f
   clk.mark(2);
   ++S->next_run;   // the plan is consumed whatever happens below
   sl.posted = false;
+  rc = shard_run_consumed(ctx, S, t, s, kind, col, clk, lr, b1, b2, eps, losses, pos, neg, stream);
+  if (rc != GQE_OK) {
+    // the caller may catch the error and go on: without this the plan posted ahead would be taken for the next step's, the
+    // open hipEvent brackets would never close and the buffer-reuse event of this step would be missing
+    S->poisoned = true;
+    S->poison_why = ctx->err;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int k = 5; k <= 6; ++k)
+      if (ctx->timing_open[k]) {
+        (void)hipEventRecord(ctx->timed[k].back().stop, st);
+        ctx->timing_open[k] = false;
+      }
+    if ((t & 3) == 3) {
+      const int k = (int)((t >> 2) & 1);
+      if (!S->ring_ev[k]) (void)hipEventCreateWithFlags(&S->ring_ev[k], hipEventDisableTiming);
+      if (S->ring_ev[k] && hipEventRecord(S->ring_ev[k], st) == hipSuccess) {
+        S->ring_ev_step[k] = t;
+        S->ring_ev_set[k] = true;
+      }
+    }
+  }
+  return rc;
+}
+
+int shard_run_consumed(gqe_ctx* ctx, ShardSession* S, uint64_t t, int s, int kind, ShardCollected& col, ShardClock& clk, float lr, float b1,
+                       float b2, float eps, float* losses, float* pos, float* neg, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const Layout& L = ctx->lay;
+  const int d = ctx->cfg.dim;
+  ShardPlanSlot& sl = S->slot[s];
+  ShardPins& pn = S->pins[sl.pin];
+  int rc;
   float* rows_send = reinterpret_cast<float*>(ctx->ws + L.contrib_off);   // the (idle) entry space doubles as the serve buffer
   float* fetched = reinterpret_cast<float*>(ctx->ws + L.shard_fetch);
   float* csend = reinterpret_cast<float*>(ctx->ws + L.shard_csend);
@@ -637,6 +678,7 @@ int gqe_shard_post(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
   ShardSession* S = ctx->shard_sess;
   if (!S) return fail(ctx, GQE_ERR_STATE, "gqe_shard_open has not been called");
   if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
+  if (S->poisoned) return shard_poisoned(ctx, S);
   if (S->cap_req != ctx->lay.shard_cap_send) return fail(ctx, GQE_ERR_STATE, "the workspace was re-bound with other capacities: close and re-open the session");
   if (S->next_post - S->next_run >= GQE_SHARD_SLOTS) return fail(ctx, GQE_ERR_STATE, "%d plans are already posted: run one first", GQE_SHARD_SLOTS);
   if (!batches || n_batches < 1 || n_batches > GQE_MAX_BATCHES || !idx || n_idx < 1) return fail(ctx, GQE_ERR_ARG, "gqe_shard_post: bad arguments");

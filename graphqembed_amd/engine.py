@@ -296,6 +296,13 @@ class Engine(object):
     def reserve(self, max_queries, max_batches):
         if max_queries <= self.max_queries and max_batches <= self.max_batches:
             return
+        if getattr(self, "_shard_session_open", False):
+            # the session's plan board, pinned feeds and planning thread are sized for the bound capacities, and the peers do
+            # not grow with this rank: growing here would leave the posted plans pointing into a workspace that is gone
+            raise GqeError(-3, "a step of %d queries / %d batches exceeds what this Engine was sized for (%d / %d) while a row-sharded "
+                           "session is open: build every rank's Engine with max_queries / max_batches for the LARGEST step (the "
+                           "cross-rank maximum), or shard_close(), reserve() the same capacities on every rank and re-open"
+                           % (max_queries, max_batches, self.max_queries, self.max_batches))
         self.max_queries = max(max_queries, self.max_queries)
         self.max_batches = max(max_batches, self.max_batches)
         if self.workspace is not None:
@@ -355,10 +362,12 @@ class Engine(object):
         self._check(self.lib.gqe_shard_open(self.ctx, None if session is None else session.encode(),
                                             None if nccl_comm is None else C.c_void_p(int(nccl_comm)),
                                             None if transport is None else C.byref(transport)))
+        self._shard_session_open = True
 
     def shard_close(self):
         if getattr(self, "ctx", None):
             self._check(self.lib.gqe_shard_close(self.ctx))
+        self._shard_session_open = False
 
     def prepare_shard(self, descs, idx, keys=None, with_negatives=True):
         """Freeze one step for gqe_shard_post: ctypes descriptors, the HOST index feed of GLOBAL rows (numpy int32) and,

@@ -18,13 +18,29 @@ from .data_utils import BIO_SYNTH_EDGES_PER_KIND, BIO_SYNTH_KINDS, BIO_SYNTH_SIZ
 from .graph import Formula, _reverse_relation
 
 
+def zipf_draw(rng, n, size, exponent, perm=None):
+    """``size`` draws from {0 .. n-1} with P(rank k) ~ 1 / (k + 1)^exponent (inverse CDF); ``perm`` maps rank -> item
+    (the hubs are then scattered over the id range, as in a real graph, instead of being the first ids)."""
+    w = 1.0 / np.power(np.arange(1, n + 1, dtype=np.float64), exponent)
+    cdf = np.cumsum(w)
+    k = np.searchsorted(cdf, rng.random_sample(size) * cdf[-1], side="right")
+    k = np.minimum(k, n - 1)
+    return k if perm is None else perm[k]
+
+
 class CsrGraph(object):
     """Directed relations as CSR over local node indices of the source mode."""
 
-    def __init__(self, mode_sizes, kinds=BIO_SYNTH_KINDS, edges_per_kind=BIO_SYNTH_EDGES_PER_KIND, seed=0):
+    def __init__(self, mode_sizes, kinds=BIO_SYNTH_KINDS, edges_per_kind=BIO_SYNTH_EDGES_PER_KIND, seed=0, zipf=None):
+        """``zipf`` = exponent s: edge endpoints are drawn with P(node of degree rank k) ~ 1 / (k + 1)^s instead of
+        uniformly — the heavy-tailed degree distribution of the reference's data (protein hubs in Bio, popular
+        communities in Reddit: graph.py:108-122 keeps the real adjacency).  One rank order per mode, shared by all of the
+        mode's relations: a hub is a hub in every relation it takes part in."""
         rng = np.random.RandomState(seed)
         self.mode_sizes = dict(mode_sizes)
         self.modes = sorted(mode_sizes)
+        self.zipf = zipf
+        hub_order = {m: np.random.RandomState(seed + 101 + i).permutation(mode_sizes[m]) for i, m in enumerate(self.modes)} if zipf else None
         # rows of each mode's embedding table: len(node_maps[mode]) + 1 with the extra -1 key (bio/data_utils.py:14-17)
         self.table_rows = {m: n + 2 for m, n in self.mode_sizes.items()}
         self.bags = {}           # mode -> (ptr int32[n+1], ids int32[nnz]) for nn.EmbeddingBag feature modes
@@ -37,8 +53,12 @@ class CsrGraph(object):
                 self.relations[ma].append((mb, name))
             if (ma, name) not in self.relations[mb]:
                 self.relations[mb].append((ma, name))
-            u = rng.randint(0, mode_sizes[ma], size=edges_per_kind)
-            v = rng.randint(0, mode_sizes[mb], size=edges_per_kind)
+            if zipf:
+                u = zipf_draw(rng, mode_sizes[ma], edges_per_kind, zipf, hub_order[ma])
+                v = zipf_draw(rng, mode_sizes[mb], edges_per_kind, zipf, hub_order[mb])
+            else:
+                u = rng.randint(0, mode_sizes[ma], size=edges_per_kind)
+                v = rng.randint(0, mode_sizes[mb], size=edges_per_kind)
             if ma == mb:
                 keep = u != v
                 u, v = u[keep], v[keep]
@@ -182,9 +202,9 @@ post-burn-in schedule (train_helpers.py:51,64-72) over {1/2/3-chain, 2/3-inter, 
 weights 1 / 0.01 / 0.005, intersections once with regular and once with hard negatives."""
 
 
-def bio_synth(seed=0, sizes=None, edges_per_kind=None):
+def bio_synth(seed=0, sizes=None, edges_per_kind=None, zipf=None):
     return CsrGraph(sizes or BIO_SYNTH_SIZES, BIO_SYNTH_KINDS,
-                    edges_per_kind or BIO_SYNTH_EDGES_PER_KIND, seed=seed)
+                    edges_per_kind or BIO_SYNTH_EDGES_PER_KIND, seed=seed, zipf=zipf)
 
 
 REDDIT_SYNTH_KINDS = (("user", "up", "post"), ("user", "down", "post"), ("user", "make", "post"), ("user", "comment", "post"),
@@ -198,21 +218,26 @@ REDDIT_SYNTH_WORDS = 50000
 REDDIT_SYNTH_BAG_LEN = (5, 30)
 
 
-def reddit_synth(seed=0, sizes=None, edges_per_kind=None, n_words=None, bag_len=None):
+def reddit_synth(seed=0, sizes=None, edges_per_kind=None, n_words=None, bag_len=None, zipf=None):
     """BASELINE config 5 stand-in (the Reddit data of the reference is private): 3 modes, 12
     directed relations, user 500 k / post 400 k / community 2 k nodes, 1 M uniform random edges per kind.  Features as
     reddit/data_utils_new.py:153-169: user and community are ``nn.Embedding(N + 1, d)`` with row = node + 1; a post
     is an ``nn.EmbeddingBag(num_words, d)`` (mode mean) over its word set — here 5..30 uniform words of a 50 k
-    vocabulary.  Bag i + 1 belongs to post i (bag 0 is a dummy, so that "row = node + 1" holds for every mode)."""
+    vocabulary.  Bag i + 1 belongs to post i (bag 0 is a dummy, so that "row = node + 1" holds for every mode).
+    ``zipf`` = exponent: node degrees AND word frequencies follow 1 / rank^zipf (a real vocabulary is Zipfian:
+    reddit/data_utils_new.py:155,162-169 builds the EmbeddingBag over the posts' actual words)."""
     sizes = dict(sizes or REDDIT_SYNTH_SIZES)
-    g = CsrGraph(sizes, REDDIT_SYNTH_KINDS, edges_per_kind or REDDIT_SYNTH_EDGES_PER_KIND, seed=seed)
+    g = CsrGraph(sizes, REDDIT_SYNTH_KINDS, edges_per_kind or REDDIT_SYNTH_EDGES_PER_KIND, seed=seed, zipf=zipf)
     n_words = int(n_words or REDDIT_SYNTH_WORDS)
     lo, hi = bag_len or REDDIT_SYNTH_BAG_LEN
     rng = np.random.RandomState(seed + 7)
     lens = rng.randint(lo, hi + 1, size=sizes["post"] + 1)
     ptr = np.zeros(sizes["post"] + 2, dtype=np.int64)
     ptr[1:] = np.cumsum(lens)
-    ids = rng.randint(0, n_words, size=int(ptr[-1]))
+    if zipf:
+        ids = zipf_draw(rng, n_words, int(ptr[-1]), zipf, np.random.RandomState(seed + 11).permutation(n_words))
+    else:
+        ids = rng.randint(0, n_words, size=int(ptr[-1]))
     g.bags = {"post": (ptr.astype(np.int32), ids.astype(np.int32))}
     g.table_rows = {"user": sizes["user"] + 1, "community": sizes["community"] + 1, "post": n_words}
     return g

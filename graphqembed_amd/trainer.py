@@ -54,7 +54,9 @@ class TensorizedTrainer(object):
         margin launch and the optimiser step (parallel.exchange_sparse, or the dense all-reduce for bag modes).
         With an Engine built with ``shard=(rank, world)`` (row-sharded tables, owner-computes Adam) the trainer drives
         the row-sharded protocol instead: ``plan_of(formula)`` must then return the FormulaPlan on the engine's (local)
-        layout, and ``optimizer.step()`` steps the rank's own shards."""
+        layout; the library's own Adam steps the rank's shards inside gqe_shard_step, so ``optimizer`` only supplies the
+        hyper-parameters: it must be an Adam (``FusedAdam``, or a ``torch.optim.Adam`` whose ``param_groups[0]`` carries
+        lr / betas / eps) — anything else is refused instead of silently trained with defaults."""
         self.model = model_or_engine
         self.opt = optimizer
         self.types = list(pools_by_type.keys())
@@ -76,6 +78,8 @@ class TensorizedTrainer(object):
         self.sharded = self.engine is not None and getattr(self.engine, "sharded", False)
         if self.sharded and plan_of is None:
             raise Exception("row-sharded training needs plan_of(formula) -> FormulaPlan on the engine's layout")
+        if self.sharded:
+            self._adam_hyper()                                 # refuse a non-Adam optimiser up front
         self.ema_loss = None
         self.iterations = 0
         self.queries_seen = 0
@@ -128,6 +132,19 @@ class TensorizedTrainer(object):
         self.queries_seen += sum(len(x[1]) for x in items)
         return losses
 
+    def _adam_hyper(self):
+        """(lr, betas, eps) of the optimiser the caller handed over, read at every step (a scheduler may change lr).
+        gqe_shard_step runs torch.optim.Adam semantics only: SGD, or an object that names no hyper-parameters, raises."""
+        opt = self.opt
+        groups = getattr(opt, "param_groups", None)
+        src = groups[0] if groups else {k: getattr(opt, k) for k in ("lr", "betas", "eps") if hasattr(opt, k)}
+        missing = [k for k in ("lr", "betas", "eps") if k not in src]
+        if missing or "momentum" in src or type(opt).__name__.lower().endswith("sgd"):
+            raise Exception("row-sharded training steps its shards with the library's Adam (gqe_shard_step): the optimiser must be "
+                            "an Adam with explicit lr / betas / eps (FusedAdam or torch.optim.Adam); got %s%s"
+                            % (type(opt).__name__, (" without " + ", ".join(missing)) if missing else ""))
+        return float(src["lr"]), (float(src["betas"][0]), float(src["betas"][1])), float(src["eps"])
+
     def _shard_ps(self, items):
         packed = [(self.plan_of(f), t, ng, a, w, m) for (f, t, ng, a, w, m) in items]
         descs, idx, _ = pack_margin_batches(packed)
@@ -154,7 +171,13 @@ class TensorizedTrainer(object):
         if next_items is not None:
             self._posted = self._shard_ps(next_items)
             eng.shard_post(self._posted)
-        losses = eng.shard_step(ps, getattr(self.opt, "lr", 0.01), getattr(self.opt, "betas", (0.9, 0.999)), getattr(self.opt, "eps", 1e-8))
+        lr, betas, eps = self._adam_hyper()
+        try:
+            losses = eng.shard_step(ps, lr, betas, eps)
+        except Exception:
+            self._posted = None          # the session is poisoned (gqe_shard_step): whatever was posted ahead is gone with it
+            self._session_open = False
+            raise
         err = getattr(self._session, "error", None)
         if err is not None:
             raise err

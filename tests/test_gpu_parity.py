@@ -888,7 +888,7 @@ def test_lazy_adam_with_a_bag_mode():
         e.close()
 
 
-def _full_size_vs_oracle(workload, d, dec, inter, min_params, n_relations):
+def _full_size_vs_oracle(workload, d, dec, inter, min_params, n_relations, zipf=None, min_longest_list=0):
     """One full-mix iteration (9 x 512 queries, ONE grouped launch, index feed resident in HBM) of a BASELINE workload at its
     REAL table sizes against the fp64 oracle (the oracle only gathers the rows a batch names, so it stays cheap):
       * scores and losses;
@@ -900,10 +900,20 @@ def _full_size_vs_oracle(workload, d, dec, inter, min_params, n_relations):
     from graphqembed_amd import synth
     from graphqembed_amd.tensorize import FormulaPlan, pack_margin_batches, table_key
     B = 512
-    wl = bench.Workload(workload, d, dec, inter, synth.FULL_MIX, B, n_distinct=1)
+    wl = bench.Workload(workload, d, dec, inter, synth.FULL_MIX, B, n_distinct=1, zipf=zipf)
     assert wl.layout.total >= min_params and sum(len(v) for v in wl.g.relations.values()) == n_relations
     eng = wl.engine()
     items = wl.item_sets[0]
+    if min_longest_list:     # a skewed batch: some row collects hundreds of contributions
+        from collections import Counter
+        c = Counter()
+        for (f, t, ng, a, w, m) in items:
+            if f.target_mode not in wl.g.bags:
+                c.update((f.target_mode, int(x)) for x in np.concatenate([t, ng]))
+            for i, am in enumerate(f.anchor_modes):
+                if am not in wl.g.bags:
+                    c.update((am, int(x)) for x in a[i])
+        assert c.most_common(1)[0][1] >= min_longest_list, c.most_common(3)
     host = eng.params.cpu().numpy()
     params = {k: host[off:off + int(np.prod(shape))].reshape(shape) for k, (off, shape) in eng.layout.entries.items()}
     params[O.BAGS_KEY] = {m: csr for m, csr in wl.g.bags.items()}
@@ -977,3 +987,15 @@ def test_bio_synth_configs_full_size(dec, inter, P):
     """BASELINE configs 2-4 at their real size: bio-synth (97 000 nodes in 5 modes, 14 directed relations), d=128,
     P = 12 582 912 (bilinear-diag + SetIntersection) / 12 810 496 (full Bilinear) parameters — the workload bench.py times."""
     _full_size_vs_oracle("bio-synth", 128, dec, inter, P, 14)
+
+
+def test_bio_synth_zipf_full_size():
+    """The full mix on a HEAVY-TAILED bio-synth graph (node degrees ~ 1 / rank: the data shape the reference was written for,
+    graph.py:108-122): hub rows collect 100+ gradient contributions in one step.  Same checks as the uniform case."""
+    _full_size_vs_oracle("bio-synth", 128, "bilinear-diag", "min", 12582912, 14, zipf=1.0, min_longest_list=100)
+
+
+def test_reddit_synth_zipf_full_size():
+    """reddit-synth with Zipfian word frequencies and node degrees (a real vocabulary: reddit/data_utils_new.py:155,162-169):
+    the most frequent word row is linked by thousands of bag contributions in one step."""
+    _full_size_vs_oracle("reddit-synth", 256, "bilinear-diag", "min", 141 * 10 ** 6, 12, zipf=1.0, min_longest_list=50)

@@ -220,6 +220,8 @@ def _trainer_worker(rank, world, port, out_dir):
     pools = synth.make_pools(g, types, formulas_per_type=3, pool_size=1000, seed=0)    # 1000 % 64 != 0: ragged slices
 
     class Shim(object):                       # plans + the optimiser on the bare engine
+        lr, betas, eps = 0.01, (0.9, 0.999), 1e-8   # the trainer reads the hyper-parameters; gqe_shard_step does the stepping
+
         def __init__(self):
             self.plans, self.touched = {}, set()
 

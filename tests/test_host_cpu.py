@@ -222,3 +222,53 @@ def test_synthetic_query_pools_have_the_right_shape():
             assert (p.hard is not None) == ("inter" in qt)
     items = synth.mix_iteration(pools, synth.FULL_MIX, 3, 64, rank=1, world=2)
     assert len(items) == 9 and all(len(it[1]) == 64 for it in items) and abs(items[0][4] - 0.5) < 1e-12
+
+
+def test_sharded_trainer_refuses_an_optimiser_without_adam_hyperparameters():
+    """Row-sharded training steps its shards with the library's Adam; the optimiser object only supplies lr / betas / eps.
+    An SGD, or an object naming none of them, must raise instead of training with defaults."""
+    import torch
+    from graphqembed_amd.trainer import TensorizedTrainer
+
+    class Eng(object):
+        sharded = True
+
+    class Pool(object):
+        def __init__(self):
+            self.formula, self.n = G.Formula("1-chain", (("a", "r", "b"),)), 4
+            self.target = np.arange(4, dtype=np.int32)
+            self.anchors = np.arange(4, dtype=np.int32)[None]
+            self.neg = self.hard = None
+
+    class Bare(object):
+        def step(self):
+            pass
+
+    class Named(Bare):
+        lr, betas, eps = 0.02, (0.8, 0.9), 1e-6
+
+    w = torch.nn.Parameter(torch.zeros(2))
+    mk = lambda opt: TensorizedTrainer(None, opt, {"1-chain": [Pool()]}, {}, engine=Eng(), plan_of=lambda f: None)
+    for bad in (Bare(), torch.optim.SGD([w], lr=0.1)):
+        with pytest.raises(Exception, match="must be an Adam"):
+            mk(bad)
+    assert mk(Named())._adam_hyper() == (0.02, (0.8, 0.9), 1e-6)
+    assert mk(torch.optim.Adam([w], lr=0.03))._adam_hyper() == (0.03, (0.9, 0.999), 1e-8)
+
+
+def test_zipf_graphs_are_heavy_tailed():
+    """synth's Zipf option (hub nodes, Zipfian words): the largest degree / word frequency dwarfs the uniform graph's."""
+    from graphqembed_amd import synth
+    sizes = {"drug": 300, "disease": 200, "protein": 500, "sideeffect": 150, "function": 250}
+    gu = synth.bio_synth(seed=1, sizes=sizes, edges_per_kind=2000)
+    gz = synth.bio_synth(seed=1, sizes=sizes, edges_per_kind=2000, zipf=1.0)
+    rel = ("drug", "targets", "protein")
+    du, dz = np.diff(gu.csr[rel][0]), np.diff(gz.csr[rel][0])
+    assert dz.max() > 4 * du.max() and len(gz.csr[rel][1]) > 500
+    pools = synth.make_pools(gz, ["1-chain", "2-inter", "3-inter_chain"], formulas_per_type=2, pool_size=300, seed=0)
+    for plist in pools.values():
+        for p in plist:
+            assert p.target.min() >= 1 and p.anchors.min() >= 1
+    r = synth.reddit_synth(seed=0, sizes={"user": 400, "post": 300, "community": 20}, edges_per_kind=3000, n_words=500, zipf=1.0)
+    cnt = np.bincount(r.bags["post"][1], minlength=500)
+    assert cnt.max() > 8 * np.median(cnt[cnt > 0])

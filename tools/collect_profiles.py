@@ -13,6 +13,12 @@ for wl in ("bio-synth", "reddit-synth"):
                 vals.setdefault(m.group(1), {})[c] = float(m.group(2))
     out[wl] = {k: {"fetch_kib": v["FETCH_SIZE"], "write_kib": v["WRITE_SIZE"],
                    "hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)} for k, v in vals.items()}
+    # the kernels' own average durations in the kernel trace (bench.py prints them as rocprof_avg_launch_ms next to its hipEvent brackets)
+    for l in open("gpurun_out/%s_%s_kernel_stats.txt" % (tag, wl)):
+        m = re.match(r"(?:void )?(gqe_\w+)\S*.*?\s+(\d+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s*$", l)
+        if m and m.group(1) in out[wl] and "rocprof_avg_us" not in out[wl][m.group(1)]:   # first = largest total of that kernel
+            out[wl][m.group(1)]["rocprof_avg_us"] = float(m.group(4))
+            out[wl][m.group(1)]["rocprof_calls"] = int(m.group(2))
     for suffix in ("kernel_stats", "pmc_FETCH_SIZE", "pmc_WRITE_SIZE"):
         src, dst = "gpurun_out/%s_%s_%s.txt" % (tag, wl, suffix), "profiles/%s_%s_%s.txt" % (tag, wl, suffix)
         text = open(src).read().replace("/tmp/code/williamleif__graphqembed/repo/", "").replace("/root/repo/", "")
@@ -29,4 +35,4 @@ for name in ("bench_default", "bench_2rank_gloo"):
         lines = [l for l in open(p) if l.startswith("{")]
         if lines:
             open("profiles/%s_%s_line.json" % (tag, name), "w").write(lines[0])
-print(json.dumps({w: {k: v["hbm_bytes_per_launch"] for k, v in out[w].items()} for w in out if w != "source"}))
+print(json.dumps({w: {k: (v["hbm_bytes_per_launch"], v.get("rocprof_avg_us")) for k, v in out[w].items()} for w in out if w != "source"}))
