@@ -89,6 +89,24 @@ struct GqeBagTable {
   int32_t pad;
 };
 
+// Hot rows (heavy-tailed graphs: hub nodes, frequent words).  A row's gradient list is walked by ONE lane group, one dependent
+// 4-byte load per entry (~0.27 us each): fine for the handful of entries a row of a uniform graph collects, hopeless for a hub
+// that collects hundreds per step (a Zipfian word: thousands).  The optimiser pass measures every list it walks; a row whose
+// list reaches `min_len` entries is PROMOTED: it gets a slot of GQE_HOT_REPS dense accumulators of d floats, and from the next
+// step on its contributions are ADDED there with fire-and-forget float atomics (replica = a hash of the pusher, so that same-
+// address atomics — ~12 ns each at the memory side — spread over GQE_HOT_REPS chains) instead of being written as entries and
+// linked.  The pass that steps the row sums the replicas and re-zeroes them.  slot[] is indexed like head[].
+// Off (slot == NULL) wherever sums have to be order-independent: the replicated exchange mode, gqe_set_ordered_sums.
+#define GQE_HOT_REPS 8
+#define GQE_HOT_SLOTS 2048
+#define GQE_HOT_MIN_LEN 24
+struct GqeHot {
+  int32_t* slot;     // [total rows]: -1 = not hot, else the row's accumulator slot
+  float* acc;        // [GQE_HOT_REPS][cap][d]
+  int32_t* count;    // slots handed out so far (may run past cap: rows promoted beyond it stay on lists)
+  int32_t cap, min_len;
+};
+
 struct GqeDynPlan {
   int32_t n_batches, tiles, units, first;  // first != 0: this launch starts the weighted total (=), else +=
   int32_t total_index, pad[3];             // pad[0]: chunks per pair-GEMM unit; pad[1]: write-through stores (vstore_wt)
@@ -172,6 +190,7 @@ struct GqeRowsArgs {
   int d;
   float lr, b1, b2, eps;
   bool with_grad, sorted;
+  GqeHot hot;
   // the step's small dense tensors ride in extra workgroups of the same launch (dense_chunks == 0: none)
   const GqeDevSeg* dsegs;
   int n_dsegs;
@@ -211,6 +230,7 @@ struct GqeOptArgs {
   bool lazy;          // tables carry per-row step counts (GqeLazyArgs)
   bool nt;            // stream p / m / v of the tables with the non-temporal policy (tables larger than the Infinity Cache)
   GqeLazyArgs lz;
+  GqeHot hot;
   hipStream_t stream;
 };
 
@@ -238,6 +258,7 @@ struct GqeFusedArgs {
   const float* fetched;   // row-sharded mode: the rows of this call, fetched from their owners (else NULL)
   float* contrib_bag;     // where bag contributions go (= contrib, except in row-sharded mode: the optimiser's entry space)
   long long bag_shift;    // ... and the first entry index they may use there
+  GqeHot hot;             // hot rows (slot == NULL: off)
 };
 
 hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a);

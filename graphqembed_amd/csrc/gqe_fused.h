@@ -59,7 +59,27 @@ struct TileEnv {
   int32_t max_entries;
   int d, DP, wave, lane, q0;  // q0 = first query of this tile
   bool wt;                    // write-through stores for what the next kernels read (vstore_wt)
+  // hot rows (GqeHot, gqe_dev.h; only the two pointers travel — the capacity is GQE_HOT_SLOTS): hot_slot == NULL -> every
+  // contribution is an entry on a list
+  const int32_t* hot_slot;
+  float* hot_acc;
+  int rep;                    // the replica of a hot row's accumulators this workgroup adds to: the id of its XCD — all atomics on
+                              // one replica then come from ONE L2, where they execute; a line that several XCDs add to travels
+                              // between their L2s with every change of hands
+  int hotv;                   // lane role * RPW + rr: the hot slot of the plain row this wave owns for that role (-1: not hot).
+                              // ONE vector load issued in front of the row gathers (same in-order counter: it has landed when
+                              // the rows have) — five scalar loads would share their counter with the LDS reads of the indices
+                              // and chain five L2 round trips in front of the gathers (+1.5 us per tile, measured)
 };
+
+// A hot row's contribution is ADDED to one of its GQE_HOT_REPS dense accumulators (fire-and-forget float atomics) instead of
+// being written as an entry and linked: the optimiser pass then reads GQE_HOT_REPS vectors instead of chasing a list of
+// hundreds (hub nodes) or thousands (frequent words) of entries, one dependent load each.
+template <int NC>
+__device__ __forceinline__ void hot_add(const TileEnv& e, int slot, const Vec<NC>& gx) {
+  float* acc = e.hot_acc + ((size_t)e.rep * GQE_HOT_SLOTS + slot) * e.d;
+  vatomic_add<NC>(acc, gx, e.d, e.lane);
+}
 
 // Rows another kernel (on whatever XCD) reads next — scratch rows for the pair GEMM, contribution entries for the optimiser
 // pass — are WRITTEN THROUGH (sc1) in launches of few tiles: the L2 of an XCD is not coherent with the others', so plain
@@ -573,11 +593,15 @@ __device__ __forceinline__ void rows_finish(RowSet<NC>& rs) {
 
 template <int NC>
 __device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_base, int role, int r, int row,
-                                                 const Vec<NC>& xhat, float nrm, const Vec<NC>& g, int& old_head) {
+                                                 const Vec<NC>& xhat, float nrm, const Vec<NC>& g, int& old_head, int hot) {
   const float pg = vdot<NC>(xhat, g);
   const float inv = gqe_rcp(nrm);
   Vec<NC> gx;
   VEC_OP(gx, (g.v[c] - xhat.v[c] * pg) * inv);
+  if (hot >= 0) {   // wave-uniform: a hot row (hub node) — no entry, no link
+    hot_add<NC>(e, hot, gx);
+    return;
+  }
   const int64_t entry = e.sharded ? (int64_t)row : e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
   vstore_wt<NC>(e.wt, e.contrib + entry * e.d, gx, e.d, e.lane);
   // The returned previous head is only needed for next[entry]; that store is deferred to the end of the
@@ -615,15 +639,30 @@ __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t h
   const int base = (int)entry * max_len;
   for (int c0 = 0; c0 < len; c0 += 64) {
     const int k = c0 + e.lane;
+    int hs = -1;   // this lane's word row is hot: its slot
     if (k < len) {
       const int node = base + k;
       const int w = ids[p0 + k];
-      e.link_contrib[node] = (int)entry;
-      const int old = __hip_atomic_exchange(e.head + head_base + w, e.max_entries + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (DEFER && c0 == 0)
-        old_head = old;   // lane k keeps word k's previous head until push_links
-      else
-        e.next[e.max_entries + node] = old;
+      if (e.hot_slot) hs = e.hot_slot[head_base + w];
+      if (hs < 0) {
+        e.link_contrib[node] = (int)entry;
+        const int old = __hip_atomic_exchange(e.head + head_base + w, e.max_entries + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (DEFER && c0 == 0)
+          old_head = old;   // lane k keeps word k's previous head until push_links
+        else
+          e.next[e.max_entries + node] = old;
+      } else if (DEFER && c0 == 0) {
+        old_head = GQE_NO_PUSH;   // nothing was linked for this word
+      }
+    }
+    // frequent words: the bag's contribution is added to each hot word's accumulators, one wave-wide atomic row per word
+    if (e.hot_slot) {
+      unsigned long long todo = __ballot(hs >= 0);
+      while (todo) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        hot_add<NC>(e, __builtin_amdgcn_readlane(hs, l), gx);
+      }
     }
   }
 }
@@ -639,7 +678,8 @@ template <int NC>
 __device__ __forceinline__ void scatter_row(const TileEnv& e, const GqeBagTable& bags, int bag, int64_t head_base, int role, int r,
                                             const RowSet<NC>& rs, int rr, const Vec<NC>& g, int& old_head, int& bag_len) {
   if (bag < 0)
-    scatter_norm_bwd<NC>(e, head_base, role, r, rs.row[rr], rs.x[rr], rs.nrm[rr], g, old_head);
+    scatter_norm_bwd<NC>(e, head_base, role, r, rs.row[rr], rs.x[rr], rs.nrm[rr], g, old_head,
+                         e.hot_slot ? __builtin_amdgcn_readlane(e.hotv, role * RPW + rr) : -1);
   else
     scatter_norm_bwd_bag<NC>(e, head_base, role, r, bags.ptr[bag], bags.ids[bag], rs.x[rr], rs.nrm[rr], g, bag, rs.row[rr], bags.max_len, old_head, bag_len);
 }
@@ -669,7 +709,7 @@ __device__ __forceinline__ void push_links(const TileEnv& e, const int (&olds)[R
     for (int role = 0; role < 2 + GQE_MAX_BRANCH; ++role) {
       const int64_t q = e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + e.wave * RPW + rr);
       if (blens[rr][role] > 0) {
-        if (e.lane < blens[rr][role]) e.next[e.max_entries + (int)(e.bag_shift + q) * max_len + e.lane] = olds[rr][role];
+        if (e.lane < blens[rr][role] && olds[rr][role] != GQE_NO_PUSH) e.next[e.max_entries + (int)(e.bag_shift + q) * max_len + e.lane] = olds[rr][role];
       } else if (e.lane == 0 && olds[rr][role] != GQE_NO_PUSH) {
         e.next[q] = olds[rr][role];
       }
@@ -756,7 +796,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
                                                                 int32_t* __restrict__ link_counter, int max_entries,
                                                                 const float* __restrict__ fetched,
                                                                 float* __restrict__ contrib_bag, long long bag_shift,
-                                                                long long* __restrict__ prof) {
+                                                                const GqeHot hot, long long* __restrict__ prof) {
   static_assert(FW == GQE_FW, "FW only distinguishes the kernels of the per-GQE_FW translation units");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // Debug profile (gqe_debug_profile; tools/kbench.py reads it): GQE_PROF_SLOTS wall_clock64 stamps per workgroup.
@@ -804,6 +844,15 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
   e.wave = (DEC == DEC_BILINEAR && NC >= 4) ? (int)(threadIdx.x >> 6) : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   e.lane = threadIdx.x & 63;
   e.q0 = ((int)blockIdx.x - b.tile_begin) * GQE_TQ;
+  e.hot_slot = BWD ? hot.slot : nullptr;
+  e.hot_acc = hot.acc;
+  e.rep = 0;
+  e.hotv = -1;
+  if (BWD && hot.slot) {
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    e.rep = xcc & (GQE_HOT_REPS - 1);
+  }
   const int DP = e.DP, lane = e.lane, wave = e.wave;
   const int B = b.B;
   const bool has_neg = b.has_neg != 0;
@@ -849,12 +898,15 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
   int tbag = f->target_bag;
   int64_t a_table[GQE_MAX_BRANCH] = {0, 0, 0};
   int a_bag[GQE_MAX_BRANCH] = {-1, -1, -1};
+  int64_t t_head = 0, a_head[GQE_MAX_BRANCH] = {0, 0, 0};   // list-head bases: where a row's hot slot is looked up (backward only)
   if (EARLY) {
     t_table = f->target_table;
+    if (BWD) t_head = f->target_head;
 #pragma unroll
     for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
       a_table[i] = f->anchor_table[i];
       a_bag[i] = f->anchor_bag[i];
+      if (BWD) a_head[i] = f->anchor_head[i];
     }
   }
 
@@ -879,16 +931,32 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
     GQE_PIN(qtype);
     GQE_PIN(t_table);
     GQE_PIN(tbag);
+    if (BWD) GQE_PIN(t_head);
 #pragma unroll
     for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
       GQE_PIN(a_table[i]);
       GQE_PIN(a_bag[i]);
+      if (BWD) GQE_PIN(a_head[i]);
     }
   }
 #undef GQE_PIN
   const bool stage = STAGE && qtype > 2;
   __syncthreads();
   GQE_STAMP(1);
+  if (BWD && e.hot_slot && !e.sharded && lane < 5 * RPW) {
+    // hot slots of the plain rows this wave owns: lane role * RPW + rr (bag roles: their WORD rows are looked up where they are linked)
+    const int role = lane / RPW;
+    const int row = s_idx[role * GQE_TQ + wave * RPW + (lane - role * RPW)];
+    int64_t hb = GQE_DSC(t_head, f->target_head);
+    int bg = tbag;
+#pragma unroll
+    for (int i = 0; i < GQE_MAX_BRANCH; ++i)
+      if (role == 2 + i) {
+        hb = GQE_DSC(a_head[i], f->anchor_head[i]);
+        bg = GQE_DSC(a_bag[i], f->anchor_bag[i]);
+      }
+    if (row >= 0 && bg < 0) e.hotv = e.hot_slot[hb + row];
+  }
   // the relation vectors of an intersection tile (<= 2 per branch + the final projection): requested here, in front of
   // the rows, instead of one dependent L2 round trip per branch in the forward and again in the backward
   // (16-wave tiles; the 8-wave tiles keep two rows per role in registers and load the vectors where they use them)
@@ -1629,11 +1697,11 @@ static hipError_t launch_fused_v(const GqeFusedArgs& a) {
   if (a.bwd)
     hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true, GQE_FW>), dim3(a.plan.tiles), dim3(GQE_FWT), lds, a.stream, a.plan,
                        a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags, a.link_contrib, a.link_counter,
-                       a.max_entries, a.fetched, a.contrib_bag, a.bag_shift, a.prof);
+                       a.max_entries, a.fetched, a.contrib_bag, a.bag_shift, a.hot, a.prof);
   else
     hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, false, GQE_FW>), dim3(a.plan.tiles), dim3(GQE_FWT), lds, a.stream, a.plan,
                        a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags, a.link_contrib, a.link_counter,
-                       a.max_entries, a.fetched, a.contrib_bag, a.bag_shift, a.prof);
+                       a.max_entries, a.fetched, a.contrib_bag, a.bag_shift, a.hot, a.prof);
   return hipGetLastError();
 }
 

@@ -73,6 +73,7 @@ struct Layout {  // byte offsets inside the bound workspace
   size_t shard_req_send, shard_req_recv, shard_fetch, shard_csend;  // row-sharded mode (0 otherwise)
   int64_t shard_cap_send, shard_cap_recv;                          // entries
   size_t seg_off, act_off, formula_off, head_off, rows_off, next_off, contrib_off, linkc_off, counter_off, last_off, ring_off, total;
+  size_t hot_slot_off, hot_acc_off;   // hot rows (GqeHot): slot per table row, GQE_HOT_REPS x GQE_HOT_SLOTS accumulators of dim floats
   int64_t max_entries, max_links;  // max_entries = per-rank capacity x world (the exchange gathers every rank's entries)
 };
 
@@ -331,7 +332,9 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
   L.counter_off = L.linkc_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(L.max_links, 1), 256);
   L.last_off = L.counter_off + 256;  // lazy Adam: per-row step counts + per-table coefficient rings
   L.ring_off = L.last_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
-  L.total = L.ring_off + align_up(sizeof(float) * 2 * GQE_LAZY_TABLES * GQE_LAZY_RING, 256);
+  L.hot_slot_off = L.ring_off + align_up(sizeof(float) * 2 * GQE_LAZY_TABLES * GQE_LAZY_RING, 256);
+  L.hot_acc_off = L.hot_slot_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
+  L.total = L.hot_acc_off + align_up(sizeof(float) * (size_t)GQE_HOT_REPS * GQE_HOT_SLOTS * ctx->cfg.dim, 256);
   L.shard_req_send = L.shard_req_recv = L.shard_fetch = L.shard_csend = 0;
   if (ctx->shard_on) {
     L.shard_req_send = L.total;
@@ -558,6 +561,29 @@ int formula_of(gqe_ctx* ctx, const gqe_batch& s, int bi, int* out_id) {
   return GQE_OK;
 }
 
+// Hot rows (GqeHot, gqe_dev.h).  `produce`: the struct for a kernel that ADDS contributions (the fused kernel) — off where list
+// sums have to be order-independent (replicated exchange mode, gqe_set_ordered_sums) or GQE_HOT=0; consumers always get the live
+// struct: whatever sits in the accumulators has to be stepped.
+GqeHot hot_args(const gqe_ctx* ctx, bool produce) {
+  static const int min_len = [] {   // GQE_HOT_MIN_LEN: list length at which a row is promoted (tests lower it)
+    const char* e = getenv("GQE_HOT_MIN_LEN");
+    return e && atoi(e) > 0 ? atoi(e) : GQE_HOT_MIN_LEN;
+  }();
+  static const bool off = [] {
+    const char* e = getenv("GQE_HOT");
+    return e && atoi(e) == 0;
+  }();
+  const Layout& L = ctx->lay;
+  GqeHot h;
+  h.slot = reinterpret_cast<int32_t*>(ctx->ws + L.hot_slot_off);
+  h.acc = reinterpret_cast<float*>(ctx->ws + L.hot_acc_off);
+  h.count = reinterpret_cast<int32_t*>(ctx->ws + L.counter_off + 64);
+  h.cap = GQE_HOT_SLOTS;
+  h.min_len = off ? 0x7fffffff : min_len;
+  if (produce && (off || ctx->world > 1 || ctx->ordered_sums)) h.slot = nullptr;
+  return h;
+}
+
 bool any_dense(const gqe_ctx* ctx) {
   for (const Table& t : ctx->tables)
     if (t.dense) return true;
@@ -646,6 +672,7 @@ void lazy_rows_args(const gqe_ctx* ctx, GqeRowsArgs& ra, hipStream_t st) {
   ra.eps = ctx->lz_eps;
   ra.with_grad = false;
   ra.sorted = false;
+  ra.hot = hot_args(ctx, false);
   ra.stream = st;
 }
 
@@ -846,6 +873,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   fa.link_contrib = reinterpret_cast<int32_t*>(ctx->ws + L.linkc_off);
   fa.link_counter = reinterpret_cast<int32_t*>(ctx->ws + L.counter_off);
   fa.max_entries = (int32_t)L.max_entries;
+  fa.hot = hot_args(ctx, true);
   if (bwd && !ctx->bags.empty()) ctx->links_used = true;
 
   // ---- launches of <= GQE_LAUNCH_BATCHES batches; per-call data travels as kernel arguments ----
@@ -1240,6 +1268,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
   oa.contrib = reinterpret_cast<const float*>(ctx->ws + ctx->lay.contrib_off);
   oa.link_contrib = reinterpret_cast<const int32_t*>(ctx->ws + ctx->lay.linkc_off);
   oa.max_entries = (int32_t)ctx->lay.max_entries;
+  oa.hot = hot_args(ctx, false);
   oa.d = d;
   oa.lr = lr;
   oa.b1 = b1;
@@ -1612,10 +1641,13 @@ int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* strea
   for (int k = 0; k < (int)ctx->formulas.size(); ++k) ctx->formulas_dirty.push_back(k);
   // empty gradient lists: head[row] = -1; link-node allocator at 0
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.head_off, 0xff, L.rows_off - L.head_off, reinterpret_cast<hipStream_t>(stream)));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.counter_off, 0, sizeof(int32_t), reinterpret_cast<hipStream_t>(stream)));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.counter_off, 0, 256, reinterpret_cast<hipStream_t>(stream)));   // + the hot-slot counter
   ctx->links_used = false;
   // lazy Adam: every row is current for its table's step count, empty rings
-  HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.ring_off, 0, L.total - L.ring_off, reinterpret_cast<hipStream_t>(stream)));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.ring_off, 0, L.hot_slot_off - L.ring_off, reinterpret_cast<hipStream_t>(stream)));
+  // hot rows: none yet, empty accumulators
+  HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.hot_slot_off, 0xff, L.hot_acc_off - L.hot_slot_off, reinterpret_cast<hipStream_t>(stream)));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.hot_acc_off, 0, sizeof(float) * (size_t)GQE_HOT_REPS * GQE_HOT_SLOTS * ctx->cfg.dim, reinterpret_cast<hipStream_t>(stream)));
   for (auto& t : ctx->tables) {
     t.pending = false;
     t.since_full = 0;
@@ -1697,7 +1729,24 @@ int gqe_set_limits(gqe_ctx* ctx, int32_t max_tensors, int32_t max_formulas) {
 
 int gqe_set_ordered_sums(gqe_ctx* ctx, int32_t enable) {
   if (!ctx) return GQE_ERR_ARG;
+  if (enable && !ctx->ordered_sums && ctx->ws) {
+    // order-independent sums and hot rows exclude each other (float atomics arrive in any order): the kernels of this mode are
+    // compiled without the accumulator path, so no row may stay hot and nothing may sit in an accumulator
+    bool pending = ctx->entries_used != 0;
+    for (const Table& t : ctx->tables) pending = pending || t.pending;
+    if (pending) return fail(ctx, GQE_ERR_STATE, "gradients pending: step or gqe_zero_grads before gqe_set_ordered_sums");
+    HIP_TRY(ctx, hipMemset(ctx->ws + ctx->lay.hot_slot_off, 0xff, ctx->lay.hot_acc_off - ctx->lay.hot_slot_off));
+  }
   ctx->ordered_sums = enable != 0;
+  return GQE_OK;
+}
+
+int gqe_hot_rows(gqe_ctx* ctx, int32_t* n_hot) {
+  if (!ctx || !n_hot) return GQE_ERR_ARG;
+  if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
+  int32_t n = 0;
+  HIP_TRY(ctx, hipMemcpy(&n, ctx->ws + ctx->lay.counter_off + 64, sizeof n, hipMemcpyDeviceToHost));
+  *n_hot = std::min<int32_t>(n, GQE_HOT_SLOTS);
   return GQE_OK;
 }
 

@@ -218,10 +218,10 @@ __device__ __forceinline__ void opt_update(float4& pp, float4& mm, float4& vv, c
 // Sum of a row's gradient list (float4 slice c4 of every contribution).  len = number of nodes walked.
 template <bool SORTED>
 __device__ __forceinline__ float4 list_gradient(int h0, const int32_t* __restrict__ next, const float* __restrict__ contrib,
-                                                const int32_t* __restrict__ link_contrib, int max_entries, int d, int c4) {
+                                                const int32_t* __restrict__ link_contrib, int max_entries, int d, int c4, int& len) {
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 acc = zero4;
-  int len = 0;
+  len = 0;
   for (int h = h0; h >= 0; h = next[h]) {
     const int ce = (h < max_entries) ? h : link_contrib[h - max_entries];  // bag link node -> its contribution
     const float4 c = *reinterpret_cast<const float4*>(contrib + (size_t)ce * d + c4);
@@ -272,6 +272,35 @@ __device__ __forceinline__ float4 list_gradient(int h0, const int32_t* __restric
   return acc;
 }
 
+// ---- hot rows (GqeHot, gqe_dev.h) -------------------------------------------------------------------------
+// the gradient a hot row collected this step: the sum of its replicas, which are re-zeroed on the way
+__device__ __forceinline__ float4 hot_take(const GqeHot& hot, int hs, int d, int c4) {
+  // (hot rows are a few hundred of ~10^5: two loads in flight, not GQE_HOT_REPS — the streaming pass around this keeps its
+  // <= 64 VGPRs, i.e. its occupancy)
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 s = zero4;
+#pragma unroll 1
+  for (int x = 0; x < GQE_HOT_REPS; x += 2) {
+    float* p0 = hot.acc + ((size_t)x * hot.cap + hs) * d + c4;
+    float* p1 = p0 + (size_t)hot.cap * d;
+    const float4 a = *reinterpret_cast<const float4*>(p0), b = *reinterpret_cast<const float4*>(p1);
+    s.x += a.x + b.x;
+    s.y += a.y + b.y;
+    s.z += a.z + b.z;
+    s.w += a.w + b.w;
+    *reinterpret_cast<float4*>(p0) = zero4;
+    *reinterpret_cast<float4*>(p1) = zero4;
+  }
+  return s;
+}
+
+// a list of `len` entries was just walked for row `hrow`: long enough -> the row's later contributions go to a slot
+__device__ __forceinline__ void hot_promote(const GqeHot& hot, long long hrow, int len) {
+  if (len < hot.min_len) return;
+  const int s = __hip_atomic_fetch_add(hot.count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (s < hot.cap) hot.slot[hrow] = s;
+}
+
 // ------------------------------------------------------------------------------------------
 // Lazy rows (gqe_set_lazy_adam).  A row without a gradient still moves under Adam (its momentum decays), which
 // is why the eager pass streams every row of every stepped table each iteration.  But those zero-gradient steps
@@ -313,7 +342,8 @@ __device__ __forceinline__ void opt_body(const long long first_chunk, const long
                                                              const int32_t* __restrict__ link_contrib, int max_entries,
                                                              int d, float lr, float b1, float b2, float eps,
                                                              const GqeStepCoef& coef, const GqeOptActive& active,
-                                                             const GqeActSeg* __restrict__ act, int n_act, const GqeLazyArgs& lazy) {
+                                                             const GqeActSeg* __restrict__ act, int n_act, const GqeLazyArgs& lazy,
+                                                             const GqeHot& hot) {
   // Which tensor owns chunk ch, and its Adam coefficients.  Kernel-argument form (act == NULL): a prefix over the
   // <= GQE_MAX_SEGS universe entries in LDS.  Table form: a binary search in the uploaded list of active tensors.
   __shared__ int32_t s_begin[GQE_MAX_SEGS + 1];  // chunk prefix over the universe (from the host); inactive tensors own 0 chunks
@@ -363,12 +393,26 @@ __device__ __forceinline__ void opt_body(const long long first_chunk, const long
         if (MODE != GQE_OPT_MATERIALIZE) *reinterpret_cast<float4*>(g + off) = zero4;
       }
       bool had = false;
+      // (requested next to the list head: no extra round trip; never in the order-independent instantiations, which no hot row
+      // can reach: gqe_set_ordered_sums clears the slots, the exchange mode never promotes)
+      const int hs = (!SORTED && hot.slot) ? hot.slot[sg.head_base + row] : -1;
       if (LISTS) {
         const int h0 = head[sg.head_base + row];
         had = h0 >= 0;
-        const float4 acc = list_gradient<SORTED>(h0, next, contrib, link_contrib, max_entries, d, c4);
-        if (had && c4 == 0) head[sg.head_base + row] = -1;
-        if (MODE == GQE_OPT_ZERO) continue;
+        int len;
+        const float4 acc = list_gradient<SORTED>(h0, next, contrib, link_contrib, max_entries, d, c4, len);
+        if (had && c4 == 0) {
+          head[sg.head_base + row] = -1;
+          if (!SORTED && hot.slot && hs < 0) hot_promote(hot, sg.head_base + row, len);
+        }
+        gg.x += acc.x;
+        gg.y += acc.y;
+        gg.z += acc.z;
+        gg.w += acc.w;
+      }
+      if (hs >= 0) {   // a hot row: what it collected sits in its accumulators (usually next to an empty list)
+        const float4 acc = hot_take(hot, hs, d, c4);
+        had = true;
         gg.x += acc.x;
         gg.y += acc.y;
         gg.z += acc.z;
@@ -470,9 +514,9 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
                                                              const int32_t* __restrict__ link_contrib, int max_entries,
                                                              int d, float lr, float b1, float b2, float eps,
                                                              GqeStepCoef coef, GqeOptActive active,
-                                                             const GqeActSeg* __restrict__ act, int n_act, GqeLazyArgs lazy) {
+                                                             const GqeActSeg* __restrict__ act, int n_act, GqeLazyArgs lazy, GqeHot hot) {
   opt_body<MODE, LISTS, DENSE_T, SORTED, LAZY, NT>(blockIdx.x, gridDim.x, segs, n_segs, total_chunks, p, g, m, v, head, next,
-                                                    contrib, link_contrib, max_entries, d, lr, b1, b2, eps, coef, active, act, n_act, lazy);
+                                                    contrib, link_contrib, max_entries, d, lr, b1, b2, eps, coef, active, act, n_act, lazy, hot);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -558,7 +602,7 @@ static void launch_opt_mode(const GqeOptArgs& a, unsigned blocks) {
 #define GON(L, D, S, Z, N)                                                                                                \
   hipLaunchKernelGGL((gqe_opt_kernel<MODE, L, D, S, Z, N>), dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.n_segs, \
                      a.total_chunks, a.p, a.g, a.m, a.v, a.head, a.next, a.contrib, a.link_contrib, a.max_entries, a.d, a.lr, a.b1,  \
-                     a.b2, a.eps, a.coef, a.active, a.act, a.n_act, a.lz)
+                     a.b2, a.eps, a.coef, a.active, a.act, a.n_act, a.lz, a.hot)
 #define GO(L, D, S, Z) GON(L, D, S, Z, false)
   if (a.nt && MODE == GQE_OPT_ADAM && !a.lazy) {  // eager Adam over tables larger than the Infinity Cache: non-temporal p / m / v
     if (a.lists) {
@@ -608,15 +652,17 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_rows_kernel(const GqeRowSegs 
                                                               float lr, float b1, float b2, float eps, int n_row_blocks,
                                                               const GqeDevSeg* __restrict__ dsegs, int n_dsegs,
                                                               long long dense_chunks, GqeStepCoef dcoef, GqeOptActive dactive,
-                                                              const GqeActSeg* __restrict__ dact, int n_dact) {
+                                                              const GqeActSeg* __restrict__ dact, int n_dact, GqeHot hot) {
   if ((int)blockIdx.x >= n_row_blocks) {
     // the step's small dense tensors (relation vectors / matrices, Pre / Post): the ordinary chunk loop
     GqeLazyArgs none;
     none.last = nullptr;
     none.ring = nullptr;
+    GqeHot no_hot;
+    no_hot.slot = nullptr;
     opt_body<GQE_OPT_ADAM, false, false, false, false>((long long)blockIdx.x - n_row_blocks, (long long)gridDim.x - n_row_blocks,
                                                        dsegs, n_dsegs, dense_chunks, p, g, m, v, head, next, contrib, nullptr,
-                                                       max_entries, d, lr, b1, b2, eps, dcoef, dactive, dact, n_dact, none);
+                                                       max_entries, d, lr, b1, b2, eps, dcoef, dactive, dact, n_dact, none, no_hot);
     return;
   }
   // the coefficient rings go through LDS: a replay of k steps would otherwise chain k dependent global loads
@@ -652,12 +698,24 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_rows_kernel(const GqeRowSegs 
   float4 mm = *reinterpret_cast<const float4*>(m + off);
   float4 vv = *reinterpret_cast<const float4*>(v + off);
   const int h0 = WITH_GRAD ? head[hrow] : -1;
+  const int hs = (WITH_GRAD && !SORTED && hot.slot) ? hot.slot[hrow] : -1;
   from = __shfl(from, (threadIdx.x & 63) / tpr * tpr);
   if (from >= target) return;  // someone else brought (or is bringing) the row there
   float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
   if (WITH_GRAD && h0 >= 0) {
-    gg = list_gradient<SORTED>(h0, next, contrib, nullptr, max_entries, d, c4);
-    if (c4 == 0) head[hrow] = -1;
+    int len;
+    gg = list_gradient<SORTED>(h0, next, contrib, nullptr, max_entries, d, c4, len);
+    if (c4 == 0) {
+      head[hrow] = -1;
+      if (!SORTED && hot.slot && hs < 0) hot_promote(hot, hrow, len);
+    }
+  }
+  if (hs >= 0) {   // a hot row: its contributions of this step sit in its accumulators
+    const float4 acc = hot_take(hot, hs, d, c4);
+    gg.x += acc.x;
+    gg.y += acc.y;
+    gg.z += acc.z;
+    gg.w += acc.w;
   }
   lazy_advance(pp, mm, vv, gg, from, target, t.grad_step[lt], s_ring + lt * GQE_LAZY_RING, t.step_size[lt], t.bc2_sqrt[lt],
                t.grad_step[lt], b1, b2, eps);
@@ -674,7 +732,7 @@ hipError_t gqe_launch_rows(const GqeRowsArgs& a) {
 #define GO(G, S)                                                                                                          \
   hipLaunchKernelGGL((gqe_rows_kernel<G, S>), dim3(row_blocks + dense_blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.t,  \
                      a.idx, a.last, a.ring, a.p, a.g, a.m, a.v, a.head, a.next, a.contrib, a.max_entries, a.d, a.lr, a.b1,   \
-                     a.b2, a.eps, (int)row_blocks, a.dsegs, a.n_dsegs, a.dense_chunks, a.dcoef, a.dactive, a.dact, a.n_dact)
+                     a.b2, a.eps, (int)row_blocks, a.dsegs, a.n_dsegs, a.dense_chunks, a.dcoef, a.dactive, a.dact, a.n_dact, a.hot)
   if (a.with_grad) {
     if (a.sorted) GO(true, true); else GO(true, false);
   } else {

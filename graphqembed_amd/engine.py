@@ -97,6 +97,7 @@ SYMBOLS = OrderedDict([
     ("gqe_import_entries", (C.c_int, [_P, C.c_int64, _P])),
     ("gqe_set_shard", (C.c_int, [_P, C.c_int32, C.c_int32])),
     ("gqe_set_ordered_sums", (C.c_int, [_P, C.c_int32])),
+    ("gqe_hot_rows", (C.c_int, [_P, C.POINTER(C.c_int32)])),
     ("gqe_shard_layout", (C.c_int, [_P, C.POINTER(gqe_shard_buffers)])),
     ("gqe_shard_plan", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P, _P])),
     ("gqe_shard_serve", (C.c_int, [_P, _P, C.c_int64, _P, _P])),
@@ -592,6 +593,12 @@ class Engine(object):
         """gqe_allreduce_grads: lists -> dense gradient arena, then ncclAllReduce (RCCL) over ``nccl_comm`` (an
         ncclComm_t as an integer / c_void_p, e.g. from parallel.RcclComm)."""
         self._check(self.lib.gqe_allreduce_grads(self.ctx, C.c_void_p(int(nccl_comm)), self._stream()))
+
+    def hot_rows(self):
+        """Rows promoted to dense gradient accumulators so far (include/gqe.h, gqe_hot_rows); synchronises."""
+        n = C.c_int32(0)
+        self._check(self.lib.gqe_hot_rows(self.ctx, C.byref(n)))
+        return int(n.value)
 
     def materialize(self):
         """Fold pending per-row gradient lists into the dense gradient arena (gqe_materialize_grads)."""

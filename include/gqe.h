@@ -290,6 +290,15 @@ int gqe_set_shard(gqe_ctx* ctx, int32_t rank, int32_t world);   /* before gqe_wo
  * gqe_set_exchange mode (replicas must round identically); optional elsewhere — a row-sharded row has one owner, so ranks
  * agree without it — and off by default: it costs the optimiser pass ~14 % (53.9 vs 47.1 us on bio-synth). */
 int gqe_set_ordered_sums(gqe_ctx* ctx, int32_t enable);
+/* Hot rows — what replaces the reference's dense `index_add` backward of nn.Embedding / nn.EmbeddingBag (bio/data_utils.py:17,
+ * reddit/data_utils_new.py:155) on HEAVY-TAILED data.  A row's gradient contributions normally hang on a per-row list that one
+ * lane group walks (fine for the few entries a row of a sparse graph collects per step).  The optimiser pass measures the lists
+ * it walks; a row whose list reaches 24 entries in one step (a hub node, a frequent word) is promoted: from the next step on its
+ * contributions are added into 8 dense accumulators of dim floats with float atomics, and the pass sums those instead of
+ * chasing hundreds or thousands of links.  Automatic, up to 2048 rows per ctx; off in gqe_set_exchange mode and with
+ * gqe_set_ordered_sums (atomic sums are order-dependent); GQE_HOT=0 in the environment disables it, GQE_HOT_MIN_LEN=n changes
+ * the promotion threshold.  gqe_hot_rows: how many rows have been promoted so far (synchronises the device). */
+int gqe_hot_rows(gqe_ctx* ctx, int32_t* n_hot);
 int gqe_shard_layout(gqe_ctx* ctx, gqe_shard_buffers* out);     /* after gqe_bind_workspace */
 /* idx: HOST index feed of GLOBAL table rows laid out as gqe_batch describes (with_negatives: margin layout).  Outputs
  * (host): positions[n_idx] — the feed to hand to gqe_margin_fwd_bwd / gqe_forward (device copy); requests[n_idx] — grouped

@@ -973,6 +973,45 @@ def _full_size_vs_oracle(workload, d, dec, inter, min_params, n_relations, zipf=
         bad = torch.nonzero(touched & ~m_k).flatten()[:4].tolist()
         assert not bad, (k, bad, [float(gmax[r]) for r in bad], float(gmax.max()))
     assert bool(torch.isfinite(eng.params).all())
+    if zipf:
+        # The Adam pass above walked the hub rows' long lists and PROMOTED them (include/gqe.h, gqe_hot_rows): from now on their
+        # contributions are added into dense accumulators with float atomics instead of being linked.  Two more steps through
+        # that path: gradients against the oracle on the parameters of the moment (materialize folds accumulators and lists
+        # alike), then a step that must consume every accumulator.
+        assert eng.hot_rows() >= 4, eng.hot_rows()
+        for rnd in range(2):
+            host = eng.params.cpu().numpy()
+            params = {k: host[off:off + int(np.prod(shape))].reshape(shape) for k, (off, shape) in eng.layout.entries.items()}
+            params[O.BAGS_KEY] = {m: csr for m, csr in wl.g.bags.items()}
+            grads = {k: np.zeros(v.shape, dtype=np.float32) for k, v in params.items() if k != O.BAGS_KEY}
+            grads[O.BAGS_KEY] = params[O.BAGS_KEY]
+            want_l = []
+            for (f, t, ng, a, w, m) in items:
+                l, _, _, _ = O.margin_fwd_bwd(params, O.make_plan(f.query_type, f.rels), dec, inter, t, ng, a, margin=m, weight=w, grads=grads)
+                want_l.append(l)
+            losses, _, _ = eng.margin_fwd_bwd(descs, didx, n)
+            np.testing.assert_allclose(losses.cpu().numpy()[:-1], want_l, rtol=LOSS_RTOL)
+            if rnd == 0:
+                eng.materialize()
+                got = eng.grads.cpu().numpy()
+                for k, (off, shape) in eng.layout.entries.items():
+                    gk, wk = got[off:off + int(np.prod(shape))].reshape(shape), grads[k]
+                    scale = max(float(np.abs(wk).max()), 1e-12)
+                    np.testing.assert_allclose(gk, wk, rtol=3e-3, atol=3e-5 * scale, err_msg="hot-row step: " + k)
+            before = eng.params.clone()
+            eng.adam_step(keys)
+            eng.materialize()
+            assert float(eng.grads.abs().max()) == 0.0                       # nothing left on a list or in an accumulator
+            if rnd == 1:   # a step fed by accumulators alone (no materialised gradient): the hub rows moved
+                for k in keys:
+                    if not k.startswith("enc."):
+                        continue
+                    off, shape = eng.layout.entries[k]
+                    gmax = np.abs(grads[k]).reshape(shape[0], -1).max(axis=1)
+                    hub = int(np.argmax(np.abs(grads[k]).reshape(shape[0], -1).sum(axis=1)))
+                    if gmax[hub] > 0:
+                        assert bool((eng.params[off + hub * shape[1]: off + (hub + 1) * shape[1]] != before[off + hub * shape[1]: off + (hub + 1) * shape[1]]).any()), (k, hub)
+        assert bool(torch.isfinite(eng.params).all())
     eng.close()
 
 
