@@ -75,10 +75,10 @@ struct TileEnv {
 // A hot row's contribution is ADDED to one of its GQE_HOT_REPS dense accumulators (fire-and-forget float atomics) instead of
 // being written as an entry and linked: the optimiser pass then reads GQE_HOT_REPS vectors instead of chasing a list of
 // hundreds (hub nodes) or thousands (frequent words) of entries, one dependent load each.
-template <int NC>
+template <int NC, bool FULL>
 __device__ __forceinline__ void hot_add(const TileEnv& e, int slot, const Vec<NC>& gx) {
   float* acc = e.hot_acc + ((size_t)e.rep * GQE_HOT_SLOTS + slot) * e.d;
-  vatomic_add<NC>(acc, gx, e.d, e.lane);
+  gatomic_add<NC, FULL>(acc, gx, e.d, e.lane);
 }
 
 // Rows another kernel (on whatever XCD) reads next — scratch rows for the pair GEMM, contribution entries for the optimiser
@@ -86,17 +86,12 @@ __device__ __forceinline__ void hot_add(const TileEnv& e, int slot, const Vec<NC
 // stores sit dirty in it until the write-back at the kernel boundary, and at B = 512 that burst is on the step's critical
 // path (fused 28.7 -> 27.4 us, step 87.0 -> 85.6 us in an A / B / C on one box).  Launches with thousands of tiles keep plain
 // stores: there the boundary is amortised and write-through cost 1.5 % (B = 8192: 227 -> 230.5 us).
-template <int NC>
+template <int NC, bool FULL>
 __device__ __forceinline__ void vstore_wt(bool wt, float* p, const Vec<NC>& x, int d, int lane) {
-  if (wt) {   // workgroup-uniform
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int j = lane + 64 * c;
-      if (j < d) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p + j), "v"(x.v[c]) : "memory");
-    }
-  } else {
-    vstore<NC>(p, x, d, lane);
-  }
+  if (wt)   // workgroup-uniform
+    gstore_sc1<NC, FULL>(p, x, d, lane);
+  else
+    gstore<NC, FULL>(p, x, d, lane);
 }
 
 __device__ __forceinline__ float* scratch_row(const TileEnv& e, int slot, int r) {
@@ -111,21 +106,35 @@ __device__ __forceinline__ float* scratch_row(const TileEnv& e, int slot, int r)
 //   TRANS = false: A[i][k] = M[i][k]  (M . x : "project", decoders.py:150; Pre/Post forward)
 //   TRANS = true : A[i][k] = M[k][i]  (M^T . x : x^T M of decoders.py:145; every backward)
 // ------------------------------------------------------------------------------------------
-template <bool TRANS, int KB>
-__device__ __forceinline__ void load_a_slab(float4 (&a)[KB], const float* __restrict__ M, int d, int nkb, int i0, int lq,
-                                            int lk, int kb0) {
+// Guarded kernels (FULL = false, d < 64 NC): the contractions run over the PADDED extent with compile-time trip counts — a
+// runtime k-block count made every slab element conditionally zero and the row-block loop a real loop, and the 16-wave
+// kernels spilled hundreds of registers at their 128-VGPR limit.  The matrix is addressed as ONE buffer of d * d floats:
+// k-rows past d of M^T (and whole output row blocks past d, which are skipped anyway) are out of range and read 0; columns
+// k >= d of a row of M read the next row's (finite) values and meet the zero columns of the source tile.
+template <bool TRANS, int KB, int KBT, bool FULL>
+__device__ __forceinline__ void load_a_slab(float4 (&a)[KB], const float* __restrict__ M, int d, int i0, int lq, int lk, int kb0) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(M), 0, FULL ? 0 : d * d * 4, 0x00020000);
 #pragma unroll
   for (int j = 0; j < KB; ++j) {
     const int kb = kb0 + j;
-    if (kb < nkb) {
+    if (kb >= KBT) {   // (compile time: the last group of a slab whose k-block count is not a multiple of the group)
+      a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (FULL) {
       if (!TRANS) {
         a[j] = *reinterpret_cast<const float4*>(M + (size_t)(i0 + lq) * d + kb * 16 + 4 * lk);
       } else {
         const float* mp = M + (size_t)(kb * 16 + 4 * lk) * d + i0 + lq;
         a[j] = make_float4(mp[0], mp[d], mp[2 * d], mp[3 * d]);
       }
+    } else if (!TRANS) {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, ((i0 + lq) * d + kb * 16 + 4 * lk) * 4, 0, 0);
+      a[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
     } else {
-      a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int o = ((kb * 16 + 4 * lk) * d + i0 + lq) * 4;
+      a[j] = make_float4(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0)),
+                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o + 4 * d, 0, 0)),
+                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o + 8 * d, 0, 0)),
+                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o + 12 * d, 0, 0)));
     }
   }
 }
@@ -295,49 +304,57 @@ __device__ __forceinline__ float keep_if_bit(float g, int meta, int bit) {  // g
 // dst[q][i] = sum_k A[i][k] src[q][k]   (one source tile), A streamed from L2
 // (one accumulator: the 8-wave d <= 128 kernels can afford the whole slab in flight here even at their 80-VGPR budget)
 #define GQE_KG1 ((GQE_FW == 8 && NC == 2) ? 8 : GQE_KG)
-template <bool TRANS, int NC>
+template <bool TRANS, int NC, bool FULL>
 __device__ __forceinline__ void tile_matmul(float* __restrict__ dst, const float* __restrict__ M,
                                             const float* __restrict__ src, int d, int DP, int wave, int lane) {
   constexpr int KB = 4 * NC, KG = KB < GQE_KG1 ? KB : GQE_KG1;
-  const int lq = lane & 15, lk = lane >> 4, nkb = d >> 4;
-  for (int i0 = wave * 16; i0 < d; i0 += GQE_FW * 16) {
+  const int lq = lane & 15, lk = lane >> 4;
+  auto block = [&](const int i0) __attribute__((always_inline)) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g0 = 0; g0 < KB; g0 += KG) {
       float4 a[KG];
-      load_a_slab<TRANS, KG>(a, M, d, nkb, i0, lq, lk, g0);
+      load_a_slab<TRANS, KG, KB, FULL>(a, M, d, i0, lq, lk, g0);
 #pragma unroll
       for (int kb = 0; kb < KG; ++kb) {
-        if (g0 + kb < nkb) {
+        if (g0 + kb < KB) {
           const float4 b = *reinterpret_cast<const float4*>(src + lq * DP + (g0 + kb) * 16 + 4 * lk);
           acc = mfma4(a[kb], b, acc);
         }
       }
     }
     *reinterpret_cast<float4*>(dst + lq * DP + i0 + 4 * lk) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  };
+  if (FULL) {   // (the form the straight-line kernels were tuned with: their register allocation is sensitive to it)
+    for (int i0 = wave * 16; i0 < d; i0 += GQE_FW * 16) block(i0);
+  } else {      // compile-time trip count, row blocks past d skipped by a wave-uniform test: a loop over a run-time d made the
+                // guarded 16-wave kernels spill hundreds of registers
+#pragma unroll
+    for (int i0b = 0; i0b < 64 * NC; i0b += GQE_FW * 16)
+      if (i0b + wave * 16 < d) block(i0b + wave * 16);
   }
 }
 
 // SetIntersection forward for NB branches at once (decoders.py:288-299):
 //   z_b = Pre . e_b ; h = agg_b relu(z_b) ; meta = (relu signs << 4) | first arg-min
 // The Pre slab is loaded once and shared by the branches; relu / min / mean run on the accumulators.
-template <int NC, int NB>
+template <int NC, int NB, bool FULL>
 __device__ __forceinline__ void pre_intersect(float* __restrict__ th, int* __restrict__ tmeta,
                                               const float* __restrict__ P, float* const (&te)[GQE_MAX_BRANCH], int d,
                                               int DP, int wave, int lane, int inter_min) {
   constexpr int KB = 4 * NC, KG = KB < GQE_KG ? KB : GQE_KG;
-  const int lq = lane & 15, lk = lane >> 4, nkb = d >> 4;
-  for (int i0 = wave * 16; i0 < d; i0 += GQE_FW * 16) {
+  const int lq = lane & 15, lk = lane >> 4;
+  auto block = [&](const int i0) __attribute__((always_inline)) {
     f32x4 acc[NB];
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi) acc[bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g0 = 0; g0 < KB; g0 += KG) {
       float4 a[KG];
-      load_a_slab<false, KG>(a, P, d, nkb, i0, lq, lk, g0);
+      load_a_slab<false, KG, KB, FULL>(a, P, d, i0, lq, lk, g0);
 #pragma unroll
       for (int kb = 0; kb < KG; ++kb) {
-        if (g0 + kb < nkb) {
+        if (g0 + kb < KB) {
 #pragma unroll
           for (int bi = 0; bi < NB; ++bi) {
             const float4 b = *reinterpret_cast<const float4*>(te[bi] + lq * DP + (g0 + kb) * 16 + 4 * lk);
@@ -377,6 +394,14 @@ __device__ __forceinline__ void pre_intersect(float* __restrict__ th, int* __res
     }
     *reinterpret_cast<float4*>(th + lq * DP + i0 + 4 * lk) = make_float4(hv[0], hv[1], hv[2], hv[3]);
     *reinterpret_cast<int4*>(tmeta + lq * DP + i0 + 4 * lk) = make_int4(mv[0], mv[1], mv[2], mv[3]);
+  };
+  if (FULL) {   // (the form the straight-line kernels were tuned with: their register allocation is sensitive to it)
+    for (int i0 = wave * 16; i0 < d; i0 += GQE_FW * 16) block(i0);
+  } else {      // compile-time trip count, row blocks past d skipped by a wave-uniform test: a loop over a run-time d made the
+                // guarded 16-wave kernels spill hundreds of registers
+#pragma unroll
+    for (int i0b = 0; i0b < 64 * NC; i0b += GQE_FW * 16)
+      if (i0b + wave * 16 < d) block(i0b + wave * 16);
   }
 }
 
@@ -428,24 +453,24 @@ __device__ __forceinline__ void pre_intersect_bwd_staged(float* const (&te)[GQE_
 
 // SetIntersection backward for NB branches at once: g_e_b = Pre^T . g_z_b with
 // g_z_b = mask_b(meta) (.) g_h built on the fly as the B operand (never materialised in LDS).
-template <int NC, int NB>
+template <int NC, int NB, bool FULL>
 __device__ __forceinline__ void pre_intersect_bwd(float* const (&te)[GQE_MAX_BRANCH], const float* __restrict__ P,
                                                   const float* __restrict__ tgh, const int* __restrict__ tmeta, int d,
                                                   int DP, int wave, int lane, int inter_min) {
   constexpr int KB = 4 * NC, KG = KB < GQE_KG ? KB : GQE_KG;
-  const int lq = lane & 15, lk = lane >> 4, nkb = d >> 4;
+  const int lq = lane & 15, lk = lane >> 4;
   const float gsc = inter_min ? 1.f : 1.f / (float)NB;  // mean: every live branch gets g_h / n (mask_gz)
-  for (int i0 = wave * 16; i0 < d; i0 += GQE_FW * 16) {
+  auto block = [&](const int i0) __attribute__((always_inline)) {
     f32x4 acc[NB];
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi) acc[bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g0 = 0; g0 < KB; g0 += KG) {
       float4 a[KG];
-      load_a_slab<true, KG>(a, P, d, nkb, i0, lq, lk, g0);
+      load_a_slab<true, KG, KB, FULL>(a, P, d, i0, lq, lk, g0);
 #pragma unroll
       for (int kb = 0; kb < KG; ++kb) {
-        if (g0 + kb < nkb) {
+        if (g0 + kb < KB) {
           const float4 g4 = *reinterpret_cast<const float4*>(tgh + lq * DP + (g0 + kb) * 16 + 4 * lk);
           const float4 gh = make_float4(g4.x * gsc, g4.y * gsc, g4.z * gsc, g4.w * gsc);
           const int4 mt = *reinterpret_cast<const int4*>(tmeta + lq * DP + (g0 + kb) * 16 + 4 * lk);
@@ -462,6 +487,14 @@ __device__ __forceinline__ void pre_intersect_bwd(float* const (&te)[GQE_MAX_BRA
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi)
       *reinterpret_cast<float4*>(te[bi] + lq * DP + i0 + 4 * lk) = make_float4(acc[bi][0], acc[bi][1], acc[bi][2], acc[bi][3]);
+  };
+  if (FULL) {   // (the form the straight-line kernels were tuned with: their register allocation is sensitive to it)
+    for (int i0 = wave * 16; i0 < d; i0 += GQE_FW * 16) block(i0);
+  } else {      // compile-time trip count, row blocks past d skipped by a wave-uniform test: a loop over a run-time d made the
+                // guarded 16-wave kernels spill hundreds of registers
+#pragma unroll
+    for (int i0b = 0; i0b < 64 * NC; i0b += GQE_FW * 16)
+      if (i0b + wave * 16 < d) block(i0b + wave * 16);
   }
 }
 
@@ -477,13 +510,13 @@ struct RowSet {
   int row[RPW];  // bag modes: the row is bag `row` = ids[ptr[row] .. ptr[row + 1])
 };
 
-template <int NC>
+template <int NC, bool FULL>
 __device__ __forceinline__ void rows_issue(RowSet<NC>& rs, const TileEnv& e, int64_t table, const int* s_rows) {
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr) {
     const int row = __builtin_amdgcn_readfirstlane(s_rows[e.wave * RPW + rr]);   // wave-uniform: scalar address arithmetic
     rs.row[rr] = row;
-    rs.x[rr] = vload<NC>(e.rows + (e.sharded ? 0 : table) + (size_t)(row < 0 ? 0 : row) * e.d, e.d, e.lane);
+    rs.x[rr] = gload<NC, FULL>(e.rows + (e.sharded ? 0 : table) + (size_t)(row < 0 ? 0 : row) * e.d, e.d, e.lane);
   }
 }
 
@@ -520,7 +553,7 @@ __device__ __forceinline__ void bag_ids(int (&wid)[RPW], const BagSpan (&sp)[RPW
   for (int rr = 0; rr < RPW; ++rr) wid[rr] = (e.lane < min(sp[rr].len, 64)) ? ids[sp[rr].p0 + e.lane] : 0;
 }
 
-template <int NC>
+template <int NC, bool FULL>
 __device__ __forceinline__ void bag_rows(RowSet<NC>& rs, const BagSpan (&sp)[RPW], const int (&wid0)[RPW], const TileEnv& e, int64_t table,
                                          const int32_t* __restrict__ ids) {
   // word rows in flight per wave (the adds keep the word order: the sum equals a one-by-one loop's); the full-Bilinear d = 256
@@ -538,7 +571,7 @@ __device__ __forceinline__ void bag_rows(RowSet<NC>& rs, const BagSpan (&sp)[RPW
 #pragma unroll
         for (int u = 0; u < BU; ++u) {
           const int w = __builtin_amdgcn_readlane(wid, min(k0 + u, m - 1));
-          v[u] = vload<NC>(e.params + table + (size_t)w * e.d, e.d, e.lane);
+          v[u] = gload<NC, FULL>(e.params + table + (size_t)w * e.d, e.d, e.lane);
         }
 #pragma unroll
         for (int u = 0; u < BU; ++u)
@@ -559,10 +592,10 @@ __device__ __forceinline__ void bag_rows(RowSet<NC>& rs, const BagSpan (&sp)[RPW
 //   intersections      v = the intersected (and projected) query vector, s0 = max(|v|, eps)       score = cos(t, v)
 //   bilinear-diag chain v = a (.) prod w                                                          score = t . v
 //   TransE chain       v = a, s0 = max(|a|, eps), s1 = a . sum w, s2 = |sum w|^2                 score = cos(a, t + sum w)
-template <int NC>
+template <int NC, bool FULL>
 __device__ __forceinline__ void store_query_record(const TileEnv& e, int r, const Vec<NC>& v, float s0, float s1, float s2) {
   float* rec = e.ws + e.b.scratch_base + (size_t)(e.q0 + r) * (e.d + 4);
-  vstore<NC>(rec, v, e.d, e.lane);
+  gstore<NC, FULL>(rec, v, e.d, e.lane);
   if (e.lane == 0) {
     rec[e.d] = s0;
     rec[e.d + 1] = s1;
@@ -579,7 +612,9 @@ __device__ __forceinline__ void rows_finish(RowSet<NC>& rs) {
       rs.nrm[rr] = 1.f;
     } else {
       const float n = gqe_sqrt(vdot<NC>(rs.x[rr], rs.x[rr]));
-      rs.nrm[rr] = n;
+      // wave-uniform, but computed by the VALU: parked in an SGPR until the backward divides by it (up to ten of these norms
+      // otherwise sit in VGPRs through every contraction phase — the 80-VGPR kernels spilled exactly them)
+      rs.nrm[rr] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(n)));
       const float inv = gqe_rcp(n);
       VEC_OP(rs.x[rr], rs.x[rr].v[c] * inv);
     }
@@ -591,7 +626,7 @@ __device__ __forceinline__ void rows_finish(RowSet<NC>& rs) {
 // the optimiser pass (or gqe_materialize_grads) sums the lists.  role: 0 target, 1 negative, 2+i anchor i.
 #define GQE_NO_PUSH (-2147483647 - 1)
 
-template <int NC>
+template <int NC, bool FULL>
 __device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_base, int role, int r, int row,
                                                  const Vec<NC>& xhat, float nrm, const Vec<NC>& g, int& old_head, int hot) {
   const float pg = vdot<NC>(xhat, g);
@@ -599,16 +634,23 @@ __device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_
   Vec<NC> gx;
   VEC_OP(gx, (g.v[c] - xhat.v[c] * pg) * inv);
   if (hot >= 0) {   // wave-uniform: a hot row (hub node) — no entry, no link
-    hot_add<NC>(e, hot, gx);
+    hot_add<NC, FULL>(e, hot, gx);
     return;
   }
   const int64_t entry = e.sharded ? (int64_t)row : e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
-  vstore_wt<NC>(e.wt, e.contrib + entry * e.d, gx, e.d, e.lane);
+  vstore_wt<NC, FULL>(e.wt, e.contrib + entry * e.d, gx, e.d, e.lane);
   // The returned previous head is only needed for next[entry]; that store is deferred to the end of the
   // kernel (push_links) so that the wave never stalls on the atomic's round trip.
   if (e.lane == 0 && !e.sharded) {
-    old_head = __hip_atomic_exchange(e.head + head_base + row, (int)entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int old = __hip_atomic_exchange(e.head + head_base + row, (int)entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     e.next[entry - e.max_entries] = (int)(head_base + row);  // entry -> list head, for the data-parallel exchange
+    // 8-wave kernels (the many-tile throughput shape, up to three workgroups per CU, some held to 80 VGPRs): the link is stored
+    // at once — the wave waits for the exchange's round trip, which the co-resident workgroups cover, and ten registers per
+    // lane (one previous head per row and role) are not carried to the end of the kernel
+    if (GQE_FW == 8)
+      e.next[entry] = old;
+    else
+      old_head = old;
   }
 }
 
@@ -617,7 +659,7 @@ __device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_
 // (k = position of the word in the bag): no allocator, no counter to reset.  As for plain rows, the previous list heads
 // the exchanges return are only needed for next[node]; those stores are deferred to the end of the kernel (push_bag_links)
 // for the first 64 words of a bag, so that the wave does not stall on the atomics' round trip once per bag role.
-template <int NC>
+template <int NC, bool FULL>
 __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t head_base, int role, int r,
                                                      const int32_t* __restrict__ ptr, const int32_t* __restrict__ ids,
                                                      const Vec<NC>& xhat, float nrm, const Vec<NC>& g, int bag_slot,
@@ -633,7 +675,7 @@ __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t h
   Vec<NC> gx;
   VEC_OP(gx, (g.v[c] - xhat.v[c] * pg) * inv);
   const int64_t entry = e.bag_shift + e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
-  vstore_wt<NC>(e.wt, e.contrib_bag + entry * e.d, gx, e.d, e.lane);
+  vstore_wt<NC, FULL>(e.wt, e.contrib_bag + entry * e.d, gx, e.d, e.lane);
   // entry -> "bag b of bag table s", for the data-parallel exchange: the importer re-expands the bag itself
   if (e.lane == 0) e.next[entry - e.max_entries] = GQE_BAG_CODE(bag_slot, bi);
   const int base = (int)entry * max_len;
@@ -661,7 +703,7 @@ __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t h
       while (todo) {
         const int l = __builtin_ctzll(todo);
         todo &= todo - 1;
-        hot_add<NC>(e, __builtin_amdgcn_readlane(hs, l), gx);
+        hot_add<NC, FULL>(e, __builtin_amdgcn_readlane(hs, l), gx);
       }
     }
   }
@@ -669,19 +711,19 @@ __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t h
 
 // Row-sharded mode: every fetched row owns a slot of the send buffer, and the owner links whatever arrives — a query
 // whose hinge is inactive has to send zeros (the buffer still holds the previous step's contribution there).
-template <int NC>
+template <int NC, bool FULL>
 __device__ __forceinline__ void sharded_zero(const TileEnv& e, int bag, int row) {
-  if (e.sharded && bag < 0 && row >= 0) vstore<NC>(e.contrib + (size_t)row * e.d, vzero<NC>(), e.d, e.lane);
+  if (e.sharded && bag < 0 && row >= 0) gstore<NC, FULL>(e.contrib + (size_t)row * e.d, vzero<NC>(), e.d, e.lane);
 }
 
-template <int NC>
+template <int NC, bool FULL>
 __device__ __forceinline__ void scatter_row(const TileEnv& e, const GqeBagTable& bags, int bag, int64_t head_base, int role, int r,
                                             const RowSet<NC>& rs, int rr, const Vec<NC>& g, int& old_head, int& bag_len) {
   if (bag < 0)
-    scatter_norm_bwd<NC>(e, head_base, role, r, rs.row[rr], rs.x[rr], rs.nrm[rr], g, old_head,
+    scatter_norm_bwd<NC, FULL>(e, head_base, role, r, rs.row[rr], rs.x[rr], rs.nrm[rr], g, old_head,
                          e.hot_slot ? __builtin_amdgcn_readlane(e.hotv, role * RPW + rr) : -1);
   else
-    scatter_norm_bwd_bag<NC>(e, head_base, role, r, bags.ptr[bag], bags.ids[bag], rs.x[rr], rs.nrm[rr], g, bag, rs.row[rr], bags.max_len, old_head, bag_len);
+    scatter_norm_bwd_bag<NC, FULL>(e, head_base, role, r, bags.ptr[bag], bags.ids[bag], rs.x[rr], rs.nrm[rr], g, bag, rs.row[rr], bags.max_len, old_head, bag_len);
 }
 
 // next[entry] = previous head, for every contribution this wave pushed; bag roles: lane k holds the previous head of the
@@ -736,14 +778,14 @@ __device__ __forceinline__ void vecgrads_init(VecGrads<NC>& vg) {
   for (int k = 0; k < GQE_VG_SLOTS; ++k) vg.param[k] = -1;
 }
 
-template <int NC>
-__device__ __forceinline__ void vecgrads_commit(const TileEnv& e, float* lds /* >= SLOTS*8*d floats */, long long* s_param,
+template <int NC, bool FULL>
+__device__ __forceinline__ void vecgrads_commit(const TileEnv& e, float* lds /* >= SLOTS * GQE_FW * 64 NC floats */, long long* s_param,
                                                 const VecGrads<NC>& vg, float* red, float loss_part,
                                                 const int (&olds)[RPW][2 + GQE_MAX_BRANCH], const int (&blens)[RPW][2 + GQE_MAX_BRANCH], int max_len) {
   __syncthreads();  // every wave is done with the tiles this staging area overlays
 #pragma unroll
   for (int k = 0; k < GQE_VG_SLOTS; ++k) {
-    if (vg.param[k] >= 0) vstore<NC>(lds + (size_t)(k * GQE_FW + e.wave) * e.d, vg.g[k], e.d, e.lane);
+    if (vg.param[k] >= 0) lstore<NC>(lds + (size_t)(k * GQE_FW + e.wave) * (64 * NC), vg.g[k], e.lane);
     if (threadIdx.x == 0) s_param[k] = vg.param[k];
   }
   if (e.lane == 0) red[e.wave] = loss_part;  // the hinge partials ride on the same two barriers (red lies behind the staging area)
@@ -751,25 +793,25 @@ __device__ __forceinline__ void vecgrads_commit(const TileEnv& e, float* lds /* 
   const long long param = e.wave < GQE_VG_SLOTS ? s_param[e.wave] : -1;
   Vec<NC> s = vzero<NC>();
   if (param >= 0) {
-    s = vload<NC>(lds + (size_t)(e.wave * GQE_FW) * e.d, e.d, e.lane);
+    s = lload<NC>(lds + (size_t)(e.wave * GQE_FW) * (64 * NC), e.lane);
 #pragma unroll
     for (int w = 1; w < GQE_FW; ++w) {
-      Vec<NC> t = vload<NC>(lds + (size_t)(e.wave * GQE_FW + w) * e.d, e.d, e.lane);
+      Vec<NC> t = lload<NC>(lds + (size_t)(e.wave * GQE_FW + w) * (64 * NC), e.lane);
       VEC_OP(s, s.v[c] + t.v[c]);
     }
   }
   // the list links (they wait for the heads the scatter's exchanges returned) go out BEFORE this wave's atomic row: behind
   // it their wait would also cover the atomics' own round trip (0.8 us on the waves that flush a vector)
   push_links(e, olds, blens, max_len);
-  if (param >= 0) vatomic_add<NC>(e.grads + param, s, e.d, e.lane);
+  if (param >= 0) gatomic_add<NC, FULL>(e.grads + param, s, e.d, e.lane);
 }
 
-template <int NC>
+template <int NC, bool FULL>
 __device__ __forceinline__ void tile_to_scratch(const TileEnv& e, int slot, const float* tile) {
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr) {
     const int r = e.wave * RPW + rr;
-    vstore_wt<NC>(e.wt, scratch_row(e, slot, r), vload<NC>(tile + r * e.DP, e.d, e.lane), e.d, e.lane);
+    vstore_wt<NC, FULL>(e.wt, scratch_row(e, slot, r), lload<NC>(tile + r * e.DP, e.lane), e.d, e.lane);
   }
 }
 
@@ -837,7 +879,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
   e.max_entries = max_entries;
   e.d = d;
   e.wt = plan.pad[1] != 0;
-  e.DP = d + 4;
+  e.DP = 64 * NC + 4;   // tiles are padded to whole 64-float chunks: columns past d hold 0 (guarded kernels, see gqe_common.h)
   // the wave index as an SGPR: everything derived from it (the rows a wave owns, their bounds checks, row base addresses) is then
   // scalar arithmetic and scalar branches instead of 64-bit VALU address math and EXEC masks issued for all 64 lanes
   // (not in the full-Bilinear d = 256 kernel: the extra SGPRs spill into VGPR lanes it does not have)
@@ -882,6 +924,16 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
   constexpr bool STAGE = MLP && DEC != DEC_BILINEAR && FULL && NC <= 2 && FW == 16;
   constexpr int MR = STAGE ? NC * NC : 1;
   float* mbuf = reinterpret_cast<float*>(s_idx + 5 * GQE_TQ);  // [d][DP], only carved for STAGE kernels
+  if (!FULL) {
+    // guarded kernels: the columns past d of every tile have to read 0 (element-wise phases and row dot products run over whole
+    // 64-float chunks without a guard); contraction epilogues only ever write columns < d, row stores write zeros there.  The
+    // last chunk of every row is cleared once — its columns below d are rewritten by whoever fills the tile.
+    float* const tiles[8] = {te[0], te[1], te[2], tt, tacc, tq, tg, reinterpret_cast<float*>(tmeta)};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) tiles[k][((int)(threadIdx.x >> 6) * RPW + rr) * e.DP + 64 * (NC - 1) + e.lane] = 0.f;
+  }
   MatRegs<MR> mr;
   // The descriptor fields the gathers need — requested here, pinned (GQE_PIN) behind the index load below, so that
   // their scalar round trip runs next to that load instead of after the barrier (left alone, the compiler sinks every
@@ -966,11 +1018,11 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
 #pragma unroll
     for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
       if (i < n) {
-        W0[i] = vload<NC>(params + f->hop_param[i][0], d, lane);
-        W1[i] = (f->n_hops[i] > 1) ? vload<NC>(params + f->hop_param[i][1], d, lane) : W0[i];
+        W0[i] = gload<NC, FULL>(params + f->hop_param[i][0], d, lane);
+        W1[i] = (f->n_hops[i] > 1) ? gload<NC, FULL>(params + f->hop_param[i][1], d, lane) : W0[i];
       }
     }
-    if (f->n_final) WF = vload<NC>(params + f->final_param, d, lane);
+    if (f->n_final) WF = gload<NC, FULL>(params + f->final_param, d, lane);
   }
   RowSet<NC> RA[GQE_MAX_BRANCH], RT, RN;
   // (the full-Bilinear d = 256 kernel has two VGPRs to spare: there the bag roles are gathered one after the other)
@@ -993,12 +1045,12 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
       }
     }
     if (tbag < 0) {
-      rows_issue<NC>(RT, e, tt, s_idx);
-      if (has_neg) rows_issue<NC>(RN, e, tt, s_idx + GQE_TQ);
+      rows_issue<NC, FULL>(RT, e, tt, s_idx);
+      if (has_neg) rows_issue<NC, FULL>(RN, e, tt, s_idx + GQE_TQ);
     }
 #pragma unroll
     for (int i = 0; i < GQE_MAX_BRANCH; ++i)
-      if (i < n && abag[i] < 0) rows_issue<NC>(RA[i], e, GQE_DSC(a_table[i], f->anchor_table[i]), s_idx + (2 + i) * GQE_TQ);
+      if (i < n && abag[i] < 0) rows_issue<NC, FULL>(RA[i], e, GQE_DSC(a_table[i], f->anchor_table[i]), s_idx + (2 + i) * GQE_TQ);
     if (tbag >= 0) {
       bag_ids(wt, st, e, bags.ids[tbag]);
       if (has_neg) bag_ids(wn, sn, e, bags.ids[tbag]);
@@ -1007,22 +1059,22 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
     for (int i = 0; i < GQE_MAX_BRANCH; ++i)
       if (i < n && abag[i] >= 0) bag_ids(wa[i], sa[i], e, bags.ids[abag[i]]);
     if (tbag >= 0) {
-      bag_rows<NC>(RT, st, wt, e, tt, bags.ids[tbag]);
-      if (has_neg) bag_rows<NC>(RN, sn, wn, e, tt, bags.ids[tbag]);
+      bag_rows<NC, FULL>(RT, st, wt, e, tt, bags.ids[tbag]);
+      if (has_neg) bag_rows<NC, FULL>(RN, sn, wn, e, tt, bags.ids[tbag]);
     }
 #pragma unroll
     for (int i = 0; i < GQE_MAX_BRANCH; ++i)
-      if (i < n && abag[i] >= 0) bag_rows<NC>(RA[i], sa[i], wa[i], e, GQE_DSC(a_table[i], f->anchor_table[i]), bags.ids[abag[i]]);
+      if (i < n && abag[i] >= 0) bag_rows<NC, FULL>(RA[i], sa[i], wa[i], e, GQE_DSC(a_table[i], f->anchor_table[i]), bags.ids[abag[i]]);
   } else {
     auto gather = [&](RowSet<NC>& rs, int64_t table, const int* s_rows, int bag) {
       if (bag < 0) {
-        rows_issue<NC>(rs, e, table, s_rows);
+        rows_issue<NC, FULL>(rs, e, table, s_rows);
       } else {
         BagSpan sp[RPW];
         int wid[RPW];
         bag_spans<NC>(sp, rs, e, s_rows, bags.ptr[bag]);
         bag_ids(wid, sp, e, bags.ids[bag]);
-        bag_rows<NC>(rs, sp, wid, e, table, bags.ids[bag]);
+        bag_rows<NC, FULL>(rs, sp, wid, e, table, bags.ids[bag]);
       }
     };
     gather(RT, GQE_DSC(t_table, f->target_table), s_idx, tbag);
@@ -1079,7 +1131,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
 #pragma unroll
       for (int h = 0; h < GQE_MAX_HOPS; ++h) {
         if (h < K) {
-          w[h] = vload<NC>(params + f->hop_param[0][h], d, lane);
+          w[h] = gload<NC, FULL>(params + f->hop_param[0][h], d, lane);
           VEC_OP(wcomb, (DEC == DEC_DIAG) ? wcomb.v[c] * w[h].v[c] : wcomb.v[c] + w[h].v[c]);
         } else {
           VEC_OP(w[h], (DEC == DEC_DIAG) ? 1.f : 0.f);
@@ -1125,7 +1177,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
           Vec<NC> v = a;
           if (DEC == DEC_DIAG) VEC_OP(v, a.v[c] * wcomb.v[c]);
           const float aw = (DEC == DEC_DIAG) ? 0.f : vdot<NC>(a, wcomb), ww = (DEC == DEC_DIAG) ? 0.f : vdot<NC>(wcomb, wcomb);
-          store_query_record<NC>(e, wave * RPW + rr, v, nap, aw, ww);
+          store_query_record<NC, FULL>(e, wave * RPW + rr, v, nap, aw, ww);
           continue;
         }
         if (lane == 0) {
@@ -1154,13 +1206,13 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
             VEC_OP(ga, cp * (up.v[c] * ipp - sp * a.v[c] * iaa) + cn * (un.v[c] * ipn - sn * a.v[c] * iaa));
             VEC_OP(gw_acc, gw_acc.v[c] + gtp.v[c] + gtn.v[c]);
           }
-          scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0], blens[rr][0]);
-          scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1], blens[rr][1]);
-          scatter_row<NC>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2], blens[rr][2]);
+          scatter_row<NC, FULL>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0], blens[rr][0]);
+          scatter_row<NC, FULL>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1], blens[rr][1]);
+          scatter_row<NC, FULL>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2], blens[rr][2]);
         } else {
-          sharded_zero<NC>(e, f->target_bag, RT.row[rr]);
-          sharded_zero<NC>(e, f->target_bag, RN.row[rr]);
-          sharded_zero<NC>(e, f->anchor_bag[0], RA[0].row[rr]);
+          sharded_zero<NC, FULL>(e, f->target_bag, RT.row[rr]);
+          sharded_zero<NC, FULL>(e, f->target_bag, RN.row[rr]);
+          sharded_zero<NC, FULL>(e, f->anchor_bag[0], RA[0].row[rr]);
         }
       }
       if (BWD) {
@@ -1188,17 +1240,17 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
 #pragma unroll
       for (int rr = 0; rr < RPW; ++rr) {
         const int r = wave * RPW + rr;
-        vstore<NC>(cur[0] + r * DP, RT.x[rr], d, lane);
-        if (has_neg) vstore<NC>(cur[1] + r * DP, RN.x[rr], d, lane);
+        lstore<NC>(cur[0] + r * DP, RT.x[rr], lane);
+        if (has_neg) lstore<NC>(cur[1] + r * DP, RN.x[rr], lane);
         if (BWD) {
-          vstore_wt<NC>(e.wt, scratch_row(e, f->slot_act[0][0], r), RT.x[rr], d, lane);
-          vstore_wt<NC>(e.wt, scratch_row(e, f->slot_act[1][0], r), RN.x[rr], d, lane);
+          vstore_wt<NC, FULL>(e.wt, scratch_row(e, f->slot_act[0][0], r), RT.x[rr], d, lane);
+          vstore_wt<NC, FULL>(e.wt, scratch_row(e, f->slot_act[1][0], r), RN.x[rr], d, lane);
         }
       }
       for (int h = 0; h < K; ++h) {
         __syncthreads();
         for (int s = 0; s < nside; ++s)
-          tile_matmul<true, NC>(alt[s], params + f->hop_param[0][h], cur[s], d, DP, wave, lane);
+          tile_matmul<true, NC, FULL>(alt[s], params + f->hop_param[0][h], cur[s], d, DP, wave, lane);
         __syncthreads();
         for (int s = 0; s < nside; ++s) {
           float* tmp = cur[s];
@@ -1206,7 +1258,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
           alt[s] = tmp;
         }
         if (BWD && h + 1 < K)
-          for (int s = 0; s < nside; ++s) tile_to_scratch<NC>(e, f->slot_act[s][h + 1], cur[s]);
+          for (int s = 0; s < nside; ++s) tile_to_scratch<NC, FULL>(e, f->slot_act[s][h + 1], cur[s]);
       }
       // scores + gradient seeds; g_u overwrites u in place
 #pragma unroll
@@ -1220,7 +1272,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           if (s < nside) {
-            u[s] = vload<NC>(cur[s] + r * DP, d, lane);
+            u[s] = lload<NC>(cur[s] + r * DP, lane);
             nu[s] = fmaxf(gqe_sqrt(vdot<NC>(u[s], u[s])), COS_EPS);
             su[s] = vdot<NC>(u[s], a) * gqe_rcp(nu[s] * nac);
           } else {
@@ -1243,19 +1295,19 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
           Vec<NC> gu;
           VEC_OP(gu, cf[s] * (a.v[c] * iun - u[s].v[c] * iuu));
           VEC_OP(ga, ga.v[c] + cf[s] * (u[s].v[c] * iun - a.v[c] * iaa));
-          vstore<NC>(cur[s] + r * DP, gu, d, lane);
+          lstore<NC>(cur[s] + r * DP, gu, lane);
         }
-        if (act) scatter_row<NC>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2], blens[rr][2]);
-        else if (q < B) sharded_zero<NC>(e, f->anchor_bag[0], RA[0].row[rr]);
+        if (act) scatter_row<NC, FULL>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2], blens[rr][2]);
+        else if (q < B) sharded_zero<NC, FULL>(e, f->anchor_bag[0], RA[0].row[rr]);
       }
       if (BWD) {
         // back through the hops: act_{h+1} = act_h M_h  =>  g_act_h = g_act_{h+1} M_h^T (= M . g per row),
         // dM_h += act_h^T g_act_{h+1}  (deferred: pair (slot_act[s][h], slot_gact[s][h]))
         for (int h = K - 1; h >= 0; --h) {
-          for (int s = 0; s < 2; ++s) tile_to_scratch<NC>(e, f->slot_gact[s][h], cur[s]);
+          for (int s = 0; s < 2; ++s) tile_to_scratch<NC, FULL>(e, f->slot_gact[s][h], cur[s]);
           __syncthreads();
           for (int s = 0; s < 2; ++s)
-            tile_matmul<false, NC>(alt[s], params + f->hop_param[0][h], cur[s], d, DP, wave, lane);
+            tile_matmul<false, NC, FULL>(alt[s], params + f->hop_param[0][h], cur[s], d, DP, wave, lane);
           __syncthreads();
           for (int s = 0; s < 2; ++s) {
             float* tmp = cur[s];
@@ -1267,8 +1319,8 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
         for (int rr = 0; rr < RPW; ++rr) {
           const int r = wave * RPW + rr;
           if (e.q0 + r >= B) continue;
-          scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, r, RT, rr, vload<NC>(cur[0] + r * DP, d, lane), olds[rr][0], blens[rr][0]);
-          scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, r, RN, rr, vload<NC>(cur[1] + r * DP, d, lane), olds[rr][1], blens[rr][1]);
+          scatter_row<NC, FULL>(e, bags, f->target_bag, f->target_head, 0, r, RT, rr, lload<NC>(cur[0] + r * DP, lane), olds[rr][0], blens[rr][0]);
+          scatter_row<NC, FULL>(e, bags, f->target_bag, f->target_head, 1, r, RN, rr, lload<NC>(cur[1] + r * DP, lane), olds[rr][1], blens[rr][1]);
         }
       }
     }
@@ -1290,23 +1342,23 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
           const int r = wave * RPW + rr;
-          vstore<NC>(src + r * DP, RA[i].x[rr], d, lane);
-          if (BWD) vstore_wt<NC>(e.wt, scratch_row(e, f->slot_x[i][0], r), RA[i].x[rr], d, lane);
+          lstore<NC>(src + r * DP, RA[i].x[rr], lane);
+          if (BWD) vstore_wt<NC, FULL>(e.wt, scratch_row(e, f->slot_x[i][0], r), RA[i].x[rr], d, lane);
         }
         for (int h = 0; h < nh; ++h) {
           __syncthreads();
-          tile_matmul<false, NC>(dst, params + f->hop_param[i][h], src, d, DP, wave, lane);
+          tile_matmul<false, NC, FULL>(dst, params + f->hop_param[i][h], src, d, DP, wave, lane);
           __syncthreads();
           float* tmp = src;
           src = dst;
           dst = tmp;
-          if (BWD && h + 1 < nh) tile_to_scratch<NC>(e, f->slot_x[i][h + 1], src);
+          if (BWD && h + 1 < nh) tile_to_scratch<NC, FULL>(e, f->slot_x[i][h + 1], src);
         }
-        if (MLP && BWD) tile_to_scratch<NC>(e, f->slot_e[i], te[i]);
+        if (MLP && BWD) tile_to_scratch<NC, FULL>(e, f->slot_e[i], te[i]);
       } else {
         if (!PREW) {
-          W0[i] = vload<NC>(params + f->hop_param[i][0], d, lane);
-          W1[i] = (nh > 1) ? vload<NC>(params + f->hop_param[i][1], d, lane) : W0[i];
+          W0[i] = gload<NC, FULL>(params + f->hop_param[i][0], d, lane);
+          W1[i] = (nh > 1) ? gload<NC, FULL>(params + f->hop_param[i][1], d, lane) : W0[i];
         }
         const Vec<NC>& w0 = W0[i];
         const Vec<NC>& w1 = W1[i];
@@ -1316,8 +1368,8 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
           Vec<NC> x = RA[i].x[rr];
           VEC_OP(x, (DEC == DEC_DIAG) ? x.v[c] * w0.v[c] : x.v[c] + w0.v[c]);
           if (nh > 1) VEC_OP(x, (DEC == DEC_DIAG) ? x.v[c] * w1.v[c] : x.v[c] + w1.v[c]);
-          vstore<NC>(te[i] + r * DP, x, d, lane);
-          if (MLP && BWD) vstore_wt<NC>(e.wt, scratch_row(e, f->slot_e[i], r), x, d, lane);
+          lstore<NC>(te[i] + r * DP, x, lane);
+          if (MLP && BWD) vstore_wt<NC, FULL>(e.wt, scratch_row(e, f->slot_e[i], r), x, d, lane);
         }
       }
     }
@@ -1340,9 +1392,9 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
         if (BWD) mat_issue<MR>(mr, params + f->pre_param);    // ... and Pre is requested again for the backward
       } else {
         if (n == 3)
-          pre_intersect<NC, 3>(tacc, tmeta, params + f->pre_param, te, d, DP, wave, lane, inter_min);
+          pre_intersect<NC, 3, FULL>(tacc, tmeta, params + f->pre_param, te, d, DP, wave, lane, inter_min);
         else
-          pre_intersect<NC, 2>(tacc, tmeta, params + f->pre_param, te, d, DP, wave, lane, inter_min);
+          pre_intersect<NC, 2, FULL>(tacc, tmeta, params + f->pre_param, te, d, DP, wave, lane, inter_min);
       }
       __syncthreads();
     } else {
@@ -1353,7 +1405,6 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           const int j = lane + 64 * c;
-          if (j >= d) continue;
           float best = te[0][r * DP + j];
           int meta = 0x70;
 #pragma unroll
@@ -1378,11 +1429,11 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
     GQE_STAMP(3);
     float* tqq = tacc;  // where q lives
     if (MLP) {
-      if (BWD) tile_to_scratch<NC>(e, f->slot_hh, tacc);
+      if (BWD) tile_to_scratch<NC, FULL>(e, f->slot_hh, tacc);
       if (STAGE)
         tile_matmul_staged<false, NC>(tq, mbuf, tacc, DP, wave, lane);
       else
-        tile_matmul<false, NC>(tq, params + f->post_param, tacc, d, DP, wave, lane);  // q = Post . h
+        tile_matmul<false, NC, FULL>(tq, params + f->post_param, tacc, d, DP, wave, lane);  // q = Post . h
       __syncthreads();
       tqq = tq;
     }
@@ -1390,19 +1441,19 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
     float* tqpre = tqq;  // q before the final projection (needed by its backward)
     if (f->n_final) {
       if (DEC == DEC_BILINEAR) {
-        if (BWD) tile_to_scratch<NC>(e, f->slot_fx, tqq);
+        if (BWD) tile_to_scratch<NC, FULL>(e, f->slot_fx, tqq);
         if (!MLP) __syncthreads();
-        tile_matmul<false, NC>(te[0], params + f->final_param, tqq, d, DP, wave, lane);
+        tile_matmul<false, NC, FULL>(te[0], params + f->final_param, tqq, d, DP, wave, lane);
         __syncthreads();
       } else {
-        if (!PREW) WF = vload<NC>(params + f->final_param, d, lane);
+        if (!PREW) WF = gload<NC, FULL>(params + f->final_param, d, lane);
         const Vec<NC>& w = WF;
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
           const int r = wave * RPW + rr;
-          Vec<NC> x = vload<NC>(tqq + r * DP, d, lane);
+          Vec<NC> x = lload<NC>(tqq + r * DP, lane);
           VEC_OP(x, (DEC == DEC_DIAG) ? x.v[c] * w.v[c] : x.v[c] + w.v[c]);
-          vstore<NC>(te[0] + r * DP, x, d, lane);
+          lstore<NC>(te[0] + r * DP, x, lane);
         }
       }
       tqq = te[0];
@@ -1413,10 +1464,10 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
     for (int rr = 0; rr < RPW; ++rr) {
       const int r = wave * RPW + rr;
       const int q = e.q0 + r;
-      Vec<NC> qv = vload<NC>(tqq + r * DP, d, lane);
+      Vec<NC> qv = lload<NC>(tqq + r * DP, lane);
       const float nq = fmaxf(gqe_sqrt(vdot<NC>(qv, qv)), COS_EPS);
       if (eval_mode) {
-        if (q < B) store_query_record<NC>(e, r, qv, nq, 0.f, 0.f);
+        if (q < B) store_query_record<NC, FULL>(e, r, qv, nq, 0.f, 0.f);
         continue;
       }
       const Vec<NC>& tp = RT.x[rr];
@@ -1437,16 +1488,16 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
       const float ipq = gqe_rcp(ncp * nq), inq = gqe_rcp(ncn * nq), iqq = gqe_rcp(nq * nq);
       Vec<NC> gq, gtp, gtn;
       VEC_OP(gq, cp * (tp.v[c] * ipq - sp * qv.v[c] * iqq) + cn * (tn.v[c] * inq - sn * qv.v[c] * iqq));
-      vstore<NC>(tg + r * DP, gq, d, lane);
+      lstore<NC>(tg + r * DP, gq, lane);
       if (act) {
         const float ipp = sp * gqe_rcp(ncp * ncp), inn = sn * gqe_rcp(ncn * ncn);
         VEC_OP(gtp, cp * (qv.v[c] * ipq - tp.v[c] * ipp));
         VEC_OP(gtn, cn * (qv.v[c] * inq - tn.v[c] * inn));
-        scatter_row<NC>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0], blens[rr][0]);
-        scatter_row<NC>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1], blens[rr][1]);
+        scatter_row<NC, FULL>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0], blens[rr][0]);
+        scatter_row<NC, FULL>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1], blens[rr][1]);
       } else if (q < B) {
-        sharded_zero<NC>(e, f->target_bag, RT.row[rr]);
-        sharded_zero<NC>(e, f->target_bag, RN.row[rr]);
+        sharded_zero<NC, FULL>(e, f->target_bag, RT.row[rr]);
+        sharded_zero<NC, FULL>(e, f->target_bag, RN.row[rr]);
       }
     }
     GQE_STAMP(5);
@@ -1456,24 +1507,24 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
       float* tgc = tg;
       if (f->n_final) {
         if (DEC == DEC_BILINEAR) {
-          tile_to_scratch<NC>(e, f->slot_fg, tg);
+          tile_to_scratch<NC, FULL>(e, f->slot_fg, tg);
           __syncthreads();
-          tile_matmul<true, NC>(te[1], params + f->final_param, tg, d, DP, wave, lane);
+          tile_matmul<true, NC, FULL>(te[1], params + f->final_param, tg, d, DP, wave, lane);
           __syncthreads();
           tgc = te[1];
         } else {
-          if (!PREW) WF = vload<NC>(params + f->final_param, d, lane);
+          if (!PREW) WF = gload<NC, FULL>(params + f->final_param, d, lane);
           const Vec<NC>& w = WF;
           Vec<NC> gw = vzero<NC>();
 #pragma unroll
           for (int rr = 0; rr < RPW; ++rr) {
             const int r = wave * RPW + rr;
-            Vec<NC> g = vload<NC>(tg + r * DP, d, lane);
+            Vec<NC> g = lload<NC>(tg + r * DP, lane);
             if (DEC == DEC_DIAG) {
-              Vec<NC> qp = vload<NC>(tqpre + r * DP, d, lane);
+              Vec<NC> qp = lload<NC>(tqpre + r * DP, lane);
               VEC_OP(gw, gw.v[c] + g.v[c] * qp.v[c]);
               VEC_OP(g, g.v[c] * w.v[c]);
-              vstore<NC>(tg + r * DP, g, d, lane);
+              lstore<NC>(tg + r * DP, g, lane);
             } else {
               VEC_OP(gw, gw.v[c] + g.v[c]);
             }
@@ -1485,7 +1536,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
       // ---- backward of Post: g_h -> tacc (h itself is already parked in scratch) ----
       float* tgh = tgc;  // grad wrt h (MLP) or wrt the intersection output (simple)
       if (MLP) {
-        tile_to_scratch<NC>(e, f->slot_gq, tgc);
+        tile_to_scratch<NC, FULL>(e, f->slot_gq, tgc);
         GQE_WSTAMP(1);
         __syncthreads();
         if (STAGE) {
@@ -1497,7 +1548,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
           mat_commit<MR>(mr, mbuf, d, DP);  // Pre again; the barrier in front of its contraction is below
           GQE_WSTAMP(5);
         } else {
-          tile_matmul<true, NC>(tacc, params + f->post_param, tgc, d, DP, wave, lane);  // g_h = Post^T g_q
+          tile_matmul<true, NC, FULL>(tacc, params + f->post_param, tgc, d, DP, wave, lane);  // g_h = Post^T g_q
           __syncthreads();
         }
         tgh = tacc;
@@ -1531,8 +1582,8 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
 #pragma unroll
           for (int c = 0; c < NC; ++c) {
             const int j = lane + 64 * c;
-            gh[c] = (j < d) ? tgh[r * DP + j] * gsc : 0.f;
-            mt[c] = (j < d) ? tmeta[r * DP + j] : 0;
+            gh[c] = tgh[r * DP + j] * gsc;   // (columns past d: 0)
+            mt[c] = tmeta[r * DP + j];
           }
 #pragma unroll
           for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
@@ -1540,7 +1591,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
             Vec<NC> gz;
 #pragma unroll
             for (int c = 0; c < NC; ++c) gz.v[c] = keep_if_bit(gh[c], mt[c], 8 + i);
-            vstore_wt<NC>(e.wt, scratch_row(e, f->slot_gz[i], r), gz, d, lane);
+            vstore_wt<NC, FULL>(e.wt, scratch_row(e, f->slot_gz[i], r), gz, d, lane);
           }
         }
         if (STAGE) {
@@ -1553,9 +1604,9 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
             pre_intersect_bwd_staged<NC, 2>(te, mbuf, tgh, tmeta, DP, wave, lane, inter_min);
         } else {
           if (n == 3)
-            pre_intersect_bwd<NC, 3>(te, params + f->pre_param, tgh, tmeta, d, DP, wave, lane, inter_min);
+            pre_intersect_bwd<NC, 3, FULL>(te, params + f->pre_param, tgh, tmeta, d, DP, wave, lane, inter_min);
           else
-            pre_intersect_bwd<NC, 2>(te, params + f->pre_param, tgh, tmeta, d, DP, wave, lane, inter_min);
+            pre_intersect_bwd<NC, 2, FULL>(te, params + f->pre_param, tgh, tmeta, d, DP, wave, lane, inter_min);
         }
         GQE_STAMP(13);
         GQE_WSTAMP(7);
@@ -1574,7 +1625,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
               const int j = lane + 64 * c;
-              if (j < d) dstt[r * DP + j] = mask_gz(tgh[r * DP + j], tmeta[r * DP + j], i, inter_min, inv_n, false);
+              dstt[r * DP + j] = mask_gz(tgh[r * DP + j], tmeta[r * DP + j], i, inter_min, inv_n, false);
             }
           }
         }
@@ -1588,9 +1639,9 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
           float* tcur = (!MLP && tgh == te[i]) ? tt : te[i];
           float* tnext = tq;  // tq is dead in the backward; tt may hold another branch's masked gradient
           for (int h = nh - 1; h >= 0; --h) {
-            tile_to_scratch<NC>(e, f->slot_gy[i][h], tcur);
+            tile_to_scratch<NC, FULL>(e, f->slot_gy[i][h], tcur);
             __syncthreads();
-            tile_matmul<true, NC>(tnext, params + f->hop_param[i][h], tcur, d, DP, wave, lane);
+            tile_matmul<true, NC, FULL>(tnext, params + f->hop_param[i][h], tcur, d, DP, wave, lane);
             __syncthreads();
             float* tmp = tcur;
             tcur = tnext;
@@ -1600,14 +1651,14 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
           for (int rr = 0; rr < RPW; ++rr) {
             const int r = wave * RPW + rr;
             if (e.q0 + r >= B) continue;
-            scatter_row<NC>(e, bags, f->anchor_bag[i], f->anchor_head[i], 2 + i, r, RA[i], rr, vload<NC>(tcur + r * DP, d, lane),
+            scatter_row<NC, FULL>(e, bags, f->anchor_bag[i], f->anchor_head[i], 2 + i, r, RA[i], rr, lload<NC>(tcur + r * DP, lane),
                             olds[rr][2 + i], blens[rr][2 + i]);
           }
           __syncthreads();  // tt / tq are rewritten by the next branch
         } else {
           if (!PREW) {
-            W0[i] = vload<NC>(params + f->hop_param[i][0], d, lane);
-            W1[i] = (nh > 1) ? vload<NC>(params + f->hop_param[i][1], d, lane) : W0[i];
+            W0[i] = gload<NC, FULL>(params + f->hop_param[i][0], d, lane);
+            W1[i] = (nh > 1) ? gload<NC, FULL>(params + f->hop_param[i][1], d, lane) : W0[i];
           }
           const Vec<NC>& w0 = W0[i];
           const Vec<NC>& w1 = W1[i];
@@ -1619,12 +1670,12 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
             const Vec<NC>& x = RA[i].x[rr];
             Vec<NC> g;
             if (MLP) {
-              g = vload<NC>(te[i] + r * DP, d, lane);
+              g = lload<NC>(te[i] + r * DP, lane);
             } else {
 #pragma unroll
               for (int c = 0; c < NC; ++c) {
                 const int j = lane + 64 * c;
-                g.v[c] = (j < d) ? mask_gz(tgh[r * DP + j], tmeta[r * DP + j], i, inter_min, inv_n, false) : 0.f;
+                g.v[c] = mask_gz(tgh[r * DP + j], tmeta[r * DP + j], i, inter_min, inv_n, false);
               }
             }
             if (DEC == DEC_DIAG) {
@@ -1638,14 +1689,23 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
             } else {
               VEC_OP(gw0, gw0.v[c] + g.v[c]);
             }
-            scatter_row<NC>(e, bags, f->anchor_bag[i], f->anchor_head[i], 2 + i, r, RA[i], rr, g, olds[rr][2 + i], blens[rr][2 + i]);
+            scatter_row<NC, FULL>(e, bags, f->anchor_bag[i], f->anchor_head[i], 2 + i, r, RA[i], rr, g, olds[rr][2 + i], blens[rr][2 + i]);
           }
-          vg.g[2 * i] = gw0;
-          vg.param[2 * i] = f->hop_param[i][0];
-          if (nh > 1) {
-            vg.g[2 * i + 1] = (DEC == DEC_DIAG) ? gw1 : gw0;
-            vg.param[2 * i + 1] = f->hop_param[i][1];
-          }
+          // (slot indices spelled out per branch: indexed with the loop variable, the TransE 8-wave d = 128 kernels kept the
+          // slots in a dynamically indexed private array — 40 B of scratch without a single spilled register)
+#define GQE_VG_SET(I)                                          \
+  if (i == I) {                                                \
+    vg.g[2 * I] = gw0;                                         \
+    vg.param[2 * I] = f->hop_param[I][0];                      \
+    if (nh > 1) {                                              \
+      vg.g[2 * I + 1] = (DEC == DEC_DIAG) ? gw1 : gw0;         \
+      vg.param[2 * I + 1] = f->hop_param[I][1];                \
+    }                                                          \
+  }
+          GQE_VG_SET(0)
+          GQE_VG_SET(1)
+          GQE_VG_SET(2)
+#undef GQE_VG_SET
         }
       }
     }
@@ -1656,7 +1716,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
     // mean hinge loss of the batch (model.py:124-126) and the weighted iteration loss: reduce the waves in
     // LDS (thousands of same-address device atomics serialise at ~12 ns each) and park one partial per tile.
     if (DEC != DEC_BILINEAR) {
-      vecgrads_commit<NC>(e, smem, reinterpret_cast<long long*>(s_idx), vg, red, loss_part, olds, blens, bags.max_len);
+      vecgrads_commit<NC, FULL>(e, smem, reinterpret_cast<long long*>(s_idx), vg, red, loss_part, olds, blens, bags.max_len);
     } else {
       __syncthreads();
       if (lane == 0) red[wave] = loss_part;
@@ -1681,7 +1741,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
 // per-(DEC, MLP) launcher, instantiated once per translation unit (gqe_fused_inst.hip)
 // ------------------------------------------------------------------------------------------
 inline size_t gqe_fused_lds_bytes_impl(int d, bool stage, bool compact) {
-  const int DP = d + 4;
+  const int DP = 64 * ((d + 63) / 64) + 4;   // tiles padded to whole 64-float chunks
   if (compact) return (size_t)(5 * GQE_TQ * DP + 64 + 5 * GQE_TQ) * sizeof(float);
   return (size_t)(8 * GQE_TQ * DP + GQE_FW * d + 5 * GQE_TQ + (stage ? d * DP : 0)) * sizeof(float);
 }
@@ -1710,26 +1770,19 @@ static hipError_t launch_fused_dm(const GqeFusedArgs& a) {
   const int nc = (a.d + 63) / 64;
   const bool full = (a.d % 64) == 0;
 #if GQE_FW == 16
-  switch (nc) {  // d <= 128 and d = 256 (straight-line code, <= 125 VGPRs, no scratch)
-    case 1:
-      if (full) return launch_fused_v<DEC, MLP, 1, true>(a);
-      if constexpr (DEC != DEC_BILINEAR) return launch_fused_v<DEC, MLP, 1, false>(a);   // (full Bilinear at d < 64: the 8-wave shape)
-      return hipErrorInvalidValue;
-    case 2: return full ? launch_fused_v<DEC, MLP, 2, true>(a) : hipErrorInvalidValue;  // guarded d in (64, 128): the 8-wave shape
-    case 4: return full ? launch_fused_v<DEC, MLP, 4, true>(a) : hipErrorInvalidValue;
+  // every accepted d (a multiple of 16 up to 256) runs a 16-wave kernel of NC = ceil(d / 64) chunks: straight-line FULL code at
+  // d = 64 / 128 / 256, the guarded form (buffer-addressed rows, padded tiles: gqe_common.h) everywhere else
+  switch (nc) {
+    case 1: return full ? launch_fused_v<DEC, MLP, 1, true>(a) : launch_fused_v<DEC, MLP, 1, false>(a);
+    case 2: return full ? launch_fused_v<DEC, MLP, 2, true>(a) : launch_fused_v<DEC, MLP, 2, false>(a);
+    case 3: return launch_fused_v<DEC, MLP, 3, false>(a);   // (d = 192 too)
+    case 4: return full ? launch_fused_v<DEC, MLP, 4, true>(a) : launch_fused_v<DEC, MLP, 4, false>(a);
     default: return hipErrorInvalidValue;
   }
 #else
-  switch (nc) {  // d = 128 with many tiles (two workgroups per CU) and every guarded d > 64 (256 VGPRs per lane: the guarded
-                 // 16-wave kernels spilled at their 128-VGPR limit); full Bilinear at d < 64 (171 VGPRs, no scratch)
-    case 1:
-      if constexpr (DEC == DEC_BILINEAR) return full ? hipErrorInvalidValue : launch_fused_v<DEC, MLP, 1, false>(a);
-      return hipErrorInvalidValue;
-    case 2: return full ? launch_fused_v<DEC, MLP, 2, true>(a) : launch_fused_v<DEC, MLP, 2, false>(a);
-    case 3: return launch_fused_v<DEC, MLP, 3, false>(a);
-    case 4: return full ? hipErrorInvalidValue : launch_fused_v<DEC, MLP, 4, false>(a);
-    default: return hipErrorInvalidValue;
-  }
+  // 8 waves, two rows per wave: d = 128 launches with many tiles (two / three workgroups per CU)
+  if (nc == 2 && full) return launch_fused_v<DEC, MLP, 2, true>(a);
+  return hipErrorInvalidValue;
 #endif
 }
 

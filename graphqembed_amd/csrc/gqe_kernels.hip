@@ -528,35 +528,31 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_opt_kernel(const GqeDevSeg* _
 GQE_DECL(0, 0) GQE_DECL(0, 1) GQE_DECL(1, 0) GQE_DECL(1, 1) GQE_DECL(2, 0) GQE_DECL(2, 1)
 #undef GQE_DECL
 
-// Which workgroup shape runs a launch (gqe_fused.h): 16 waves (one query row per wave) up to d = 128 and at d = 256;
-// 8 waves (two rows per wave, 256 VGPRs) for the guarded d in (128, 256) variants, and at d = 128 when the launch has
-// so many tiles that two co-resident workgroups per CU (2 x 74 KB of LDS, 2 x 8 waves at <= 128 VGPRs) beat the shorter
+// Which workgroup shape runs a launch (gqe_fused.h): 16 waves (one query row per wave) for every accepted d — straight-line FULL
+// code at d = 64 / 128 / 256, the guarded form (buffer-addressed rows and matrices, padded LDS tiles) elsewhere; 8 waves (two rows
+// per wave) only at d = 128 when the launch has so many tiles that two or three co-resident workgroups per CU beat the shorter
 // per-tile chain of the 16-wave shape.
 int gqe_fused_waves(int dec, int d, int tiles) {
-  if (d == 256) return 16;  // FULL variant: fits 128 VGPRs without scratch; every wave owns an MFMA row block
-  if (d > 128) return 8;    // guarded variants
-  if (d > 64 && (d % 64) != 0) return 8;  // guarded d in (64, 128): 256 VGPRs per lane instead of spilling at 128
-  if (dec == DEC_BILINEAR && d < 64) return 8;  // full Bilinear, guarded d < 64: 171 VGPRs (the 16-wave form spilled at 128)
   static const int min_tiles = [] {   // GQE_DEBUG_FW8_MIN_TILES: tuning runs only
     const char* e = getenv("GQE_DEBUG_FW8_MIN_TILES");
     return e ? atoi(e) : GQE_FW8_MIN_TILES;
   }();
+  (void)dec;
   if (d == 128 && tiles > min_tiles) return 8;
   return 16;
 }
 
-// Which (decoder, intersection, dim) the library vouches for.  Every kernel the dispatcher can select for a supported
-// configuration is free of register spills and of the allocator's "spill / copy ahead of the EXEC restore" placement
-// (the root cause of the corrupted gradients / memory faults of two spilling guarded kernels in round 2);
-// tests/test_build_meta.py checks that against the code objects and the assembly of the built library.  What is refused:
-// full Bilinear at d % 64 != 0 above 64 and at d = 192 (its guarded 8-wave kernels spill up to 476 registers), and the
-// SetIntersection (min / mean) decoders at d in (192, 256) (3-24 spilled registers; one of those kernels carries the
-// bad placement).
+// Which (decoder, intersection, dim) the library accepts: every multiple of 16 up to GQE_MAX_DIM, with every decoder pair —
+// what the reference's `--embed_dim` allows in practice (bio/train.py:13).  Every kernel the dispatcher can select is free of
+// register spills and of the allocator's "spill / copy ahead of the EXEC restore" placement;
+// tests/test_build_meta.py checks that against the code objects and the assembly of the built library.  (Round 3 refused full
+// Bilinear at d not in {16 .. 64, 128, 256} and the MLP intersections at d in (192, 256): their guarded kernels spilled; the
+// guarded kernels now address rows and matrices through buffer descriptors — no lane-divergent bounds guard — and run their
+// contractions over the padded extent with compile-time trip counts.)
 int gqe_config_supported(int dec, int inter, int d) {
+  (void)inter;
+  if (dec < 0 || dec > DEC_BILINEAR) return 0;
   if (d < 16 || d > GQE_MAX_DIM || d % 16) return 0;
-  if (dec == DEC_BILINEAR) return d <= 64 || d == 128 || d == 256;
-  const bool mlp = inter == GQE_INTER_MIN || inter == GQE_INTER_MEAN;
-  if (mlp && d > 192 && d < 256) return 0;
   return 1;
 }
 

@@ -117,10 +117,10 @@ typedef struct {
 } gqe_segment;
 
 int gqe_abi_version(void);
-/* 1 if gqe_create accepts (decoder, inter, dim): dim a multiple of 16 in [16, GQE_MAX_DIM], except the combinations whose
- * fused kernel the compiler can only build with register spills (full Bilinear: only 16, 32, 48, 64, 128, 256; SetIntersection
- * min / mean: not 208, 224, 240) — spilling variants corrupted results once (a register-allocator placement bug)
- * and are refused rather than trusted.  No GPU needed. */
+/* 1 if gqe_create accepts (decoder, inter, dim): every multiple of 16 in [16, GQE_MAX_DIM] with every decoder / intersection
+ * pair (the reference takes any --embed_dim, bio/train.py:13).  No GPU needed.  (Until round 3 the combinations whose guarded
+ * kernels spilled registers were refused: full Bilinear outside {16 .. 64, 128, 256}, the MLP intersections at 208 / 224 / 240;
+ * DESIGN.md §3 has the history.) */
 int gqe_dim_supported(int32_t decoder, int32_t inter, int32_t dim);
 const char* gqe_last_error(const gqe_ctx* ctx);   /* ctx may be NULL: last create error */
 

@@ -8,7 +8,7 @@ placed a live-range-split copy and spill stores at the top of the JOIN block of 
 EVERY instantiation the dispatcher can select for a configuration gqe_create accepts:
   * no spilled VGPRs;
   * no allocator-inserted instruction ahead of an EXEC restore (tools/exec_check.py on the kept assembly).
-Configurations that would need a spilling kernel are refused by gqe_create (gqe_dim_supported)."""
+Every (decoder, intersection, d % 16 == 0) configuration is accepted (gqe_dim_supported) and has spill-free kernels."""
 import ctypes
 import os
 import sys
@@ -60,17 +60,23 @@ def selectable(lib):
 
 
 def test_supported_configurations(lib):
-    """BASELINE's dims (128, 256) and the golden fixtures' (32) with every decoder; what is refused is exactly the list
-    include/gqe.h states."""
+    """Every multiple of 16 up to 256 with every decoder / intersection pair (the reference takes any --embed_dim,
+    bio/train.py:13); nothing else."""
     for dec in (0, 1, 2):
         for inter in INTERS.values():
-            for d in (32, 64, 128, 256):
+            for d in DIMS:
                 assert lib.gqe_dim_supported(dec, inter, d), (dec, inter, d)
-    refused = sorted((dec, inter, d) for dec in (0, 1, 2) for inter in INTERS.values() for d in DIMS if not lib.gqe_dim_supported(dec, inter, d))
-    want = sorted([(2, i, d) for i in INTERS.values() for d in DIMS if d not in (16, 32, 48, 64, 128, 256)] +
-                  [(dec, i, d) for dec in (0, 1) for i in (0, 1) for d in (208, 224, 240)])
-    assert refused == want
     assert not lib.gqe_dim_supported(0, 0, 24) and not lib.gqe_dim_supported(0, 0, 272) and not lib.gqe_dim_supported(1, 2, 0)
+    assert not lib.gqe_dim_supported(3, 0, 128) and not lib.gqe_dim_supported(-1, 0, 128)
+
+
+def test_no_unreachable_fused_kernels_are_built(kernels, lib):
+    """Every gqe_fused_kernel instantiation in the library is one the dispatcher can select (round 3 shipped 14 spilling
+    variants that nothing could reach)."""
+    from kernel_meta import fused_variant
+    built = set(fused_variant(k["name"]) for k in kernels if fused_variant(k["name"]))
+    sel = set(selectable(lib))
+    assert built == sel, (sorted(built - sel), sorted(sel - built))
 
 
 def test_every_selectable_fused_kernel_is_free_of_spills(kernels, lib):
@@ -85,21 +91,21 @@ def test_every_selectable_fused_kernel_is_free_of_spills(kernels, lib):
         assert k["vgpr"] <= (128 if v[5] == 16 else 256), (v, k["vgpr"])
 
 
-def test_sixteen_wave_full_kernels_use_no_scratch(kernels):
-    """d = 64 / 128 / 256 (FULL) tiles of 16 waves — BASELINE's kernels — forward and backward, every decoder and both
-    intersection kinds: no scratch at all (a dynamically indexed local array would show here too)."""
+def test_fused_kernels_use_no_scratch(kernels, lib):
+    """Every fused kernel the dispatcher can select — every decoder, both intersection kinds, every accepted d, 16- and 8-wave
+    shapes, forward and backward: no scratch at all (a spilled register or a dynamically indexed local array would show here;
+    round 3's TransE 8-wave d = 128 kernels carried such an array, 40 B, without a spill)."""
     from kernel_meta import fused_variant
+    sel = selectable(lib)
     seen = 0
     for k in kernels:
         v = fused_variant(k["name"])
-        if not v:
+        if not v or v not in sel:
             continue
-        dec, mlp, nc, full, bwd, fw = v
-        if fw == 16 and full:
-            seen += 1
-            assert k["scratch"] == 0 and k["vgpr_spill"] == 0, "%s: %d B scratch, %d spilled VGPRs" % (k["name"][:60], k["scratch"], k["vgpr_spill"])
-            assert k["vgpr"] <= 128, k
-    assert seen == 3 * 2 * 3 * 2, seen     # DEC x MLP x NC in {1, 2, 4} x {fwd, bwd}
+        seen += 1
+        assert k["scratch"] == 0 and k["vgpr_spill"] == 0, "%s: %d B scratch, %d spilled VGPRs" % (k["name"][:60], k["scratch"], k["vgpr_spill"])
+        assert k["vgpr"] <= (128 if v[5] == 16 else 256), k
+    assert seen == len(sel) and seen >= 3 * 2 * (7 + 1) * 2, seen     # DEC x MLP x (16-wave NC / FULL variants + the 8-wave shape) x {fwd, bwd}
 
 
 def test_streaming_and_gemm_kernels_use_no_scratch(kernels):
