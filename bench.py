@@ -365,20 +365,15 @@ def make_step(eng, prepared, dist, exchange, n_distinct, ex_events=None):
         if eng.lazy_adam and dist is None:                         # the next iteration's rows ride in this step's row launch
             eng.lazy_prefetch(prepared[(i + 1) % n_distinct])
         if dist is not None:
-            rec = ex_events is not None and (i % 4) == 0
-            if rec:
-                import torch
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+            ev = {} if (ex_events is not None and (i % 4) == 0) else None   # per-phase events on every 4th step
             if exchange == "sparse":                               # contribution entries all-gathered over xGMI
-                parallel.exchange_sparse(eng, dist)
+                parallel.exchange_sparse(eng, dist, events=ev)
             elif exchange == "dense":                              # lists -> dense arena, RCCL sum over xGMI
-                parallel.exchange_gradients(eng.grads, dist, engine=eng)
+                parallel.exchange_gradients(eng.grads, dist, engine=eng, events=ev)
             else:                                                  # contributions to the rows' owners, small tensors all-reduced
                 parallel.shard_exchange(eng, dist, ps)
-            if rec:
-                e1.record()
-                ex_events.append((e0, e1))
+            if ev:
+                ex_events.append(ev)
         eng.run_adam(ps["adam"])
 
     posted = {"next": None}
@@ -436,7 +431,12 @@ def measure(wl, args, dist, rank, world, exchange="sparse", lazy=False, steps=No
     if ex_events:
         torch.cuda.synchronize()
         ev = ex_events[len(ex_events) // 5:]
-        out["exchange_ms_per_step"] = round(float(np.mean([a.elapsed_time(b) for a, b in ev])), 4)
+        order = ["start", "exported", "gathered", "imported"] if exchange == "sparse" else ["start", "materialized", "reduced"]
+        names = {"exported": "export_entries", "gathered": "all_gather_of_slabs", "imported": "import_entries",
+                 "materialized": "lists_to_dense_gradient", "reduced": "all_reduce_of_the_arena"}
+        out["exchange_ms_per_step"] = round(float(np.mean([x[order[0]][0].elapsed_time(x[order[-1]][0]) for x in ev])), 4)
+        out["exchange_parts_ms"] = {names[b]: round(float(np.mean([x[a][0].elapsed_time(x[b][0]) for x in ev])), 4)
+                                    for a, b in zip(order[:-1], order[1:])}
     if dist is not None:
         ones = torch.ones(1, device=eng.device)
         dist.all_reduce(ones)
@@ -731,7 +731,8 @@ def main():
             r2, e2, _ = measure(wl, args, dist, rank, world, exchange=other, lazy=False, check_replicas=True, **short)
             e2.close()
             forms[other] = r2
-        out["exchange"] = {name: {"ms_per_step": r["ms_per_step"], "exchange_ms_per_step": r.get("exchange_ms_per_step"), "value": r["value"],
+        out["exchange"] = {name: {"ms_per_step": r["ms_per_step"], "exchange_ms_per_step": r.get("exchange_ms_per_step"),
+                                  "exchange_parts_ms": r.get("exchange_parts_ms"), "value": r["value"],
                                   "optimiser_ms": r["roofline"]["avg_launch_ms"], "optimiser_bytes_per_launch": r["roofline"]["algorithmic_bytes_per_launch"],
                                   "replicas_identical": r.get("replicas_identical")} for name, r in forms.items()}
         eng = None

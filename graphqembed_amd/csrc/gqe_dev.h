@@ -283,7 +283,8 @@ struct GqeShardTabs {
   long long offset[GQE_LAZY_TABLES], head_base[GQE_LAZY_TABLES];  // local tables in gqe_set_tables order
 };
 hipError_t gqe_launch_shard_serve(const float* params, const int32_t* req, long long n, float* out, int d, const GqeShardTabs& t,
-                                  long long own_lo, long long own_n, float* own_out, hipStream_t stream);
+                                  long long own_lo, long long own_n, float* own_out, int32_t* head, int32_t* next, long long own_entry,
+                                  int link, hipStream_t stream);
 hipError_t gqe_launch_shard_link(int32_t* head, int32_t* next, const int32_t* req, long long n, long long own_lo, long long own_n,
                                  long long own_entry, hipStream_t stream);
 hipError_t gqe_launch_export(float* contrib, const int32_t* rows, const float* grads, int d, long long slab_base, int32_t n,

@@ -157,6 +157,7 @@ struct gqe_ctx {
   std::vector<TimedLaunch> timed[kTimingKinds];
   ShardSession* shard_sess = nullptr;   // gqe_shard_open
   bool shard_internal = false;          // gqe_shard_step is driving the phase entry points
+  bool shard_link_early = false;        // ... a margin step: its serve kernel links the entries that will answer the requests
   // ... which keeps this rank's OWN block in place (no copy through the send / receive buffers): requests
   // [own_lo, own_lo + own_n) of the received list are its own, their rows are served into the fetched buffer at row own_fetch
   // and their contributions are linked as entries own_entry + k (the send region is part of the entry space)
@@ -1950,8 +1951,12 @@ int gqe_shard_serve(gqe_ctx* ctx, const int32_t* requests, int64_t n, float* row
   }
   const bool own = ctx->shard_internal && ctx->own_n > 0;
   float* fetched = reinterpret_cast<float*>(ctx->ws + ctx->lay.shard_fetch);
+  // gqe_shard_step (margin steps): the serve kernel also links the entries that will answer these requests (shard_link_early)
+  const int link = ctx->shard_internal && ctx->shard_link_early ? 1 : 0;
   HIP_TRY(ctx, gqe_launch_shard_serve(ctx->params, requests, n, rows_out, ctx->cfg.dim, t, own ? ctx->own_lo : 0, own ? ctx->own_n : 0,
-                                      own ? fetched + ctx->own_fetch * ctx->cfg.dim : nullptr, reinterpret_cast<hipStream_t>(stream)));
+                                      own ? fetched + ctx->own_fetch * ctx->cfg.dim : nullptr,
+                                      reinterpret_cast<int32_t*>(ctx->ws + ctx->lay.head_off), reinterpret_cast<int32_t*>(ctx->ws + ctx->lay.next_off),
+                                      own ? ctx->own_entry : 0, link, reinterpret_cast<hipStream_t>(stream)));
   return GQE_OK;
 }
 
@@ -1963,8 +1968,9 @@ int gqe_shard_link(gqe_ctx* ctx, const int32_t* requests, int64_t n, void* strea
   if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "row-sharded mode: the previous step's contributions are still linked (step first)");
   const Layout& L = ctx->lay;
   const bool own = ctx->shard_internal && ctx->own_n > 0;
-  HIP_TRY(ctx, gqe_launch_shard_link(reinterpret_cast<int32_t*>(ctx->ws + L.head_off), reinterpret_cast<int32_t*>(ctx->ws + L.next_off), requests, n,
-                                     own ? ctx->own_lo : 0, own ? ctx->own_n : 0, own ? ctx->own_entry : 0, reinterpret_cast<hipStream_t>(stream)));
+  if (!(ctx->shard_internal && ctx->shard_link_early))   // (gqe_shard_step: the serve kernel of this step linked them already; bookkeeping only)
+    HIP_TRY(ctx, gqe_launch_shard_link(reinterpret_cast<int32_t*>(ctx->ws + L.head_off), reinterpret_cast<int32_t*>(ctx->ws + L.next_off), requests, n,
+                                       own ? ctx->own_lo : 0, own ? ctx->own_n : 0, own ? ctx->own_entry : 0, reinterpret_cast<hipStream_t>(stream)));
   ctx->shard_sent = false;
   if (n > 0) {
     ctx->entries_used = n;

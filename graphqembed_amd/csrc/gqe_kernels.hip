@@ -1085,9 +1085,15 @@ hipError_t gqe_launch_auc(const float* pos, long long n_pos, const float* neg, l
 #define GQE_SERVE_U 4
 // Requests [own_lo, own_lo + own_n) are this rank's own: their rows go straight to where the fused kernel reads them
 // (own_out, the own block of the fetched-row buffer) instead of through the send buffer and a copy.
+// link != 0 (a margin step driven by gqe_shard_step): the contribution that will answer request j is linked onto its row's list
+// HERE — entry j of the receive buffer, or own_entry + (j - own_lo) for this rank's own block — while the row is being served:
+// which entry belongs to which row is known from the request list alone, long before the contributions arrive, so the step
+// needs no separate link launch between the second all-to-all and the optimiser pass.
 __global__ __launch_bounds__(GQE_THREADS) void gqe_shard_serve_kernel(const float* __restrict__ p, const int32_t* __restrict__ req,
                                                                      long long n, float* __restrict__ out, int d, const GqeShardTabs t,
-                                                                     long long own_lo, long long own_n, float* __restrict__ own_out) {
+                                                                     long long own_lo, long long own_n, float* __restrict__ own_out,
+                                                                     int32_t* __restrict__ head, int32_t* __restrict__ next, long long own_entry,
+                                                                     int link) {
   const int tpr = d >> 2;
   const int gpb = GQE_THREADS / tpr;                     // lane groups per workgroup
   const int g = threadIdx.x / tpr, c4 = (threadIdx.x - g * tpr) * 4;
@@ -1111,6 +1117,10 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_shard_serve_kernel(const floa
   for (int u = 0; u < GQE_SERVE_U; ++u) {
     const long long j = j0 + u, k = j - own_lo;
     if (j < n) *reinterpret_cast<float4*>((k >= 0 && k < own_n ? own_out + k * d : out + j * d) + c4) = v[u];
+    if (link && c4 == 0 && j < n && h[u] >= 0) {
+      const int e = (int)(k >= 0 && k < own_n ? own_entry + k : j);
+      next[e] = __hip_atomic_exchange(head + h[u], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -1128,11 +1138,12 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_shard_link_kernel(int32_t* __
 }
 
 hipError_t gqe_launch_shard_serve(const float* params, const int32_t* req, long long n, float* out, int d, const GqeShardTabs& t,
-                                  long long own_lo, long long own_n, float* own_out, hipStream_t stream) {
+                                  long long own_lo, long long own_n, float* own_out, int32_t* head, int32_t* next, long long own_entry,
+                                  int link, hipStream_t stream) {
   if (n < 1) return hipSuccess;
   const long long rows_per_block = (long long)(GQE_THREADS / (d >> 2)) * GQE_SERVE_U;
   hipLaunchKernelGGL(gqe_shard_serve_kernel, dim3((unsigned)((n + rows_per_block - 1) / rows_per_block)), dim3(GQE_THREADS), 0, stream,
-                     params, req, n, out, d, t, own_lo, own_n, own_out);
+                     params, req, n, out, d, t, own_lo, own_n, own_out, head, next, own_entry, link);
   return hipGetLastError();
 }
 

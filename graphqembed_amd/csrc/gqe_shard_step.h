@@ -441,7 +441,11 @@ int shard_run_consumed(gqe_ctx* ctx, ShardSession* S, uint64_t t, int s, int kin
   float* csend = reinterpret_cast<float*>(ctx->ws + L.shard_csend);
   float* crecv = reinterpret_cast<float*>(ctx->ws + L.contrib_off);
   ctx->shard_internal = true;
-  struct Guard { gqe_ctx* c; ~Guard() { c->shard_internal = false; } } guard{ctx};
+  // a margin step links while it serves: which entry answers which request is known now, so no link launch is needed between
+  // the contributions' all-to-all and the optimiser pass (GQE_SHARD_LINK_LATE=1 keeps the separate launch: A / B runs)
+  static const bool link_late = getenv("GQE_SHARD_LINK_LATE") != nullptr;
+  ctx->shard_link_early = kind == 1 && !link_late;
+  struct Guard { gqe_ctx* c; ~Guard() { c->shard_internal = false; c->shard_link_early = false; } } guard{ctx};
   // ---- rows: the owners bring what they serve up to date (lazy Adam), gather it, and the rows travel to the requesters ----
   rc = timing_begin(ctx, 5, st);
   if (rc != GQE_OK) return rc;
@@ -669,6 +673,15 @@ int gqe_shard_close(gqe_ctx* ctx) {
   if (!ctx) return GQE_ERR_ARG;
   shard_session_free(ctx->shard_sess);
   ctx->shard_sess = nullptr;
+  return GQE_OK;
+}
+
+int gqe_shard_profile(gqe_ctx* ctx, double us[10], int64_t* steps) {
+  if (!ctx || !us || !steps) return GQE_ERR_ARG;
+  ShardSession* S = ctx->shard_sess;
+  if (!S) return fail(ctx, GQE_ERR_STATE, "gqe_shard_open has not been called");
+  for (int k = 0; k < 10; ++k) us[k] = S->host_us[k];
+  *steps = S->host_n;
   return GQE_OK;
 }
 

@@ -104,6 +104,7 @@ SYMBOLS = OrderedDict([
     ("gqe_shard_link", (C.c_int, [_P, _P, C.c_int64, _P])),
     ("gqe_shard_open", (C.c_int, [_P, C.c_char_p, _P, C.POINTER(gqe_transport)])),
     ("gqe_shard_close", (C.c_int, [_P])),
+    ("gqe_shard_profile", (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)])),
     ("gqe_shard_post", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, C.POINTER(gqe_segment), C.c_int32])),
     ("gqe_shard_step", (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P])),
     ("gqe_shard_forward", (C.c_int, [_P, _P, _P])),
@@ -369,6 +370,14 @@ class Engine(object):
         if getattr(self, "ctx", None):
             self._check(self.lib.gqe_shard_close(self.ctx))
         self._shard_session_open = False
+
+    def shard_profile(self):
+        """(planning-thread us per step, caller-thread us per step, steps) of the open session — include/gqe.h, gqe_shard_profile
+        (zeros unless GQE_SHARD_PROFILE is set)."""
+        us, n = (C.c_double * 10)(), C.c_int64(0)
+        self._check(self.lib.gqe_shard_profile(self.ctx, us, C.byref(n)))
+        k = max(int(n.value), 1)
+        return sum(us[0:2]) / k, sum(us[2:10]) / k, int(n.value)
 
     def prepare_shard(self, descs, idx, keys=None, with_negatives=True):
         """Freeze one step for gqe_shard_post: ctypes descriptors, the HOST index feed of GLOBAL rows (numpy int32) and,

@@ -71,23 +71,43 @@ def dp_weight(loss_weight, world):
     return loss_weight / float(world)
 
 
-def exchange_sparse(engine, dist):
+def _mark(events, name):
+    """events: None, or a dict the caller collects per-phase torch.cuda.Event pairs in (bench.py: exchange_parts_ms)."""
+    if events is None:
+        return None
+    import torch
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    events.setdefault(name, []).append(e)
+    return e
+
+
+def exchange_sparse(engine, dist, events=None):
     """Sparse form (module docstring): ONE in-place all-gather of the ranks' slabs.  Call between the margin
     launch and the optimiser step; every rank must use the same slab size (same formulas and batch sizes, or
-    Engine.exchange_reserve)."""
+    Engine.exchange_reserve).  ``events``: a dict that receives an event at every phase boundary (start, exported,
+    gathered, imported)."""
+    _mark(events, "start")
     S, slabs = engine.export_entries()
+    _mark(events, "exported")
     r = engine.rank
     dist.all_gather_into_tensor(slabs, slabs[r * S:(r + 1) * S])
+    _mark(events, "gathered")
     engine.import_entries(S)
+    _mark(events, "imported")
 
 
-def exchange_gradients(flat_grads, dist, engine=None):
+def exchange_gradients(flat_grads, dist, engine=None, events=None):
     """Sum the dense gradient arena over the ranks (in place).  With an Engine, the per-row
-    gradient lists are folded into the dense arena first (gqe_materialize_grads)."""
+    gradient lists are folded into the dense arena first (gqe_materialize_grads).  ``events``: as exchange_sparse
+    (start, materialized, reduced)."""
+    _mark(events, "start")
     if engine is not None:
         engine.materialize()
+    _mark(events, "materialized")
     if dist is not None:
         dist.all_reduce(flat_grads)
+    _mark(events, "reduced")
     return flat_grads
 
 

@@ -354,6 +354,12 @@ typedef struct {
 } gqe_transport;
 int gqe_shard_open(gqe_ctx* ctx, const char* session, void* nccl_comm, const gqe_transport* transport);
 int gqe_shard_close(gqe_ctx* ctx);
+/* Host time of the open session, accumulated since gqe_shard_open when GQE_SHARD_PROFILE is set in the environment (else zeros):
+ * us[0..1] = the PLANNING thread (owner sort, publication), us[2..9] = the caller's thread inside gqe_shard_step / _forward
+ * (collect, serve launch, rows exchange, fused + GEMM launches, contributions exchange, link + all-reduces, optimiser, event);
+ * sums over *steps steps.  What a host loop spends beyond us[2..9] per step is time it waited for the GPU (the ring of pinned
+ * feeds is 8 steps deep), not work. */
+int gqe_shard_profile(gqe_ctx* ctx, double us[10], int64_t* steps);
 int gqe_shard_post(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx, int32_t with_negatives,
                    const gqe_segment* segs, int32_t n_segs);
 int gqe_shard_step(gqe_ctx* ctx, float lr, float beta1, float beta2, float eps, float* losses, float* pos_scores, float* neg_scores,

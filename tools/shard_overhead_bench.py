@@ -14,6 +14,7 @@ import bench
 from graphqembed_amd import parallel, synth
 
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29877")
+os.environ["GQE_SHARD_PROFILE"] = "1"                # host time per phase inside the library (gqe_shard_profile)
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 wl = bench.Workload("bio-synth", 128, "bilinear-diag", "min", synth.FULL_MIX, 512)
@@ -73,6 +74,16 @@ for label, shard in (("plain", None), ("phases driven from Python (torch.distrib
         step(i)
     host = (time.perf_counter() - t0) / 200
     torch.cuda.synchronize()
-    print("%-74s %7.1f us/step (median of 20 x 100 steps), host enqueue %6.1f us/step" % (label, np.median(times) * 1e6, host * 1e6), flush=True)
+    line = "%-74s %7.1f us/step (median of 20 x 100 steps)" % (label, np.median(times) * 1e6)
+    if one_call:
+        # the un-synchronised loop runs ahead of the GPU until the ring of 8 pinned feeds is full and then waits for step t - 8:
+        # what it takes beyond the library's own work is back-pressure, not host work
+        plan_us, main_us, n = eng.shard_profile()
+        line += ("; host: main thread %.1f us/step inside gqe_shard_step, planning thread %.1f us/step (owner sort + publication, off the "
+                 "critical path), un-synchronised loop %.1f us/step of which %.1f us is back-pressure (waiting for the GPU)"
+                 % (main_us, plan_us, host * 1e6, max(host * 1e6 - main_us, 0.0)))
+    else:
+        line += ", host enqueue %6.1f us/step" % (host * 1e6)
+    print(line, flush=True)
     eng.close()
 dist.destroy_process_group()
