@@ -113,28 +113,25 @@ __device__ __forceinline__ float* scratch_row(const TileEnv& e, int slot, int r)
 // k >= d of a row of M read the next row's (finite) values and meet the zero columns of the source tile.
 template <bool TRANS, int KB, int KBT, bool FULL>
 __device__ __forceinline__ void load_a_slab(float4 (&a)[KB], const float* __restrict__ M, int d, int i0, int lq, int lk, int kb0) {
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(M), 0, FULL ? 0 : d * d * 4, 0x00020000);
+  // The matrix is addressed as ONE buffer (guarded kernels: its d * d floats are the range check described above).  A lane's
+  // offset inside the slab is computed ONCE; the k-block step is a wave-uniform SGPR / immediate offset of the instruction, so a
+  // load costs no VALU address arithmetic (64-bit pointer adds per load were a tenth of the 8-wave kernels' instructions).
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(M), 0, d * d * 4, 0x00020000);
+  const int voff = TRANS ? ((4 * lk) * d + i0 + lq) * 4 : ((i0 + lq) * d + 4 * lk) * 4;
 #pragma unroll
   for (int j = 0; j < KB; ++j) {
     const int kb = kb0 + j;
     if (kb >= KBT) {   // (compile time: the last group of a slab whose k-block count is not a multiple of the group)
       a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else if (FULL) {
-      if (!TRANS) {
-        a[j] = *reinterpret_cast<const float4*>(M + (size_t)(i0 + lq) * d + kb * 16 + 4 * lk);
-      } else {
-        const float* mp = M + (size_t)(kb * 16 + 4 * lk) * d + i0 + lq;
-        a[j] = make_float4(mp[0], mp[d], mp[2 * d], mp[3 * d]);
-      }
     } else if (!TRANS) {
-      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, ((i0 + lq) * d + kb * 16 + 4 * lk) * 4, 0, 0);
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, kb * 64, 0);
       a[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
     } else {
-      const int o = ((kb * 16 + 4 * lk) * d + i0 + lq) * 4;
-      a[j] = make_float4(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0)),
-                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o + 4 * d, 0, 0)),
-                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o + 8 * d, 0, 0)),
-                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o + 12 * d, 0, 0)));
+      const int so = kb * 64 * d;   // 16 k-rows of d floats
+      a[j] = make_float4(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, so, 0)),
+                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, so + 4 * d, 0)),
+                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, so + 8 * d, 0)),
+                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, so + 12 * d, 0)));
     }
   }
 }
