@@ -1032,7 +1032,7 @@ int universe_index(gqe_ctx* ctx, int64_t offset, int64_t numel, int table) {
   g.is_table = table >= 0 ? 1 : 0;
   g.table_index = table;
   if (table >= 0) {
-    const int tpr = d / 4, rpc = GQE_THREADS / tpr;
+    const int tpr = d / 4, rpc = (64 / tpr) * GQE_WAVES;   // a row's threads stay inside one wave (gqe_kernels.hip, opt_body)
     g.rows = ctx->tables[table].rows;
     g.head_base = ctx->tables[table].head_base;
     g.n_chunks = (g.rows + rpc - 1) / rpc;
@@ -1439,6 +1439,12 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
         if (rc != GQE_OK) return rc;
       }
       if (oa.total_chunks > 0) HIP_TRY(ctx, gqe_launch_opt(oa));
+      // every row of the tables this pass covered is now current for its table's step count: the per-row counts are set
+      // behind the launch, not by it (a row's threads may sit in two waves: see the kernel)
+      for (size_t t = 0; t < ctx->tables.size(); ++t)
+        if (seen[t] && lazy_table_ok(ctx, (int)t))
+          HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->ws + L.last_off + sizeof(int32_t) * (size_t)ctx->tables[t].head_base),
+                                         oa.lz.t.target[t], (size_t)ctx->tables[t].rows, st));
       if (timed) {
         rc = timing_end(ctx, 2, st);
         if (rc != GQE_OK) return rc;

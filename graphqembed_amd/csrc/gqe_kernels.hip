@@ -351,10 +351,15 @@ __device__ __forceinline__ void opt_body(const long long first_chunk, const long
     if ((int)threadIdx.x <= n_segs) s_begin[threadIdx.x] = active.begin[threadIdx.x];
     __syncthreads();
   }
-  const int tpr = d >> 2;               // threads per table row
-  const int rpc = GQE_THREADS / tpr;    // table rows per chunk
-  const int lr_row = threadIdx.x / tpr;
-  const int c4 = (threadIdx.x - lr_row * tpr) * 4;
+  // d / 4 threads per table row, and a row NEVER straddles two waves: a wave holds floor(64 / tpr) rows (its last lanes idle
+  // when d / 4 does not divide 64: d = 48, 80, 96, ...).  The row's first thread resets the list head (and, in lazy mode, used
+  // to set the row's step count) after every thread of the row has read it — guaranteed only inside one wave.
+  const int tpr = d >> 2;
+  const int rpw = 64 / tpr;                       // rows per wave
+  const int rpc = rpw * GQE_WAVES;                // table rows per chunk (gqe_host.cpp, universe_index: the same formula)
+  const int wl = threadIdx.x & 63, wrow = wl / tpr;
+  const int lr_row = wrow < rpw ? (int)(threadIdx.x >> 6) * rpw + wrow : rpc;   // rpc = an idle lane
+  const int c4 = (wl - wrow * tpr) * 4;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   int si = 0;
   for (long long ch = first_chunk; ch < total_chunks; ch += chunk_stride) {
@@ -446,7 +451,9 @@ __device__ __forceinline__ void opt_body(const long long first_chunk, const long
         if (from < target) {
           lazy_advance(pp, mm, vv, gg, from, target, lazy.t.grad_step[lt], lazy.ring + lt * GQE_LAZY_RING, step_size, bc2_sqrt,
                        lazy.t.grad_step[lt], b1, b2, eps);
-          if (c4 == 0) lazy.last[sg.head_base + row] = target;
+          // (last[row] := target is the HOST's memset behind this launch: the d / 4 threads of a row straddle two waves
+          // whenever d / 4 does not divide 64 — d = 48, 80, 96, ... — and a store from the row's first thread here was read
+          // as `from` by the threads of the other wave, which then skipped their elements)
           *reinterpret_cast<float4*>(m + off) = mm;
           *reinterpret_cast<float4*>(v + off) = vv;
           *reinterpret_cast<float4*>(p + off) = pp;

@@ -315,3 +315,87 @@ def test_tuning_switches_do_not_change_results(env):
                         "-k", "eight_wave and 128 and bilinear-diag"], cwd=root, env=dict(os.environ, **env), stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:]
+
+
+@pytest.mark.parametrize("dec,inter,d", [("bilinear-diag", "min", 128), ("transe", "mean-simple", 48)])
+def test_hot_rows_state_machine(dec, inter, d):
+    """Hot rows (include/gqe.h, gqe_hot_rows): on a toy world with 50-90 rows per mode and hundreds of queries per batch, EVERY
+    row's gradient list is long, so the first optimiser pass promotes them and every later call goes through the dense
+    accumulators instead of the lists — plain rows and, for the bag mode, word rows.  Every consumer of the lists has to consume
+    the accumulators too: materialize (gradients vs the fp64 oracle), zero_grads (nothing left), SGD and Adam steps (against a
+    hot-rows-free engine built from the same parameters: GQE_HOT has no per-engine switch, so the reference run is the
+    ordered-sums engine, whose kernels are compiled without the accumulator path), lazy Adam, and gqe_set_ordered_sums after
+    promotion (slots cleared: lists again)."""
+    import torch
+    from gpu_utils import (TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, read_arena, toy_batch)
+    from graphqembed_amd.tensorize import pack_margin_batches
+    from test_gpu_parity import assert_grads_close
+    rng = np.random.RandomState(11 + d)
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS, bag_modes=("b",))
+    B = 300
+
+    def batches(eng, seed):
+        r = np.random.RandomState(seed)
+        items = []
+        for j, qtype in enumerate(("1-chain", "2-inter", "3-inter_chain", "3-chain")):
+            t, g, a = toy_batch(r, qtype, B - 7 * j, hub=(j == 1))
+            items.append((plan_for(eng, qtype, TOY_FORMULAS[qtype]), t, g, a, [1.0, 0.5, 0.25, 0.1][j], 1.0))
+        return items
+
+    def oracle_grads(p, items_spec):
+        grads = O.zero_grads_like(p)
+        for (qtype, t, g, a, w) in items_spec:
+            O.margin_fwd_bwd(p, O.make_plan(qtype, TOY_FORMULAS[qtype]), dec, inter, t, g, a, weight=w, grads=grads)
+        grads.pop(O.BAGS_KEY, None)
+        return grads
+
+    hot = engine_from_params(params, d, dec, inter, max_queries=4 * B, max_batches=4)
+    ref = engine_from_params(params, d, dec, inter, max_queries=4 * B, max_batches=4, ordered_sums=True)   # never promotes
+    lazy = engine_from_params(params, d, dec, inter, max_queries=4 * B, max_batches=4, lazy_adam=True)
+    keys = list(hot.layout.entries)
+    assert hot.hot_rows() == 0
+    for step in range(4):
+        for eng in (hot, ref, lazy):
+            descs, idx, n = pack_margin_batches(batches(eng, 100 + step))
+            eng.margin_fwd_bwd(descs, idx, n)
+            eng.adam_step(keys)
+        if step == 0:
+            assert hot.hot_rows() >= 20 and ref.hot_rows() == 0, (hot.hot_rows(), ref.hot_rows())
+    torch.cuda.synchronize()
+    scale = float(ref.params.abs().max())
+    # accumulators sum in arrival order: agreement to rounding (amplified by Adam's g / (|g| + eps) on noise-sized gradients)
+    assert float((hot.params - ref.params).abs().max()) <= 2e-3 * scale + 0.021, float((hot.params - ref.params).abs().max())
+    assert float((hot.params - ref.params).abs().mean()) <= 2e-4, float((hot.params - ref.params).abs().mean())
+    assert float((lazy.params - ref.params).abs().mean()) <= 2e-4 and lazy.hot_rows() >= 20
+    # materialize folds accumulators and lists alike: gradients against the fp64 oracle on the parameters of the moment
+    cur = read_arena(hot, hot.params)
+    if O.BAGS_KEY in params:
+        cur[O.BAGS_KEY] = params[O.BAGS_KEY]
+    items = batches(hot, 777)
+    spec = [(qt, it[1], it[2], it[3], it[4]) for qt, it in zip(("1-chain", "2-inter", "3-inter_chain", "3-chain"), items)]
+    descs, idx, n = pack_margin_batches(items)
+    hot.margin_fwd_bwd(descs, idx, n)
+    assert_grads_close(read_arena(hot, hot.grads), oracle_grads(cur, spec), "hot rows, materialised")
+    hot.zero_grads(keys)
+    # zero_grads drops what sits in the accumulators
+    hot.margin_fwd_bwd(descs, idx, n)
+    hot.zero_grads(keys)
+    hot.materialize()
+    assert float(hot.grads.abs().max()) == 0.0
+    # an SGD step fed by the accumulators
+    before = read_arena(hot, hot.params)
+    want = oracle_grads(cur, spec)
+    hot.margin_fwd_bwd(descs, idx, n)
+    hot.sgd_step(keys, lr=0.5)
+    after = read_arena(hot, hot.params)
+    for k in keys:
+        np.testing.assert_allclose(after[k], before[k] - 0.5 * want[k], rtol=2e-3, atol=2e-5 * max(1.0, float(np.abs(want[k]).max())), err_msg=k)
+    # ordered sums after promotion: the slots are cleared, gradients come from the lists again
+    hot._check(hot.lib.gqe_set_ordered_sums(hot.ctx, 1))
+    cur = read_arena(hot, hot.params)
+    if O.BAGS_KEY in params:
+        cur[O.BAGS_KEY] = params[O.BAGS_KEY]
+    hot.margin_fwd_bwd(descs, idx, n)
+    assert_grads_close(read_arena(hot, hot.grads), oracle_grads(cur, spec), "ordered sums after promotion")
+    for eng in (hot, ref, lazy):
+        eng.close()

@@ -661,7 +661,10 @@ def _disjoint_batch(rng, qtype, B, lo_frac, hi_frac):
 
 
 @pytest.mark.parametrize("dec,inter,d", [("bilinear-diag", "min", 32), ("bilinear", "mean", 32), ("transe", "min-simple", 32),
-                                         ("bilinear-diag", "min", 64), ("bilinear", "mean", 64), ("transe", "mean", 128)])
+                                         ("bilinear-diag", "min", 64), ("bilinear", "mean", 64), ("transe", "mean", 128),
+                                         # d / 4 does not divide 64: a table row's threads must not straddle two waves of the
+                                         # optimiser pass (round 4: lazy full passes lost elements at d = 48, 80, 96, ...)
+                                         ("bilinear-diag", "min", 48), ("transe", "mean", 80), ("bilinear", "min-simple", 144)])
 def test_lazy_adam_is_bit_identical_to_the_eager_schedule(dec, inter, d):
     """gqe_set_lazy_adam: rows without a gradient are not streamed every step; their zero-gradient Adam steps are
     replayed when the row is next read or stepped.  150 iterations on two engines (eager / lazy) with batches built
@@ -721,8 +724,10 @@ def test_lazy_adam_is_bit_identical_to_the_eager_schedule(dec, inter, d):
     torch.cuda.synchronize()
     assert torch.equal(ahead.params, eager.params) and torch.equal(ahead.exp_avg, eager.exp_avg) and torch.equal(ahead.exp_avg_sq, eager.exp_avg_sq)
     ahead.close()
-    # lazy really was lazy: before the sync its arena differs from the eager one ...
-    assert not torch.equal(lazy._params, eager._params)
+    # lazy really was lazy: before the sync its arena differs from the eager one ... (where the sparse row launch exists: d / 4
+    # threads per row must divide a wave; elsewhere every lazy step is a full pass and nothing ever lags)
+    if 64 % (d // 4) == 0:
+        assert not torch.equal(lazy._params, eager._params)
     # ... and after it (the properties synchronise) everything is bit-identical
     assert torch.equal(lazy.params, eager.params)
     assert torch.equal(lazy.exp_avg, eager.exp_avg)
