@@ -93,16 +93,22 @@ struct GqeBagTable {
 // 4-byte load per entry (~0.27 us each): fine for the handful of entries a row of a uniform graph collects, hopeless for a hub
 // that collects hundreds per step (a Zipfian word: thousands).  The optimiser pass measures every list it walks; a row whose
 // list reaches `min_len` entries is PROMOTED: it gets a slot of GQE_HOT_REPS dense accumulators of d floats, and from the next
-// step on its contributions are ADDED there with fire-and-forget float atomics (replica = a hash of the pusher, so that same-
-// address atomics — ~12 ns each at the memory side — spread over GQE_HOT_REPS chains) instead of being written as entries and
-// linked.  The pass that steps the row sums the replicas and re-zeroes them.  slot[] is indexed like head[].
+// step on its contributions are ADDED there with fire-and-forget float atomics (replica = the pusher's XCD and wave, so that
+// same-address atomics — 24 ns each wherever they come from — spread over GQE_HOT_REPS chains) instead of being written as
+// entries and linked.  The pass that steps the row sums the replicas and re-zeroes them.  slot[] is indexed like head[].
 // Off (slot == NULL) wherever sums have to be order-independent: the replicated exchange mode, gqe_set_ordered_sums.
-#define GQE_HOT_REPS 8
+// Replicas of a slot are ADJACENT in memory (acc[slot][replica][d]): with acc[replica][slot][d] a slot's replicas lay 2 MB
+// apart — a power of two, the same channel — and 8 replicas bought nothing; adjacent, 8 / 16 / 32 replicas take the fused kernel
+// of reddit-synth Zipf from 184 us to 126 / 121 / 113 us (64: no further gain; profiles/r04_experiment_hot_layout.log).
+#ifndef GQE_HOT_REPS
+#define GQE_HOT_REPS 32
+#endif
 #define GQE_HOT_SLOTS 2048
 #define GQE_HOT_MIN_LEN 24
+#define GQE_HOT_ROW(rep, slot) ((size_t)(slot) * GQE_HOT_REPS + (rep))
 struct GqeHot {
   int32_t* slot;     // [total rows]: -1 = not hot, else the row's accumulator slot
-  float* acc;        // [GQE_HOT_REPS][cap][d]
+  float* acc;        // [cap][GQE_HOT_REPS][d]
   int32_t* count;    // slots handed out so far (may run past cap: rows promoted beyond it stay on lists)
   int32_t cap, min_len;
 };

@@ -63,9 +63,7 @@ struct TileEnv {
   // contribution is an entry on a list
   const int32_t* hot_slot;
   float* hot_acc;
-  int rep;                    // the replica of a hot row's accumulators this workgroup adds to: the id of its XCD — all atomics on
-                              // one replica then come from ONE L2, where they execute; a line that several XCDs add to travels
-                              // between their L2s with every change of hands
+  int rep;                    // the replica of a hot row's accumulators this wave adds to: (its XCD, its wave index mod 4)
   int hotv;                   // lane role * RPW + rr: the hot slot of the plain row this wave owns for that role (-1: not hot).
                               // ONE vector load issued in front of the row gathers (same in-order counter: it has landed when
                               // the rows have) — five scalar loads would share their counter with the LDS reads of the indices
@@ -77,7 +75,7 @@ struct TileEnv {
 // hundreds (hub nodes) or thousands (frequent words) of entries, one dependent load each.
 template <int NC, bool FULL>
 __device__ __forceinline__ void hot_add(const TileEnv& e, int slot, const Vec<NC>& gx) {
-  float* acc = e.hot_acc + ((size_t)e.rep * GQE_HOT_SLOTS + slot) * e.d;
+  float* acc = e.hot_acc + GQE_HOT_ROW(e.rep, slot) * e.d;
   gatomic_add<NC, FULL>(acc, gx, e.d, e.lane);
 }
 
@@ -890,7 +888,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
   if (BWD && hot.slot) {
     int xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    e.rep = xcc & (GQE_HOT_REPS - 1);
+    e.rep = ((xcc & 7) * (GQE_HOT_REPS / 8) + (e.wave % (GQE_HOT_REPS / 8))) & (GQE_HOT_REPS - 1);
   }
   const int DP = e.DP, lane = e.lane, wave = e.wave;
   const int B = b.B;

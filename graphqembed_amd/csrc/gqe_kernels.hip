@@ -281,8 +281,8 @@ __device__ __forceinline__ float4 hot_take(const GqeHot& hot, int hs, int d, int
   float4 s = zero4;
 #pragma unroll 1
   for (int x = 0; x < GQE_HOT_REPS; x += 2) {
-    float* p0 = hot.acc + ((size_t)x * hot.cap + hs) * d + c4;
-    float* p1 = p0 + (size_t)hot.cap * d;
+    float* p0 = hot.acc + GQE_HOT_ROW(x, hs) * d + c4;
+    float* p1 = p0 + d;
     const float4 a = *reinterpret_cast<const float4*>(p0), b = *reinterpret_cast<const float4*>(p1);
     s.x += a.x + b.x;
     s.y += a.y + b.y;

@@ -1,6 +1,7 @@
 // atomic_probe.hip — how fast do float atomics on ONE 256-byte row go (gfx950)?  The hot-row accumulators (GqeHot) take
 // thousands of wave-wide atomic rows per step on the same addresses; this measures the cost per atomic row
-//   (a) from workgroups of ONE XCD, (b) from all eight, (c) spread over 8 per-XCD replicas, (d) LDS ds_add_f32 for comparison.
+//   (a) from workgroups of ONE XCD, (b) from all eight, (c) spread over 8 per-XCD replicas 16 KB apart, (d) over 8 / 32 replicas
+//   that sit NEXT to each other (the layout hot_acc uses), (e) LDS ds_add_f32 for comparison.
 //   hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics tools/probes/atomic_probe.hip -o /tmp/atomic_probe && /tmp/atomic_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -11,7 +12,10 @@ __global__ void k_atomic(float* acc, int per_wave, int mode, int floats) {
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= 7;
   if (mode == 0 && xcc != 0) return;                       // one XCD only
-  float* p = acc + (mode == 2 ? (size_t)xcc * 4096 : 0);   // per-XCD replica
+  float* p = acc;
+  if (mode == 2) p += (size_t)xcc * 4096;                                         // per-XCD replica, 16 KB apart
+  if (mode == 3) p += (size_t)xcc * floats;                                       // 8 adjacent replicas
+  if (mode == 4) p += (size_t)(xcc * 4 + ((threadIdx.x >> 6) & 3)) * floats;      // 32 adjacent replicas: (XCD, wave mod 4)
   const int lane = threadIdx.x & 63;
   for (int i = 0; i < per_wave; ++i)
     for (int c = 0; c < floats / 64; ++c) unsafeAtomicAdd(p + lane + 64 * c, 1.0f);
@@ -37,7 +41,7 @@ int main() {
   hipEventCreate(&b);
   const int blocks = 256, threads = 1024, per_wave = 64;   // 256 x 16 waves x 64 rows = 262144 atomic rows
   for (int floats : {64, 256}) {
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 5; ++mode) {
       for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(a);
         hipLaunchKernelGGL(k_atomic, dim3(blocks), dim3(threads), 0, 0, acc, per_wave, mode, floats);
@@ -47,9 +51,10 @@ int main() {
       float ms;
       hipEventElapsedTime(&ms, a, b);
       const double rows = (double)blocks * 16 * per_wave / (mode == 0 ? 8 : 1);
-      printf("global rows of %d floats, %s: %.1f us for %.0f rows -> %.1f ns per row%s\n", floats,
-             mode == 0 ? "ONE XCD, one target" : mode == 1 ? "8 XCDs, one target" : "8 XCDs, per-XCD replicas", ms * 1e3, rows,
-             ms * 1e6 / rows * (mode == 2 ? 8 : 1), mode == 2 ? " per replica chain" : "");
+      const char* names[5] = {"ONE XCD, one target", "8 XCDs, one target", "8 XCDs, 8 replicas 16 KB apart", "8 XCDs, 8 adjacent replicas",
+                              "8 XCDs, 32 adjacent replicas"};
+      printf("global rows of %d floats, %s: %.1f us for %.0f rows -> %.1f ns per row overall\n", floats, names[mode], ms * 1e3, rows,
+             ms * 1e6 / rows);
     }
   }
   float* out;
