@@ -294,7 +294,7 @@ int gqe_set_ordered_sums(gqe_ctx* ctx, int32_t enable);
  * reddit/data_utils_new.py:155) on HEAVY-TAILED data.  A row's gradient contributions normally hang on a per-row list that one
  * lane group walks (fine for the few entries a row of a sparse graph collects per step).  The optimiser pass measures the lists
  * it walks; a row whose list reaches 24 entries in one step (a hub node, a frequent word) is promoted: from the next step on its
- * contributions are added into 8 dense accumulators of dim floats with float atomics, and the pass sums those instead of
+ * contributions are added into 32 dense accumulators of dim floats with float atomics, and the pass sums those instead of
  * chasing hundreds or thousands of links.  Automatic, up to 2048 rows per ctx; off in gqe_set_exchange mode and with
  * gqe_set_ordered_sums (atomic sums are order-dependent); GQE_HOT=0 in the environment disables it, GQE_HOT_MIN_LEN=n changes
  * the promotion threshold.  gqe_hot_rows: how many rows have been promoted so far (synchronises the device). */
