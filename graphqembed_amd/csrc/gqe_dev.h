@@ -106,6 +106,11 @@ struct GqeBagTable {
 #define GQE_HOT_SLOTS 2048
 #define GQE_HOT_MIN_LEN 24
 #define GQE_HOT_ROW(rep, slot) ((size_t)(slot) * GQE_HOT_REPS + (rep))
+// Row-sharded margin steps run by a session (gqe_shard_step): an index of the position feed that is >= GQE_OWN_ROW names row
+// (index - GQE_OWN_ROW) of this rank's OWN shard of the role's table — the fused kernel reads it where it lives and links its
+// contribution itself, exactly as in the unsharded step; smaller indices are positions in the fetched-row buffer.
+#define GQE_OWN_ROW (1 << 30)
+
 struct GqeHot {
   int32_t* slot;     // [total rows]: -1 = not hot, else the row's accumulator slot
   float* acc;        // [cap][GQE_HOT_REPS][d]

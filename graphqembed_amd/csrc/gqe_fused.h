@@ -41,7 +41,8 @@ struct TileEnv {
   // Row-sharded data parallelism (gqe_set_shard): the embedding rows of this call were fetched from their owner ranks
   // into one buffer, in the order of the index feed; an index is then a position in that buffer (whatever its table),
   // the row's gradient contribution is written to the same position of the send buffer, and nothing is linked here —
-  // the owner links what it receives.
+  // the owner links what it receives.  Indices >= GQE_OWN_ROW (gqe_dev.h) are rows of this rank's own shard: gathered from the
+  // arena and linked here, like every row of an unsharded step.
   const float* rows;  // where rows are gathered from: the parameter arena, or the fetched-row buffer
   bool sharded;
   // Bag (EmbeddingBag) tables stay replicated in row-sharded mode: their rows are gathered from the local replica, and a
@@ -511,7 +512,10 @@ __device__ __forceinline__ void rows_issue(RowSet<NC>& rs, const TileEnv& e, int
   for (int rr = 0; rr < RPW; ++rr) {
     const int row = __builtin_amdgcn_readfirstlane(s_rows[e.wave * RPW + rr]);   // wave-uniform: scalar address arithmetic
     rs.row[rr] = row;
-    rs.x[rr] = gload<NC, FULL>(e.rows + (e.sharded ? 0 : table) + (size_t)(row < 0 ? 0 : row) * e.d, e.d, e.lane);
+    // row-sharded: a position in the fetched-row buffer, or GQE_OWN_ROW + a row of this rank's own shard (read where it lives)
+    const bool fetched = e.sharded && row < GQE_OWN_ROW;
+    const int at = row < 0 ? 0 : (e.sharded && !fetched ? row - GQE_OWN_ROW : row);
+    rs.x[rr] = gload<NC, FULL>((fetched ? e.rows : e.params + table) + (size_t)at * e.d, e.d, e.lane);
   }
 }
 
@@ -632,11 +636,15 @@ __device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_
     hot_add<NC, FULL>(e, hot, gx);
     return;
   }
-  const int64_t entry = e.sharded ? (int64_t)row : e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
-  vstore_wt<NC, FULL>(e.wt, e.contrib + entry * e.d, gx, e.d, e.lane);
+  // row-sharded: the contribution to a FETCHED row goes to the row's position in the send buffer (its owner links it); one to a
+  // row of this rank's own shard is an entry like any other, in the block behind the send buffer (bag_shift; 0 otherwise)
+  const bool fetched = e.sharded && row < GQE_OWN_ROW;   // wave-uniform
+  const int64_t entry = fetched ? (int64_t)row : e.bag_shift + e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + r);
+  vstore_wt<NC, FULL>(e.wt, (fetched ? e.contrib : e.contrib_bag) + entry * e.d, gx, e.d, e.lane);
   // The returned previous head is only needed for next[entry]; that store is deferred to the end of the
   // kernel (push_links) so that the wave never stalls on the atomic's round trip.
-  if (e.lane == 0 && !e.sharded) {
+  if (e.lane == 0 && !fetched) {
+    if (e.sharded) row -= GQE_OWN_ROW;
     const int old = __hip_atomic_exchange(e.head + head_base + row, (int)entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     e.next[entry - e.max_entries] = (int)(head_base + row);  // entry -> list head, for the data-parallel exchange
     // 8-wave kernels (the many-tile throughput shape, up to three workgroups per CU, some held to 80 VGPRs): the link is stored
@@ -708,7 +716,7 @@ __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t h
 // whose hinge is inactive has to send zeros (the buffer still holds the previous step's contribution there).
 template <int NC, bool FULL>
 __device__ __forceinline__ void sharded_zero(const TileEnv& e, int bag, int row) {
-  if (e.sharded && bag < 0 && row >= 0) gstore<NC, FULL>(e.contrib + (size_t)row * e.d, vzero<NC>(), e.d, e.lane);
+  if (e.sharded && bag < 0 && row >= 0 && row < GQE_OWN_ROW) gstore<NC, FULL>(e.contrib + (size_t)row * e.d, vzero<NC>(), e.d, e.lane);
 }
 
 template <int NC, bool FULL>
@@ -737,7 +745,7 @@ __device__ __forceinline__ void push_links(const TileEnv& e, const int (&olds)[R
 #pragma unroll
       for (int role = 0; role < 2 + GQE_MAX_BRANCH; ++role)
         if (olds[rr][role] != GQE_NO_PUSH)
-          e.next[e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + e.wave * RPW + rr)] = olds[rr][role];
+          e.next[e.bag_shift + e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + e.wave * RPW + rr)] = olds[rr][role];
     return;
   }
 #pragma unroll
@@ -748,7 +756,7 @@ __device__ __forceinline__ void push_links(const TileEnv& e, const int (&olds)[R
       if (blens[rr][role] > 0) {
         if (e.lane < blens[rr][role] && olds[rr][role] != GQE_NO_PUSH) e.next[e.max_entries + (int)(e.bag_shift + q) * max_len + e.lane] = olds[rr][role];
       } else if (e.lane == 0 && olds[rr][role] != GQE_NO_PUSH) {
-        e.next[q] = olds[rr][role];
+        e.next[e.bag_shift + q] = olds[rr][role];
       }
     }
 }

@@ -162,6 +162,9 @@ struct gqe_ctx {
   // [own_lo, own_lo + own_n) of the received list are its own, their rows are served into the fetched buffer at row own_fetch
   // and their contributions are linked as entries own_entry + k (the send region is part of the entry space)
   int64_t own_lo = 0, own_n = 0, own_fetch = 0, own_entry = 0;
+  // ... unless the step's plan named the own rows directly (GQE_OWN_ROW, margin steps of a session that keeps the own block in
+  // place): then nothing is served or linked for the own block — the fused kernel reads the shard and links like an unsharded step
+  bool own_direct = false;
   bool ordered_sums = false;            // gqe_set_ordered_sums
   std::vector<TimedLaunch> event_pool;  // recycled hipEvent pairs (creation is not free)
 };
@@ -319,7 +322,9 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
     // behind the received entries: the block this rank's fused kernel writes its contributions to (the SEND buffer is part
     // of the entry space, so the contributions to rows this rank owns itself are linked where they are), and one more
     // block for the contributions of bag (replicated) tables, which are linked locally
-    L.max_entries = L.shard_cap_recv + L.shard_cap_send + (ctx->bags.empty() ? 0 : L.shard_cap_send);
+    // (the same block takes the contributions to rows of this rank's OWN shard that the fused kernel links itself,
+    // GQE_OWN_ROW: a role is a bag role or a plain one, so the (role, query) entries of the two never collide)
+    L.max_entries = L.shard_cap_recv + 2 * L.shard_cap_send;
   }
   // entry -> list head it was pushed on (-1: not pushed); sits exactly max_entries ints below next[], so the
   // kernels address it as next[entry - max_entries]
@@ -1787,8 +1792,10 @@ int gqe_shard_layout(gqe_ctx* ctx, gqe_shard_buffers* out) {
 
 // The owner sort of gqe_shard_plan.  Reads the ctx only (tables, bags, shard geometry) and reports errors through `err`,
 // so the session's planning thread can run it next to the caller's thread (gqe_shard_step.h).
+// own_direct: rows of this rank's own shard are named as GQE_OWN_ROW + local row in the position feed (margin steps of a
+// session; the request list still holds them — the lazy replay and the sparse optimiser feed walk it).
 int shard_plan_impl(const gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx, int32_t with_negatives,
-                    int32_t* positions, int32_t* requests, int64_t* send_counts, char* err, size_t err_len) {
+                    int32_t* positions, int32_t* requests, int64_t* send_counts, char* err, size_t err_len, bool own_direct = false) {
   auto bad = [&](int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -1800,7 +1807,8 @@ int shard_plan_impl(const gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batc
   if ((int)ctx->tables.size() > GQE_LAZY_TABLES) return bad(GQE_ERR_STATE, "row-sharded mode supports at most %d tables", GQE_LAZY_TABLES);
   if (!batches || n_batches < 1 || n_batches > GQE_MAX_BATCHES || !idx || n_idx < 1 || !positions || !requests || !send_counts)
     return bad(GQE_ERR_ARG, "gqe_shard_plan: bad arguments");
-  const int W = ctx->shard_world;
+  const int W = ctx->shard_world, me = ctx->shard_rank;
+  if (!with_negatives) own_direct = false;
   // the runs of the feed that name rows of one table (the layout of gqe_batch's index block), in feed order
   struct Run { int64_t off, n; int table; };
   Run runs[GQE_MAX_BATCHES * (3 + GQE_MAX_BRANCH)];   // table < 0: a run of list offsets (not rows)
@@ -1908,7 +1916,7 @@ int shard_plan_impl(const gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batc
       for (int64_t j = 0; j < runs[k].n; ++j) {
         const int64_t r = p[j];
         worst = std::max(worst, r);
-        out[j] = (int32_t)(base + j);
+        out[j] = own_direct ? (int32_t)(GQE_OWN_ROW + r) : (int32_t)(base + j);
         requests[base + j] = (int32_t)(hb + r);
       }
       at[0] += runs[k].n;
@@ -1922,9 +1930,10 @@ int shard_plan_impl(const gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batc
       const int64_t local = pow2 ? (r >> shift) : (r / W);
       worst = std::max(worst, local);
       const int64_t pos = at[o]++;
-      out[j] = (int32_t)pos;
+      out[j] = own_direct && o == me ? (int32_t)(GQE_OWN_ROW + local) : (int32_t)pos;
       requests[pos] = (int32_t)(hb + local);
     }
+    if (own_direct && rows >= GQE_OWN_ROW) return bad(GQE_ERR_ARG, "row-sharded step: a shard of more than 2^30 rows");
     if (worst >= rows)
       return bad(GQE_ERR_ARG, "a global row of the batch run at %lld is outside its table (%lld local rows x %d ranks)", (long long)runs[k].off, (long long)rows, W);
   }
@@ -1956,11 +1965,12 @@ int gqe_shard_serve(gqe_ctx* ctx, const int32_t* requests, int64_t n, float* row
     t.head_base[k] = ctx->tables[k].head_base;
   }
   const bool own = ctx->shard_internal && ctx->own_n > 0;
+  const bool direct = own && ctx->own_direct;   // the own block is neither served nor linked here
   float* fetched = reinterpret_cast<float*>(ctx->ws + ctx->lay.shard_fetch);
   // gqe_shard_step (margin steps): the serve kernel also links the entries that will answer these requests (shard_link_early)
   const int link = ctx->shard_internal && ctx->shard_link_early ? 1 : 0;
   HIP_TRY(ctx, gqe_launch_shard_serve(ctx->params, requests, n, rows_out, ctx->cfg.dim, t, own ? ctx->own_lo : 0, own ? ctx->own_n : 0,
-                                      own ? fetched + ctx->own_fetch * ctx->cfg.dim : nullptr,
+                                      own && !direct ? fetched + ctx->own_fetch * ctx->cfg.dim : nullptr,
                                       reinterpret_cast<int32_t*>(ctx->ws + ctx->lay.head_off), reinterpret_cast<int32_t*>(ctx->ws + ctx->lay.next_off),
                                       own ? ctx->own_entry : 0, link, reinterpret_cast<hipStream_t>(stream)));
   return GQE_OK;
@@ -1976,7 +1986,8 @@ int gqe_shard_link(gqe_ctx* ctx, const int32_t* requests, int64_t n, void* strea
   const bool own = ctx->shard_internal && ctx->own_n > 0;
   if (!(ctx->shard_internal && ctx->shard_link_early))   // (gqe_shard_step: the serve kernel of this step linked them already; bookkeeping only)
     HIP_TRY(ctx, gqe_launch_shard_link(reinterpret_cast<int32_t*>(ctx->ws + L.head_off), reinterpret_cast<int32_t*>(ctx->ws + L.next_off), requests, n,
-                                       own ? ctx->own_lo : 0, own ? ctx->own_n : 0, own ? ctx->own_entry : 0, reinterpret_cast<hipStream_t>(stream)));
+                                       own ? ctx->own_lo : 0, own ? ctx->own_n : 0, own ? (ctx->own_direct ? -1 : ctx->own_entry) : 0,
+                                       reinterpret_cast<hipStream_t>(stream)));
   ctx->shard_sent = false;
   if (n > 0) {
     ctx->entries_used = n;

@@ -1096,6 +1096,8 @@ hipError_t gqe_launch_auc(const float* pos, long long n_pos, const float* neg, l
 // HERE — entry j of the receive buffer, or own_entry + (j - own_lo) for this rank's own block — while the row is being served:
 // which entry belongs to which row is known from the request list alone, long before the contributions arrive, so the step
 // needs no separate link launch between the second all-to-all and the optimiser pass.
+// own_out == NULL with own_n > 0: the own block is not served at all (the fused kernel reads those rows from the shard and
+// links their contributions itself, GQE_OWN_ROW): the launch covers the n - own_n requests of the other ranks.
 __global__ __launch_bounds__(GQE_THREADS) void gqe_shard_serve_kernel(const float* __restrict__ p, const int32_t* __restrict__ req,
                                                                      long long n, float* __restrict__ out, int d, const GqeShardTabs t,
                                                                      long long own_lo, long long own_n, float* __restrict__ own_out,
@@ -1105,10 +1107,17 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_shard_serve_kernel(const floa
   const int gpb = GQE_THREADS / tpr;                     // lane groups per workgroup
   const int g = threadIdx.x / tpr, c4 = (threadIdx.x - g * tpr) * 4;
   if (g >= gpb) return;
+  const bool skip_own = own_out == nullptr && own_n > 0;
   const long long j0 = ((long long)blockIdx.x * gpb + g) * GQE_SERVE_U;
+  long long jj[GQE_SERVE_U];   // the request a slot of this lane group handles (n: none)
   int h[GQE_SERVE_U];
 #pragma unroll
-  for (int u = 0; u < GQE_SERVE_U; ++u) h[u] = j0 + u < n ? req[j0 + u] : -1;
+  for (int u = 0; u < GQE_SERVE_U; ++u) {
+    jj[u] = j0 + u;
+    if (skip_own && jj[u] >= own_lo) jj[u] += own_n;
+    if (jj[u] > n) jj[u] = n;
+    h[u] = jj[u] < n ? req[jj[u]] : -1;
+  }
   float4 v[GQE_SERVE_U];
 #pragma unroll
   for (int u = 0; u < GQE_SERVE_U; ++u) {
@@ -1122,7 +1131,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_shard_serve_kernel(const floa
   }
 #pragma unroll
   for (int u = 0; u < GQE_SERVE_U; ++u) {
-    const long long j = j0 + u, k = j - own_lo;
+    const long long j = jj[u], k = skip_own ? -1 : j - own_lo;
     if (j < n) *reinterpret_cast<float4*>((k >= 0 && k < own_n ? own_out + k * d : out + j * d) + c4) = v[u];
     if (link && c4 == 0 && j < n && h[u] >= 0) {
       const int e = (int)(k >= 0 && k < own_n ? own_entry + k : j);
@@ -1140,16 +1149,19 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_shard_link_kernel(int32_t* __
   if (j >= n) return;
   const int h = req[j];
   const long long k = j - own_lo;
-  const int e = (int)(k >= 0 && k < own_n ? own_entry + k : j);
+  const bool own = k >= 0 && k < own_n;
+  if (own && own_entry < 0) return;   // (the fused kernel linked the own block's contributions itself: GQE_OWN_ROW)
+  const int e = (int)(own ? own_entry + k : j);
   if (h >= 0) next[e] = __hip_atomic_exchange(head + h, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 hipError_t gqe_launch_shard_serve(const float* params, const int32_t* req, long long n, float* out, int d, const GqeShardTabs& t,
                                   long long own_lo, long long own_n, float* own_out, int32_t* head, int32_t* next, long long own_entry,
                                   int link, hipStream_t stream) {
-  if (n < 1) return hipSuccess;
+  const long long work = own_out == nullptr && own_n > 0 ? n - own_n : n;
+  if (work < 1) return hipSuccess;
   const long long rows_per_block = (long long)(GQE_THREADS / (d >> 2)) * GQE_SERVE_U;
-  hipLaunchKernelGGL(gqe_shard_serve_kernel, dim3((unsigned)((n + rows_per_block - 1) / rows_per_block)), dim3(GQE_THREADS), 0, stream,
+  hipLaunchKernelGGL(gqe_shard_serve_kernel, dim3((unsigned)((work + rows_per_block - 1) / rows_per_block)), dim3(GQE_THREADS), 0, stream,
                      params, req, n, out, d, t, own_lo, own_n, own_out, head, next, own_entry, link);
   return hipGetLastError();
 }

@@ -91,6 +91,7 @@ struct ShardPins {
 struct ShardSession {
   // host time per phase, accumulated when GQE_SHARD_PROFILE is set (printed by gqe_shard_close)
   bool profile = false;
+  bool own_direct = false;  // margin steps name the rows of the own shard directly (GQE_OWN_ROW): whenever the own block stays in place
   bool self_rccl = false;   // GQE_SHARD_SELF_VIA_RCCL: send this rank's own block through RCCL too (measuring / testing the transport with one rank)
   double host_us[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long host_n = 0;
@@ -232,7 +233,7 @@ void shard_plan_job(ShardSession* S, uint64_t t) {
   ShardPost* P = S->post(me, s);
   if (rc == GQE_OK)
     rc = shard_plan_impl(S->ctx, sl.batches.data(), (int32_t)sl.batches.size(), sl.idx, sl.n_idx, sl.with_neg ? 1 : 0, pn.pos, S->requests(me, s),
-                         sl.send_counts, sl.plan_err, sizeof sl.plan_err);
+                         sl.send_counts, sl.plan_err, sizeof sl.plan_err, S->own_direct);
   clk.mark(0);
   sl.n_send = 0;
   for (int o = 0; o < W; ++o) {
@@ -445,7 +446,7 @@ int shard_run_consumed(gqe_ctx* ctx, ShardSession* S, uint64_t t, int s, int kin
   // the contributions' all-to-all and the optimiser pass (GQE_SHARD_LINK_LATE=1 keeps the separate launch: A / B runs)
   static const bool link_late = getenv("GQE_SHARD_LINK_LATE") != nullptr;
   ctx->shard_link_early = kind == 1 && !link_late;
-  struct Guard { gqe_ctx* c; ~Guard() { c->shard_internal = false; c->shard_link_early = false; } } guard{ctx};
+  struct Guard { gqe_ctx* c; ~Guard() { c->shard_internal = false; c->shard_link_early = false; c->own_direct = false; } } guard{ctx};
   // ---- rows: the owners bring what they serve up to date (lazy Adam), gather it, and the rows travel to the requesters ----
   rc = timing_begin(ctx, 5, st);
   if (rc != GQE_OK) return rc;
@@ -469,6 +470,7 @@ int shard_run_consumed(gqe_ctx* ctx, ShardSession* S, uint64_t t, int s, int kin
   // kernel writes them
   const bool in_place = S->custom ? S->tr.skips_own_block != 0 : !S->self_rccl;
   ctx->own_lo = ctx->own_n = ctx->own_fetch = ctx->own_entry = 0;
+  ctx->own_direct = kind == 1 && S->own_direct;
   if (in_place) {
     for (int j = 0; j < S->rank; ++j) {
       ctx->own_lo += col.recv_counts[j];
@@ -599,6 +601,7 @@ int gqe_shard_open(gqe_ctx* ctx, const char* session, void* nccl_comm, const gqe
     }
     S->comm = nccl_comm;
   }
+  S->own_direct = (S->custom ? S->tr.skips_own_block != 0 : !S->self_rccl) && getenv("GQE_SHARD_OWN_VIA_BUFFER") == nullptr;   // (the switch: A / B runs)
   // ---- the plan board ----
   S->bytes = shard_board_bytes(W, S->cap_req, &S->post_bytes);
   if (W == 1) {

@@ -330,9 +330,11 @@ int gqe_shard_link(gqe_ctx* ctx, const int32_t* requests, int64_t n, void* strea
  *                                                           to stay valid until the step has run: the owner sort happens on
  *                                                           the session's planning thread, next to the caller's thread),
  *                                                           segs = the tensors its batches touch (gqe_segment.step unused)
- *   gqe_shard_step(ctx, lr, b1, b2, eps, losses, pos, neg, stream) run the oldest posted plan: serve -> all-to-all of rows ->
- *                                                           fused forward / backward + pair GEMM -> all-to-all of contributions ->
- *                                                           link -> all-reduce of the small gradients -> Adam on the own shards
+ *   gqe_shard_step(ctx, lr, b1, b2, eps, losses, pos, neg, stream) run the oldest posted plan: serve (+ link) the other ranks'
+ *                                                           requests -> all-to-all of rows -> fused forward / backward + pair
+ *                                                           GEMM on fetched rows and, in place, on the rows of the own shard ->
+ *                                                           all-to-all of contributions -> all-reduce of the small gradients ->
+ *                                                           Adam on the own shards
  *   gqe_shard_post(.., 0, NULL, 0) + gqe_shard_forward(ctx, scores, stream)   the same for gqe_forward, candidate lists included:
  *                                                           the list offsets pass through the plan, every candidate is fetched from
  *                                                           its owner like any other row (once per naming: the whole index feed of
@@ -348,8 +350,9 @@ typedef struct {
                     int64_t elem_bytes, void* stream);
   int (*all_reduce_sum_f32)(void* user, float* buf, int64_t n, void* stream);
   /* non-zero: all_to_all leaves the CALLER'S OWN block (block `rank` of both buffers) untouched.  The library then keeps that
-   * block in place — its rows are served straight into the fetched-row buffer, its contributions are linked where the fused
-   * kernel wrote them — as it does on its RCCL path; 0: the transport moves every block, the own one included. */
+   * block in place, as it does on its RCCL path: in a margin step the fused kernel reads the rows of the rank's own shard
+   * where they live and links their contributions itself (nothing is served or copied for them); in a forward call they are
+   * served straight into the fetched-row buffer.  0: the transport moves every block, the own one included. */
   int32_t skips_own_block;
 } gqe_transport;
 int gqe_shard_open(gqe_ctx* ctx, const char* session, void* nccl_comm, const gqe_transport* transport);

@@ -2,7 +2,7 @@
 """What the row-sharded protocol costs when nothing has to travel: ONE rank over the real nccl (RCCL) backend, so every
 all-to-all / all-reduce is a self-copy executed by RCCL — serve, fetch, fused launch on fetched rows, contributions back,
 link, all-reduce, Adam — against the plain single-GPU step on the same batches.  The difference is the fixed cost of the
-three collectives + two small kernels + one memset per step (launch latencies and host time), i.e. the floor under the
+collectives + the serve kernel for the other ranks (none at one rank since round 4: own rows are read in place), i.e. the floor under the
 exchange time of an N-GPU run.   python tools/shard_overhead_bench.py"""
 import os, sys, time
 import numpy as np
