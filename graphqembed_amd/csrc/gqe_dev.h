@@ -55,7 +55,31 @@ struct GqeDevFormula {
   int32_t slot_fx, slot_fg;                       // bilinear final projection: input, grad wrt output
   int32_t slot_act[2][GQE_MAX_HOPS];              // bilinear chain: act_h of the +/- side
   int32_t slot_gact[2][GQE_MAX_HOPS];             // bilinear chain: grad wrt act_{h+1}
+  // Operand-ordered copies of the d x d matrices this formula contracts with (GQE_TILE_INDEX below): float offsets into the
+  // WORKSPACE of the copy of M; the copy of M^T sits tile_t floats behind it.  -1: not a matrix (vectors of bilinear-diag / TransE)
+  int64_t hop_tile[GQE_MAX_BRANCH][GQE_MAX_HOPS];
+  int64_t final_tile, pre_tile, post_tile, tile_t;
 };
+
+// ---- operand-ordered ("tiled") copies of the d x d matrices ---------------------------------------------------------
+// The A operand of v_mfma_f32_16x16x4_f32 for output rows i0 .. i0+15 and k-block kb is, per lane l = (i & 15) + 16 * ((k & 15) >> 2),
+// the four floats M[i][16 kb + 4 (l >> 4) .. + 3].  Read from the row-major matrix that is 16 B per lane at a stride of one matrix
+// row — 16 half-used cache lines per wave load, and for M^T four 4-byte loads per lane; at d = 256 the Post contraction took
+// 8.1 us against a 3.4 us MFMA pipe bound with one tile on the whole chip (the L1's line rate, not L2 contention).  The library
+// therefore keeps, for every matrix a formula names, a copy of M and one of M^T in exactly that order — tile (i >> 4, k >> 4) is
+// 1 KB, a wave load reads it as ONE contiguous kilobyte:
+//     float index of M[i][k] = (((i >> 4) * (d >> 4) + (k >> 4)) * 64 + (i & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3)
+// The copies are rewritten by the optimiser pass together with the matrix (gqe_opt_kernel, dense segments) and rebuilt by
+// gqe_retile_kernel when the caller changed parameters itself (gqe_params_changed) or a formula names a new matrix.
+#define GQE_TILE_INDEX(i, k, d) ((((size_t)((i) >> 4) * ((d) >> 4) + ((k) >> 4)) * 64 + ((i) & 15) + 16 * (((k) & 15) >> 2)) * 4 + ((k) & 3))
+#define GQE_RETILE_MAX 64   // matrices per launch of the rebuild kernel (kernel arguments)
+struct GqeRetileArgs {
+  int n;
+  long long tile_t;                    // copy of M^T = copy of M + tile_t floats
+  long long param[GQE_RETILE_MAX];     // float offset of the matrix in the parameter arena
+  long long tile[GQE_RETILE_MAX];      // float offset of its copy in the workspace
+};
+hipError_t gqe_launch_retile(const GqeRetileArgs& a, const float* params, float* ws, int d, hipStream_t stream);
 
 // Dynamic part of a batch (sizes, offsets of this call), passed BY VALUE in the kernel arguments:
 // no plan upload, no event between the host and the launch.
@@ -134,6 +158,7 @@ struct GqeDevSeg {
   int64_t rows, head_base;  // tables only
   int32_t is_table;
   int32_t table_index;      // tables only: index in gqe_set_tables order (slot of the lazy-Adam per-table arguments)
+  float *tile, *tile_T;     // d x d tensors: their operand-ordered copies (GQE_TILE_INDEX), rewritten with the parameter; else NULL
 };
 
 // Table form of "which tensors does this pass step, and with which Adam bias corrections": one entry per ACTIVE

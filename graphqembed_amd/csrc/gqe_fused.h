@@ -105,32 +105,26 @@ __device__ __forceinline__ float* scratch_row(const TileEnv& e, int slot, int r)
 //   TRANS = false: A[i][k] = M[i][k]  (M . x : "project", decoders.py:150; Pre/Post forward)
 //   TRANS = true : A[i][k] = M[k][i]  (M^T . x : x^T M of decoders.py:145; every backward)
 // ------------------------------------------------------------------------------------------
+// The matrix is read from its OPERAND-ORDERED copy (gqe_dev.h, GQE_TILE_INDEX; M selects the copy of M or of M^T — the loader
+// is the same for both): the A operand of row block i0 and k-block kb is one contiguous kilobyte, 16 B per lane.  The copy is
+// addressed as ONE buffer of d * d floats: the lane's offset inside the row block's tiles is computed once, the k-block step is a
+// wave-uniform immediate of the instruction (no VALU address arithmetic per load).
 // Guarded kernels (FULL = false, d < 64 NC): the contractions run over the PADDED extent with compile-time trip counts — a
-// runtime k-block count made every slab element conditionally zero and the row-block loop a real loop, and the 16-wave
-// kernels spilled hundreds of registers at their 128-VGPR limit.  The matrix is addressed as ONE buffer of d * d floats:
-// k-rows past d of M^T (and whole output row blocks past d, which are skipped anyway) are out of range and read 0; columns
-// k >= d of a row of M read the next row's (finite) values and meet the zero columns of the source tile.
-template <bool TRANS, int KB, int KBT, bool FULL>
+// run-time k-block count made every slab element conditionally zero and the row-block loop a real loop, and the 16-wave
+// kernels spilled hundreds of registers at their 128-VGPR limit.  k-blocks past d / 16 of a row block read the NEXT row
+// block's tiles (finite values) or, behind the last one, nothing (out of range: 0) — and meet the zero columns of the source tile.
+template <int KB, int KBT, bool FULL>
 __device__ __forceinline__ void load_a_slab(float4 (&a)[KB], const float* __restrict__ M, int d, int i0, int lq, int lk, int kb0) {
-  // The matrix is addressed as ONE buffer (guarded kernels: its d * d floats are the range check described above).  A lane's
-  // offset inside the slab is computed ONCE; the k-block step is a wave-uniform SGPR / immediate offset of the instruction, so a
-  // load costs no VALU address arithmetic (64-bit pointer adds per load were a tenth of the 8-wave kernels' instructions).
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(M), 0, d * d * 4, 0x00020000);
-  const int voff = TRANS ? ((4 * lk) * d + i0 + lq) * 4 : ((i0 + lq) * d + 4 * lk) * 4;
+  const int voff = (i0 >> 4) * (d >> 4) * 1024 + (lq + 16 * lk) * 16;
 #pragma unroll
   for (int j = 0; j < KB; ++j) {
     const int kb = kb0 + j;
     if (kb >= KBT) {   // (compile time: the last group of a slab whose k-block count is not a multiple of the group)
       a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else if (!TRANS) {
-      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, kb * 64, 0);
-      a[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
     } else {
-      const int so = kb * 64 * d;   // 16 k-rows of d floats
-      a[j] = make_float4(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, so, 0)),
-                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, so + 4 * d, 0)),
-                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, so + 8 * d, 0)),
-                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, so + 12 * d, 0)));
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, kb * 1024, 0);
+      a[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
     }
   }
 }
@@ -146,6 +140,13 @@ __device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 a
 // The A slab of an output row block is fetched in groups of <= KG k-blocks (KG float4 per lane in flight): all of it
 // at d <= 128, two / three / four rounds beyond — a 16-float4 slab (d = 256) next to the rows a wave keeps in registers
 // would spill.
+// the operand-ordered copy of a matrix of the formula (TR: of its transpose), gqe_dev.h
+#define GQE_TILED(TR, field) (ws + f->field + ((TR) ? f->tile_t : 0))
+// KB k-blocks in groups of KG: double-buffered half-groups whenever the slab takes more than one group and splits evenly
+#define GQE_DBUF(KB, KG) (!GQE_NO_DBUF && GQE_FW == 16 && (KB) > (KG) && (KG) % 2 == 0 && (KB) % ((KG) / 2) == 0)
+#ifndef GQE_NO_DBUF
+#define GQE_NO_DBUF 0
+#endif
 #define GQE_KG ((GQE_FW == 8 && NC >= 2) ? (NC >= 4 ? 2 : 4) : ((GQE_DEC == DEC_BILINEAR && NC >= 4) ? 4 : 8))  // 8-wave d > 128 kernels (two rows per role) and the full-Bilinear d = 256 kernel: smaller groups keep them off the spill cliff
 
 // ---- matrices staged in LDS (the intersection's Pre / Post at d <= 128) -----------------------------------------
@@ -307,15 +308,37 @@ __device__ __forceinline__ void tile_matmul(float* __restrict__ dst, const float
   const int lq = lane & 15, lk = lane >> 4;
   auto block = [&](const int i0) __attribute__((always_inline)) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (GQE_DBUF(KB, KG)) {
+      // the slab does not fit the registers at once: two half-groups in flight, the next one requested as soon as the MFMAs that
+      // read its registers are issued (load-all / contract-all per group left every wave of the tile waiting for L2 at the same
+      // time, twice per contraction: Post at d = 256 took 8.1 us against a 3.4 us pipe bound)
+      constexpr int H = KG / 2, NG = KB / H;
+      float4 a[2][H];
+      load_a_slab<H, KB, FULL>(a[0], M, d, i0, lq, lk, 0);
+      load_a_slab<H, KB, FULL>(a[1], M, d, i0, lq, lk, H);
 #pragma unroll
-    for (int g0 = 0; g0 < KB; g0 += KG) {
-      float4 a[KG];
-      load_a_slab<TRANS, KG, KB, FULL>(a, M, d, i0, lq, lk, g0);
+      for (int g = 0; g < NG; ++g) {
 #pragma unroll
-      for (int kb = 0; kb < KG; ++kb) {
-        if (g0 + kb < KB) {
-          const float4 b = *reinterpret_cast<const float4*>(src + lq * DP + (g0 + kb) * 16 + 4 * lk);
-          acc = mfma4(a[kb], b, acc);
+        for (int kb = 0; kb < H; ++kb) {
+          const float4 b = *reinterpret_cast<const float4*>(src + lq * DP + (g * H + kb) * 16 + 4 * lk);
+          acc = mfma4(a[g & 1][kb], b, acc);
+        }
+        if (g + 2 < NG) {
+          __builtin_amdgcn_sched_barrier(0);   // (not hoisted above the MFMAs: a third half-group in registers)
+          load_a_slab<H, KB, FULL>(a[g & 1], M, d, i0, lq, lk, (g + 2) * H);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int g0 = 0; g0 < KB; g0 += KG) {
+        float4 a[KG];
+        load_a_slab<KG, KB, FULL>(a, M, d, i0, lq, lk, g0);
+#pragma unroll
+        for (int kb = 0; kb < KG; ++kb) {
+          if (g0 + kb < KB) {
+            const float4 b = *reinterpret_cast<const float4*>(src + lq * DP + (g0 + kb) * 16 + 4 * lk);
+            acc = mfma4(a[kb], b, acc);
+          }
         }
       }
     }
@@ -344,17 +367,39 @@ __device__ __forceinline__ void pre_intersect(float* __restrict__ th, int* __res
     f32x4 acc[NB];
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi) acc[bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (GQE_DBUF(KB, KG)) {   // two half-groups in flight (tile_matmul)
+      constexpr int H = KG / 2, NG = KB / H;
+      float4 a[2][H];
+      load_a_slab<H, KB, FULL>(a[0], P, d, i0, lq, lk, 0);
+      load_a_slab<H, KB, FULL>(a[1], P, d, i0, lq, lk, H);
 #pragma unroll
-    for (int g0 = 0; g0 < KB; g0 += KG) {
-      float4 a[KG];
-      load_a_slab<false, KG, KB, FULL>(a, P, d, i0, lq, lk, g0);
+      for (int g = 0; g < NG; ++g) {
 #pragma unroll
-      for (int kb = 0; kb < KG; ++kb) {
-        if (g0 + kb < KB) {
+        for (int kb = 0; kb < H; ++kb) {
 #pragma unroll
           for (int bi = 0; bi < NB; ++bi) {
-            const float4 b = *reinterpret_cast<const float4*>(te[bi] + lq * DP + (g0 + kb) * 16 + 4 * lk);
-            acc[bi] = mfma4(a[kb], b, acc[bi]);
+            const float4 b = *reinterpret_cast<const float4*>(te[bi] + lq * DP + (g * H + kb) * 16 + 4 * lk);
+            acc[bi] = mfma4(a[g & 1][kb], b, acc[bi]);
+          }
+        }
+        if (g + 2 < NG) {
+          __builtin_amdgcn_sched_barrier(0);
+          load_a_slab<H, KB, FULL>(a[g & 1], P, d, i0, lq, lk, (g + 2) * H);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int g0 = 0; g0 < KB; g0 += KG) {
+        float4 a[KG];
+        load_a_slab<KG, KB, FULL>(a, P, d, i0, lq, lk, g0);
+#pragma unroll
+        for (int kb = 0; kb < KG; ++kb) {
+          if (g0 + kb < KB) {
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi) {
+              const float4 b = *reinterpret_cast<const float4*>(te[bi] + lq * DP + (g0 + kb) * 16 + 4 * lk);
+              acc[bi] = mfma4(a[kb], b, acc[bi]);
+            }
           }
         }
       }
@@ -460,24 +505,41 @@ __device__ __forceinline__ void pre_intersect_bwd(float* const (&te)[GQE_MAX_BRA
     f32x4 acc[NB];
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi) acc[bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // one k-block of the batched contraction: the B operand of branch b is g_h masked by bit 8 + b of the meta word
+    // (pre_intersect): two VALU ops per element instead of mask_gz's five
+    auto kblock = [&](const float4& av, const int kbi) __attribute__((always_inline)) {
+      const float4 g4 = *reinterpret_cast<const float4*>(tgh + lq * DP + kbi * 16 + 4 * lk);
+      const float4 gh = make_float4(g4.x * gsc, g4.y * gsc, g4.z * gsc, g4.w * gsc);
+      const int4 mt = *reinterpret_cast<const int4*>(tmeta + lq * DP + kbi * 16 + 4 * lk);
 #pragma unroll
-    for (int g0 = 0; g0 < KB; g0 += KG) {
-      float4 a[KG];
-      load_a_slab<true, KG, KB, FULL>(a, P, d, i0, lq, lk, g0);
+      for (int bi = 0; bi < NB; ++bi) {
+        const float4 b = make_float4(keep_if_bit(gh.x, mt.x, 8 + bi), keep_if_bit(gh.y, mt.y, 8 + bi), keep_if_bit(gh.z, mt.z, 8 + bi),
+                                     keep_if_bit(gh.w, mt.w, 8 + bi));
+        acc[bi] = mfma4(av, b, acc[bi]);
+      }
+    };
+    if constexpr (GQE_DBUF(KB, KG)) {   // two half-groups in flight (tile_matmul)
+      constexpr int H = KG / 2, NG = KB / H;
+      float4 a[2][H];
+      load_a_slab<H, KB, FULL>(a[0], P, d, i0, lq, lk, 0);
+      load_a_slab<H, KB, FULL>(a[1], P, d, i0, lq, lk, H);
 #pragma unroll
-      for (int kb = 0; kb < KG; ++kb) {
-        if (g0 + kb < KB) {
-          const float4 g4 = *reinterpret_cast<const float4*>(tgh + lq * DP + (g0 + kb) * 16 + 4 * lk);
-          const float4 gh = make_float4(g4.x * gsc, g4.y * gsc, g4.z * gsc, g4.w * gsc);
-          const int4 mt = *reinterpret_cast<const int4*>(tmeta + lq * DP + (g0 + kb) * 16 + 4 * lk);
+      for (int g = 0; g < NG; ++g) {
 #pragma unroll
-          for (int bi = 0; bi < NB; ++bi) {
-            // bit 8 + b of the meta word (pre_intersect): two VALU ops per element instead of mask_gz's five
-            const float4 b = make_float4(keep_if_bit(gh.x, mt.x, 8 + bi), keep_if_bit(gh.y, mt.y, 8 + bi), keep_if_bit(gh.z, mt.z, 8 + bi),
-                                         keep_if_bit(gh.w, mt.w, 8 + bi));
-            acc[bi] = mfma4(a[kb], b, acc[bi]);
-          }
+        for (int kb = 0; kb < H; ++kb) kblock(a[g & 1][kb], g * H + kb);
+        if (g + 2 < NG) {
+          __builtin_amdgcn_sched_barrier(0);
+          load_a_slab<H, KB, FULL>(a[g & 1], P, d, i0, lq, lk, (g + 2) * H);
         }
+      }
+    } else {
+#pragma unroll
+      for (int g0 = 0; g0 < KB; g0 += KG) {
+        float4 a[KG];
+        load_a_slab<KG, KB, FULL>(a, P, d, i0, lq, lk, g0);
+#pragma unroll
+        for (int kb = 0; kb < KG; ++kb)
+          if (g0 + kb < KB) kblock(a[kb], g0 + kb);
       }
     }
 #pragma unroll
@@ -1253,7 +1315,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
       for (int h = 0; h < K; ++h) {
         __syncthreads();
         for (int s = 0; s < nside; ++s)
-          tile_matmul<true, NC, FULL>(alt[s], params + f->hop_param[0][h], cur[s], d, DP, wave, lane);
+          tile_matmul<true, NC, FULL>(alt[s], GQE_TILED(true, hop_tile[0][h]), cur[s], d, DP, wave, lane);
         __syncthreads();
         for (int s = 0; s < nside; ++s) {
           float* tmp = cur[s];
@@ -1310,7 +1372,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
           for (int s = 0; s < 2; ++s) tile_to_scratch<NC, FULL>(e, f->slot_gact[s][h], cur[s]);
           __syncthreads();
           for (int s = 0; s < 2; ++s)
-            tile_matmul<false, NC, FULL>(alt[s], params + f->hop_param[0][h], cur[s], d, DP, wave, lane);
+            tile_matmul<false, NC, FULL>(alt[s], GQE_TILED(false, hop_tile[0][h]), cur[s], d, DP, wave, lane);
           __syncthreads();
           for (int s = 0; s < 2; ++s) {
             float* tmp = cur[s];
@@ -1350,7 +1412,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
         }
         for (int h = 0; h < nh; ++h) {
           __syncthreads();
-          tile_matmul<false, NC, FULL>(dst, params + f->hop_param[i][h], src, d, DP, wave, lane);
+          tile_matmul<false, NC, FULL>(dst, GQE_TILED(false, hop_tile[i][h]), src, d, DP, wave, lane);
           __syncthreads();
           float* tmp = src;
           src = dst;
@@ -1395,9 +1457,9 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
         if (BWD) mat_issue<MR>(mr, params + f->pre_param);    // ... and Pre is requested again for the backward
       } else {
         if (n == 3)
-          pre_intersect<NC, 3, FULL>(tacc, tmeta, params + f->pre_param, te, d, DP, wave, lane, inter_min);
+          pre_intersect<NC, 3, FULL>(tacc, tmeta, GQE_TILED(false, pre_tile), te, d, DP, wave, lane, inter_min);
         else
-          pre_intersect<NC, 2, FULL>(tacc, tmeta, params + f->pre_param, te, d, DP, wave, lane, inter_min);
+          pre_intersect<NC, 2, FULL>(tacc, tmeta, GQE_TILED(false, pre_tile), te, d, DP, wave, lane, inter_min);
       }
       __syncthreads();
     } else {
@@ -1436,7 +1498,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
       if (STAGE)
         tile_matmul_staged<false, NC>(tq, mbuf, tacc, DP, wave, lane);
       else
-        tile_matmul<false, NC, FULL>(tq, params + f->post_param, tacc, d, DP, wave, lane);  // q = Post . h
+        tile_matmul<false, NC, FULL>(tq, GQE_TILED(false, post_tile), tacc, d, DP, wave, lane);  // q = Post . h
       __syncthreads();
       tqq = tq;
     }
@@ -1446,7 +1508,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
       if (DEC == DEC_BILINEAR) {
         if (BWD) tile_to_scratch<NC, FULL>(e, f->slot_fx, tqq);
         if (!MLP) __syncthreads();
-        tile_matmul<false, NC, FULL>(te[0], params + f->final_param, tqq, d, DP, wave, lane);
+        tile_matmul<false, NC, FULL>(te[0], GQE_TILED(false, final_tile), tqq, d, DP, wave, lane);
         __syncthreads();
       } else {
         if (!PREW) WF = gload<NC, FULL>(params + f->final_param, d, lane);
@@ -1512,7 +1574,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
         if (DEC == DEC_BILINEAR) {
           tile_to_scratch<NC, FULL>(e, f->slot_fg, tg);
           __syncthreads();
-          tile_matmul<true, NC, FULL>(te[1], params + f->final_param, tg, d, DP, wave, lane);
+          tile_matmul<true, NC, FULL>(te[1], GQE_TILED(true, final_tile), tg, d, DP, wave, lane);
           __syncthreads();
           tgc = te[1];
         } else {
@@ -1551,7 +1613,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
           mat_commit<MR>(mr, mbuf, d, DP);  // Pre again; the barrier in front of its contraction is below
           GQE_WSTAMP(5);
         } else {
-          tile_matmul<true, NC, FULL>(tacc, params + f->post_param, tgc, d, DP, wave, lane);  // g_h = Post^T g_q
+          tile_matmul<true, NC, FULL>(tacc, GQE_TILED(true, post_tile), tgc, d, DP, wave, lane);  // g_h = Post^T g_q
           __syncthreads();
         }
         tgh = tacc;
@@ -1607,9 +1669,9 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
             pre_intersect_bwd_staged<NC, 2>(te, mbuf, tgh, tmeta, DP, wave, lane, inter_min);
         } else {
           if (n == 3)
-            pre_intersect_bwd<NC, 3, FULL>(te, params + f->pre_param, tgh, tmeta, d, DP, wave, lane, inter_min);
+            pre_intersect_bwd<NC, 3, FULL>(te, GQE_TILED(true, pre_tile), tgh, tmeta, d, DP, wave, lane, inter_min);
           else
-            pre_intersect_bwd<NC, 2, FULL>(te, params + f->pre_param, tgh, tmeta, d, DP, wave, lane, inter_min);
+            pre_intersect_bwd<NC, 2, FULL>(te, GQE_TILED(true, pre_tile), tgh, tmeta, d, DP, wave, lane, inter_min);
         }
         GQE_STAMP(13);
         GQE_WSTAMP(7);
@@ -1644,7 +1706,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
           for (int h = nh - 1; h >= 0; --h) {
             tile_to_scratch<NC, FULL>(e, f->slot_gy[i][h], tcur);
             __syncthreads();
-            tile_matmul<true, NC, FULL>(tnext, params + f->hop_param[i][h], tcur, d, DP, wave, lane);
+            tile_matmul<true, NC, FULL>(tnext, GQE_TILED(true, hop_tile[i][h]), tcur, d, DP, wave, lane);
             __syncthreads();
             float* tmp = tcur;
             tcur = tnext;

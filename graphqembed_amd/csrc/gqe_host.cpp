@@ -73,6 +73,12 @@ struct Layout {  // byte offsets inside the bound workspace
   size_t shard_req_send, shard_req_recv, shard_fetch, shard_csend;  // row-sharded mode (0 otherwise)
   int64_t shard_cap_send, shard_cap_recv;                          // entries
   size_t seg_off, act_off, formula_off, head_off, rows_off, next_off, contrib_off, linkc_off, counter_off, last_off, ring_off, total;
+  // operand-ordered copies of the d x d matrices (gqe_dev.h, GQE_TILE_INDEX): a mirror of the arena's non-table spans for M,
+  // a second one for M^T (tile_floats floats each)
+  size_t tile_off;
+  int64_t tile_floats;
+  int n_tile_spans;
+  int64_t tile_span_lo[8], tile_span_hi[8], tile_span_base[8];   // arena floats [lo, hi) -> mirror floats from base (base = lo mod 64)
   size_t hot_slot_off, hot_acc_off;   // hot rows (GqeHot): slot per table row, GQE_HOT_REPS x GQE_HOT_SLOTS accumulators of dim floats
   int64_t max_entries, max_links;  // max_entries = per-rank capacity x world (the exchange gathers every rank's entries)
 };
@@ -95,6 +101,10 @@ struct gqe_ctx {
   std::vector<Table> tables;
   std::vector<Bag> bags;
   bool links_used = false;  // link nodes were allocated since the last consumption
+  // the d x d matrices the registered formulas contract with (arena offsets, sorted); tiles_dirty: their operand-ordered copies
+  // have to be rebuilt before the next fused launch (new workspace, new matrix, gqe_params_changed)
+  std::vector<int64_t> matrices;
+  bool tiles_dirty = true;
   int64_t total_rows = 0;
   int64_t entries_used = 0;
   bool lazy = false;                 // gqe_set_lazy_adam
@@ -340,7 +350,25 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
   L.ring_off = L.last_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
   L.hot_slot_off = L.ring_off + align_up(sizeof(float) * 2 * GQE_LAZY_TABLES * GQE_LAZY_RING, 256);
   L.hot_acc_off = L.hot_slot_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
-  L.total = L.hot_acc_off + align_up(sizeof(float) * (size_t)GQE_HOT_REPS * GQE_HOT_SLOTS * ctx->cfg.dim, 256);
+  L.tile_off = L.hot_acc_off + align_up(sizeof(float) * (size_t)GQE_HOT_REPS * GQE_HOT_SLOTS * ctx->cfg.dim, 256);
+  {
+    GqeSpans sp = dense_spans(ctx);
+    if (sp.n < 0) {   // more than 8 non-table spans: mirror the whole arena
+      sp.n = 1;
+      sp.off[0] = 0;
+      sp.len[0] = ctx->n_arena;
+    }
+    L.n_tile_spans = sp.n;
+    int64_t at = 0;
+    for (int k = 0; k < sp.n; ++k) {
+      L.tile_span_lo[k] = sp.off[k];
+      L.tile_span_hi[k] = sp.off[k] + sp.len[k];
+      L.tile_span_base[k] = at + (sp.off[k] & 63);   // mirror(off) = off (mod 64 floats): float4 stores / 16-byte lane loads stay aligned
+      at = (int64_t)align_up((size_t)(L.tile_span_base[k] + sp.len[k]), 64);
+    }
+    L.tile_floats = at;
+  }
+  L.total = L.tile_off + align_up(sizeof(float) * 2 * (size_t)L.tile_floats, 256);
   L.shard_req_send = L.shard_req_recv = L.shard_fetch = L.shard_csend = 0;
   if (ctx->shard_on) {
     L.shard_req_send = L.total;
@@ -413,6 +441,53 @@ int table_of(const gqe_ctx* ctx, int64_t offset) {
 }
 
 // Validate one caller batch and return the index of its (cached) static descriptor.
+// float offset (in the workspace) of the operand-ordered copy of the matrix at arena offset `off`; -1 without a workspace
+int64_t tile_of(const gqe_ctx* ctx, int64_t off) {
+  if (!ctx->ws || off < 0) return -1;
+  const Layout& L = ctx->lay;
+  for (int k = 0; k < L.n_tile_spans; ++k)
+    if (off >= L.tile_span_lo[k] && off < L.tile_span_hi[k]) return (int64_t)(L.tile_off / sizeof(float)) + L.tile_span_base[k] + (off - L.tile_span_lo[k]);
+  return -1;
+}
+
+// the tile fields of a formula descriptor (they depend on the bound workspace), and its matrices into the registry
+void formula_tiles(gqe_ctx* ctx, GqeDevFormula& f) {
+  const bool bil = ctx->cfg.decoder == GQE_DEC_BILINEAR;
+  auto reg = [&](int64_t off) {
+    if (off < 0) return (int64_t)-1;
+    auto it = std::lower_bound(ctx->matrices.begin(), ctx->matrices.end(), off);
+    if (it == ctx->matrices.end() || *it != off) {
+      ctx->matrices.insert(it, off);
+      ctx->tiles_dirty = true;
+    }
+    return tile_of(ctx, off);
+  };
+  for (int i = 0; i < GQE_MAX_BRANCH; ++i)
+    for (int h = 0; h < GQE_MAX_HOPS; ++h) f.hop_tile[i][h] = (bil && h < f.n_hops[i]) ? reg(f.hop_param[i][h]) : -1;
+  f.final_tile = (bil && f.n_final) ? reg(f.final_param) : -1;
+  f.pre_tile = reg(f.pre_param);     // (-1 unless the formula is an MLP intersection)
+  f.post_tile = reg(f.post_param);
+  f.tile_t = ctx->lay.tile_floats;
+}
+
+// rebuild the copies of every registered matrix from the parameter arena
+int retile(gqe_ctx* ctx, hipStream_t st) {
+  if (!ctx->ws || !ctx->params) return GQE_OK;
+  GqeRetileArgs ra;
+  ra.tile_t = ctx->lay.tile_floats;
+  for (size_t a = 0; a < ctx->matrices.size(); a += GQE_RETILE_MAX) {
+    ra.n = (int)std::min<size_t>(GQE_RETILE_MAX, ctx->matrices.size() - a);
+    for (int k = 0; k < ra.n; ++k) {
+      ra.param[k] = ctx->matrices[a + (size_t)k];
+      ra.tile[k] = tile_of(ctx, ra.param[k]);
+      if (ra.tile[k] < 0) return fail(ctx, GQE_ERR_STATE, "internal: the matrix at offset %lld has no place for its operand copy", (long long)ra.param[k]);
+    }
+    HIP_TRY(ctx, gqe_launch_retile(ra, ctx->params, reinterpret_cast<float*>(ctx->ws), ctx->cfg.dim, st));
+  }
+  ctx->tiles_dirty = false;
+  return GQE_OK;
+}
+
 int formula_of(gqe_ctx* ctx, const gqe_batch& s, int bi, int* out_id) {
   const int d = ctx->cfg.dim;
   const bool bil = ctx->cfg.decoder == GQE_DEC_BILINEAR;
@@ -543,6 +618,7 @@ int formula_of(gqe_ctx* ctx, const gqe_batch& s, int bi, int* out_id) {
   if (nslot > kMaxSlots || njob > GQE_MAX_JOBS) return fail(ctx, GQE_ERR_ARG, "internal: %d scratch slots / %d jobs", nslot, njob);
   f.n_slots = nslot;
   f.n_jobs = njob;
+  formula_tiles(ctx, f);
   int slot;
   if ((int)ctx->formulas.size() < ctx->cap_formulas) {
     slot = (int)ctx->formulas.size();
@@ -769,6 +845,12 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
                 "gqe_materialize_grads first", (long long)ctx->entries_used, (long long)entries, (long long)L.max_entries);
 
   int rc;
+  // ---- the operand-ordered copies of the matrices, when something other than the library's optimiser changed them ----
+  static const bool always_retile = getenv("GQE_ALWAYS_RETILE") != nullptr;   // (tests: the copies never trusted)
+  if (ctx->tiles_dirty || always_retile) {
+    rc = retile(ctx, st);
+    if (rc != GQE_OK) return rc;
+  }
   // ---- new / replaced formula descriptors -> device table (rare): contiguous runs of stale slots, one copy each ----
   if (!ctx->formulas_dirty.empty()) {
     std::vector<int>& dirty = ctx->formulas_dirty;
@@ -1025,6 +1107,17 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   return GQE_OK;
 }
 
+// every d x d tensor outside the tables is kept in operand order next to its parameter (whether a formula names it yet or not)
+void universe_tiles(const gqe_ctx* ctx, GqeDevSeg& g) {
+  g.tile = g.tile_T = nullptr;
+  const int64_t d = ctx->cfg.dim;
+  if (g.is_table || g.numel != d * d) return;
+  const int64_t t = tile_of(ctx, g.offset);
+  if (t < 0) return;
+  g.tile = reinterpret_cast<float*>(ctx->ws) + t;
+  g.tile_T = g.tile + ctx->lay.tile_floats;
+}
+
 int universe_index(gqe_ctx* ctx, int64_t offset, int64_t numel, int table) {
   for (size_t i = 0; i < ctx->universe.size(); ++i)
     if (ctx->universe[i].offset == offset && ctx->universe[i].numel == numel) return (int)i;
@@ -1043,6 +1136,7 @@ int universe_index(gqe_ctx* ctx, int64_t offset, int64_t numel, int table) {
     g.n_chunks = (g.rows + rpc - 1) / rpc;
   } else {
     g.n_chunks = (numel + GQE_OPT_CHUNK - 1) / GQE_OPT_CHUNK;
+    universe_tiles(ctx, g);
   }
   ctx->universe.push_back(g);
   return (int)ctx->universe.size() - 1;
@@ -1575,6 +1669,13 @@ int gqe_bind_arena(gqe_ctx* ctx, float* params, float* grads, float* exp_avg, fl
   ctx->m = exp_avg;
   ctx->v = exp_avg_sq;
   ctx->n_arena = n;
+  ctx->tiles_dirty = true;
+  return GQE_OK;
+}
+
+int gqe_params_changed(gqe_ctx* ctx) {
+  if (!ctx) return GQE_ERR_ARG;
+  ctx->tiles_dirty = true;
   return GQE_OK;
 }
 
@@ -1649,8 +1750,13 @@ int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* strea
   ctx->ws_bytes = bytes;
   ctx->lay = L;
   ctx->universe_uploaded = 0;
+  for (GqeDevSeg& g : ctx->universe) universe_tiles(ctx, g);
   ctx->formulas_dirty.clear();  // the new workspace holds no descriptors yet: all cached slots are stale
-  for (int k = 0; k < (int)ctx->formulas.size(); ++k) ctx->formulas_dirty.push_back(k);
+  for (int k = 0; k < (int)ctx->formulas.size(); ++k) {
+    formula_tiles(ctx, ctx->formulas[(size_t)k]);
+    ctx->formulas_dirty.push_back(k);
+  }
+  ctx->tiles_dirty = true;
   // empty gradient lists: head[row] = -1; link-node allocator at 0
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.head_off, 0xff, L.rows_off - L.head_off, reinterpret_cast<hipStream_t>(stream)));
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.counter_off, 0, 256, reinterpret_cast<hipStream_t>(stream)));   // + the hot-slot counter

@@ -331,6 +331,35 @@ __device__ __forceinline__ void lazy_advance(float4& pp, float4& mm, float4& vv,
   }
 }
 
+// The operand-ordered copies of a d x d parameter (gqe_dev.h, GQE_TILE_INDEX): M[i][k .. k+3] goes to one float4 of the copy of M
+// and to column i of rows k .. k+3 of the copy of M^T.
+__device__ __forceinline__ void tile_store(float* __restrict__ A, float* __restrict__ T, int d, long long e0, const float4& pp) {
+  const int i = (int)(e0 / d), k = (int)(e0 - (long long)i * d);
+  *reinterpret_cast<float4*>(A + GQE_TILE_INDEX(i, k, d)) = pp;
+  float* t = T + GQE_TILE_INDEX(k, i, d);   // (k % 4 == 0: rows k .. k+3 of M^T are lanes l .. l+3 of one tile, 4 floats apart)
+  t[0] = pp.x;
+  t[4] = pp.y;
+  t[8] = pp.z;
+  t[12] = pp.w;
+}
+
+// rebuilds the copies of the listed matrices from the parameter arena (gqe_params_changed, a formula naming a new matrix)
+__global__ __launch_bounds__(GQE_THREADS) void gqe_retile_kernel(const GqeRetileArgs a, const float* __restrict__ params, float* __restrict__ ws, int d) {
+  const int per = (d * d + GQE_OPT_CHUNK - 1) / GQE_OPT_CHUNK;   // chunks of 1024 floats per matrix
+  const int mi = blockIdx.x / per;
+  const long long e0 = (long long)(blockIdx.x - mi * per) * GQE_OPT_CHUNK + (long long)threadIdx.x * 4;
+  if (mi >= a.n || e0 >= (long long)d * d) return;
+  const float4 pp = *reinterpret_cast<const float4*>(params + a.param[mi] + e0);
+  tile_store(ws + a.tile[mi], ws + a.tile[mi] + a.tile_t, d, e0, pp);
+}
+
+hipError_t gqe_launch_retile(const GqeRetileArgs& a, const float* params, float* ws, int d, hipStream_t stream) {
+  if (a.n < 1) return hipSuccess;
+  const int per = (d * d + GQE_OPT_CHUNK - 1) / GQE_OPT_CHUNK;
+  hipLaunchKernelGGL(gqe_retile_kernel, dim3((unsigned)(a.n * per)), dim3(GQE_THREADS), 0, stream, a, params, ws, d);
+  return hipGetLastError();
+}
+
 template <int MODE, bool LISTS, bool DENSE_T, bool SORTED, bool LAZY, bool NT = false>
 __device__ __forceinline__ void opt_body(const long long first_chunk, const long long chunk_stride,
                                          const GqeDevSeg* __restrict__ segs, int n_segs,
@@ -491,6 +520,7 @@ __device__ __forceinline__ void opt_body(const long long first_chunk, const long
         *reinterpret_cast<float4*>(v + off) = vv;
       }
       *reinterpret_cast<float4*>(p + off) = pp;
+      if (sg.tile) tile_store(sg.tile, sg.tile_T, d, e0, pp);   // a d x d matrix: its operand-ordered copies follow it
     } else {
       for (long long k = e0; k < sg.numel; ++k) {
         const long long o = sg.offset + k;

@@ -81,6 +81,7 @@ SYMBOLS = OrderedDict([
     ("gqe_create", (C.c_int, [C.POINTER(gqe_config), C.POINTER(_P)])),
     ("gqe_destroy", (C.c_int, [_P])),
     ("gqe_bind_arena", (C.c_int, [_P, _P, _P, _P, _P, C.c_int64])),
+    ("gqe_params_changed", (C.c_int, [_P])),
     ("gqe_set_tables", (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32])),
     ("gqe_set_bag", (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int32])),
     ("gqe_set_limits", (C.c_int, [_P, C.c_int32, C.c_int32])),
@@ -279,8 +280,16 @@ class Engine(object):
 
     @property
     def params(self):
+        """The parameter arena.  Handing it out may be followed by a write the library cannot see (initialisation, a checkpoint
+        load): the operand-ordered copies of the d x d matrices are rebuilt before the next forward / backward launch
+        (gqe_params_changed).  Code that keeps the tensor and writes to it LATER calls ``params_changed()`` itself."""
         self.sync()
+        self.params_changed()
         return self._params
+
+    def params_changed(self):
+        if getattr(self, "ctx", None):
+            self._check(self.lib.gqe_params_changed(self.ctx))
 
     @property
     def exp_avg(self):

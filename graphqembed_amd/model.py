@@ -97,6 +97,7 @@ class QueryEncoderDecoder(nn.Module):
         """The parameters are views of the arena: rows that still owe deferred Adam steps (lazy mode) are settled
         first, otherwise those steps would later be replayed on top of the loaded values."""
         self.engine.sync()
+        self.engine.params_changed()      # values arrive behind the library's back: its operand copies of the matrices are rebuilt
         return super(QueryEncoderDecoder, self).load_state_dict(state_dict, *args, **kwargs)
 
     def plan(self, formula):
@@ -142,6 +143,7 @@ class QueryEncoderDecoder(nn.Module):
             raise Exception("queries and source_nodes differ in length")
         target, anchors = self._rows(formula, queries, source_nodes)
         descs, idx, n = pack_forward_batches([(self.plan(formula), target, anchors)])
+        self.engine.params_changed()      # (the reference's entry points: the nn.Parameter views may have been written to)
         return self.engine.forward(descs, idx, n)
 
     def margin_loss(self, formula, queries, hard_negatives=False, margin=1):
@@ -150,6 +152,7 @@ class QueryEncoderDecoder(nn.Module):
         neg_nodes = reference_negative_nodes(self.graph, formula, queries, hard_negatives)
         target, anchors = self._rows(formula, queries, [q.target_node for q in queries])
         neg = self.enc.rows(neg_nodes, formula.target_mode)
+        self.engine.params_changed()
         return _MarginLossFn.apply(self._autograd_anchor, self, self.plan(formula), target, neg, anchors, float(margin))
 
     # -- fused fast path -----------------------------------------------------------
@@ -158,7 +161,8 @@ class QueryEncoderDecoder(nn.Module):
 
         items: [(formula, target_rows[n], neg_rows[n], anchor_rows[k,n], loss_weight, margin)]
         Accumulates d(sum_i w_i loss_i) into the gradient arena and returns
-        (losses[len(items)+1] device tensor, pos, neg)."""
+        (losses[len(items)+1] device tensor, pos, neg).  The fast path trusts that parameter VALUES are only written by
+        the fused optimiser (and load_state_dict): after any other write call ``engine.params_changed()``."""
         packed = [(self.plan(f), t, ng, a, w, m) for (f, t, ng, a, w, m) in items]
         descs, idx, n_scores = pack_margin_batches(packed)
         out = self.engine.margin_fwd_bwd(descs, idx if idx_device is None else idx_device,
@@ -180,6 +184,7 @@ class QueryEncoderDecoder(nn.Module):
         anchors = np.stack([self.enc.rows([q.anchor_nodes[i] for q in queries], m)
                             for i, m in enumerate(formula.anchor_modes)])
         descs, idx, n = pack_candidate_batches([(self.plan(formula), anchors, ptr, rows)])
+        self.engine.params_changed()
         return self.engine.forward(descs, idx, n), ptr
 
     def candidate_percentiles(self, formula, queries, candidate_nodes):
@@ -193,6 +198,7 @@ class QueryEncoderDecoder(nn.Module):
         """items: [(formula, target_rows, anchor_rows)] -> one scores tensor (concatenated)."""
         packed = [(self.plan(f), t, a) for (f, t, a) in items]
         descs, idx, n = pack_forward_batches(packed)
+        self.engine.params_changed()
         return self.engine.forward(descs, idx, n)
 
 

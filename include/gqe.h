@@ -131,6 +131,13 @@ int gqe_destroy(gqe_ctx* ctx);
 /* Bind the parameter / gradient / Adam-moment arenas (device pointers, n floats each).
  * grads, exp_avg, exp_avg_sq may be NULL for inference-only use. */
 int gqe_bind_arena(gqe_ctx* ctx, float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n);
+/* The library keeps, in its workspace, copies of the d x d matrices the formulas contract with (the intersection's Pre / Post,
+ * the relation matrices of the full Bilinear decoder) in the order the matrix cores consume them.  Its own optimiser steps
+ * (gqe_adam_step / gqe_sgd_step / gqe_shard_step / the feeder) rewrite the copies together with the parameters.  A caller that
+ * writes parameter VALUES into the arena itself — initialisation after the first forward / backward call, a checkpoint load
+ * (load_state_dict), an optimiser of its own — calls this before the next gqe_forward / gqe_margin_fwd_bwd: the copies are rebuilt
+ * by one small launch in front of it.  (gqe_bind_arena and gqe_bind_workspace imply it.)  No GPU work, no synchronisation. */
+int gqe_params_changed(gqe_ctx* ctx);
 
 /* Declare which arena tensors are embedding tables (offset in floats, number of rows of d floats).
  * Row gradients of tables are kept as per-row contribution lists (one 4-byte atomic per row instead

@@ -399,3 +399,54 @@ def test_hot_rows_state_machine(dec, inter, d):
     assert_grads_close(read_arena(hot, hot.grads), oracle_grads(cur, spec), "ordered sums after promotion")
     for eng in (hot, ref, lazy):
         eng.close()
+
+
+@pytest.mark.parametrize("dec,inter,d", [("bilinear", "min", 64), ("bilinear-diag", "mean", 256), ("transe", "min", 80)])
+def test_operand_copies_follow_every_parameter_write(dec, inter, d):
+    """The fused kernels read the d x d matrices from operand-ordered copies in the workspace (include/gqe.h,
+    gqe_params_changed).  Whoever writes the parameters, the copies have to follow: the library's Adam and SGD passes (copies
+    rewritten in the pass), a caller's own write announced by gqe_params_changed (rebuilt by a launch in front of the next call),
+    a re-bound workspace.  After each of them the scores of an intersection batch and a chain batch have to equal those of a
+    FRESH engine created from the current parameter values."""
+    import torch
+    from gpu_utils import (TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, read_arena, toy_batch)
+    from graphqembed_amd.tensorize import pack_forward_batches, pack_margin_batches
+    rng = np.random.RandomState(5 + d)
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
+    eng = engine_from_params(params, d, dec, inter)
+    r = np.random.RandomState(1)
+    spec = [(q,) + toy_batch(r, q, 40) for q in ("3-inter_chain", "3-chain", "2-inter", "3-chain_inter")]
+
+    def scores(e):
+        packed = [(plan_for(e, q, TOY_FORMULAS[q]), t, a) for (q, t, g, a) in spec]
+        descs, idx, n = pack_forward_batches(packed)
+        return e.forward(descs, idx, n).cpu().numpy()
+
+    def check(what):
+        fresh = engine_from_params(read_arena(eng, eng._params), d, dec, inter)
+        want = scores(fresh)
+        fresh.close()
+        got = scores(eng)
+        assert np.isfinite(want).all()
+        np.testing.assert_array_equal(got, want, err_msg=what)
+
+    check("after creation")
+    keys = None
+    for step, opt in enumerate(("adam", "adam", "sgd", "adam")):
+        items = [(plan_for(eng, q, TOY_FORMULAS[q]), t, g, a, 1.0, 1.0) for (q, t, g, a) in spec]
+        descs, idx, n_scores = pack_margin_batches(items)
+        eng.margin_fwd_bwd(descs, idx, n_scores=n_scores)
+        keys = sorted(set().union(*[it[0].touched for it in items]))
+        (eng.adam_step if opt == "adam" else eng.sgd_step)(keys)
+        check("after %s step %d" % (opt, step))
+    # a write behind the library's back: every matrix of the layout scaled in place through a tensor the test kept
+    flat = eng._params
+    mats = [k for k, (off, shape) in eng.layout.entries.items() if len(shape) == 2 and not k.startswith("enc.")]
+    assert mats
+    for k in mats:
+        eng.layout.view(flat, k).mul_(0.5).add_(0.01)
+    eng.params_changed()
+    check("after gqe_params_changed")
+    eng.reserve(4 * eng.max_queries, eng.max_batches)          # a larger workspace: the copies live in it
+    check("after the workspace was re-bound")
+    eng.close()
