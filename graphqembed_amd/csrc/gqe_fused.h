@@ -153,8 +153,10 @@ __device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 a
 // A d x d matrix every tile of a batch contracts with sits in L2, ~1 us away, and a contraction phase cannot start
 // before its slab arrives.  The staged path takes that round trip off the tile's dependent chain: all threads of the
 // workgroup request the NEXT matrix into registers (MR float4 each) while the current phase runs, and drop it into one
-// LDS buffer [d][d + 4] between two phases; the MFMA A operand is then an LDS read — a `ds_read_b128` for M . x, four
-// `ds_read_b32` down a column for M^T . x (the transposed global read is four 4-byte loads per lane and k-block).
+// LDS buffer between two phases.  What is staged is the matrix's OPERAND-ORDERED copy (gqe_dev.h, GQE_TILE_INDEX; the copy of M
+// for M . x, the copy of M^T for M^T . x): global -> registers -> LDS is a straight copy of d * d floats, and the MFMA A operand
+// of (row block, k-block) is one `ds_read_b128` per lane out of a contiguous kilobyte — no bank conflict, for either orientation
+// (until round 4 the row-major matrix sat in a [d][d + 4] buffer: M^T . x read it with four `ds_read_b32` down a column).
 template <int MR>  // MR = 1 (d = 64) or 4 (d = 128) float4 per thread; named members: the values have to stay in VGPRs
 struct MatRegs {
   float4 v0, v1, v2, v3;
@@ -175,8 +177,7 @@ __device__ __forceinline__ void mat_issue(MatRegs<MR>& m, const float* __restric
 }
 
 __device__ __forceinline__ void mat_st(float* __restrict__ mb, int d, int DP, int j, const float4& v) {
-  const int at = 4 * ((int)threadIdx.x + GQE_FWT * j);
-  *reinterpret_cast<float4*>(mb + (at / d) * DP + (at % d)) = v;
+  *reinterpret_cast<float4*>(mb + 4 * ((int)threadIdx.x + GQE_FWT * j)) = v;
 }
 
 template <int MR>
@@ -189,11 +190,9 @@ __device__ __forceinline__ void mat_commit(const MatRegs<MR>& m, float* __restri
   }
 }
 
-template <bool TRANS>
-__device__ __forceinline__ float4 lds_a(const float* __restrict__ mb, int DP, int i0, int lq, int lk, int kb) {
-  if (!TRANS) return *reinterpret_cast<const float4*>(mb + (i0 + lq) * DP + kb * 16 + 4 * lk);
-  const float* mp = mb + (kb * 16 + 4 * lk) * DP + i0 + lq;
-  return make_float4(mp[0], mp[DP], mp[2 * DP], mp[3 * DP]);
+template <int NC>
+__device__ __forceinline__ float4 lds_a(const float* __restrict__ mb, int i0, int lq, int lk, int kb) {
+  return *reinterpret_cast<const float4*>(mb + (((i0 >> 4) * (4 * NC) + kb) * 64 + lq + 16 * lk) * 4);
 }
 
 // Staged contractions (A from the LDS copy `mb`, row stride DP; FULL dims, 16-wave tiles: waves 0 .. d/16-1 own one
@@ -211,7 +210,7 @@ __device__ __forceinline__ void tile_matmul_staged(float* __restrict__ dst, cons
   float4 a[2][G], b[2][G];
 #pragma unroll
   for (int j = 0; j < G; ++j) {
-    a[0][j] = lds_a<TRANS>(mb, DP, i0, lq, lk, j);
+    a[0][j] = lds_a<NC>(mb, i0, lq, lk, j);
     b[0][j] = *reinterpret_cast<const float4*>(src + lq * DP + j * 16 + 4 * lk);
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -220,7 +219,7 @@ __device__ __forceinline__ void tile_matmul_staged(float* __restrict__ dst, cons
     if (g + 1 < NG) {
 #pragma unroll
       for (int j = 0; j < G; ++j) {
-        a[(g + 1) & 1][j] = lds_a<TRANS>(mb, DP, i0, lq, lk, (g + 1) * G + j);
+        a[(g + 1) & 1][j] = lds_a<NC>(mb, i0, lq, lk, (g + 1) * G + j);
         b[(g + 1) & 1][j] = *reinterpret_cast<const float4*>(src + lq * DP + ((g + 1) * G + j) * 16 + 4 * lk);
       }
     }
@@ -243,14 +242,14 @@ __device__ __forceinline__ void pre_intersect_staged(float* __restrict__ th, int
 #pragma unroll
   for (int bi = 0; bi < NB; ++bi) acc[bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float4 a[2], b[2][NB];
-  a[0] = lds_a<false>(mb, DP, i0, lq, lk, 0);
+  a[0] = lds_a<NC>(mb, i0, lq, lk, 0);
 #pragma unroll
   for (int bi = 0; bi < NB; ++bi) b[0][bi] = *reinterpret_cast<const float4*>(te[bi] + lq * DP + 4 * lk);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     if (kb + 1 < KB) {
-      a[(kb + 1) & 1] = lds_a<false>(mb, DP, i0, lq, lk, kb + 1);
+      a[(kb + 1) & 1] = lds_a<NC>(mb, i0, lq, lk, kb + 1);
 #pragma unroll
       for (int bi = 0; bi < NB; ++bi)
         b[(kb + 1) & 1][bi] = *reinterpret_cast<const float4*>(te[bi] + lq * DP + (kb + 1) * 16 + 4 * lk);
@@ -465,14 +464,14 @@ __device__ __forceinline__ void pre_intersect_bwd_staged(float* const (&te)[GQE_
   for (int bi = 0; bi < NB; ++bi) acc[bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float4 a[2], gh[2];
   int4 mt[2];
-  a[0] = lds_a<true>(mb, DP, i0, lq, lk, 0);
+  a[0] = lds_a<NC>(mb, i0, lq, lk, 0);
   gh[0] = *reinterpret_cast<const float4*>(tgh + lq * DP + 4 * lk);
   mt[0] = *reinterpret_cast<const int4*>(tmeta + lq * DP + 4 * lk);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     if (kb + 1 < KB) {
-      a[(kb + 1) & 1] = lds_a<true>(mb, DP, i0, lq, lk, kb + 1);
+      a[(kb + 1) & 1] = lds_a<NC>(mb, i0, lq, lk, kb + 1);
       gh[(kb + 1) & 1] = *reinterpret_cast<const float4*>(tgh + lq * DP + (kb + 1) * 16 + 4 * lk);
       mt[(kb + 1) & 1] = *reinterpret_cast<const int4*>(tmeta + lq * DP + (kb + 1) * 16 + 4 * lk);
     }
@@ -1165,7 +1164,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
 
   // Pre is requested once the rows are in (192 tiles pulling the same 64 KB out of the same L2 lines next to the
   // gathers delayed those by ~1.5 us); it lands while the branch vectors are built
-  if (stage) mat_issue<MR>(mr, params + f->pre_param);
+  if (stage) mat_issue<MR>(mr, GQE_TILED(false, pre_tile));
   GQE_STAMP(9);
   const bool is_chain = qtype <= 2;
   const float gscale = b.grad_scale;  // loss_weight / B
@@ -1442,7 +1441,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
     if (MLP) {
       if (STAGE) {  // Pre arrived while the branch vectors were built; Post is requested now and lands behind the phase
         mat_commit<MR>(mr, mbuf, d, DP);
-        mat_issue<MR>(mr, params + f->post_param);
+        mat_issue<MR>(mr, GQE_TILED(false, post_tile));
       }
       __syncthreads();
       GQE_STAMP(10);
@@ -1454,7 +1453,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
         GQE_STAMP(11);
         __syncthreads();
         mat_commit<MR>(mr, mbuf, d, DP);                      // Post replaces Pre
-        if (BWD) mat_issue<MR>(mr, params + f->pre_param);    // ... and Pre is requested again for the backward
+        if (BWD) mat_issue<MR>(mr, GQE_TILED(true, post_tile));   // ... and the copy of Post^T is requested for the backward
       } else {
         if (n == 3)
           pre_intersect<NC, 3, FULL>(tacc, tmeta, GQE_TILED(false, pre_tile), te, d, DP, wave, lane, inter_min);
@@ -1603,14 +1602,18 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
       if (MLP) {
         tile_to_scratch<NC, FULL>(e, f->slot_gq, tgc);
         GQE_WSTAMP(1);
+        if (STAGE) {   // Post^T (requested behind the forward's Post contraction) replaces Post; Pre^T is requested for the next phase
+          mat_commit<MR>(mr, mbuf, d, DP);
+          mat_issue<MR>(mr, GQE_TILED(true, pre_tile));
+        }
         __syncthreads();
         if (STAGE) {
           GQE_WSTAMP(2);
-          tile_matmul_staged<true, NC>(tacc, mbuf, tgc, DP, wave, lane);  // Post is still staged
+          tile_matmul_staged<true, NC>(tacc, mbuf, tgc, DP, wave, lane);  // the copy of Post^T (committed in front of the barrier above)
           GQE_WSTAMP(3);
           __syncthreads();
           GQE_WSTAMP(4);
-          mat_commit<MR>(mr, mbuf, d, DP);  // Pre again; the barrier in front of its contraction is below
+          mat_commit<MR>(mr, mbuf, d, DP);  // the copy of Pre^T; the barrier in front of its contraction is below
           GQE_WSTAMP(5);
         } else {
           tile_matmul<true, NC, FULL>(tacc, GQE_TILED(true, post_tile), tgc, d, DP, wave, lane);  // g_h = Post^T g_q
