@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Step time of one engine (run_margin + run_adam on the default stream, no library events), for A / B runs of library
+switches or builds (GQE_LIB=...): python tools/probes/step_probe.py [--dim 128] [--decoder bilinear-diag] [--batch 512]
+[--workload bio-synth]"""
+import argparse, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from graphqembed_amd import synth
+ap = argparse.ArgumentParser()
+ap.add_argument("--dim", type=int, default=128)
+ap.add_argument("--decoder", default="bilinear-diag")
+ap.add_argument("--batch", type=int, default=512)
+ap.add_argument("--workload", default="bio-synth")
+a = ap.parse_args()
+wl = bench.Workload(a.workload, a.dim, a.decoder, "min", synth.FULL_MIX, a.batch)
+eng = wl.engine()
+prep = wl.prepare(eng)
+n = wl.n_distinct
+
+
+def run(k0, k):
+    for i in range(k0, k0 + k):
+        ps = prep[i % n]
+        eng.run_margin(ps)
+        eng.run_adam(ps["adam"])
+
+
+run(0, 50)
+torch.cuda.synchronize()
+ts = []
+for rep in range(20):
+    t0 = time.perf_counter()
+    run(50 + 100 * rep, 100)
+    torch.cuda.synchronize()
+    ts.append((time.perf_counter() - t0) / 100)
+loss = float(prep[(50 + 2000 - 1) % n]["losses"][-1].item())
+print("%s d=%d %s B=%d: %.1f us/step (median of 20 x 100), final loss %.6f, params checksum %.6f"
+      % (a.workload, a.dim, a.decoder, a.batch, np.median(ts) * 1e6, loss, float(eng._params.double().abs().sum())), flush=True)
