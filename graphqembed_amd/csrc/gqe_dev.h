@@ -307,6 +307,19 @@ hipError_t gqe_launch_expand_ptr(const int32_t* cand_ptr, int n_queries, int n_c
 hipError_t gqe_launch_rank(const float* scores, const int32_t* ptr, int nq, double* percentile, hipStream_t stream);
 hipError_t gqe_launch_auc(const float* pos, long long n_pos, const float* neg, long long n_neg, unsigned long long* count2, hipStream_t stream);
 hipError_t gqe_launch_opt(const GqeOptArgs& a);
+
+// A deferred pair-GEMM launch riding in FRONT of an Adam pass's chunks in one launch (gqe_set_deferred_gemm, gqe_opt_gemm_kernel):
+// workgroup 0 finalizes the losses, workgroups 1 .. plan.units are GEMM units, the pass's chunks follow.  The pass covers the
+// tables and the vectors — nothing the units write; the d x d matrices are stepped by a second, small launch behind it.
+#define GQE_RIDE_MAX_UNITS 1024   // beyond: the GEMM is MFMA work of its own (B = 8192: 73 us) and keeps its LDS-staged kernel
+struct GqeGemmRide {
+  GqeDynPlan plan;
+  const GqeDevFormula* formulas;
+  const float* ws;
+  const float* tile_loss;
+  float* losses;
+};
+hipError_t gqe_launch_opt_gemm(const GqeOptArgs& a, const GqeGemmRide& r);
 hipError_t gqe_launch_rows(const GqeRowsArgs& a);
 // non-table floats of the arena (dense gradients that travel with the exchanged slab)
 struct GqeSpans {

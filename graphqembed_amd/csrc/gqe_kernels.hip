@@ -11,6 +11,30 @@
 // lanes).  Jobs are derived on the device from the cached formula descriptor + the kernel-argument plan.
 // The extra last block turns the per-tile hinge sums of the fused kernel into losses[].
 // ------------------------------------------------------------------------------------------
+// finalize block: per-batch mean hinge loss (model.py:124-126) and the weighted iteration loss from the per-tile partials of
+// the fused kernel — plain stores, nothing to zero, no atomics.
+__device__ __forceinline__ void finalize_losses(const GqeDynPlan& plan, const float* __restrict__ tile_loss, float* __restrict__ losses) {
+  __shared__ float s_w[GQE_LAUNCH_BATCHES];
+  const int t = threadIdx.x;
+  // one wave per batch: lanes stride the tile partials (independent loads), DPP-reduce
+  for (int k = t >> 6; k < plan.n_batches; k += GQE_WAVES) {
+    const GqeDynBatch b = plan.b[k];
+    float l = 0.f;
+    for (int i = t & 63; i < b.Bpad / GQE_TQ; i += 64) l += tile_loss[b.tile_begin + i];
+    l = wave_sum(l) * b.inv_B;
+    if ((t & 63) == 0) {
+      losses[b.loss_index] = l;
+      s_w[k] = l * b.loss_weight;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    float tot = plan.first ? 0.f : losses[plan.total_index];
+    for (int k = 0; k < plan.n_batches; ++k) tot += s_w[k];
+    losses[plan.total_index] = tot;
+  }
+}
+
 __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDynPlan plan,
                                                                    const GqeDevFormula* __restrict__ formulas,
                                                                    const float* __restrict__ ws,
@@ -23,28 +47,8 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
     if (prof && threadIdx.x == 0) prof[((size_t)plan.tiles + blockIdx.x) * GQE_PROF_SLOTS + (k)] = (long long)wall_clock64(); \
   } while (0)
   GQE_GSTAMP(0);
-  if (blockIdx.x == 0) {
-    // finalize block (first, so that it is not queued behind the GEMM units): per-batch mean hinge loss (model.py:124-126) and the weighted iteration loss from the
-    // per-tile partials of the fused kernel — plain stores, nothing to zero, no atomics.
-    __shared__ float s_w[GQE_LAUNCH_BATCHES];
-    const int t = threadIdx.x;
-    // one wave per batch: lanes stride the tile partials (independent loads), DPP-reduce
-    for (int k = t >> 6; k < plan.n_batches; k += GQE_WAVES) {
-      const GqeDynBatch b = plan.b[k];
-      float l = 0.f;
-      for (int i = t & 63; i < b.Bpad / GQE_TQ; i += 64) l += tile_loss[b.tile_begin + i];
-      l = wave_sum(l) * b.inv_B;
-      if ((t & 63) == 0) {
-        losses[b.loss_index] = l;
-        s_w[k] = l * b.loss_weight;
-      }
-    }
-    __syncthreads();
-    if (t == 0) {
-      float tot = plan.first ? 0.f : losses[plan.total_index];
-      for (int k = 0; k < plan.n_batches; ++k) tot += s_w[k];
-      losses[plan.total_index] = tot;
-    }
+  if (blockIdx.x == 0) {   // (first, so that it is not queued behind the GEMM units)
+    finalize_losses(plan, tile_loss, losses);
     return;
   }
   // one workgroup = one unit (batch, job, K chunk of GQE_GEMM_KCHUNK queries, 64x64 block of the d x d gradient).
@@ -627,6 +631,109 @@ hipError_t gqe_launch_pair_gemm(const GqeFusedArgs& a, float* losses) {
   const int blocks = a.plan.units + 1;  // + the finalize block
   hipLaunchKernelGGL(gqe_pair_gemm_kernel, dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.plan, a.formulas, a.ws, a.grads, a.d,
                      a.tile_loss, losses, a.prof);
+  return hipGetLastError();
+}
+
+// ---- the pair GEMM riding in an Adam pass's launch (GqeGemmRide, gqe_dev.h; gqe_set_deferred_gemm) ----------------------
+// The table chunks of the pass do not depend on the matrix gradients, and the pass is HBM-bound while a GEMM unit is a short
+// latency chain: side by side in one launch the units cost the pass nothing measurable and the step loses the GEMM's own launch
+// (12.6 us + a kernel boundary at the headline shape).  A unit here lives inside the optimiser kernel's register budget
+// (<= 64 VGPRs: eight streaming waves per SIMD) and takes no LDS (a static allocation would be charged to every chunk's
+// workgroup; as gqe_pair_gemm_kernel's unit — 146 VGPRs, 40 KB — the whole launch ran at three workgroups per CU and the pass
+// alone lost 4.5 us).  It may be slow: the table chunks stream for ~45 us.  Wave w owns the 64 x 16 block (rows i0 .. i0+63,
+// columns j0 + 16 w ..) of the unit's 64 x 64 block; per step of four queries a lane reads ONE float4 of L — four consecutive
+// gradient rows: the A operands of four MFMAs whose output rows interleave (row = i0 + 4 * (lane & 15) + t) — and one float of R.
+#define GQE_RIDE_DEPTH 4   // steps of operands in flight per lane (8 measured the same)
+__device__ __forceinline__ void gemm_ride_unit(const GqeDynPlan& plan, const GqeDevFormula* __restrict__ formulas, const float* __restrict__ ws,
+                                               float* __restrict__ grads, int d, int unit) {
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int il = lane & 15, lk = lane >> 4;
+  int bi = 0;
+#pragma unroll
+  for (int k = 1; k < GQE_LAUNCH_BATCHES; ++k) bi += (unit >= plan.unit_begin[k]) ? 1 : 0;
+  const GqeDynBatch b = plan.b[bi];
+  const GqeDevFormula* __restrict__ f = formulas + b.formula;
+  constexpr int MT = GQE_GEMM_MT;
+  const int mper = d / MT, macros = mper * mper;   // (d % 64 == 0: the host only lets such launches ride)
+  const int kmul = plan.pad[0];
+  const int chunks = (b.Bpad + GQE_GEMM_KCHUNK * kmul - 1) / (GQE_GEMM_KCHUNK * kmul);
+  int u = unit - b.unit_begin;
+  const int job = u / (chunks * macros);
+  u -= job * chunks * macros;
+  const int chunk = u / macros;
+  const int mt = u - chunk * macros;
+  const int i0 = (mt / mper) * MT, j0 = (mt % mper) * MT;
+  const int k_first = chunk * GQE_GEMM_KCHUNK * kmul;
+  const int k_end = min(k_first + GQE_GEMM_KCHUNK * kmul, b.Bpad);   // Bpad % 16 == 0: whole steps of four queries
+  const size_t slot_floats = (size_t)b.Bpad * d;
+  const float* L = ws + b.scratch_base + (size_t)f->job_L[job] * slot_floats + (size_t)lk * d + i0 + 4 * il;
+  const float* R = ws + b.scratch_base + (size_t)f->job_R[job] * slot_floats + (size_t)lk * d + j0 + 16 * wave + il;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int steps = (k_end - k_first) >> 2;
+  float4 a[GQE_RIDE_DEPTH];
+  float bv[GQE_RIDE_DEPTH];
+#pragma unroll
+  for (int s = 0; s < GQE_RIDE_DEPTH; ++s) {
+    const int k = k_first + 4 * min(s, steps - 1);
+    a[s] = *reinterpret_cast<const float4*>(L + (size_t)k * d);
+    bv[s] = R[(size_t)k * d];
+  }
+  for (int s0 = 0; s0 < steps; s0 += GQE_RIDE_DEPTH) {
+#pragma unroll
+    for (int j = 0; j < GQE_RIDE_DEPTH; ++j) {
+      const int s = s0 + j;
+      if (s < steps) {   // wave-uniform
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, bv[j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, bv[j], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, bv[j], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, bv[j], acc[3], 0, 0, 0);
+        const int k = k_first + 4 * min(s + GQE_RIDE_DEPTH, steps - 1);   // (the last steps re-read the final rows: no branch)
+        a[j] = *reinterpret_cast<const float4*>(L + (size_t)k * d);
+        bv[j] = R[(size_t)k * d];
+      }
+    }
+  }
+  // D[4 * lk + r][il] of MFMA t is gradient row i0 + 4 * (4 * lk + r) + t, column j0 + 16 * wave + il
+  float* out = grads + f->job_param[job] + (size_t)(i0 + 16 * lk) * d + j0 + 16 * wave + il;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) unsafeAtomicAdd(out + (size_t)(4 * r + t) * d, acc[t][r]);
+}
+
+template <bool NT>
+__global__ __launch_bounds__(GQE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void gqe_opt_gemm_kernel(
+    const GqeDevSeg* __restrict__ segs, int n_segs, long long total_chunks, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+    float* __restrict__ v, int32_t* __restrict__ head, const int32_t* __restrict__ next, const float* __restrict__ contrib,
+    const int32_t* __restrict__ link_contrib, int max_entries, int d, float lr, float b1, float b2, float eps, GqeStepCoef coef,
+    GqeOptActive active, const GqeActSeg* __restrict__ act, int n_act, GqeHot hot, GqeGemmRide ride) {
+  if (blockIdx.x == 0) {
+    finalize_losses(ride.plan, ride.tile_loss, ride.losses);
+    return;
+  }
+  const int front = ride.plan.units + 1;
+  if ((int)blockIdx.x < front) {
+    gemm_ride_unit(ride.plan, ride.formulas, ride.ws, g, d, (int)blockIdx.x - 1);
+    return;
+  }
+  GqeLazyArgs lazy;   // (never read: LAZY = false)
+  opt_body<GQE_OPT_ADAM, true, false, false, false, NT>((long long)blockIdx.x - front, (long long)gridDim.x - front, segs, n_segs, total_chunks, p, g, m,
+                                                       v, head, next, contrib, link_contrib, max_entries, d, lr, b1, b2, eps, coef, active, act,
+                                                       n_act, lazy, hot);
+}
+
+hipError_t gqe_launch_opt_gemm(const GqeOptArgs& a, const GqeGemmRide& r) {
+  long long blocks = a.total_chunks < 262144 ? a.total_chunks : 262144;
+  if (blocks < 1) blocks = 1;
+  blocks += r.plan.units + 1;
+#define GQE_RIDE(N)                                                                                                                     \
+  hipLaunchKernelGGL((gqe_opt_gemm_kernel<N>), dim3((unsigned)blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.n_segs, a.total_chunks, a.p, \
+                     a.g, a.m, a.v, a.head, a.next, a.contrib, a.link_contrib, a.max_entries, a.d, a.lr, a.b1, a.b2, a.eps, a.coef, a.active,  \
+                     a.act, a.n_act, a.hot, r)
+  if (a.nt) GQE_RIDE(true); else GQE_RIDE(false);
+#undef GQE_RIDE
   return hipGetLastError();
 }
 

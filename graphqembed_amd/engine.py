@@ -82,6 +82,8 @@ SYMBOLS = OrderedDict([
     ("gqe_destroy", (C.c_int, [_P])),
     ("gqe_bind_arena", (C.c_int, [_P, _P, _P, _P, _P, C.c_int64])),
     ("gqe_params_changed", (C.c_int, [_P])),
+    ("gqe_set_deferred_gemm", (C.c_int, [_P, C.c_int32])),
+    ("gqe_deferred_gemm_rides", (C.c_int64, [_P])),
     ("gqe_set_tables", (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32])),
     ("gqe_set_bag", (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int32])),
     ("gqe_set_limits", (C.c_int, [_P, C.c_int32, C.c_int32])),
@@ -286,6 +288,15 @@ class Engine(object):
         self.sync()
         self.params_changed()
         return self._params
+
+    def set_deferred_gemm(self, enable=True):
+        """gqe_set_deferred_gemm (include/gqe.h): the matrix-gradient launch of margin_fwd_bwd / run_margin rides in the next
+        Adam step's launch; ``losses`` of a margin call are then only defined BEHIND that step."""
+        self._check(self.lib.gqe_set_deferred_gemm(self.ctx, 1 if enable else 0))
+
+    def gemm_rides(self):
+        """How many Adam passes carried a deferred pair GEMM so far (gqe_deferred_gemm_rides)."""
+        return int(self.lib.gqe_deferred_gemm_rides(self.ctx))
 
     def params_changed(self):
         if getattr(self, "ctx", None):

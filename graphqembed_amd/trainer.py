@@ -76,6 +76,11 @@ class TensorizedTrainer(object):
         self._slab = 0
         self.plan_of = plan_of
         self.sharded = self.engine is not None and getattr(self.engine, "sharded", False)
+        # one GPU, the library's own optimiser: step() is margin_step + opt.step() back to back and hands the losses out behind
+        # both, so the matrix-gradient units may ride in the Adam pass's launch (include/gqe.h, gqe_set_deferred_gemm)
+        from .model import _FusedOptimizer
+        if self.engine is not None and self.world == 1 and not self.sharded and isinstance(optimizer, _FusedOptimizer):
+            self.engine.set_deferred_gemm(True)
         if self.sharded and plan_of is None:
             raise Exception("row-sharded training needs plan_of(formula) -> FormulaPlan on the engine's layout")
         if self.sharded:

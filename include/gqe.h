@@ -138,6 +138,19 @@ int gqe_bind_arena(gqe_ctx* ctx, float* params, float* grads, float* exp_avg, fl
  * (load_state_dict), an optimiser of its own — calls this before the next gqe_forward / gqe_margin_fwd_bwd: the copies are rebuilt
  * by one small launch in front of it.  (gqe_bind_arena and gqe_bind_workspace imply it.)  No GPU work, no synchronisation. */
 int gqe_params_changed(gqe_ctx* ctx);
+/* Training loops that call gqe_margin_fwd_bwd and gqe_adam_step back to back, and read losses[] only behind the step, may let
+ * the deferred matrix-gradient launch (Pre / Post / Bilinear relation matrices: dM += L^T R over the batch) wait for the
+ * optimiser: with enable != 0 gqe_margin_fwd_bwd launches only the fused kernel; the matrix-gradient units and the block that
+ * turns the per-tile hinge sums into losses[] run in FRONT of the next gqe_adam_step's chunks, in the same launch (the pass over
+ * the tables does not depend on them and is HBM-bound, the units are a short latency chain), and the d x d matrices are stepped
+ * by a small second launch.  Any other call that needs the gradients first (gqe_materialize_grads, gqe_sgd_step,
+ * gqe_zero_grads, another gqe_margin_fwd_bwd / gqe_forward, lazy or order-independent passes) launches the deferred work on its
+ * own, as without the switch.  THE CONTRACT: losses[] (and the dense gradient of the matrices) of a gqe_margin_fwd_bwd call are
+ * defined once the next such call has been enqueued on the same stream — not right behind gqe_margin_fwd_bwd.  Results are the
+ * same sums in another atomic order (float atomics: not bit-reproducible either way).  Off by default; one GPU, replicated
+ * parameters (the row-sharded step exchanges the gradients between the two launches). */
+int gqe_set_deferred_gemm(gqe_ctx* ctx, int32_t enable);
+int64_t gqe_deferred_gemm_rides(gqe_ctx* ctx);   /* Adam passes that carried a deferred launch so far (diagnostics, tests) */
 
 /* Declare which arena tensors are embedding tables (offset in floats, number of rows of d floats).
  * Row gradients of tables are kept as per-row contribution lists (one 4-byte atomic per row instead

@@ -450,3 +450,62 @@ def test_operand_copies_follow_every_parameter_write(dec, inter, d):
     eng.reserve(4 * eng.max_queries, eng.max_batches)          # a larger workspace: the copies live in it
     check("after the workspace was re-bound")
     eng.close()
+
+
+@pytest.mark.parametrize("dec,inter,d", [("bilinear-diag", "min", 128), ("bilinear", "mean", 64), ("transe", "min", 192)])
+def test_deferred_pair_gemm_is_the_same_training_run(dec, inter, d):
+    """gqe_set_deferred_gemm (include/gqe.h): the matrix-gradient units and the losses' finalize block of a margin call run in
+    front of the next Adam pass's chunks, the matrices are stepped by a second launch.  Same batches through an engine with and
+    one without the switch: losses (read behind the step), every parameter after every step, and the Adam moments agree to
+    float-atomic reordering; and everything that needs the gradients BEFORE an Adam step — materialize, a second margin call,
+    an SGD step, zero_grads, a forward call — finds them complete (the deferred launch is flushed on its own)."""
+    import torch
+    from gpu_utils import (TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, read_arena, toy_batch)
+    from graphqembed_amd.tensorize import pack_forward_batches, pack_margin_batches
+    rng = np.random.RandomState(17 + d)
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
+    plain = engine_from_params(params, d, dec, inter)
+    lazyg = engine_from_params(params, d, dec, inter)
+    lazyg.set_deferred_gemm(True)
+    r = np.random.RandomState(2)
+    qtypes = ("3-inter_chain", "2-chain", "2-inter", "3-chain_inter", "3-inter")
+
+    def margin(e, spec):
+        items = [(plan_for(e, q, TOY_FORMULAS[q]), t, g, a, 1.0 / (1 + j), 1.0) for j, (q, t, g, a) in enumerate(spec)]
+        descs, idx, n_scores = pack_margin_batches(items)
+        losses, _, _ = e.margin_fwd_bwd(descs, idx, n_scores=n_scores)
+        return losses, sorted(set().union(*[it[0].touched for it in items]))
+
+    def close(a, b, what, rtol=1e-4, atol=1e-5):
+        # (two runs of ONE engine differ as much: the order of a row's list and of the float atomics is not fixed, and Adam
+        # turns a last-bit difference of a small gradient into a visible one of the step)
+        for k in a:
+            np.testing.assert_allclose(b[k], a[k], rtol=rtol, atol=atol, err_msg="%s %s" % (what, k))
+
+    for step in range(4):
+        spec = [(q,) + toy_batch(r, q, 150 + 16 * j) for j, q in enumerate(qtypes)]
+        l0, keys = margin(plain, spec)
+        l1, _ = margin(lazyg, spec)
+        plain.adam_step(keys)
+        lazyg.adam_step(keys)
+        np.testing.assert_allclose(l1.cpu().numpy(), l0.cpu().numpy(), rtol=1e-6, err_msg="losses behind step %d" % step)
+        close(read_arena(plain, plain._params), read_arena(lazyg, lazyg._params), "params after step %d" % step)
+        close(read_arena(plain, plain._exp_avg_sq), read_arena(lazyg, lazyg._exp_avg_sq), "second moments after step %d" % step, rtol=1e-3, atol=1e-9)
+    # consumers other than an Adam step
+    spec = [(q,) + toy_batch(r, q, 96) for q in qtypes[:3]]
+    for e in (plain, lazyg):
+        margin(e, spec)
+        e.materialize()
+    close(read_arena(plain, plain.grads), read_arena(lazyg, lazyg.grads), "materialized gradient", rtol=1e-4, atol=1e-7)
+    for e in (plain, lazyg):
+        e.zero_grads(list(e.layout.entries))
+    assert float(lazyg.grads.abs().max()) == 0.0
+    for e in (plain, lazyg):
+        _, keys = margin(e, spec)
+        packed = [(plan_for(e, q, TOY_FORMULAS[q]), t, a) for (q, t, g, a) in spec]
+        descs, idx, n = pack_forward_batches(packed)
+        e.forward(descs, idx, n)                            # overwrites nothing the pending units need: they were launched first
+        e.sgd_step(keys)
+    close(read_arena(plain, plain._params), read_arena(lazyg, lazyg._params), "params after margin + forward + sgd")
+    plain.close()
+    lazyg.close()

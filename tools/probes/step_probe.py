@@ -14,10 +14,13 @@ ap.add_argument("--dim", type=int, default=128)
 ap.add_argument("--decoder", default="bilinear-diag")
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--workload", default="bio-synth")
+ap.add_argument("--defer", action="store_true", help="gqe_set_deferred_gemm: the pair GEMM rides in the Adam pass's launch")
 a = ap.parse_args()
 wl = bench.Workload(a.workload, a.dim, a.decoder, "min", synth.FULL_MIX, a.batch)
 eng = wl.engine()
 prep = wl.prepare(eng)
+if a.defer:
+    eng.set_deferred_gemm(True)
 n = wl.n_distinct
 
 
@@ -37,5 +40,5 @@ for rep in range(20):
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) / 100)
 loss = float(prep[(50 + 2000 - 1) % n]["losses"][-1].item())
-print("%s d=%d %s B=%d: %.1f us/step (median of 20 x 100), final loss %.6f, params checksum %.6f"
+print(("deferred GEMM " if a.defer else "") + "%s d=%d %s B=%d: %.1f us/step (median of 20 x 100), final loss %.6f, params checksum %.6f"
       % (a.workload, a.dim, a.decoder, a.batch, np.median(ts) * 1e6, loss, float(eng._params.double().abs().sum())), flush=True)
