@@ -320,6 +320,17 @@ struct GqeGemmRide {
   float* losses;
 };
 hipError_t gqe_launch_opt_gemm(const GqeOptArgs& a, const GqeGemmRide& r);
+// ... and that second launch: Adam on up to GQE_MATSTEP_MAX d x d matrices named in the kernel arguments (no universe scan, one
+// round trip to memory: it sits between the pass and the next fused kernel, on the step's critical path)
+#define GQE_MATSTEP_MAX 48
+struct GqeMatStep {
+  int n;
+  long long off[GQE_MATSTEP_MAX];                  // arena offset of the matrix
+  float* tile[GQE_MATSTEP_MAX];                    // its operand-ordered copy (the copy of the transpose: + tile_t floats)
+  float step_size[GQE_MATSTEP_MAX], bc2_sqrt[GQE_MATSTEP_MAX];
+  long long tile_t;
+};
+hipError_t gqe_launch_matstep(const GqeMatStep& a, float* p, float* g, float* m, float* v, int d, float b1, float b2, float eps, hipStream_t stream);
 hipError_t gqe_launch_rows(const GqeRowsArgs& a);
 // non-table floats of the arena (dense gradients that travel with the exchanged slab)
 struct GqeSpans {

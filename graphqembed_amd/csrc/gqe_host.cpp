@@ -1639,8 +1639,22 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
         if (rc != GQE_OK) return rc;
       }
       if (ob.total_chunks > 0) {
-        ob.lists = false;
-        HIP_TRY(ctx, gqe_launch_opt(ob));
+        // the matrices by name in the kernel arguments, GQE_MATSTEP_MAX per launch (one launch at every shape measured)
+        GqeMatStep ms;
+        ms.n = 0;
+        ms.tile_t = ctx->lay.tile_floats;
+        for (size_t ui = 0; ui < nu; ++ui) {
+          if (!ustep[ui] || !is_matrix(ui)) continue;
+          ms.off[ms.n] = ctx->universe[ui].offset;
+          ms.tile[ms.n] = ctx->universe[ui].tile;
+          ms.step_size[ms.n] = uss[ui];
+          ms.bc2_sqrt[ms.n] = ubc[ui];
+          if (++ms.n == GQE_MATSTEP_MAX) {
+            HIP_TRY(ctx, gqe_launch_matstep(ms, oa.p, oa.g, oa.m, oa.v, d, b1, b2, eps, st));
+            ms.n = 0;
+          }
+        }
+        HIP_TRY(ctx, gqe_launch_matstep(ms, oa.p, oa.g, oa.m, oa.v, d, b1, b2, eps, st));
       }
       if (timed) {
         rc = timing_end(ctx, 1, st);

@@ -724,6 +724,30 @@ __global__ __launch_bounds__(GQE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
                                                        n_act, lazy, hot);
 }
 
+__global__ __launch_bounds__(GQE_THREADS) void gqe_matstep_kernel(const GqeMatStep a, float* __restrict__ p, float* __restrict__ g,
+                                                                 float* __restrict__ m, float* __restrict__ v, int d, float b1, float b2, float eps) {
+  const int per = (d * d) / GQE_OPT_CHUNK;   // (d % 64 == 0: whole chunks)
+  const int mi = blockIdx.x / per;
+  const long long e0 = (long long)(blockIdx.x - mi * per) * GQE_OPT_CHUNK + (long long)threadIdx.x * 4;
+  const long long off = a.off[mi] + e0;
+  const float4 gg = *reinterpret_cast<const float4*>(g + off);
+  float4 pp = *reinterpret_cast<const float4*>(p + off);
+  float4 mm = *reinterpret_cast<const float4*>(m + off);
+  float4 vv = *reinterpret_cast<const float4*>(v + off);
+  *reinterpret_cast<float4*>(g + off) = make_float4(0.f, 0.f, 0.f, 0.f);
+  opt_update<GQE_OPT_ADAM>(pp, mm, vv, gg, a.step_size[mi], a.bc2_sqrt[mi], 0.f, b1, b2, eps);
+  *reinterpret_cast<float4*>(m + off) = mm;
+  *reinterpret_cast<float4*>(v + off) = vv;
+  *reinterpret_cast<float4*>(p + off) = pp;
+  tile_store(a.tile[mi], a.tile[mi] + a.tile_t, d, e0, pp);
+}
+
+hipError_t gqe_launch_matstep(const GqeMatStep& a, float* p, float* g, float* m, float* v, int d, float b1, float b2, float eps, hipStream_t stream) {
+  if (a.n < 1) return hipSuccess;
+  hipLaunchKernelGGL(gqe_matstep_kernel, dim3((unsigned)(a.n * ((d * d) / GQE_OPT_CHUNK))), dim3(GQE_THREADS), 0, stream, a, p, g, m, v, d, b1, b2, eps);
+  return hipGetLastError();
+}
+
 hipError_t gqe_launch_opt_gemm(const GqeOptArgs& a, const GqeGemmRide& r) {
   long long blocks = a.total_chunks < 262144 ? a.total_chunks : 262144;
   if (blocks < 1) blocks = 1;
