@@ -27,6 +27,11 @@ roofline  = the dominant kernel, the fused Adam pass.  ``achieved`` = the bytes 
             ``frac_of_measured_copy_peak`` against the 6.29 TB/s a float4 copy reaches (MI355X_MICROARCH.md).
             SURVEY.md §8d's 32 B/param figure is kept as ``survey_bytes_per_launch`` for reference only — 8 B/param
             of it are never moved.  ``traffic`` = PMC HBM bytes of the last profiled run (profiles/).
+            One GPU, eager Adam: the step runs with gqe_set_deferred_gemm (include/gqe.h) — the pair-GEMM units and the
+            loss finalize ride in front of the pass's chunks, in ITS launch (gqe_opt_gemm_kernel: ``roofline.kernel`` says so;
+            the bytes then include the units' operand rows, ``optimiser_pass_bytes_per_launch`` is the pass alone), and the
+            d x d matrices are stepped by a small launch behind it (``kernels.pair_gemm.matrix_step_launch``).  The losses are
+            read behind the timed loop.  GQE_BENCH_NO_DEFERRED_GEMM=1 measures the three-launch step of rounds 1-3.
 kernels   = fused forward/backward and pair GEMM: mean launch time, algorithmic bytes, and the fp32 MFMA rate of
             their d x d contractions against the 157.3 TF/s exact-fp32 MFMA peak.
 configs   = (N=1) the other measurement configurations of SURVEY.md §8d, each with ms/step and kernel times:
@@ -286,7 +291,7 @@ def kernel_block(eng, prepared, used, ms_per_step, lazy=False, world=1, d=128, t
         opt_kernel = ("gqe_opt_gemm_kernel (the Adam pass over the tables and vectors — row gradients from per-row lists — with the "
                       "step's pair-GEMM units and loss finalize in front of its chunks; bytes = the pass's + the units' operand rows)")
     rp_opt, rp_fused = rp("gqe_opt_gemm_kernel" if rides else "gqe_opt_kernel"), rp("gqe_fused_kernel")
-    rp_gemm = rp("gqe_opt_kernel") if rides else rp("gqe_pair_gemm_kernel")
+    rp_gemm = rp("gqe_matstep_kernel") if rides else rp("gqe_pair_gemm_kernel")
     out = {
         "roofline": {"bound": "hbm", "kernel": opt_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 4),
@@ -301,7 +306,7 @@ def kernel_block(eng, prepared, used, ms_per_step, lazy=False, world=1, d=128, t
                                       "mfma_flop_per_launch": ff, "mfma_TFs": tfs(ff, ms_fused),
                                       "mfma_frac_of_f32_peak": round(ff / (ms_fused * 1e-3) / 1e12 / MFMA_F32_TFS, 4) if ms_fused > 0 and ff else None},
                     "pair_gemm": ({"rides_in": "roofline.kernel (gqe_set_deferred_gemm): no launch of its own", "mfma_flop_per_launch": gf,
-                                   "matrix_step_launch": {"kernel": "gqe_opt_kernel over the d x d matrices, behind the pass", "avg_launch_ms": round(ms_gemm, 5),
+                                   "matrix_step_launch": {"kernel": "gqe_matstep_kernel: Adam on the d x d matrices, behind the pass", "avg_launch_ms": round(ms_gemm, 5),
                                                           "rocprof_avg_launch_ms": rp_gemm, "launches": n_gemm}} if rides else
                                   {"avg_launch_ms": round(ms_gemm, 5), "rocprof_avg_launch_ms": rp_gemm, "launches": n_gemm, "mfma_flop_per_launch": gf,
                                    "mfma_TFs": tfs(gf, ms_gemm),
@@ -709,7 +714,7 @@ def main():
     sparse = world > 1 and args.exchange == "sparse"
     sharded = world > 1 and args.exchange == "sharded"
     res["roofline"]["traffic"] = None if (world > 1 or args.lazy_adam or (d, B, args.decoder, args.inter_decoder) != ((256 if reddit else 128), 512, "bilinear-diag", "min")) \
-        else pmc_traffic("gqe_opt_kernel", args.workload)
+        else pmc_traffic("gqe_opt_gemm_kernel" if res["roofline"]["kernel"].startswith("gqe_opt_gemm_kernel") else "gqe_opt_kernel", args.workload)
     label = "Reddit" if reddit else "Bio"
     out = {
         "metric": "queries/sec, %s full conjunctive mix d=%d, at 1/2/4/8 MI355X" % (label, d),
