@@ -115,6 +115,15 @@ def test_streaming_and_gemm_kernels_use_no_scratch(kernels):
             assert k["scratch"] == 0, (n[:60], k["scratch"])
         if n.startswith("_Z14gqe_opt_kernelILi0E"):   # Adam pass: 8 waves per SIMD needs <= 64 VGPRs
             assert k["vgpr"] <= 64, (n[:60], k["vgpr"])
+    # the pass that carries the deferred pair GEMM's units (gqe_set_deferred_gemm): the units must not cost the streaming chunks
+    # their occupancy — <= 64 registers in total (accumulators included), no LDS beyond the pass's own segment table, no spill
+    ride = [k for k in kernels if k["name"].startswith("_Z19gqe_opt_gemm_kernel")]
+    assert len(ride) == 2, [k["name"][:40] for k in ride]
+    for k in ride:
+        assert k["vgpr"] + k["agpr"] <= 64 and k["scratch"] == 0 and k["vgpr_spill"] == 0 and k["lds"] <= 1024, k
+    for name in ("gqe_matstep_kernel", "gqe_retile_kernel"):
+        ks = [k for k in kernels if name in k["name"]]
+        assert len(ks) == 1 and ks[0]["scratch"] == 0, (name, ks)
 
 
 def test_no_allocator_code_ahead_of_an_exec_restore(lib):
