@@ -435,6 +435,8 @@ void drop_formulas(gqe_ctx* ctx) {
   ctx->formula_used.clear();
   ctx->formulas_dirty.clear();
   ctx->formula_ids.clear();
+  ctx->matrices.clear();   // (the registry of what the formulas contract with: rebuilt as they are registered again)
+  ctx->tiles_dirty = true;
 }
 
 bool off_ok(const gqe_ctx* ctx, int64_t off, int64_t numel) {
@@ -458,10 +460,16 @@ int64_t tile_of(const gqe_ctx* ctx, int64_t off) {
 }
 
 // the tile fields of a formula descriptor (they depend on the bound workspace), and its matrices into the registry
-void formula_tiles(gqe_ctx* ctx, GqeDevFormula& f) {
+// returns false if one of them does not lie in the non-table part of the arena (it has no place in the mirror)
+bool formula_tiles(gqe_ctx* ctx, GqeDevFormula& f) {
   const bool bil = ctx->cfg.decoder == GQE_DEC_BILINEAR;
+  bool ok = true;
   auto reg = [&](int64_t off) {
     if (off < 0) return (int64_t)-1;
+    if (ctx->ws && tile_of(ctx, off) < 0) {
+      ok = false;
+      return (int64_t)-1;
+    }
     auto it = std::lower_bound(ctx->matrices.begin(), ctx->matrices.end(), off);
     if (it == ctx->matrices.end() || *it != off) {
       ctx->matrices.insert(it, off);
@@ -475,6 +483,7 @@ void formula_tiles(gqe_ctx* ctx, GqeDevFormula& f) {
   f.pre_tile = reg(f.pre_param);     // (-1 unless the formula is an MLP intersection)
   f.post_tile = reg(f.post_param);
   f.tile_t = ctx->lay.tile_floats;
+  return ok;
 }
 
 // rebuild the copies of every registered matrix from the parameter arena
@@ -636,7 +645,8 @@ int formula_of(gqe_ctx* ctx, const gqe_batch& s, int bi, int* out_id) {
   if (nslot > kMaxSlots || njob > GQE_MAX_JOBS) return fail(ctx, GQE_ERR_ARG, "internal: %d scratch slots / %d jobs", nslot, njob);
   f.n_slots = nslot;
   f.n_jobs = njob;
-  formula_tiles(ctx, f);
+  if (!formula_tiles(ctx, f))
+    return fail(ctx, GQE_ERR_ARG, "batch %d: a d x d matrix of the formula (Pre / Post / a Bilinear relation matrix) lies inside a registered table", bi);
   int slot;
   if ((int)ctx->formulas.size() < ctx->cap_formulas) {
     slot = (int)ctx->formulas.size();
@@ -1863,7 +1873,7 @@ int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* strea
   for (GqeDevSeg& g : ctx->universe) universe_tiles(ctx, g);
   ctx->formulas_dirty.clear();  // the new workspace holds no descriptors yet: all cached slots are stale
   for (int k = 0; k < (int)ctx->formulas.size(); ++k) {
-    formula_tiles(ctx, ctx->formulas[(size_t)k]);
+    (void)formula_tiles(ctx, ctx->formulas[(size_t)k]);   // (checked when the formula was registered: the tables have not changed since)
     ctx->formulas_dirty.push_back(k);
   }
   ctx->tiles_dirty = true;
