@@ -80,6 +80,8 @@ struct GqeRetileArgs {
   long long tile[GQE_RETILE_MAX];      // float offset of its copy in the workspace
 };
 hipError_t gqe_launch_retile(const GqeRetileArgs& a, const float* params, float* ws, int d, hipStream_t stream);
+// GQE_CHECK_TILES=1 (debug): counts the elements of the listed matrices whose copy of M differs from the parameter (bit compare)
+hipError_t gqe_launch_tilecheck(const GqeRetileArgs& a, const float* params, const float* ws, int d, int32_t* mismatches, hipStream_t stream);
 
 // Dynamic part of a batch (sizes, offsets of this call), passed BY VALUE in the kernel arguments:
 // no plan upload, no event between the host and the launch.

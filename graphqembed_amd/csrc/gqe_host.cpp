@@ -515,6 +515,31 @@ int flush_ride(gqe_ctx* ctx, hipStream_t st) {
   return timing_end(ctx, 1, st);
 }
 
+// GQE_CHECK_TILES=1 (debug; synchronises the stream): are the copies what the parameters say?  A caller that writes parameter
+// values without gqe_params_changed gets an error here instead of results computed with the old matrices.
+int check_tiles(gqe_ctx* ctx, hipStream_t st) {
+  if (!ctx->ws || !ctx->params || ctx->matrices.empty()) return GQE_OK;
+  int32_t* cnt = reinterpret_cast<int32_t*>(ctx->ws + ctx->lay.counter_off + 192);
+  HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t), st));
+  GqeRetileArgs ra;
+  ra.tile_t = ctx->lay.tile_floats;
+  for (size_t a = 0; a < ctx->matrices.size(); a += GQE_RETILE_MAX) {
+    ra.n = (int)std::min<size_t>(GQE_RETILE_MAX, ctx->matrices.size() - a);
+    for (int k = 0; k < ra.n; ++k) {
+      ra.param[k] = ctx->matrices[a + (size_t)k];
+      ra.tile[k] = tile_of(ctx, ra.param[k]);
+    }
+    HIP_TRY(ctx, gqe_launch_tilecheck(ra, ctx->params, reinterpret_cast<const float*>(ctx->ws), ctx->cfg.dim, cnt, st));
+  }
+  int32_t bad = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&bad, cnt, sizeof bad, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (bad)
+    return fail(ctx, GQE_ERR_STATE, "GQE_CHECK_TILES: %d float4 groups of the d x d matrices differ from their operand-ordered copies: parameter values "
+                "were written without gqe_params_changed()", bad);
+  return GQE_OK;
+}
+
 int formula_of(gqe_ctx* ctx, const gqe_batch& s, int bi, int* out_id) {
   const int d = ctx->cfg.dim;
   const bool bil = ctx->cfg.decoder == GQE_DEC_BILINEAR;
@@ -882,6 +907,12 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   if (ctx->tiles_dirty || always_retile) {
     rc = retile(ctx, st);
     if (rc != GQE_OK) return rc;
+  } else {
+    static const bool check = getenv("GQE_CHECK_TILES") != nullptr;
+    if (check) {
+      rc = check_tiles(ctx, st);
+      if (rc != GQE_OK) return rc;
+    }
   }
   // ---- new / replaced formula descriptors -> device table (rare): contiguous runs of stale slots, one copy each ----
   if (!ctx->formulas_dirty.empty()) {

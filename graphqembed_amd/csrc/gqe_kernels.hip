@@ -357,6 +357,30 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_retile_kernel(const GqeRetile
   tile_store(ws + a.tile[mi], ws + a.tile[mi] + a.tile_t, d, e0, pp);
 }
 
+__global__ __launch_bounds__(GQE_THREADS) void gqe_tilecheck_kernel(const GqeRetileArgs a, const float* __restrict__ params, const float* __restrict__ ws,
+                                                                   int d, int32_t* __restrict__ mismatches) {
+  const int per = (d * d + GQE_OPT_CHUNK - 1) / GQE_OPT_CHUNK;
+  const int mi = blockIdx.x / per;
+  const long long e0 = (long long)(blockIdx.x - mi * per) * GQE_OPT_CHUNK + (long long)threadIdx.x * 4;
+  if (mi >= a.n || e0 >= (long long)d * d) return;
+  const int i = (int)(e0 / d), k = (int)(e0 - (long long)i * d);
+  const float4 pp = *reinterpret_cast<const float4*>(params + a.param[mi] + e0);
+  const float4 tt = *reinterpret_cast<const float4*>(ws + a.tile[mi] + GQE_TILE_INDEX(i, k, d));
+  const float* t = ws + a.tile[mi] + a.tile_t + GQE_TILE_INDEX(k, i, d);
+  const bool same = __float_as_int(pp.x) == __float_as_int(tt.x) && __float_as_int(pp.y) == __float_as_int(tt.y) &&
+                    __float_as_int(pp.z) == __float_as_int(tt.z) && __float_as_int(pp.w) == __float_as_int(tt.w) &&
+                    __float_as_int(pp.x) == __float_as_int(t[0]) && __float_as_int(pp.y) == __float_as_int(t[4]) &&
+                    __float_as_int(pp.z) == __float_as_int(t[8]) && __float_as_int(pp.w) == __float_as_int(t[12]);
+  if (!same) atomicAdd(mismatches, 1);
+}
+
+hipError_t gqe_launch_tilecheck(const GqeRetileArgs& a, const float* params, const float* ws, int d, int32_t* mismatches, hipStream_t stream) {
+  if (a.n < 1) return hipSuccess;
+  const int per = (d * d + GQE_OPT_CHUNK - 1) / GQE_OPT_CHUNK;
+  hipLaunchKernelGGL(gqe_tilecheck_kernel, dim3((unsigned)(a.n * per)), dim3(GQE_THREADS), 0, stream, a, params, ws, d, mismatches);
+  return hipGetLastError();
+}
+
 hipError_t gqe_launch_retile(const GqeRetileArgs& a, const float* params, float* ws, int d, hipStream_t stream) {
   if (a.n < 1) return hipSuccess;
   const int per = (d * d + GQE_OPT_CHUNK - 1) / GQE_OPT_CHUNK;

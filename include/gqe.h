@@ -136,7 +136,10 @@ int gqe_bind_arena(gqe_ctx* ctx, float* params, float* grads, float* exp_avg, fl
  * (gqe_adam_step / gqe_sgd_step / gqe_shard_step / the feeder) rewrite the copies together with the parameters.  A caller that
  * writes parameter VALUES into the arena itself — initialisation after the first forward / backward call, a checkpoint load
  * (load_state_dict), an optimiser of its own — calls this before the next gqe_forward / gqe_margin_fwd_bwd: the copies are rebuilt
- * by one small launch in front of it.  (gqe_bind_arena and gqe_bind_workspace imply it.)  No GPU work, no synchronisation. */
+ * by one small launch in front of it.  (gqe_bind_arena and gqe_bind_workspace imply it.)  No GPU work, no synchronisation.
+ * Debugging an integration: with GQE_CHECK_TILES=1 in the environment every forward / backward call first compares the copies
+ * with the parameters (synchronising) and fails with an error that names this function if a write was not announced;
+ * GQE_ALWAYS_RETILE=1 rebuilds the copies in front of every call. */
 int gqe_params_changed(gqe_ctx* ctx);
 /* Training loops that call gqe_margin_fwd_bwd and gqe_adam_step back to back, and read losses[] only behind the step, may let
  * the deferred matrix-gradient launch (Pre / Post / Bilinear relation matrices: dM += L^T R over the batch) wait for the

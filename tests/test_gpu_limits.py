@@ -509,3 +509,42 @@ def test_deferred_pair_gemm_is_the_same_training_run(dec, inter, d):
     close(read_arena(plain, plain._params), read_arena(lazyg, lazyg._params), "params after margin + forward + sgd")
     plain.close()
     lazyg.close()
+
+
+def test_check_tiles_switch_catches_an_unannounced_parameter_write():
+    """GQE_CHECK_TILES=1 (debug switch, read once per process): a forward call after a parameter write that was NOT announced with
+    gqe_params_changed fails with an error that says so, instead of scoring with the old matrices; the announced write passes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, toy_batch
+from graphqembed_amd.engine import GqeError
+from graphqembed_amd.tensorize import pack_forward_batches
+rng = np.random.RandomState(0)
+d = 64
+eng = engine_from_params(random_params(rng, d, "bilinear", "min", TOY_SIZES, TOY_KINDS), d, "bilinear", "min")
+t, g, a = toy_batch(rng, "2-inter", 32)
+def fwd():
+    descs, idx, n = pack_forward_batches([(plan_for(eng, "2-inter", TOY_FORMULAS["2-inter"]), t, a)])
+    return eng.forward(descs, idx, n)
+fwd()
+flat = eng._params                       # (not through the Engine.params property, which announces)
+mats = [k for k, (off, shape) in eng.layout.entries.items() if len(shape) == 2 and not k.startswith("enc.")]
+for k in mats:                           # (only the matrices a registered formula names are watched: touch them all)
+    eng.layout.view(flat, k).add_(1.0)
+try:
+    fwd()
+    print("NOT CAUGHT")
+except GqeError as e:
+    print("CAUGHT" if "gqe_params_changed" in str(e) else "OTHER %%s" %% e)
+eng.params_changed()
+fwd()
+print("ANNOUNCED OK")
+""" % (root, os.path.join(root, "tests"))
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, GQE_CHECK_TILES="1"), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert "CAUGHT" in p.stdout and "NOT CAUGHT" not in p.stdout and "ANNOUNCED OK" in p.stdout, p.stdout[-2000:]
