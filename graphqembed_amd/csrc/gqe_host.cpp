@@ -1057,6 +1057,9 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     // workgroup per CU at d >= 128) the tiles that start late should be the short chain tiles (~8 us), not the
     // ~30 us three-branch intersection tiles.
     bool any_candidates = false;
+    // gqe_set_deferred_gemm: may this launch's pair GEMM wait for the Adam pass (decided below, once its units are counted)?
+    const bool ride_candidate = bwd && ctx->defer_gemm && n_batches <= GQE_LAUNCH_BATCHES && !shard && ctx->world == 1 && d % 64 == 0 &&
+                                !ctx->lazy && !ctx->ordered_sums && !ctx->prof;
     // pair-GEMM units cover kmul x GQE_GEMM_KCHUNK queries: with thousands of units (large batches) a unit walks several
     // chunks before its one atomic pass over the 64 x 64 block — the units of a block all add into the same lines
     int kmul = 1;
@@ -1065,6 +1068,11 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       for (int k = 0; k < nb; ++k)
         units1 += (long long)ctx->formulas[fid[b0 + k]].n_jobs * ((align_up(batches[b0 + k].n_queries, GQE_TQ) + GQE_GEMM_KCHUNK - 1) / GQE_GEMM_KCHUNK) * macros_sq;
       while (kmul < 8 && units1 / (kmul * 2) >= GQE_GEMM_MIN_UNITS) kmul *= 2;   // ... but the launch keeps >= GQE_GEMM_MIN_UNITS units
+      // units that will ride in the Adam pass's launch (gqe_set_deferred_gemm) have tens of microseconds of slack, and what
+      // they cost the pass is their atomic rows: at least 256 queries per unit (one box, 128 / 256 / 512 per unit: headline step
+      // 80.0 / 78.2 / 78.3 us, full Bilinear 104.3 / 99.6 / 99.2, B = 1024 102.2 / 98.3 / 98.5, d = 256 182.9 / 177.2 / 183.0,
+      // d = 64 — a 22 us pass — 47.2 / 47.5 / 55.3: 512 outlasts a short pass)
+      if (ride_candidate && kmul < 2) kmul = 2;
       static const int forced = [] {   // GQE_DEBUG_GEMM_KMUL: tuning runs only
         const char* e = getenv("GQE_DEBUG_GEMM_KMUL");
         return e ? atoi(e) : 0;
@@ -1149,8 +1157,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       // deferred matrix gradients + the finalize block that turns per-tile hinge sums into losses[]
       // gqe_set_deferred_gemm: one launch of at most a few thousand units, and nobody reads the dense gradient before the
       // optimiser does — the units wait for the Adam pass and run in front of its chunks (GqeGemmRide)
-      const bool ride = ctx->defer_gemm && n_batches <= GQE_LAUNCH_BATCHES && !shard && ctx->world == 1 && d % 64 == 0 && P.units > 0 &&
-                        P.units <= GQE_RIDE_MAX_UNITS && !ctx->lazy && !ctx->ordered_sums && !ctx->prof;
+      const bool ride = ride_candidate && P.units > 0 && P.units <= GQE_RIDE_MAX_UNITS;
       if (ride) {
         ctx->ride_fa = fa;
         ctx->ride_losses = losses;
