@@ -576,6 +576,9 @@ class Engine(object):
             pp, pn = pos.data_ptr(), neg.data_ptr()
         self._check(self.lib.gqe_margin_fwd_bwd(self.ctx, arr, len(descs), ptr, n_idx, on_dev, losses.data_ptr(),
                                                 pp, pn, self._stream()))
+        # gqe_set_deferred_gemm: the library writes ``losses`` only when the next call is enqueued — the buffer has to outlive a
+        # caller that drops it (torch's caching allocator would hand the block to somebody else)
+        self._held_losses = losses
         return losses, pos, neg
 
     # -- pre-packed steps (lowest host overhead: bench / steady-state trainer) ------

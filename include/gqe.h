@@ -149,7 +149,8 @@ int gqe_params_changed(gqe_ctx* ctx);
  * by a small second launch.  Any other call that needs the gradients first (gqe_materialize_grads, gqe_sgd_step,
  * gqe_zero_grads, another gqe_margin_fwd_bwd / gqe_forward, lazy or order-independent passes) launches the deferred work on its
  * own, as without the switch.  THE CONTRACT: losses[] (and the dense gradient of the matrices) of a gqe_margin_fwd_bwd call are
- * defined once the next such call has been enqueued on the same stream — not right behind gqe_margin_fwd_bwd.  Results are the
+ * defined once the next such call has been enqueued on the same stream — not right behind gqe_margin_fwd_bwd — and the losses
+ * buffer has to stay allocated until then.  Results are the
  * same sums in another atomic order (float atomics: not bit-reproducible either way).  Off by default; one GPU, replicated
  * parameters (the row-sharded step exchanges the gradients between the two launches). */
 int gqe_set_deferred_gemm(gqe_ctx* ctx, int32_t enable);
