@@ -104,6 +104,8 @@ __device__ __forceinline__ float* scratch_row(const TileEnv& e, int slot, int r)
 // Wave w owns the 16-row output slabs i0 = 16*(w, w+8, ...).
 //   TRANS = false: A[i][k] = M[i][k]  (M . x : "project", decoders.py:150; Pre/Post forward)
 //   TRANS = true : A[i][k] = M[k][i]  (M^T . x : x^T M of decoders.py:145; every backward)
+// (Since the matrices are read from operand-ordered copies the two differ only in WHICH copy the caller passes — GQE_TILED(TRANS,
+// field) — and the template argument of the contraction helpers documents that choice at the call site.)
 // ------------------------------------------------------------------------------------------
 // The matrix is read from its OPERAND-ORDERED copy (gqe_dev.h, GQE_TILE_INDEX; M selects the copy of M or of M^T — the loader
 // is the same for both): the A operand of row block i0 and k-block kb is one contiguous kilobyte, 16 B per lane.  The copy is
