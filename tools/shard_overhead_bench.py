@@ -19,7 +19,7 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 wl = bench.Workload("bio-synth", 128, "bilinear-diag", "min", synth.FULL_MIX, 512)
 from graphqembed_amd.tensorize import FormulaPlan, pack_margin_batches
-for label, shard in (("plain", None), ("phases driven from Python (torch.distributed collectives), planned ONCE", (0, 1)),
+for label, shard in (("plain", None), ("plain + gqe_set_deferred_gemm (the sharded step cannot defer)", None), ("phases driven from Python (torch.distributed collectives), planned ONCE", (0, 1)),
                      ("gqe_shard_step, planned EVERY step, every block through RCCL", (0, 1)),
                      ("gqe_shard_step, planned EVERY step, own block kept in place (default)", (0, 1))):
     one_call = label.startswith("gqe_shard_step")
@@ -28,6 +28,8 @@ for label, shard in (("plain", None), ("phases driven from Python (torch.distrib
     else:
         os.environ.pop("GQE_SHARD_SELF_VIA_RCCL", None)
     eng = wl.engine(shard=shard)
+    if "gqe_set_deferred_gemm" in label:
+        eng.set_deferred_gemm(True)
     prepared = wl.prepare(eng, dist)                  # sharded: host feeds for gqe_shard_post
     if shard and not one_call:                        # the round-2 form: requests exchanged once per pre-sampled iteration, outside the loop
         legacy = []
