@@ -550,3 +550,63 @@ print("ANNOUNCED OK")
     p = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, GQE_CHECK_TILES="1"), stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
     assert "CAUGHT" in p.stdout and "NOT CAUGHT" not in p.stdout and "ANNOUNCED OK" in p.stdout, p.stdout[-2000:]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_deferred_pair_gemm_under_random_call_sequences(seed):
+    """The same random sequence of calls — margin, Adam step, SGD step, materialize, zero_grads, forward, two margins in a row,
+    a lazy-Adam stretch — through an engine with gqe_set_deferred_gemm and one without: whenever the sequence looks at the
+    state (parameters after a step, the dense gradient after materialize, scores), the two agree.  What rides and what is
+    flushed is the library's business; the caller only ever reads what the contract defines."""
+    import torch
+    from gpu_utils import (TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, read_arena, toy_batch)
+    from graphqembed_amd.tensorize import pack_forward_batches, pack_margin_batches
+    d, dec, inter = 64, ("bilinear", "bilinear-diag", "transe")[seed % 3], ("min", "mean", "min")[seed % 3]
+    rng = np.random.RandomState(100 + seed)
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
+    engines = [engine_from_params(params, d, dec, inter), engine_from_params(params, d, dec, inter)]
+    engines[1].set_deferred_gemm(True)
+    qtypes = ("3-inter_chain", "2-chain", "2-inter", "3-chain_inter", "3-inter", "1-chain")
+    pending = [set(), set()]          # tensors with an un-stepped gradient
+
+    def same(a, b, what, rtol=1e-4, atol=1e-5):
+        for k in a:
+            bad = np.abs(b[k] - a[k]) > atol + rtol * np.abs(a[k])
+            assert bad.mean() <= 1e-3, "%s %s: %d of %d differ, worst %.3g" % (what, k, bad.sum(), bad.size, np.abs(b[k] - a[k]).max())
+
+    r = np.random.RandomState(7 + seed)
+    rides_seen = 0
+    for op_i in range(40):
+        op = r.choice(["margin", "margin", "adam", "adam", "sgd", "materialize", "zero", "forward"])
+        spec = [(q,) + toy_batch(r, q, 48 + 16 * j) for j, q in enumerate(r.choice(qtypes, size=3, replace=False))]
+        outs = []
+        for ei, e in enumerate(engines):
+            if op == "margin":
+                items = [(plan_for(e, q, TOY_FORMULAS[q]), t, g, a, 1.0, 1.0) for (q, t, g, a) in spec]
+                descs, idx, n_scores = pack_margin_batches(items)
+                e.margin_fwd_bwd(descs, idx, n_scores=n_scores)
+                pending[ei] |= set().union(*[it[0].touched for it in items])
+            elif op in ("adam", "sgd") and pending[ei]:
+                keys = sorted(pending[ei])
+                (e.adam_step if op == "adam" else e.sgd_step)(keys)
+                pending[ei] = set()
+                outs.append(read_arena(e, e._params))
+            elif op == "materialize":
+                e.materialize()
+                outs.append(read_arena(e, e.grads))
+            elif op == "zero" and pending[ei]:
+                e.zero_grads(sorted(pending[ei]))
+                pending[ei] = set()
+                outs.append(read_arena(e, e.grads))
+            elif op == "forward":
+                packed = [(plan_for(e, q, TOY_FORMULAS[q]), t, a) for (q, t, g, a) in spec]
+                descs, idx, n = pack_forward_batches(packed)
+                outs.append({"scores": e.forward(descs, idx, n).cpu().numpy()})
+        if len(outs) == 2:
+            same(outs[0], outs[1], "op %d (%s)" % (op_i, op), atol=1e-5 if op != "forward" else 2e-5)
+    rides_seen = engines[1].gemm_rides()
+    assert engines[0].gemm_rides() == 0
+    if dec != "transe" or inter in ("min", "mean"):
+        assert rides_seen > 0, "the sequence never let a pair GEMM ride"
+    for e in engines:
+        e.close()
