@@ -727,6 +727,9 @@ def main():
                    "graph": wl.describe(), "queries_per_step_per_gpu": wl.qpi, "parallelism": "dp%d" % world,
                    "backend": None if world == 1 else backend,
                    "optimizer": "lazy (deferred, bit-exact) Adam — NON-DEFAULT mode" if args.lazy_adam else "eager dense Adam",
+                   "step_launches": ("fused forward/backward | Adam pass with the pair-GEMM units and the loss finalize in front of its chunks "
+                                     "(gqe_set_deferred_gemm) | Adam on the d x d matrices" if res["roofline"]["kernel"].startswith("gqe_opt_gemm_kernel")
+                                     else "fused forward/backward | pair GEMM + loss finalize | [exchange] | Adam pass"),
                    "gradient_exchange": "none" if world == 1 else
                    ("row-sharded tables (rank k owns rows r %% %d == k and their Adam moments), one library call per step "
                     "(gqe_shard_step over RCCL): all-to-all of the %d rows the batch reads (%d floats each), all-to-all of their "
