@@ -272,3 +272,25 @@ def test_zipf_graphs_are_heavy_tailed():
     r = synth.reddit_synth(seed=0, sizes={"user": 400, "post": 300, "community": 20}, edges_per_kind=3000, n_words=500, zipf=1.0)
     cnt = np.bincount(r.bags["post"][1], minlength=500)
     assert cnt.max() > 8 * np.median(cnt[cnt > 0])
+
+
+def test_operand_ordered_matrix_layout_is_a_permutation_the_loader_reads_linearly():
+    """GQE_TILE_INDEX (graphqembed_amd/csrc/gqe_dev.h) restated: the copy of a d x d matrix is a permutation of its elements, and
+    what load_a_slab (gqe_fused.h) reads for output row block i0, k-block kb, lane l = lq + 16 lk — sixteen bytes at byte offset
+    ((i0 / 16) (d / 16) + kb) 1024 + 16 l — are exactly M[i0 + lq][16 kb + 4 lk .. + 3], the lane's four MFMA A operands."""
+    def tile_index(i, k, d):
+        return (((i >> 4) * (d >> 4) + (k >> 4)) * 64 + (i & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3)
+
+    for d in (16, 48, 64, 80, 128, 256):
+        i, k = np.meshgrid(np.arange(d), np.arange(d), indexing="ij")
+        idx = tile_index(i, k, d)
+        assert sorted(idx.ravel().tolist()) == list(range(d * d))
+        m = np.arange(d * d, dtype=np.float32).reshape(d, d)
+        copy = np.empty(d * d, dtype=np.float32)
+        copy[idx] = m
+        for i0 in range(0, d, 16):
+            for kb in range(d // 16):
+                for lane in (0, 5, 17, 42, 63):
+                    lq, lk = lane & 15, lane >> 4
+                    off = (((i0 // 16) * (d // 16) + kb) * 1024 + 16 * lane) // 4
+                    np.testing.assert_array_equal(copy[off:off + 4], m[i0 + lq, 16 * kb + 4 * lk: 16 * kb + 4 * lk + 4])
