@@ -1157,7 +1157,9 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       // deferred matrix gradients + the finalize block that turns per-tile hinge sums into losses[]
       // gqe_set_deferred_gemm: one launch of at most a few thousand units, and nobody reads the dense gradient before the
       // optimiser does — the units wait for the Adam pass and run in front of its chunks (GqeGemmRide)
-      const bool ride = ride_candidate && P.units > 0 && P.units <= GQE_RIDE_MAX_UNITS;
+      // (a launch without matrix jobs — chains of the element-wise decoders: the reference's whole edge-only burn-in phase —
+      // still defers: its finalize block rides, and the step loses a launch that did nothing else)
+      const bool ride = ride_candidate && P.units <= GQE_RIDE_MAX_UNITS;
       if (ride) {
         ctx->ride_fa = fa;
         ctx->ride_losses = losses;

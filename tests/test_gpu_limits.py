@@ -498,7 +498,7 @@ def test_deferred_pair_gemm_is_the_same_training_run(dec, inter, d):
     for e in (plain, lazyg):
         margin(e, spec)
         e.materialize()
-    close(read_arena(plain, plain.grads), read_arena(lazyg, lazyg.grads), "materialized gradient", rtol=1e-4, atol=1e-7)
+    close(read_arena(plain, plain.grads), read_arena(lazyg, lazyg.grads), "materialized gradient", rtol=1e-4, atol=2e-6)   # (a row's list is summed in whatever order it was linked)
     for e in (plain, lazyg):
         e.zero_grads(list(e.layout.entries))
     assert float(lazyg.grads.abs().max()) == 0.0

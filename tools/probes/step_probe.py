@@ -14,9 +14,10 @@ ap.add_argument("--dim", type=int, default=128)
 ap.add_argument("--decoder", default="bilinear-diag")
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--workload", default="bio-synth")
+ap.add_argument("--mix", default="full", help="full | 1-chain (the edge-only burn-in step, SURVEY C1)")
 ap.add_argument("--defer", action="store_true", help="gqe_set_deferred_gemm: the pair GEMM rides in the Adam pass's launch")
 a = ap.parse_args()
-wl = bench.Workload(a.workload, a.dim, a.decoder, "min", synth.FULL_MIX, a.batch)
+wl = bench.Workload(a.workload, a.dim, a.decoder, "min", synth.FULL_MIX if a.mix == "full" else (synth.FULL_MIX[0],), a.batch)
 eng = wl.engine()
 prep = wl.prepare(eng)
 if a.defer:
