@@ -306,8 +306,8 @@ def kernel_block(eng, prepared, used, ms_per_step, lazy=False, world=1, d=128, t
                                       "mfma_flop_per_launch": ff, "mfma_TFs": tfs(ff, ms_fused),
                                       "mfma_frac_of_f32_peak": round(ff / (ms_fused * 1e-3) / 1e12 / MFMA_F32_TFS, 4) if ms_fused > 0 and ff else None},
                     "pair_gemm": ({"rides_in": "roofline.kernel (gqe_set_deferred_gemm): no launch of its own", "mfma_flop_per_launch": gf,
-                                   "matrix_step_launch": {"kernel": "gqe_matstep_kernel: Adam on the d x d matrices, behind the pass", "avg_launch_ms": round(ms_gemm, 5),
-                                                          "rocprof_avg_launch_ms": rp_gemm, "launches": n_gemm}} if rides else
+                                   "matrix_step_launch": ({"kernel": "gqe_matstep_kernel: Adam on the d x d matrices, behind the pass", "avg_launch_ms": round(ms_gemm, 5),
+                                                           "rocprof_avg_launch_ms": rp_gemm, "launches": n_gemm} if n_gemm else None)} if rides else
                                   {"avg_launch_ms": round(ms_gemm, 5), "rocprof_avg_launch_ms": rp_gemm, "launches": n_gemm, "mfma_flop_per_launch": gf,
                                    "mfma_TFs": tfs(gf, ms_gemm),
                                    "mfma_frac_of_f32_peak": round(gf / (ms_gemm * 1e-3) / 1e12 / MFMA_F32_TFS, 4) if ms_gemm > 0 and gf else None})},
@@ -619,8 +619,9 @@ def slim(res):
     k = res["kernels"]
     out = {"value": res["value"], "unit": "queries/s", "ms_per_step": res["ms_per_step"], "timing": res["timing"],
            "final_loss": res["final_loss"],
-           "kernels_ms": {("matrix_step (pair GEMM rides in the optimiser launch)" if "matrix_step_launch" in v else name):
-                          (v["matrix_step_launch"] if "matrix_step_launch" in v else v)["avg_launch_ms"] for name, v in k.items() if isinstance(v, dict)},
+           "kernels_ms": {("matrix_step (pair GEMM / loss finalize ride in the optimiser launch)" if "matrix_step_launch" in v else name):
+                          ((v["matrix_step_launch"] or {"avg_launch_ms": None}) if "matrix_step_launch" in v else v)["avg_launch_ms"]
+                          for name, v in k.items() if isinstance(v, dict)},
            "longest_gradient_list": res.get("longest_gradient_list"),
            "optimiser": {"avg_launch_ms": res["roofline"]["avg_launch_ms"], "achieved_GBs": res["roofline"]["achieved"],
                          "frac": res["roofline"]["frac"], "algorithmic_bytes_per_launch": res["roofline"]["algorithmic_bytes_per_launch"]},

@@ -1685,6 +1685,9 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       if (timed) {
         rc = timing_end(ctx, 2, st);
         if (rc != GQE_OK) return rc;
+      }
+      const bool timed_mat = timed && ob.total_chunks > 0;
+      if (timed_mat) {
         rc = timing_begin(ctx, 1, st);   // (the slot of the pair GEMM's own launch: what is left of it on the stream)
         if (rc != GQE_OK) return rc;
       }
@@ -1706,7 +1709,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
         }
         HIP_TRY(ctx, gqe_launch_matstep(ms, oa.p, oa.g, oa.m, oa.v, d, b1, b2, eps, st));
       }
-      if (timed) {
+      if (timed_mat) {
         rc = timing_end(ctx, 1, st);
         if (rc != GQE_OK) return rc;
       }

@@ -65,4 +65,5 @@ def test_bench_single_gpu_line_has_the_contract_keys():
     pg = out["kernels"]["pair_gemm"]                              # the headline step lets the pair GEMM ride in the Adam pass's launch
     assert "rides_in" in pg and pg["matrix_step_launch"]["launches"] > 0 and pg["mfma_flop_per_launch"] > 0
     assert out["roofline"]["kernel"].startswith("gqe_opt_gemm_kernel")
-    assert out["configs"]["C1_1chain_only"]["kernels_ms"]["pair_gemm"] > 0      # no matrix gradient to defer: the finalize launch stays
+    c1 = out["configs"]["C1_1chain_only"]["kernels_ms"]             # no matrix gradient at all: the loss finalize rides, nothing is launched behind the pass
+    assert "pair_gemm" not in c1 and [v for k, v in c1.items() if k.startswith("matrix_step")] == [None]
