@@ -272,6 +272,47 @@ struct GqeOptArgs {
   hipStream_t stream;
 };
 
+// ---- the split step (gqe_train_step; gqe_split.h) --------------------------------------------------------------------
+// Adam over the rows a step's index feed does NOT name rides in the fused launch ("rider" workgroups behind the tiles), the
+// named rows are stepped by the launch that also carries the pair-GEMM units, the d x d matrices by the small launch in front
+// of the NEXT fused launch (which also stamps that step's named rows).
+#define GQE_SPLIT_TABLES 8
+#ifndef GQE_SPLIT_WROWS
+#define GQE_SPLIT_WROWS 8       // consecutive rows of one table a rider wave owns at a time ("wave block": at d = 128 one batch of 4 x 2 row slices)
+#endif
+struct GqeSplitTabs {
+  int n;                                   // stepped tables
+  int blk_begin[GQE_SPLIT_TABLES + 1];     // prefix of their wave blocks
+  long long offset[GQE_SPLIT_TABLES], head_base[GQE_SPLIT_TABLES], rows[GQE_SPLIT_TABLES];
+  float step_size[GQE_SPLIT_TABLES], bc2_sqrt[GQE_SPLIT_TABLES];   // lr / (1 - b1^t), sqrt(1 - b2^t) of the table's step count
+};
+#define GQE_SPLIT_PWAVES 16     // progress slots per rider (its waves)
+#define GQE_SPLIT_MAX_RIDERS 1024
+#define GQE_SPLIT_SEGS 64       // index-feed segments of one fused launch: <= GQE_LAUNCH_BATCHES x (target | negative, <= 3 anchors)
+struct GqeSplitSegs {           // the rows the step's feed names: segment k = idx[idx_begin[k] .. +count) of stepped table tid[k]
+  int n, total;
+  int begin[GQE_SPLIT_SEGS + 1];     // prefix sums of the counts
+  int idx_begin[GQE_SPLIT_SEGS];     // int32 offset from the launch's idx pointer
+  int8_t tid[GQE_SPLIT_SEGS];        // slot in GqeSplitTabs (-1: skip)
+};
+struct GqeSplitRide {
+  GqeSplitTabs t;
+  float *p, *m, *v;
+  const int32_t* stamp;   // [total rows], indexed like head[]: == epoch: named by this step's feed (stepped by the second launch,
+  int epoch;              // which exchanges it with epoch + 1: claimed); anything else: an older step's — not named.  epoch += 2 per step
+  float b1, b2, eps;
+  int blocks;             // rider workgroups of the launch (0: a plain fused launch) ...
+  int lead;               // ... of which this many come FIRST in the grid (they start with the launch, on CUs of their own); the
+                          // tiles follow, then the other riders (they start where tiles have finished)
+  int waves;              // waves per rider workgroup of the fused launch (16 or 8)
+  int per, share;         // wave blocks per tail rider; a lead rider owns share * per (split_range, gqe_split.h)
+  int32_t* progress;      // [blocks][GQE_SPLIT_PWAVES]: the next wave block of (rider, wave) — set to its first block by the launch
+                          // in front (gqe_prestep_kernel), left by the rider when the tiles are through, continued by the second launch
+  int32_t* done;          // tiles of the fused launch that have finished (zeroed by the launch in front)
+  int tiles;
+  int stop;               // != 0: the riders stop when the tiles are through (else they finish their ranges)
+};
+
 // everything one fused launch needs (built by gqe_host.cpp, consumed by the per-variant launchers)
 struct GqeFusedArgs {
   GqeDynPlan plan;
@@ -297,8 +338,12 @@ struct GqeFusedArgs {
   float* contrib_bag;     // where bag contributions go (= contrib, except in row-sharded mode: the optimiser's entry space)
   long long bag_shift;    // ... and the first entry index they may use there
   GqeHot hot;             // hot rows (slot == NULL: off)
+  GqeSplitRide split;     // split.blocks > 0: rider workgroups behind the tiles (gqe_train_step)
+  int force_fw;           // 0: the dispatcher picks the workgroup shape from the tile count; 8 / 16: this shape (split steps)
 };
 
+// can the fused kernel this launch would select carry rider workgroups (split.blocks > 0)?  (the straight-line d % 64 == 0 kernels)
+int gqe_fused_can_ride(int dec, int mlp, int d, int tiles);
 hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a);
 int gqe_config_supported(int dec, int inter, int d);   // gqe_kernels.hip, next to the dispatcher
 void gqe_fused_variant(int dec, int d, int tiles, int* nc, int* full, int* fw);
@@ -334,6 +379,14 @@ struct GqeMatStep {
 };
 hipError_t gqe_launch_matstep(const GqeMatStep& a, float* p, float* g, float* m, float* v, int d, float b1, float b2, float eps, hipStream_t stream);
 hipError_t gqe_launch_rows(const GqeRowsArgs& a);
+// the split step's launch M: Adam on the pending d x d matrices (ms.n may be 0) + stamp[row] := 1 for the rows `segs` names
+hipError_t gqe_launch_prestep(const GqeMatStep& ms, float* p, float* g, float* m, float* v, int d, float b1, float b2, float eps,
+                              const GqeSplitSegs& segs, const GqeSplitRide& ride, const int32_t* idx, int32_t* stamp, hipStream_t stream);
+// ... and its launch B: loss finalize + pair-GEMM units | the named rows (claim the stamp, list / hot gradient, Adam; coefficients per
+// table in `ride.t`) | riders for what the fused launch left of the stream (ride.ticket) | the chunks of `a` (the relation vectors:
+// a pass over non-table, non-matrix tensors)
+hipError_t gqe_launch_split_rows(const GqeOptArgs& a, const GqeGemmRide& r, const GqeSplitSegs& segs, const GqeSplitRide& ride, const int32_t* idx,
+                                 int32_t* stamp);
 // non-table floats of the arena (dense gradients that travel with the exchanged slab)
 struct GqeSpans {
   int n;  // < 0: more than 8 spans (unsupported)

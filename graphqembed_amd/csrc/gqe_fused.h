@@ -33,6 +33,7 @@
 #endif
 #define GQE_FWT (64 * GQE_FW)
 #define RPW (GQE_TQ / GQE_FW)  // query rows owned by one wave
+#include "gqe_split.h"   // (after GQE_FW: the rider's depth depends on the workgroup shape)
 
 struct TileEnv {
   GqeDynBatch b;  // by value: the plan is a kernel argument, never take its address
@@ -904,27 +905,47 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
                                                                 int32_t* __restrict__ link_counter, int max_entries,
                                                                 const float* __restrict__ fetched,
                                                                 float* __restrict__ contrib_bag, long long bag_shift,
-                                                                const GqeHot hot, long long* __restrict__ prof) {
+                                                                const GqeHot hot, long long* __restrict__ prof, const GqeSplitRide ride) {
   static_assert(FW == GQE_FW, "FW only distinguishes the kernels of the per-GQE_FW translation units");
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // gqe_train_step (gqe_split.h): the workgroups behind the tiles are riders — Adam over the table rows this step's batches do
+  // not name.  They read and write nothing a tile touches, so they need no order against the tiles: they fill the wave slots
+  // the tiles leave free (8-wave tiles) or the CUs whose tiles have finished (16-wave tiles) with HBM-bound work.
+  // Grid: [ride.lead riders][plan.tiles tiles][the other riders]
+  const int tile_id = (BWD && FULL) ? (int)blockIdx.x - ride.lead : (int)blockIdx.x;
+  if (BWD && FULL && (tile_id < 0 || tile_id >= plan.tiles)) {
+    // (debug profile: start / end of the rider workgroup and the CU it ran on, in the rows behind the tiles')
+    const size_t prow = (size_t)plan.tiles + (tile_id < 0 ? blockIdx.x : blockIdx.x - plan.tiles);
+    if (prof && threadIdx.x == 0) {
+      int hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      int xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      prof[prow * GQE_PROF_SLOTS + 0] = (long long)wall_clock64();
+      prof[prow * GQE_PROF_SLOTS + 1] = ((long long)(xcc & 15) << 32) | (unsigned)hw;
+    }
+    split_rider<GQE_FW>(ride, 64 * NC, tile_id < 0 ? (int)blockIdx.x : (int)blockIdx.x - plan.tiles);
+    if (prof && threadIdx.x == 0) prof[prow * GQE_PROF_SLOTS + 8] = (long long)wall_clock64();
+    return;
+  }
   // Debug profile (gqe_debug_profile; tools/kbench.py reads it): GQE_PROF_SLOTS wall_clock64 stamps per workgroup.
   // Slots 0 .. 15: thread 0 at the phase boundaries (0 start, 1 indices, 2 rows, 3 Pre, 4 Post / final, 5 scores, 6 Post^T,
   // 7 hops + scatter, 8 end, 9 .. 14 inside the intersection phases); slots 16 + 4 p + k: lane 0 of waves 0 / 4 / 8 / 12 at
   // point p of the backward (how far apart the waves of a tile finish a vector phase).  prof == NULL: a uniform branch.
 #define GQE_STAMP(k)                                                                                              \
   do {                                                                                                            \
-    if (prof && threadIdx.x == 0) prof[(size_t)blockIdx.x * GQE_PROF_SLOTS + (k)] = (long long)wall_clock64(); \
+    if (prof && threadIdx.x == 0) prof[(size_t)tile_id * GQE_PROF_SLOTS + (k)] = (long long)wall_clock64(); \
   } while (0)
 #define GQE_WSTAMP(p)                                                                                               \
   do {                                                                                                              \
     if (prof && (threadIdx.x & 255) == 0)                                                                           \
-      prof[(size_t)blockIdx.x * GQE_PROF_SLOTS + 16 + (p) * 4 + (threadIdx.x >> 8)] = (long long)wall_clock64();    \
+      prof[(size_t)tile_id * GQE_PROF_SLOTS + 16 + (p) * 4 + (threadIdx.x >> 8)] = (long long)wall_clock64();    \
   } while (0)
   GQE_STAMP(0);
   const int d = FULL ? 64 * NC : d_arg;
   int bi = 0;  // which batch owns this tile: the plan is a kernel argument (SGPRs), 16 scalar compares
 #pragma unroll
-  for (int k = 1; k < GQE_LAUNCH_BATCHES; ++k) bi += ((int)blockIdx.x >= plan.tile_begin[k]) ? 1 : 0;
+  for (int k = 1; k < GQE_LAUNCH_BATCHES; ++k) bi += (tile_id >= plan.tile_begin[k]) ? 1 : 0;
   const GqeDynBatch b = plan.b[bi];
   const GqeDevFormula* __restrict__ f = formulas + b.formula;
   TileEnv e;
@@ -951,7 +972,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
   // (not in the full-Bilinear d = 256 kernel: the extra SGPRs spill into VGPR lanes it does not have)
   e.wave = (DEC == DEC_BILINEAR && NC >= 4) ? (int)(threadIdx.x >> 6) : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   e.lane = threadIdx.x & 63;
-  e.q0 = ((int)blockIdx.x - b.tile_begin) * GQE_TQ;
+  e.q0 = (tile_id - b.tile_begin) * GQE_TQ;
   e.hot_slot = BWD ? hot.slot : nullptr;
   e.hot_acc = hot.acc;
   e.rep = 0;
@@ -1798,10 +1819,12 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
       float l = 0.f;
 #pragma unroll
       for (int w = 0; w < GQE_FW; ++w) l += red[w];
-      tile_loss[blockIdx.x] = l;  // summed per batch by the finalize block of the pair-GEMM launch
+      tile_loss[tile_id] = l;  // summed per batch by the finalize block of the pair-GEMM launch
     }
   }
   GQE_STAMP(8);
+  // (split steps: the launch's riders stop taking rounds once every tile has left)
+  if (BWD && FULL && ride.blocks > 0 && ride.stop && threadIdx.x == 0) __hip_atomic_fetch_add(ride.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #undef GQE_STAMP
 #undef GQE_WSTAMP
 #undef GQE_DSC
@@ -1824,14 +1847,16 @@ static hipError_t launch_fused_v(const GqeFusedArgs& a) {
   }();
   const size_t lds = gqe_fused_lds_bytes_impl(a.d, MLP && DEC != DEC_BILINEAR && FULL && NC <= 2 && GQE_FW == 16,
                                               FusedShape<DEC, MLP, NC, FULL, GQE_FW>::COMPACT) + lds_pad;
+  const int riders = (a.bwd && FULL) ? a.split.blocks : 0;
+  if (a.split.blocks > 0 && !riders) return hipErrorInvalidValue;   // (gqe_fused_can_ride said no: the host does not ask)
   if (a.bwd)
-    hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true, GQE_FW>), dim3(a.plan.tiles), dim3(GQE_FWT), lds, a.stream, a.plan,
+    hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true, GQE_FW>), dim3(a.plan.tiles + riders), dim3(GQE_FWT), lds, a.stream, a.plan,
                        a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags, a.link_contrib, a.link_counter,
-                       a.max_entries, a.fetched, a.contrib_bag, a.bag_shift, a.hot, a.prof);
+                       a.max_entries, a.fetched, a.contrib_bag, a.bag_shift, a.hot, a.prof, a.split);
   else
     hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, false, GQE_FW>), dim3(a.plan.tiles), dim3(GQE_FWT), lds, a.stream, a.plan,
                        a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags, a.link_contrib, a.link_counter,
-                       a.max_entries, a.fetched, a.contrib_bag, a.bag_shift, a.hot, a.prof);
+                       a.max_entries, a.fetched, a.contrib_bag, a.bag_shift, a.hot, a.prof, a.split);
   return hipGetLastError();
 }
 

@@ -80,6 +80,8 @@ struct Layout {  // byte offsets inside the bound workspace
   int n_tile_spans;
   int64_t tile_span_lo[8], tile_span_hi[8], tile_span_base[8];   // arena floats [lo, hi) -> mirror floats from base (base = lo mod 64)
   size_t hot_slot_off, hot_acc_off;   // hot rows (GqeHot): slot per table row, GQE_HOT_REPS x GQE_HOT_SLOTS accumulators of dim floats
+  size_t stamp_off;   // split step (gqe_train_step): one int32 per table row, 1 = named by the step's index feed
+  size_t progress_off;   // ... and the riders' progress slots (GqeSplitRide::progress)
   int64_t max_entries, max_links;  // max_entries = per-rank capacity x world (the exchange gathers every rank's entries)
 };
 
@@ -110,6 +112,19 @@ struct gqe_ctx {
   // else comes first (flush_ride)
   bool defer_gemm = false, ride_pending = false;
   int64_t rides = 0;   // Adam passes that carried a deferred pair GEMM (gqe_deferred_gemm_rides)
+  // gqe_train_step's split step (gqe_split.h): split_active = the call in progress launched (or is about to launch) rider
+  // workgroups in its fused launch; split_t / split_segs / split_idx describe the stepped tables and the rows its feed names;
+  // mat_pending = d x d matrices whose Adam step waits for the next step's first launch (or flush_split)
+  bool split_active = false, split_launched = false;
+  int split_epoch = -1;   // stamp value of the current split step's named rows (odd; += 2 per step)
+  GqeSplitTabs split_t;
+  GqeSplitRide split_ride;   // the rider description of the fused launch (its second launch continues the same ticket counter)
+  GqeSplitSegs split_segs;
+  const int32_t* split_idx = nullptr;
+  float split_b1 = 0.f, split_b2 = 0.f, split_eps = 0.f;
+  std::vector<GqeMatStep> mat_pending;
+  float mat_b1 = 0.f, mat_b2 = 0.f, mat_eps = 0.f;
+  int64_t split_steps = 0;   // steps that ran as split steps (gqe_split_steps)
   GqeFusedArgs ride_fa;
   float* ride_losses = nullptr;
   int64_t total_rows = 0;
@@ -375,7 +390,9 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
     }
     L.tile_floats = at;
   }
-  L.total = L.tile_off + align_up(sizeof(float) * 2 * (size_t)L.tile_floats, 256);
+  L.stamp_off = L.tile_off + align_up(sizeof(float) * 2 * (size_t)L.tile_floats, 256);
+  L.progress_off = L.stamp_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
+  L.total = L.progress_off + align_up(sizeof(int32_t) * (size_t)GQE_SPLIT_MAX_RIDERS * GQE_SPLIT_PWAVES, 256);
   L.shard_req_send = L.shard_req_recv = L.shard_fetch = L.shard_csend = 0;
   if (ctx->shard_on) {
     L.shard_req_send = L.total;
@@ -513,6 +530,17 @@ int flush_ride(gqe_ctx* ctx, hipStream_t st) {
   if (rc != GQE_OK) return rc;
   HIP_TRY(ctx, gqe_launch_pair_gemm(ctx->ride_fa, ctx->ride_losses));
   return timing_end(ctx, 1, st);
+}
+
+// the d x d matrices a split step (gqe_train_step) left for the next step's first launch: stepped now, by a launch of their own
+// (whatever comes next is not a split step, or wants the parameters complete)
+int flush_split(gqe_ctx* ctx, hipStream_t st) {
+  if (ctx->mat_pending.empty()) return GQE_OK;
+  std::vector<GqeMatStep> pending;
+  pending.swap(ctx->mat_pending);
+  for (const GqeMatStep& ms : pending)
+    HIP_TRY(ctx, gqe_launch_matstep(ms, ctx->params, ctx->grads, ctx->m, ctx->v, ctx->cfg.dim, ctx->mat_b1, ctx->mat_b2, ctx->mat_eps, st));
+  return GQE_OK;
 }
 
 // GQE_CHECK_TILES=1 (debug; synchronises the stream): are the copies what the parameters say?  A caller that writes parameter
@@ -841,6 +869,120 @@ bool lazy_any_dirty(const gqe_ctx* ctx) {
   return false;
 }
 
+// ---- the split step (gqe_train_step; gqe_split.h) ------------------------------------------------------------------------
+// Launch M of a split step, enqueued in front of its fused launch: Adam on the d x d matrices the previous step left pending +
+// the stamps of the rows this step's feed names; then the rider description of the fused launch (fa.split).
+int split_first_launch(gqe_ctx* ctx, const gqe_batch* batches, int n_batches, const std::vector<int>& fid, const int32_t* d_idx,
+                       GqeFusedArgs& fa, hipStream_t st) {
+  const Layout& L = ctx->lay;
+  const int d = ctx->cfg.dim;
+  GqeSplitSegs& sg = ctx->split_segs;
+  memset(&sg, 0, sizeof sg);
+  auto push = [&](int64_t idx_begin, int64_t count, int64_t table_offset) -> bool {
+    if (count <= 0) return true;
+    if (sg.n == GQE_SPLIT_SEGS) return false;
+    int slot = -1;
+    for (int k = 0; k < ctx->split_t.n; ++k)
+      if (ctx->split_t.offset[k] == table_offset) slot = k;
+    sg.idx_begin[sg.n] = (int)idx_begin;
+    sg.tid[sg.n] = (int8_t)slot;
+    sg.begin[sg.n] = sg.total;
+    sg.total += (int)count;
+    sg.begin[++sg.n] = sg.total;
+    return true;
+  };
+  bool ok = true;
+  for (int bi = 0; bi < n_batches && ok; ++bi) {
+    const gqe_batch& s = batches[bi];
+    const GqeDevFormula& f = ctx->formulas[fid[bi]];
+    const int64_t B = s.n_queries, o = s.idx_offset;
+    ok = push(o, 2 * B, f.target_table);   // target | negative: the same table
+    for (int i = 0; i < f.n_anchors && ok; ++i) ok = push(o + (2 + i) * B, B, f.anchor_table[i]);
+  }
+  if (!ok) return fail(ctx, GQE_ERR_STATE, "internal: split step with more than %d index segments", GQE_SPLIT_SEGS);
+  ctx->split_idx = d_idx;
+  int32_t* stamp = reinterpret_cast<int32_t*>(ctx->ws + L.stamp_off);
+  // stamps carry the step's epoch (odd: named; + 1: named and claimed): never reset, a step that failed between its launches
+  // leaves nothing a later step would read as its own
+  ctx->split_epoch += 2;
+  if (ctx->split_epoch > (1 << 30)) {
+    HIP_TRY(ctx, hipMemsetAsync(stamp, 0, sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), st));
+    ctx->split_epoch = 1;
+  }
+  // The riders: `lead` of them come first in the grid — they own a CU each from the launch's first microsecond (the tiles are
+  // 1024-thread workgroups, one per CU; ~100 streaming CUs come close to saturating the memory system and slow the tiles'
+  // latency chains: tools/probes/rider_probe.hip, split_timeline.py) — the others follow the tiles and start where a tile has
+  // finished.  Rider j owns a fixed range of wave blocks; all of them stop with the launch's last tile, the second launch
+  // continues every range where its rider stopped.
+  static const int lead_env = [] {   // GQE_SPLIT_LEAD / GQE_SPLIT_TAIL / GQE_SPLIT_SHAPE: tuning runs only
+    const char* e = getenv("GQE_SPLIT_LEAD");
+    return e ? atoi(e) : -1;
+  }();
+  static const int tail_env = [] {
+    const char* e = getenv("GQE_SPLIT_TAIL");
+    return e ? atoi(e) : -1;
+  }();
+  static const int shape = [] {
+    const char* e = getenv("GQE_SPLIT_SHAPE");
+    return e ? atoi(e) : 0;
+  }();
+  fa.force_fw = (shape == 8 && d == 128) ? 8 : 16;
+  fa.split.t = ctx->split_t;
+  fa.split.p = ctx->params;
+  fa.split.m = ctx->m;
+  fa.split.v = ctx->v;
+  fa.split.stamp = stamp;
+  fa.split.epoch = ctx->split_epoch;
+  fa.split.done = reinterpret_cast<int32_t*>(ctx->ws + L.counter_off + 128);
+  fa.split.progress = reinterpret_cast<int32_t*>(ctx->ws + L.progress_off);
+  fa.split.b1 = ctx->split_b1;
+  fa.split.b2 = ctx->split_b2;
+  fa.split.eps = ctx->split_eps;
+  static const int waves_env = [] {
+    const char* e = getenv("GQE_SPLIT_WAVES");
+    return e ? atoi(e) : 0;
+  }();
+  fa.split.waves = (waves_env > 0 && waves_env <= fa.force_fw) ? waves_env : fa.force_fw;
+  const int total_blocks = ctx->split_t.blk_begin[ctx->split_t.n];
+  fa.split.lead = std::max(0, std::min(lead_env >= 0 ? lead_env : 96, GQE_SPLIT_MAX_RIDERS / 2));
+  const int tail = std::max(0, std::min(tail_env >= 0 ? tail_env : 64, GQE_SPLIT_MAX_RIDERS / 2));
+  fa.split.blocks = std::max(1, fa.split.lead + tail);
+  fa.split.lead = std::min(fa.split.lead, fa.split.blocks);
+  // a lead rider streams for the whole launch (~35 us), a tail rider for what is left of it when its CU becomes free: ranges 4 : 1
+  static const int share_env = [] {
+    const char* e = getenv("GQE_SPLIT_SHARE");
+    return e && atoi(e) > 0 ? atoi(e) : 4;
+  }();
+  fa.split.share = share_env;
+  const int units = fa.split.lead * fa.split.share + (fa.split.blocks - fa.split.lead);
+  fa.split.per = (total_blocks + units - 1) / units;
+  fa.split.tiles = fa.plan.tiles;
+  static const bool no_ride = getenv("GQE_SPLIT_DEBUG_NORIDE") != nullptr;   // timing experiments, WRONG results: the riders do nothing
+  if (no_ride) fa.split.waves = 0;
+  // (stopping the riders with the tiles and finishing the stream next to the units of the second launch: built, measured, off —
+  // DESIGN.md §3; GQE_SPLIT_STOP=1 turns it on for experiments)
+  static const int stop_env = [] {
+    const char* e = getenv("GQE_SPLIT_STOP");
+    return e ? atoi(e) : 0;
+  }();
+  fa.split.stop = stop_env;
+  ctx->split_ride = fa.split;
+  std::vector<GqeMatStep> pending;
+  pending.swap(ctx->mat_pending);
+  for (size_t k = 0; k + 1 < pending.size(); ++k)
+    HIP_TRY(ctx, gqe_launch_matstep(pending[k], ctx->params, ctx->grads, ctx->m, ctx->v, d, ctx->mat_b1, ctx->mat_b2, ctx->mat_eps, st));
+  GqeMatStep none;
+  memset(&none, 0, sizeof none);
+  int rc = timing_begin(ctx, 1, st);   // (the slot of the pair GEMM's / matrix step's own launch: what is left of them on the stream)
+  if (rc != GQE_OK) return rc;
+  HIP_TRY(ctx, gqe_launch_prestep(pending.empty() ? none : pending.back(), ctx->params, ctx->grads, ctx->m, ctx->v, d, ctx->mat_b1, ctx->mat_b2,
+                                  ctx->mat_eps, sg, fa.split, d_idx, stamp, st));
+  rc = timing_end(ctx, 1, st);
+  if (rc != GQE_OK) return rc;
+  ctx->split_launched = true;
+  return GQE_OK;
+}
+
 int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx,
                 int32_t idx_on_device, bool bwd, float* losses, float* pos, float* neg, void* stream) {
   if (!ctx) return GQE_ERR_ARG;
@@ -852,7 +994,10 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   {   // a pair GEMM still waiting for its optimiser pass reads the scratch rows this call is about to overwrite
-    const int rcf = flush_ride(ctx, st);
+    int rcf = flush_ride(ctx, st);
+    if (rcf != GQE_OK) return rcf;
+    // matrices a split step left pending: this call contracts with them (a split step's own first launch carries them instead)
+    if (!ctx->split_active) rcf = flush_split(ctx, st);
     if (rcf != GQE_OK) return rcf;
   }
   const int d = ctx->cfg.dim;
@@ -1025,6 +1170,8 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
   fa.link_counter = reinterpret_cast<int32_t*>(ctx->ws + L.counter_off);
   fa.max_entries = (int32_t)L.max_entries;
   fa.hot = hot_args(ctx, true);
+  memset(&fa.split, 0, sizeof fa.split);
+  fa.force_fw = 0;
   if (bwd && !ctx->bags.empty()) ctx->links_used = true;
 
   // ---- launches of <= GQE_LAUNCH_BATCHES batches; per-call data travels as kernel arguments ----
@@ -1058,8 +1205,8 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     // ~30 us three-branch intersection tiles.
     bool any_candidates = false;
     // gqe_set_deferred_gemm: may this launch's pair GEMM wait for the Adam pass (decided below, once its units are counted)?
-    const bool ride_candidate = bwd && ctx->defer_gemm && n_batches <= GQE_LAUNCH_BATCHES && !shard && ctx->world == 1 && d % 64 == 0 &&
-                                !ctx->lazy && !ctx->ordered_sums && !ctx->prof;
+    const bool ride_candidate = bwd && (ctx->defer_gemm || ctx->split_active) && n_batches <= GQE_LAUNCH_BATCHES && !shard && ctx->world == 1 && d % 64 == 0 &&
+                                !ctx->lazy && !ctx->ordered_sums && (!ctx->prof || ctx->split_active);
     // pair-GEMM units cover kmul x GQE_GEMM_KCHUNK queries: with thousands of units (large batches) a unit walks several
     // chunks before its one atomic pass over the 64 x 64 block — the units of a block all add into the same lines
     int kmul = 1;
@@ -1072,7 +1219,9 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       // they cost the pass is their atomic rows: at least 256 queries per unit (one box, 128 / 256 / 512 per unit: headline step
       // 80.0 / 78.2 / 78.3 us, full Bilinear 104.3 / 99.6 / 99.2, B = 1024 102.2 / 98.3 / 98.5, d = 256 182.9 / 177.2 / 183.0,
       // d = 64 — a 22 us pass — 47.2 / 47.5 / 55.3: 512 outlasts a short pass)
-      if (ride_candidate && kmul < 2) kmul = 2;
+      // (a split step's second launch has no 45-us stream to hide behind: its units are the launch's critical chain and keep
+      // the 128-query chunks)
+      if (ride_candidate && !ctx->split_active && kmul < 2) kmul = 2;
       static const int forced = [] {   // GQE_DEBUG_GEMM_KMUL: tuning runs only
         const char* e = getenv("GQE_DEBUG_GEMM_KMUL");
         return e ? atoi(e) : 0;
@@ -1147,6 +1296,10 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     if ((size_t)(scratch * (int64_t)sizeof(float)) > L.scratch_off + L.scratch_cap)
       return fail(ctx, GQE_ERR_WORKSPACE, "workspace too small for this call (bound for %lld queries, %d batches)",
                   (long long)ctx->cap_queries, ctx->cap_batches);
+    if (bwd && ctx->split_active) {
+      rc = split_first_launch(ctx, batches, n_batches, fid, d_idx, fa, st);
+      if (rc != GQE_OK) return rc;
+    }
     rc = timing_begin(ctx, 0, st);
     if (rc != GQE_OK) return rc;
     HIP_TRY(ctx, gqe_launch_fused(ctx->cfg.decoder, is_mlp(ctx) ? 1 : 0, fa));
@@ -1247,6 +1400,10 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     const int rcf = flush_ride(ctx, st);
     if (rcf != GQE_OK) return rcf;
   }
+  if (!ctx->split_launched) {   // matrices a split step left pending: stepped before anything else touches their gradient
+    const int rcf = flush_split(ctx, st);
+    if (rcf != GQE_OK) return rcf;
+  }
   if (flush && !lazy_any_dirty(ctx)) return GQE_OK;
   if (ctx->lazy && !flush && lazy_any_dirty(ctx) &&
       (mode == GQE_OPT_SGD || (mode == GQE_OPT_ADAM && ctx->lz_hyper &&
@@ -1338,6 +1495,22 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
           return fail(ctx, GQE_ERR_STATE, "table at offset %lld has pending gradients but is not among the stepped segments",
                       (long long)ctx->tables[t].offset);
   }
+  // A stepped dense segment that COVERS a registered d x d matrix without being that matrix's own universe entry (one flat
+  // segment over all dense parameters, a stacked [R, d, d] relation tensor): the pass moves the parameter but not its
+  // operand-ordered copies (universe_tiles: numel == d * d only).  The copies are rebuilt in front of the next fused launch,
+  // and such a pass never carries riding GEMM units (its chunks would read and zero a matrix gradient the units of the same
+  // launch are still adding to: there is no order inside a launch).
+  bool merged_matrix = false;
+  if (mode == GQE_OPT_ADAM || mode == GQE_OPT_SGD)
+    for (size_t ui = 0; ui < ustep.size() && !merged_matrix; ++ui) {
+      if (!ustep[ui]) continue;
+      const GqeDevSeg& u = ctx->universe[ui];
+      if (u.is_table || u.tile) continue;
+      auto it = std::lower_bound(ctx->matrices.begin(), ctx->matrices.end(), u.offset);
+      merged_matrix = it != ctx->matrices.end() && *it < u.offset + u.numel;
+      if (!merged_matrix && it != ctx->matrices.begin()) merged_matrix = *(it - 1) + (int64_t)d * d > u.offset;   // starts inside one
+    }
+  if (merged_matrix) ctx->tiles_dirty = true;
   if (ctx->universe_uploaded != ctx->universe.size()) {
     const size_t seg_bytes = sizeof(GqeDevSeg) * ctx->universe.size();
     RingSlot* slot;  // happens only when a tensor is stepped for the first time
@@ -1646,8 +1819,72 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     }
     if (flush) return GQE_OK;
   } else {
+    if (ctx->split_launched) {
+      // ---- launch B of a split step (gqe_train_step): the fused launch already stepped every row its feed does not name ----
+      if (mode_in != GQE_OPT_ADAM || oa.sorted || oa.dense_tables || merged_matrix)
+        return fail(ctx, GQE_ERR_STATE, "internal: split step reached a pass it cannot finish");
+      auto is_matrix = [&](size_t ui) { return ctx->universe[ui].tile != nullptr; };
+      for (size_t ui = 0; ui < nu; ++ui) {   // the tables: exactly the ones the riders stepped, with the same coefficients
+        if (!ustep[ui] || !ctx->universe[ui].is_table) continue;
+        int slot = -1;
+        for (int k = 0; k < ctx->split_t.n; ++k)
+          if (ctx->split_t.offset[k] == ctx->universe[ui].offset) slot = k;
+        if (slot < 0 || ctx->split_t.step_size[slot] != uss[ui] || ctx->split_t.bc2_sqrt[slot] != ubc[ui])
+          return fail(ctx, GQE_ERR_STATE, "internal: split step: the second launch disagrees with the riders about table %lld", (long long)ctx->universe[ui].offset);
+      }
+      oa.total_chunks = emit([&](size_t ui) { return !ctx->universe[ui].is_table && !is_matrix(ui); }, oa.active, oa.coef, &oa.act, &oa.n_act);
+      if (prefix_overflow) return fail(ctx, GQE_ERR_ARG, "optimiser pass over more than 2^31 chunks");
+      rc = upload_staging();
+      if (rc != GQE_OK) return rc;
+      GqeGemmRide r;
+      if (ctx->ride_pending) {
+        r.plan = ctx->ride_fa.plan;
+        r.formulas = ctx->ride_fa.formulas;
+        r.ws = ctx->ride_fa.ws;
+        r.tile_loss = ctx->ride_fa.tile_loss;
+        r.losses = ctx->ride_losses;
+        ctx->ride_pending = false;
+        ++ctx->rides;
+      } else {   // (more units than ride along: the pair GEMM and the finalize block already ran as a launch of their own)
+        memset(&r, 0, sizeof r);
+        r.plan.units = -1;
+      }
+      rc = timing_begin(ctx, 2, st);
+      if (rc != GQE_OK) return rc;
+      HIP_TRY(ctx, gqe_launch_split_rows(oa, r, ctx->split_segs, ctx->split_ride, ctx->split_idx,
+                                         reinterpret_cast<int32_t*>(ctx->ws + ctx->lay.stamp_off)));
+      rc = timing_end(ctx, 2, st);
+      if (rc != GQE_OK) return rc;
+      ctx->split_launched = false;
+      ++ctx->split_steps;
+      // the d x d matrices wait for the next step's first launch (split_first_launch) or for flush_split
+      ctx->mat_pending.clear();
+      ctx->mat_b1 = b1;
+      ctx->mat_b2 = b2;
+      ctx->mat_eps = eps;
+      GqeMatStep ms;
+      memset(&ms, 0, sizeof ms);
+      ms.tile_t = ctx->lay.tile_floats;
+      for (size_t ui = 0; ui < nu; ++ui) {
+        if (!ustep[ui] || !is_matrix(ui)) continue;
+        ms.off[ms.n] = ctx->universe[ui].offset;
+        ms.tile[ms.n] = ctx->universe[ui].tile;
+        ms.step_size[ms.n] = uss[ui];
+        ms.bc2_sqrt[ms.n] = ubc[ui];
+        if (++ms.n == GQE_MATSTEP_MAX) {
+          ctx->mat_pending.push_back(ms);
+          ms.n = 0;
+        }
+      }
+      if (ms.n) ctx->mat_pending.push_back(ms);
+      if (mode == GQE_OPT_ADAM)
+        for (size_t t = 0; t < ctx->tables.size(); ++t)
+          if (seen[t]) ctx->tables[t].lstep = ctx->adam_steps[ctx->tables[t].offset];
+      goto consumed;
+    }
+    {
     // (not next to the non-temporal pass over tables beyond the Infinity Cache: reddit-synth 663 -> 687 us per step with it)
-    const bool ride = ctx->ride_pending && may_ride && oa.lists && !oa.sorted && !oa.dense_tables && !oa.lazy && !oa.nt;
+    const bool ride = ctx->ride_pending && may_ride && oa.lists && !oa.sorted && !oa.dense_tables && !oa.lazy && !oa.nt && !merged_matrix;
     if (ctx->ride_pending && !ride) {
       rc = flush_ride(ctx, st);
       if (rc != GQE_OK) return rc;
@@ -1727,7 +1964,9 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
     if (mode == GQE_OPT_ADAM)
       for (size_t t = 0; t < ctx->tables.size(); ++t)
         if (seen[t]) ctx->tables[t].lstep = ctx->adam_steps[ctx->tables[t].offset];  // keeps gqe_set_lazy_adam(1) possible later
+    }
   }
+consumed:
   ctx->next_idx = nullptr;                            // a prefetch declaration holds for one optimiser step
   if (mode != GQE_OPT_ADAM) ctx->feed_valid = false;  // lists were dropped / folded: the saved feed no longer describes them
   // bookkeeping: which lists are consumed now
@@ -1818,6 +2057,8 @@ int gqe_bind_arena(gqe_ctx* ctx, float* params, float* grads, float* exp_avg, fl
   if ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(exp_avg) |
        reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
     return fail(ctx, GQE_ERR_ARG, "arenas must be 16-byte aligned");
+  if (!ctx->mat_pending.empty())
+    return fail(ctx, GQE_ERR_STATE, "the last gqe_train_step's matrix step is pending: call gqe_optimizer_sync before re-binding the arenas");
   ctx->params = params;
   ctx->grads = grads;
   ctx->m = exp_avg;
@@ -1902,6 +2143,11 @@ int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* strea
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(ctx, GQE_ERR_ARG, "workspace must be 256-byte aligned");
   if (ctx->cap_queries < 1) return fail(ctx, GQE_ERR_STATE, "call gqe_workspace_bytes first");
   if (ctx->entries_used) return fail(ctx, GQE_ERR_STATE, "gradients pending; step or materialize before re-binding the workspace");
+  if (ctx->ws) {   // a split step's pending matrix step writes the operand-ordered copies of the OLD workspace: settle it there
+    const int rcf = flush_split(ctx, reinterpret_cast<hipStream_t>(stream));
+    if (rcf != GQE_OK) return rcf;
+  }
+  ctx->mat_pending.clear();
   if (lazy_any_dirty(ctx)) return fail(ctx, GQE_ERR_STATE, "lazy Adam: call gqe_optimizer_sync before re-binding the workspace");
   // an open row-sharded session sized its plan board and pinned feeds for the bound capacities, its planning thread may be
   // sorting a posted feed against them right now, and the peers did not grow with this rank
@@ -1925,6 +2171,11 @@ int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* strea
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.counter_off, 0, 256, reinterpret_cast<hipStream_t>(stream)));   // + the hot-slot counter
   ctx->links_used = false;
   ctx->ride_pending = false;
+  // split steps: no row is stamped
+  HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.stamp_off, 0, L.total - L.stamp_off > 0 ? align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256) : 0,
+                              reinterpret_cast<hipStream_t>(stream)));
+  ctx->split_epoch = -1;
+  ctx->split_launched = false;
   // lazy Adam: every row is current for its table's step count, empty rings
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.ring_off, 0, L.hot_slot_off - L.ring_off, reinterpret_cast<hipStream_t>(stream)));
   // hot rows: none yet, empty accumulators
@@ -1979,6 +2230,10 @@ int gqe_lazy_prefetch(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches,
 
 int gqe_optimizer_sync(gqe_ctx* ctx, void* stream) {
   if (!ctx) return GQE_ERR_ARG;
+  if (ctx->ws) {   // gqe_train_step: the d x d matrices of the last split step
+    const int rc = flush_split(ctx, reinterpret_cast<hipStream_t>(stream));
+    if (rc != GQE_OK) return rc;
+  }
   if (!ctx->lazy || !ctx->ws) return GQE_OK;
   return run_opt(ctx, GQE_OPT_FLUSH, nullptr, 0, 0.f, 0.f, 0.f, 0.f, stream);
 }
@@ -2392,6 +2647,110 @@ int gqe_allreduce_grads(gqe_ctx* ctx, void* nccl_comm, void* stream) {
 
 int gqe_adam_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, float lr, float beta1, float beta2, float eps, void* stream) {
   return run_opt(ctx, GQE_OPT_ADAM, segs, n_segs, lr, beta1, beta2, eps, stream);
+}
+
+int64_t gqe_split_steps(gqe_ctx* ctx) { return ctx ? ctx->split_steps : -1; }
+
+int gqe_train_step(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx, int32_t idx_on_device,
+                   const gqe_segment* segs, int32_t n_segs, float lr, float beta1, float beta2, float eps, float* losses, void* stream) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (!batches || n_batches < 1 || !segs || n_segs < 1) return fail(ctx, GQE_ERR_ARG, "gqe_train_step: no batches / no segments given");
+  if (!ctx->params || !ctx->grads || !ctx->m || !ctx->v) return fail(ctx, GQE_ERR_STATE, "gqe_train_step: parameter, gradient and Adam moment arenas must be bound");
+  if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
+  static const bool env_off = [] {
+    const char* e = getenv("GQE_SPLIT");
+    return e && atoi(e) == 0;
+  }();
+  const int d = ctx->cfg.dim;
+  // ---- may this step run split?  Everything the second launch will check is checked here, before anything is enqueued ----
+  static const bool prof_ok = getenv("GQE_SPLIT_PROF") != nullptr;   // (debug profile of a split step: tools/probes/split_timeline.py)
+  bool split = !env_off && !ctx->lazy && !ctx->ordered_sums && ctx->world == 1 && !ctx->shard_on && (!ctx->prof || prof_ok) && ctx->bags.empty() &&
+               n_batches <= GQE_LAUNCH_BATCHES && n_segs <= ctx->cap_tensors && ctx->entries_used == 0 && !any_dense(ctx) &&
+               gqe_fused_can_ride(ctx->cfg.decoder, is_mlp(ctx) ? 1 : 0, d, 0);
+  for (const Table& t : ctx->tables) split = split && !t.pending;
+  {
+    // launches of more tiles than the 16-wave shape is chosen for (thousands of tiles, two or three 8-wave workgroups per CU)
+    // are long MFMA-bound launches next to which the Adam stream is small change — and riders that share a CU with tiles slow
+    // the tiles' latency chains far more than they gain (tools/probes/split_timeline.py): the two-call sequence
+    long long tiles = 0;
+    for (int bi = 0; bi < n_batches; ++bi) tiles += (batches[bi].n_queries + GQE_TQ - 1) / GQE_TQ;
+    split = split && tiles <= GQE_FW8_MIN_TILES;
+  }
+  std::vector<gqe_segment> resolved(segs, segs + n_segs);
+  GqeSplitTabs st;
+  memset(&st, 0, sizeof st);
+  long long stream_bytes = 0;
+  for (int i = 0; i < n_segs && split; ++i) {
+    gqe_segment& s = resolved[(size_t)i];
+    if (s.offset < 0 || (s.offset % 4) != 0 || s.numel < 1 || s.offset + s.numel > ctx->n_arena) split = false;   // (run_opt reports it)
+    if (!split) break;
+    for (int j = 0; j < i; ++j) split = split && resolved[(size_t)j].offset != s.offset;
+    // the step count this call applies: the caller's, or the library's counter + 1 (run_opt commits it)
+    if (s.step < 1) {
+      auto it = ctx->adam_steps.find(s.offset);
+      s.step = (it == ctx->adam_steps.end() ? 0 : it->second) + 1;
+    }
+    const int t = table_of(ctx, s.offset);
+    if (t < 0) {
+      // a dense segment must be a vector or exactly one registered matrix (what the riding units and the matrix step assume)
+      auto it = std::lower_bound(ctx->matrices.begin(), ctx->matrices.end(), s.offset);
+      const bool covers = (it != ctx->matrices.end() && *it < s.offset + s.numel) ||
+                          (it != ctx->matrices.begin() && *(it - 1) + (int64_t)d * d > s.offset);
+      if (covers && !(s.numel == (int64_t)d * d && it != ctx->matrices.end() && *it == s.offset)) split = false;
+      if (covers && tile_of(ctx, s.offset) < 0) split = false;
+      continue;
+    }
+    if (s.numel != ctx->tables[(size_t)t].rows * d || st.n == GQE_SPLIT_TABLES) {
+      split = false;
+      break;
+    }
+    const int k = st.n++;
+    st.offset[k] = s.offset;
+    st.head_base[k] = ctx->tables[(size_t)t].head_base;
+    st.rows[k] = ctx->tables[(size_t)t].rows;
+    st.step_size[k] = (float)((double)lr / (1.0 - std::pow((double)beta1, (double)s.step)));
+    st.bc2_sqrt[k] = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)s.step));
+    st.blk_begin[k + 1] = st.blk_begin[k] + (int)((ctx->tables[(size_t)t].rows + GQE_SPLIT_WROWS - 1) / GQE_SPLIT_WROWS);
+    stream_bytes += 12ll * s.numel;
+  }
+  split = split && st.n > 0 && stream_bytes <= GQE_NT_STREAM_BYTES;
+  // every table the batches name has to be among the stepped ones (the second launch owns their stamped rows)
+  for (int bi = 0; bi < n_batches && split; ++bi) {
+    const gqe_batch& b = batches[bi];
+    auto stepped = [&](int64_t off) {
+      for (int k = 0; k < st.n; ++k)
+        if (st.offset[k] == off) return true;
+      return false;
+    };
+    split = stepped(b.target_table) && b.n_candidates == 0 && b.n_anchors >= 1 && b.n_anchors <= GQE_MAX_BRANCH;
+    for (int i = 0; i < b.n_anchors && i < GQE_MAX_BRANCH && split; ++i) split = stepped(b.anchor_table[i]);
+  }
+  if (!split) {
+    // the two-call sequence; the matrix-gradient units may still ride in the Adam pass (the losses are defined behind it)
+    const bool defer = ctx->defer_gemm;
+    ctx->defer_gemm = true;
+    int rc = run_queries(ctx, batches, n_batches, idx, n_idx, idx_on_device, true, losses, nullptr, nullptr, stream);
+    ctx->defer_gemm = defer;
+    if (rc != GQE_OK) return rc;
+    rc = run_opt(ctx, GQE_OPT_ADAM, segs, n_segs, lr, beta1, beta2, eps, stream);
+    if (rc != GQE_OK) return rc;
+    return flush_ride(ctx, reinterpret_cast<hipStream_t>(stream));   // (a pass that could not carry them: losses[] as documented)
+  }
+  ctx->split_t = st;
+  ctx->split_b1 = beta1;
+  ctx->split_b2 = beta2;
+  ctx->split_eps = eps;
+  ctx->split_active = true;
+  ctx->split_launched = false;
+  int rc = run_queries(ctx, batches, n_batches, idx, n_idx, idx_on_device, true, losses, nullptr, nullptr, stream);
+  ctx->split_active = false;
+  if (rc == GQE_OK) rc = run_opt(ctx, GQE_OPT_ADAM, resolved.data(), n_segs, lr, beta1, beta2, eps, stream);
+  if (rc != GQE_OK) {
+    // (riders may have run without their second launch: the parameters are in an undefined state, as after any failed step)
+    ctx->split_launched = false;
+    return rc;
+  }
+  return GQE_OK;
 }
 
 int gqe_sgd_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, float lr, void* stream) {

@@ -1,8 +1,11 @@
 // gqe_kernels.hip — pair-GEMM (deferred matrix gradients), fused optimiser pass and the dispatcher of
 // the fused query kernel (gqe_fused.h, instantiated per decoder variant in gqe_fused_inst.hip).
+#include <algorithm>
 #include <cstdlib>
 #include "gqe_common.h"
 #include "gqe_adam.h"
+#define GQE_SPLIT_U 1   // the riders of the second launch live in the optimiser kernels' budget (<= 64 VGPRs, eight waves per SIMD: two slices in flight spilled 9 registers there)
+#include "gqe_split.h"
 
 // ------------------------------------------------------------------------------------------
 // deferred matrix gradients:  dM[i][j] += sum_b L[b][i] * R[b][j]   (rank-B update on the matrix cores)
@@ -301,8 +304,11 @@ __device__ __forceinline__ float4 hot_take(const GqeHot& hot, int hs, int d, int
 // a list of `len` entries was just walked for row `hrow`: long enough -> the row's later contributions go to a slot
 __device__ __forceinline__ void hot_promote(const GqeHot& hot, long long hrow, int len) {
   if (len < hot.min_len) return;
+  // every slot taken: no further increments (on heavy-tailed data thousands of long rows per step would otherwise bump the
+  // counter for ever — one contended atomic each, and after ~1e5 steps an int32 wrap that hands slots out twice)
+  if (__hip_atomic_load(hot.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hot.cap) return;
   const int s = __hip_atomic_fetch_add(hot.count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (s < hot.cap) hot.slot[hrow] = s;
+  if (s >= 0 && s < hot.cap) hot.slot[hrow] = s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -629,9 +635,18 @@ void gqe_fused_variant(int dec, int d, int tiles, int* nc, int* full, int* fw) {
   *fw = gqe_fused_waves(dec, d, tiles);
 }
 
+// rider workgroups (gqe_train_step) are compiled into the backward kernels of the straight-line dims
+int gqe_fused_can_ride(int dec, int mlp, int d, int tiles) {
+  (void)dec;
+  (void)mlp;
+  (void)tiles;
+  return (d % 64) == 0 && d != 192 && (64 % (d >> 2)) == 0;
+}
+
 hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a) {
   const int key = dec * 2 + (mlp ? 1 : 0);
-  if (gqe_fused_waves(dec, a.d, a.plan.tiles) == 8) {
+  const int fw = (a.force_fw == 8 && a.d == 128) ? 8 : (a.force_fw == 16 ? 16 : gqe_fused_waves(dec, a.d, a.plan.tiles));
+  if (fw == 8) {
     switch (key) {
       case 0: return gqe_launch_fused_0_0_w8(a);
       case 1: return gqe_launch_fused_0_1_w8(a);
@@ -748,11 +763,11 @@ __global__ __launch_bounds__(GQE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
                                                        n_act, lazy, hot);
 }
 
-__global__ __launch_bounds__(GQE_THREADS) void gqe_matstep_kernel(const GqeMatStep a, float* __restrict__ p, float* __restrict__ g,
-                                                                 float* __restrict__ m, float* __restrict__ v, int d, float b1, float b2, float eps) {
+__device__ __forceinline__ void matstep_body(const GqeMatStep& a, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                             float* __restrict__ v, int d, float b1, float b2, float eps, int block) {
   const int per = (d * d) / GQE_OPT_CHUNK;   // (d % 64 == 0: whole chunks)
-  const int mi = blockIdx.x / per;
-  const long long e0 = (long long)(blockIdx.x - mi * per) * GQE_OPT_CHUNK + (long long)threadIdx.x * 4;
+  const int mi = block / per;
+  const long long e0 = (long long)(block - mi * per) * GQE_OPT_CHUNK + (long long)threadIdx.x * 4;
   const long long off = a.off[mi] + e0;
   const float4 gg = *reinterpret_cast<const float4*>(g + off);
   float4 pp = *reinterpret_cast<const float4*>(p + off);
@@ -764,6 +779,11 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_matstep_kernel(const GqeMatSt
   *reinterpret_cast<float4*>(v + off) = vv;
   *reinterpret_cast<float4*>(p + off) = pp;
   tile_store(a.tile[mi], a.tile[mi] + a.tile_t, d, e0, pp);
+}
+
+__global__ __launch_bounds__(GQE_THREADS) void gqe_matstep_kernel(const GqeMatStep a, float* __restrict__ p, float* __restrict__ g,
+                                                                 float* __restrict__ m, float* __restrict__ v, int d, float b1, float b2, float eps) {
+  matstep_body(a, p, g, m, v, d, b1, b2, eps, (int)blockIdx.x);
 }
 
 hipError_t gqe_launch_matstep(const GqeMatStep& a, float* p, float* g, float* m, float* v, int d, float b1, float b2, float eps, hipStream_t stream) {
@@ -914,6 +934,8 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_rows_kernel(const GqeRowSegs 
 
 hipError_t gqe_launch_rows(const GqeRowsArgs& a) {
   if (a.segs.total < 1 && a.dense_chunks < 1) return hipSuccess;
+  // the kernel's lane groups (d / 4 lanes per row, claim broadcast with one __shfl) must not straddle a wave
+  if (a.segs.total > 0 && (a.d < 4 || (64 % (a.d >> 2)) != 0)) return hipErrorInvalidValue;
   const long long threads = (long long)a.segs.total * (a.d >> 2);
   const unsigned row_blocks = (unsigned)((threads + GQE_THREADS - 1) / GQE_THREADS);
   const unsigned dense_blocks = (unsigned)(a.dense_chunks < 512 ? a.dense_chunks : 512);
@@ -927,6 +949,155 @@ hipError_t gqe_launch_rows(const GqeRowsArgs& a) {
     GO(false, false);
   }
 #undef GO
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// the split step (gqe_train_step; gqe_split.h, GqeSplitRide in gqe_dev.h)
+// ------------------------------------------------------------------------------------------
+// which segment of the feed owns entry e (a scan with uniform loads of the kernel arguments), its table slot and its row
+__device__ __forceinline__ bool split_entry(const GqeSplitSegs& segs, const int32_t* __restrict__ idx, int e, int& lt, int& row) {
+  int k = 0;
+  for (int i = 1; i < segs.n; ++i) k += (e >= segs.begin[i]) ? 1 : 0;
+  lt = segs.tid[k];
+  if (lt < 0) return false;
+  row = idx[segs.idx_begin[k] + (e - segs.begin[k])];
+  return row >= 0;   // (negative: a padding query)
+}
+
+// launch M: Adam on the d x d matrices the previous step left pending (their gradients were completed by that step's riding GEMM
+// units, a kernel boundary ago; their operand-ordered copies are rewritten for the fused launch behind this one), and the stamps
+// of the rows THIS step's feed names.  Duplicates store the same value.
+__global__ __launch_bounds__(GQE_THREADS) void gqe_prestep_kernel(const GqeMatStep a, float* __restrict__ p, float* __restrict__ g,
+                                                                 float* __restrict__ m, float* __restrict__ v, int d, float b1, float b2,
+                                                                 float eps, int mat_blocks, int mark_blocks, const GqeSplitSegs segs,
+                                                                 const GqeSplitRide ride, const int32_t* __restrict__ idx,
+                                                                 int32_t* __restrict__ stamp) {
+  if ((int)blockIdx.x < mat_blocks) {
+    matstep_body(a, p, g, m, v, d, b1, b2, eps, (int)blockIdx.x);
+    return;
+  }
+  if ((int)blockIdx.x >= mat_blocks + mark_blocks) {
+    // the riders' bookkeeping (gqe_split.h): nobody has started, no tile has finished
+    const int i = ((int)blockIdx.x - mat_blocks - mark_blocks) * GQE_THREADS + (int)threadIdx.x;
+    if (i == 0) *ride.done = 0;
+    if (i < ride.blocks * GQE_SPLIT_PWAVES) {
+      const int j = i / GQE_SPLIT_PWAVES, w = i - j * GQE_SPLIT_PWAVES;
+      int lo, hi;
+      split_range(ride, j, lo, hi);
+      ride.progress[i] = w < ride.waves ? lo + w : 0x7fffffff;
+    }
+    return;
+  }
+  const int e = ((int)blockIdx.x - mat_blocks) * GQE_THREADS + (int)threadIdx.x;
+  if (e >= segs.total) return;
+  int lt, row;
+  if (!split_entry(segs, idx, e, lt, row)) return;
+  stamp[ride.t.head_base[lt] + row] = ride.epoch;
+}
+
+hipError_t gqe_launch_prestep(const GqeMatStep& ms, float* p, float* g, float* m, float* v, int d, float b1, float b2, float eps,
+                              const GqeSplitSegs& segs, const GqeSplitRide& ride, const int32_t* idx, int32_t* stamp, hipStream_t stream) {
+  const int mat_blocks = ms.n * ((d * d) / GQE_OPT_CHUNK);
+  const int mark_blocks = (segs.total + GQE_THREADS - 1) / GQE_THREADS;
+  const int book_blocks = (ride.blocks * GQE_SPLIT_PWAVES + GQE_THREADS - 1) / GQE_THREADS + 1;
+  hipLaunchKernelGGL(gqe_prestep_kernel, dim3((unsigned)(mat_blocks + mark_blocks + book_blocks)), dim3(GQE_THREADS), 0, stream, ms, p, g, m, v, d, b1, b2,
+                     eps, mat_blocks, mark_blocks, segs, ride, idx, stamp);
+  return hipGetLastError();
+}
+
+// launch B: workgroup 0 finalizes the losses, workgroups 1 .. units are the pair-GEMM units (gemm_ride_unit), then `row_blocks`
+// workgroups step the named rows — d / 4 lanes per feed entry; the entry that exchanges the row's stamp (epoch -> epoch + 1) owns the row
+// (a row named twice is stepped once), sums its gradient list and hot accumulators and applies Adam with exactly the eager pass's
+// arithmetic — and the rest are the ordinary chunk loop over the step's vectors (relation vectors: dense gradients the fused
+// tiles accumulated with atomics, complete since the kernel boundary).
+__global__ __launch_bounds__(GQE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void gqe_split_rows_kernel(
+    const GqeDevSeg* __restrict__ segs, int n_segs, long long total_chunks, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+    float* __restrict__ v, int32_t* __restrict__ head, const int32_t* __restrict__ next, const float* __restrict__ contrib, int max_entries, int d,
+    float lr, float b1, float b2, float eps, GqeStepCoef coef, GqeOptActive active, const GqeActSeg* __restrict__ act, int n_act, GqeHot hot,
+    GqeGemmRide ride, const GqeSplitSegs rsegs, const GqeSplitRide sr, const int32_t* __restrict__ idx, int32_t* __restrict__ stamp, int row_blocks,
+    int rider_blocks) {
+  const GqeSplitTabs& t = sr.t;
+  const int front = ride.plan.units + 1;   // (units == -1: the pair GEMM and the finalize block ran as a launch of their own)
+  if ((int)blockIdx.x < front) {
+    if (blockIdx.x == 0) finalize_losses(ride.plan, ride.tile_loss, ride.losses);
+    else gemm_ride_unit(ride.plan, ride.formulas, ride.ws, g, d, (int)blockIdx.x - 1);
+    return;
+  }
+  if ((int)blockIdx.x >= front + row_blocks + rider_blocks) {
+    GqeLazyArgs lazy;   // (never read: LAZY = false)
+    GqeHot no_hot;
+    no_hot.slot = nullptr;
+    opt_body<GQE_OPT_ADAM, false, false, false, false>((long long)blockIdx.x - front - row_blocks - rider_blocks,
+                                                       (long long)gridDim.x - front - row_blocks - rider_blocks, segs,
+                                                       n_segs, total_chunks, p, g, m, v, head, next, contrib, nullptr, max_entries, d, lr, b1, b2,
+                                                       eps, coef, active, act, n_act, lazy, no_hot);
+    return;
+  }
+  if ((int)blockIdx.x >= front + row_blocks) {   // what the fused launch's riders left of the untouched rows
+    split_leftover(sr, d, ((int)blockIdx.x - front - row_blocks) * GQE_WAVES + (int)(threadIdx.x >> 6));
+    return;
+  }
+  const int tpr = d >> 2;  // lanes per row: a divisor of 64 (checked by the launcher), the group never straddles a wave
+  const int e = (int)((((long long)blockIdx.x - front) * GQE_THREADS + threadIdx.x) / tpr);
+  if (e >= rsegs.total) return;
+  const int c4 = (threadIdx.x % tpr) * 4;
+  int lt, row;
+  if (!split_entry(rsegs, idx, e, lt, row)) return;
+  const long long hrow = t.head_base[lt] + row;
+  const long long off = t.offset[lt] + (long long)row * d + c4;
+  // everything the update needs is requested before the claim's round trip is awaited
+  int mine = 0;
+  if (c4 == 0) mine = __hip_atomic_exchange(stamp + hrow, sr.epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sr.epoch ? 1 : 0;
+  float4 pp = *reinterpret_cast<const float4*>(p + off);
+  float4 mm = *reinterpret_cast<const float4*>(m + off);
+  float4 vv = *reinterpret_cast<const float4*>(v + off);
+  const int h0 = head[hrow];
+  const int hs = hot.slot ? hot.slot[hrow] : -1;
+  mine = __shfl(mine, (threadIdx.x & 63) / tpr * tpr);
+  if (mine == 0) return;  // another entry of the feed names the same row and got there first
+  float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (h0 >= 0) {
+    int len;
+    gg = list_gradient<false>(h0, next, contrib, nullptr, max_entries, d, c4, len);
+    if (c4 == 0) {
+      head[hrow] = -1;
+      if (hot.slot && hs < 0) hot_promote(hot, hrow, len);
+    }
+  }
+  if (hs >= 0) {   // a hot row: its contributions of this step sit in its accumulators
+    const float4 acc = hot_take(hot, hs, d, c4);
+    gg.x += acc.x;
+    gg.y += acc.y;
+    gg.z += acc.z;
+    gg.w += acc.w;
+  }
+  opt_update<GQE_OPT_ADAM>(pp, mm, vv, gg, t.step_size[lt], t.bc2_sqrt[lt], lr, b1, b2, eps);
+  *reinterpret_cast<float4*>(m + off) = mm;
+  *reinterpret_cast<float4*>(v + off) = vv;
+  *reinterpret_cast<float4*>(p + off) = pp;
+}
+
+hipError_t gqe_launch_split_rows(const GqeOptArgs& a, const GqeGemmRide& r, const GqeSplitSegs& segs, const GqeSplitRide& ride, const int32_t* idx,
+                                 int32_t* stamp) {
+  if (a.d < 4 || (64 % (a.d >> 2)) != 0) return hipErrorInvalidValue;
+  const long long threads = (long long)segs.total * (a.d >> 2);
+  const int row_blocks = (int)((threads + GQE_THREADS - 1) / GQE_THREADS);
+  const unsigned dense_blocks = (unsigned)(a.total_chunks < 512 ? a.total_chunks : 512);
+  static const int dbg = [] {   // GQE_SPLIT_DEBUG_B (timing experiments, WRONG results): 1 = without the GEMM units, 2 = without the named rows
+    const char* e = getenv("GQE_SPLIT_DEBUG_B");
+    return e ? atoi(e) : 0;
+  }();
+  GqeGemmRide r2 = r;
+  int rb = row_blocks;
+  if (dbg & 1) r2.plan.units = 0;
+  if (dbg & 2) rb = 0;
+  // one wave per (rider, wave) pair of the fused launch: it continues where that wave stopped
+  const int riders = (ride.blocks > 0 && ride.stop) ? (ride.blocks * ride.waves + GQE_WAVES - 1) / GQE_WAVES : 0;   // (riders that do not stop leave nothing)
+  const unsigned blocks = (unsigned)(r2.plan.units + 1) + (unsigned)rb + (unsigned)riders + dense_blocks;
+  hipLaunchKernelGGL(gqe_split_rows_kernel, dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.n_segs, a.total_chunks, a.p, a.g, a.m, a.v, a.head,
+                     a.next, a.contrib, a.max_entries, a.d, a.lr, a.b1, a.b2, a.eps, a.coef, a.active, a.act, a.n_act, a.hot, r2, segs, ride, idx, stamp,
+                     rb, riders);
   return hipGetLastError();
 }
 

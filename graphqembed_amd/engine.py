@@ -117,6 +117,9 @@ SYMBOLS = OrderedDict([
     ("gqe_margin_fwd_bwd", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P, _P, _P])),
     ("gqe_allreduce_grads", (C.c_int, [_P, _P, _P])),
     ("gqe_adam_step", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P])),
+    ("gqe_train_step", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, C.POINTER(gqe_segment), C.c_int32,
+                                  C.c_float, C.c_float, C.c_float, C.c_float, _P, _P])),
+    ("gqe_split_steps", (C.c_int64, [_P])),
     ("gqe_sgd_step", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, C.c_float, _P])),
     ("gqe_zero_grads", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, _P])),
     ("gqe_feeder_create", (C.c_int, [_P, C.c_uint64, C.c_int32, C.c_float, C.c_float, C.POINTER(_P)])),
@@ -277,7 +280,8 @@ class Engine(object):
 
     # the arenas as the caller sees them: in lazy-Adam mode rows may owe deferred steps until synchronised
     def sync(self):
-        if self.lazy_adam and self.workspace is not None:
+        """gqe_optimizer_sync: lazy Adam's deferred row steps, and the matrix step a split train_step left for the next call."""
+        if self.workspace is not None and getattr(self, "ctx", None):
             self._check(self.lib.gqe_optimizer_sync(self.ctx, self._stream()))
 
     @property
@@ -615,6 +619,33 @@ class Engine(object):
         """step <= 0 in the prepared segments: libgqe keeps the per-tensor Adam step counters."""
         self._check(self.lib.gqe_adam_step(self.ctx, pa["arr"], pa["n"], lr, betas[0], betas[1], eps,
                                            stream if stream is not None else self._stream()))
+
+    def run_train_step(self, ps, pa, lr=0.01, betas=(0.9, 0.999), eps=1e-8, stream=None):
+        """gqe_train_step on a prepared margin batch + prepared Adam segments (library-kept step counters): one call per
+        iteration — run_margin + run_adam with the step's work ordered by the library (include/gqe.h)."""
+        self._check(self.lib.gqe_train_step(self.ctx, ps["arr"], ps["n"], ps["idx_ptr"], ps["n_idx"], 1, pa["arr"], pa["n"],
+                                            lr, betas[0], betas[1], eps, ps["losses"].data_ptr(),
+                                            stream if stream is not None else self._stream()))
+
+    def train_step(self, descs, idx, keys, lr=0.01, betas=(0.9, 0.999), eps=1e-8, losses=None):
+        """gqe_train_step: margin_fwd_bwd(descs, idx) + adam_step(keys) as one library call; returns losses[n + 1]."""
+        total = sum(dsc["n"] for dsc in descs)
+        self.reserve(total, len(descs))
+        arr = self.make_batches(descs)
+        keep, ptr, n_idx, on_dev = self._idx_arg(idx)
+        t = self.torch
+        if losses is None:
+            losses = t.empty(len(descs) + 1, dtype=t.float32, device=self.device)
+        keys = [k for k in self.layout.entries if k in set(keys)]   # arena order
+        segs = self._segments(keys, True)
+        self._check(self.lib.gqe_train_step(self.ctx, arr, len(descs), ptr, n_idx, on_dev, segs, len(keys), lr, betas[0], betas[1], eps,
+                                            losses.data_ptr(), self._stream()))
+        self._held_losses = losses
+        return losses
+
+    def split_steps(self):
+        """How many train_step calls ran as split steps so far (gqe_split_steps)."""
+        return int(self.lib.gqe_split_steps(self.ctx))
 
     def materialize_tables(self, keys):
         """gqe_materialize_tables: fold the pending gradient lists of the listed tables only into the dense arena."""

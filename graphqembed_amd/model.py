@@ -6,7 +6,8 @@ Same constructor and the same two public methods as the reference:
     .margin_loss(formula, queries, hard_negatives=False, margin=1) -> 0-dim loss
 (``loss.backward()`` / ``optimizer.step()`` keep working), plus the fused fast path the
 trainer uses:
-    .margin_step(items)   all (formula, slice) batches of an iteration in ONE grouped launch.
+    .margin_step(items)   all (formula, slice) batches of an iteration in ONE grouped launch;
+    .train_step(items, optimizer)   the same + the FusedAdam step as one library call (gqe_train_step).
 
 What differs is where the arithmetic happens: parameters are re-homed into one flat fp32
 arena in HBM and every score / gradient is produced by libgqe.so's HIP kernels
@@ -170,6 +171,24 @@ class QueryEncoderDecoder(nn.Module):
         for p in packed:
             self._mark_touched(p[0].touched)
         return out
+
+    def train_step(self, items, optimizer, idx_device=None):
+        """``margin_step(items)`` + ``optimizer.step()`` (a ``FusedAdam``) as ONE library call, gqe_train_step (include/gqe.h):
+        the iteration of train_helpers.py:76-79.  Knowing the optimiser step when the forward / backward is enqueued lets the
+        library run Adam over the rows the batches do not name inside the fused launch ("split step").  Returns
+        losses[len(items) + 1] (device tensor).  The d x d matrices' step is enqueued by the next library call (every entry
+        point settles it; ``state_dict()`` / ``sync()`` do so before values are read through the ``nn.Parameter`` views)."""
+        if not isinstance(optimizer, FusedAdam) or optimizer.model is not self:
+            raise Exception("train_step needs this model's FusedAdam")
+        packed = [(self.plan(f), t, ng, a, w, m) for (f, t, ng, a, w, m) in items]
+        descs, idx, _ = pack_margin_batches(packed)
+        keys = set(self._touched)          # (gradients an earlier margin_loss / margin_step left behind are stepped too)
+        for p in packed:
+            keys.update(p[0].touched)
+        losses = self.engine.train_step(descs, idx if idx_device is None else idx_device, keys, optimizer.lr, optimizer.betas, optimizer.eps)
+        self._mark_touched(keys)
+        optimizer._done()
+        return losses
 
     def forward_candidates(self, formula, queries, candidate_nodes):
         """Scores of every node of ``candidate_nodes[i]`` as the target of ``queries[i]`` — the fused

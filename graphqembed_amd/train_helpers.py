@@ -26,7 +26,7 @@ from collections import namedtuple
 import numpy as np
 import torch
 
-from .model import _FusedOptimizer
+from .model import FusedAdam, _FusedOptimizer
 from .tensorize import reference_negative_nodes
 from .utils import eval_auc_queries, eval_perc_queries
 
@@ -105,8 +105,11 @@ class LossAverage(object):
 class FusedExecutor(object):
     """The iteration's batches become index arrays; ``finish`` runs them in one grouped launch."""
 
-    def __init__(self, model):
+    def __init__(self, model, optimizer=None):
+        """``optimizer``: a FusedAdam — ``finish`` then runs the iteration's forward / backward AND its optimiser step as one
+        library call (model.train_step: gqe_train_step), and the loop's ``optimizer.step()`` finds nothing left to do."""
         self.model = model
+        self.optimizer = optimizer if isinstance(optimizer, FusedAdam) else None
         self.items = []
 
     def begin(self):
@@ -119,7 +122,10 @@ class FusedExecutor(object):
         self.items.append((formula, target, m.enc.rows(negatives, formula.target_mode), anchors, weight, 1.0))
 
     def finish(self):
-        losses, _, _ = self.model.margin_step(self.items)
+        if self.optimizer is not None:
+            losses = self.model.train_step(self.items, self.optimizer)
+        else:
+            losses, _, _ = self.model.margin_step(self.items)
         return float(losses[-1].item())
 
 
@@ -173,7 +179,7 @@ def _macro(scores):
 def run_train(model, optimizer, train_queries, val_queries, test_queries, logger,
               max_burn_in=100000, batch_size=512, log_every=100, val_every=1000, tol=1e-6,
               max_iter=int(10e7), inter_weight=0.005, path_weight=0.01, model_file=None):
-    executor = FusedExecutor(model) if isinstance(optimizer, _FusedOptimizer) else EagerExecutor(model)
+    executor = FusedExecutor(model, optimizer) if isinstance(optimizer, _FusedOptimizer) else EagerExecutor(model)
     plateau = Plateau()        # ``tol`` is accepted but, as in the reference (its convergence test is called with the
                                # defaults, train_helpers.py:52,73), not used
     average = LossAverage()

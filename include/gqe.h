@@ -404,6 +404,31 @@ int gqe_allreduce_grads(gqe_ctx* ctx, void* nccl_comm, void* stream);
  * over the listed segments only. */
 int gqe_adam_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs,
                   float lr, float beta1, float beta2, float eps, void* stream);
+/* replaces: one whole iteration of run_train's loop body — optimizer.zero_grad(); loss = run_batch(...) [model.margin_loss];
+ * loss.backward(); optimizer.step() (train_helpers.py:76-79 with torch.optim.Adam, bio/train.py:62) — as ONE call:
+ * gqe_margin_fwd_bwd(batches, idx, losses) followed by gqe_adam_step(segs, lr, beta1, beta2, eps), same arguments, same result.
+ * Knowing the optimiser step when the forward / backward is enqueued lets the library order the step's work by what depends on
+ * what instead of by call ("split step"): a dense Adam step moves every row of every stepped table, the batches
+ * name 15-20 % of them, and the update of a row the batches do not name depends on nothing the forward / backward produces.  The
+ * step becomes
+ *     launch M  Adam on the d x d matrices of the PREVIOUS gqe_train_step  +  a stamp on every table row this step's feed names
+ *     launch A  the fused forward / backward tiles  |  Adam (zero gradient) over every row without a stamp, in the same launch
+ *     launch B  loss finalize + matrix-gradient units  |  Adam over the stamped rows (gradient lists / hot accumulators)  |  the
+ *               relation vectors
+ * — every element gets exactly the arithmetic of gqe_adam_step (the oracle tests run through both).
+ * losses[] is defined when the call's work has completed on `stream`, as for gqe_margin_fwd_bwd.
+ * THE CONTRACT that differs from the two calls: the Adam step of the d x d matrices (Pre / Post, full-Bilinear relation matrices)
+ * is enqueued by the NEXT gqe_train_step, or by whatever other entry point of the library comes first (every one of them
+ * settles it: gqe_forward, gqe_margin_fwd_bwd, the optimiser calls, gqe_materialize_grads, gqe_optimizer_sync, ...).  A caller
+ * that reads the parameter or moment arenas itself — a checkpoint, an evaluation of its own — calls gqe_optimizer_sync first.
+ * Where the split does not apply the call runs the two-call sequence (with the matrix-gradient units riding in the Adam pass as
+ * under gqe_set_deferred_gemm when that applies): lazy Adam, gqe_set_exchange / gqe_set_shard, ordered sums, bag tables, tables
+ * beyond the Infinity Cache, gradients already pending from an earlier gqe_margin_fwd_bwd, dims whose kernels are not the
+ * straight-line ones (d % 64 != 0), more than GQE_LAUNCH_BATCHES batches or 8 stepped tables.  GQE_SPLIT=0 in the environment
+ * forces that sequence.  gqe_split_steps: how many calls ran as split steps (diagnostics, tests). */
+int gqe_train_step(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx, int32_t idx_on_device,
+                   const gqe_segment* segs, int32_t n_segs, float lr, float beta1, float beta2, float eps, float* losses, void* stream);
+int64_t gqe_split_steps(gqe_ctx* ctx);
 /* replaces: torch.optim.SGD(momentum=0).step() + zero_grad (bio/train.py:60) */
 int gqe_sgd_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, float lr, void* stream);
 /* replaces: optimizer.zero_grad() alone */

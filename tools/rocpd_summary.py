@@ -22,6 +22,24 @@ def main(path):
     print("%-60s %9s %5s %7s %7s %5s %5s %5s %10s %10s %10s %6s" % ("kernel", "grid", "wg", "lds", "scratch", "vgpr", "agpr", "sgpr", "min_ns", "avg_ns", "max_ns", "n"))
     for r in cur.execute(q):
         print("%-60s %9d %5d %7d %7d %5d %5d %5d %10d %10.0f %10d %6d" % ((r[0][:60],) + tuple(r[1:])))
+    # the stream's timeline in steady state: per kernel, the median duration and the median gap between the previous dispatch's
+    # end and this dispatch's start (the last 60 % of the dispatches: warm-up and initialisation kernels stay out of the medians)
+    try:
+        disp = list(cur.execute("select name, start, end from kernels order by start"))
+    except sqlite3.Error:
+        disp = []
+    if len(disp) > 20:
+        import statistics
+        tail = disp[int(len(disp) * 0.4):]
+        per = {}
+        for prev, d in zip(tail[:-1], tail[1:]):
+            per.setdefault(d[0], []).append((d[2] - d[1], d[1] - prev[2]))
+        print()
+        print("# steady state (last 60 %% of %d dispatches): median duration and median idle gap in front of each kernel, ns" % len(disp))
+        print("%-60s %8s %12s %12s" % ("kernel", "n", "duration", "gap_before"))
+        for name, v in sorted(per.items(), key=lambda kv: -sum(x[0] for x in kv[1])):
+            if len(v) >= 10:
+                print("%-60s %8d %12.0f %12.0f" % (name[:60], len(v), statistics.median(x[0] for x in v), statistics.median(x[1] for x in v)))
     try:
         rows = list(cur.execute("select * from counters_collection limit 1"))
         cols = [d[0] for d in cur.description]
