@@ -245,6 +245,12 @@ class Workload(object):
             ps["longest_list"] = int(max(int(c.max()) for c in per_row.values()))
             ps["rows_over_32"] = int(sum(int((c > 32).sum()) for c in per_row.values()))
             ps["p_touched"] = p_tab + p_den
+            ps["p_tab"], ps["rows_tab"] = p_tab, rows_tab
+            ps["p_mat"] = sum(eng.layout.numel(k) for k in keys if not k.startswith("enc.") and eng.layout.numel(k) == d * d)
+            ps["p_vec"] = p_den - ps["p_mat"]
+            # rows of the stepped plain tables the iteration's feed names at least once (the split step: stepped by its second launch)
+            ps["named_rows"] = int(sum(int((c > 0).sum()) for mode, c in per_row.items() if mode not in bag_len))
+            ps["direct"], ps["links"] = direct, links
             # the fused Adam pass: p, m, v of every table parameter in and out; p, g, m, v in / p, m, v, g := 0 out for the
             # relation / Pre / Post tensors; one list head per table row; per contribution on a row its vector, its link
             # and the head reset; per word link of a bag contribution the vector again, the link and the entry id
@@ -260,7 +266,65 @@ EVENT_NOTE = ("avg_launch_ms = mean time between the two hipEvents the library r
               "(profiles/, null for configurations that were not profiled)")
 
 
-def kernel_block(eng, prepared, used, ms_per_step, lazy=False, world=1, d=128, tag=None, deferred=False):
+def split_block(eng, used, ms_per_step, d, tag, ms_a, n_a, ms_m, n_m, ms_b, n_b):
+    """roofline / kernels / step_roofline of the split step (gqe_train_step, csrc/gqe_split.h).  Its three launches:
+      M  gqe_prestep_kernel     Adam on the previous step's d x d matrices + the stamps of the rows this step's feed names
+      A  gqe_fused_kernel       the forward / backward tiles | rider workgroups: Adam over every row the feed does not name
+      B  gqe_split_rows_kernel  loss finalize + matrix-gradient units | Adam over the named rows (gradient lists) | the vectors
+    Bytes each launch has to move (per iteration, averaged over the iterations used):
+      A  A_q of the tiles + 24 B per parameter of an unnamed row + 4 B stamp per table row
+      B  24 B per parameter of a named row + per contribution its vector, link, head and index + the stamp exchanges +
+         32 B per vector parameter + the units' operand rows
+      M  32 B per matrix parameter + its two operand-ordered copies (8 B) + index and stamp per feed entry"""
+    mean = lambda k: float(np.mean([p[k] for p in used]))
+    a_q, ff, gf = mean("aq_bytes"), mean("fused_flops"), mean("gemm_flops")
+    rows_tab, named, direct = mean("rows_tab"), mean("named_rows"), mean("direct")
+    riders = 24.0 * d * (rows_tab - named) + 4.0 * rows_tab
+    a_bytes = a_q + riders
+    b_bytes = 24.0 * d * named + direct * (4.0 * d + 8.0 + 4.0 + 4.0 + 8.0) + 32.0 * mean("p_vec") + gf * 4.0 / d
+    m_bytes = 40.0 * mean("p_mat") + 8.0 * direct
+    a_pass = mean("opt_bytes")                                     # the dense Adam step's bytes, as every other mode prices them
+    rp = (lambda k: rocprof_ms(k, tag)) if tag else (lambda k: None)
+    rp_a, rp_b, rp_m = rp("gqe_fused_kernel"), rp("gqe_split_rows_kernel"), rp("gqe_prestep_kernel")
+    gbs = lambda b, ms: round(b / (ms * 1e-3) / 1e9, 1) if ms and ms > 0 else None
+    achieved = gbs(a_bytes, ms_a) or 0.0
+    return {
+        "roofline": {"bound": "hbm",
+                     "kernel": ("gqe_fused_kernel with rider workgroups (gqe_train_step's split step): the forward / backward tiles of the "
+                                "iteration + Adam over every table row its batches do not name, in ONE launch; bytes = the tiles' A_q + "
+                                "24 B per parameter of the unnamed rows + their stamps"),
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": a_bytes, "riders_bytes_per_launch": riders, "tiles_bytes_per_launch": a_q,
+                     "avg_launch_ms": round(ms_a, 5), "launches": n_a, "rocprof_avg_launch_ms": rp_a,
+                     "frac_at_rocprof_duration": round(a_bytes / (rp_a * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if rp_a else None,
+                     "regime": ("p / m / v of the stepped tables (%.0f MB) sit inside the 256 MB Infinity Cache: a plain float4 read-modify-write of "
+                                "the same footprint reaches 7.7-8.2 TB/s here (tools/probes/rider_probe.hip), so a fraction near 0.8 is the ceiling "
+                                "of this regime, not of HBM; beyond the cache (reddit-synth) the optimiser pass is the HBM-bound kernel"
+                                % (12.0 * mean("p_tab") / 1e6)),
+                     "survey_bytes_per_launch": None},
+        "kernels": {"timing_note": EVENT_NOTE,
+                    "sum_of_event_brackets_ms": round(ms_a + ms_b + ms_m, 5),
+                    "sum_of_rocprof_durations_ms": round(rp_a + rp_b + rp_m, 5) if (rp_a and rp_b and rp_m) else None,
+                    "fused_fwd_bwd": {"avg_launch_ms": round(ms_a, 5), "rocprof_avg_launch_ms": rp_a, "launches": n_a, "algorithmic_bytes_per_launch": a_bytes,
+                                      "achieved_GBs": achieved, "carries": "rider workgroups: Adam over the rows the iteration does not name",
+                                      "mfma_flop_per_launch": ff, "mfma_TFs": round(ff / (ms_a * 1e-3) / 1e12, 2) if ms_a > 0 and ff else None,
+                                      "mfma_frac_of_f32_peak": round(ff / (ms_a * 1e-3) / 1e12 / MFMA_F32_TFS, 4) if ms_a > 0 and ff else None},
+                    "named_rows_and_pair_gemm": {"kernel": "gqe_split_rows_kernel: loss finalize + matrix-gradient units | Adam over the named rows | vectors",
+                                                 "avg_launch_ms": round(ms_b, 5), "rocprof_avg_launch_ms": rp_b, "launches": n_b,
+                                                 "algorithmic_bytes_per_launch": b_bytes, "achieved_GBs": gbs(b_bytes, ms_b),
+                                                 "mfma_flop_per_launch": gf, "mfma_TFs": round(gf / (ms_b * 1e-3) / 1e12, 2) if ms_b > 0 and gf else None},
+                    "pair_gemm": {"rides_in": "named_rows_and_pair_gemm (the split step's second launch): no launch of its own", "mfma_flop_per_launch": gf,
+                                  "matrix_step_launch": {"kernel": "gqe_prestep_kernel: Adam on the previous step's d x d matrices + the stamps of this step's named rows",
+                                                         "avg_launch_ms": round(ms_m, 5), "rocprof_avg_launch_ms": rp_m, "launches": n_m,
+                                                         "algorithmic_bytes_per_launch": m_bytes}}},
+        "step_roofline": {"algorithmic_bytes_per_step": a_pass + a_q,
+                          "achieved_GBs": round((a_pass + a_q) / (ms_per_step * 1e-3) / 1e9, 1),
+                          "frac": round((a_pass + a_q) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+
+
+def kernel_block(eng, prepared, used, ms_per_step, lazy=False, world=1, d=128, tag=None, deferred=False, train_step=False):
     """roofline / kernels / step_roofline from the library's hipEvent timings of the timed region.  ``tag``: the workload
     whose committed rocprofv3 trace this configuration corresponds to (None: not profiled).  ``deferred``:
     gqe_set_deferred_gemm is on — where the library let the pair-GEMM units ride in the Adam pass's launch, bracket 2 is that
@@ -268,6 +332,8 @@ def kernel_block(eng, prepared, used, ms_per_step, lazy=False, world=1, d=128, t
     ms_fused, n_fused = eng.timing_read(0)
     ms_gemm, n_gemm = eng.timing_read(1)
     ms_opt, n_opt = eng.timing_read(2)
+    if train_step and eng.split_steps() > 0:
+        return split_block(eng, used, ms_per_step, d, tag, ms_fused, n_fused, ms_gemm, n_gemm, ms_opt, n_opt)
     rides = bool(deferred) and eng.gemm_rides()
     a_opt = float(np.mean([p["opt_bytes"] for p in used]))
     survey = 32.0 * float(np.mean([p["p_touched"] for p in used]))
@@ -282,6 +348,7 @@ def kernel_block(eng, prepared, used, ms_per_step, lazy=False, world=1, d=128, t
     a_pass = a_opt
     if rides:   # the launch also reads every (left, right) scratch row of the step's matrix-gradient jobs once: 8 B per MFMA-contracted pair and column
         a_opt += gf * 4.0 / d
+        a_opt -= 32.0 * float(np.mean([p["p_mat"] for p in used]))   # ... and the d x d matrices are stepped by gqe_matstep_kernel, not by this launch
     achieved = a_opt / (ms_opt * 1e-3) / 1e9 if ms_opt > 0 else 0.0
 
     def tfs(flops, ms):
@@ -374,11 +441,14 @@ def summarize(times, steps):
                  "block_ms_max": round(max(times) * 1e3, 4), "steps_per_block": steps}
 
 
-def make_step(eng, prepared, dist, exchange, n_distinct, ex_events=None):
+def make_step(eng, prepared, dist, exchange, n_distinct, ex_events=None, train_step=False):
     from graphqembed_amd import parallel
 
     def step(i):
         ps = prepared[i % n_distinct]
+        if train_step:                                             # the whole iteration as one library call (gqe_train_step)
+            eng.run_train_step(ps, ps["adam"])
+            return
         eng.run_margin(ps)
         if eng.lazy_adam and dist is None:                         # the next iteration's rows ride in this step's row launch
             eng.lazy_prefetch(prepared[(i + 1) % n_distinct])
@@ -422,12 +492,16 @@ def measure(wl, args, dist, rank, world, exchange="sparse", lazy=False, steps=No
     # matrix-gradient units may ride in the Adam pass's launch (include/gqe.h, gqe_set_deferred_gemm; the library falls back
     # to the separate launch wherever riding does not apply: lazy Adam, tables beyond the Infinity Cache, > 1024 units)
     deferred = world == 1 and not lazy and os.environ.get("GQE_BENCH_NO_DEFERRED_GEMM") is None
+    # ... and as ONE call per iteration, gqe_train_step: the library then runs Adam over the rows the batches do not name inside
+    # the fused launch (the split step, csrc/gqe_split.h) wherever that applies, and the two-call sequence elsewhere.
+    # GQE_BENCH_TWO_CALLS=1 measures gqe_margin_fwd_bwd + gqe_adam_step (round 4's headline step).
+    train_step = deferred and os.environ.get("GQE_BENCH_TWO_CALLS") is None
     if deferred:
         eng.set_deferred_gemm(True)
     prepared = wl.prepare(eng, dist)
     session = parallel.shard_session(eng, dist, rank, world) if sharded else None
     ex_events = [] if (dist is not None and not sharded) else None
-    step = make_step(eng, prepared, dist, exchange, wl.n_distinct, ex_events)
+    step = make_step(eng, prepared, dist, exchange, wl.n_distinct, ex_events, train_step=train_step)
     loop = Loop(eng, dist, world)
     times = loop.run(step, warmup, steps, min_seconds=min_seconds)
     med, blocks = summarize(times, steps)
@@ -436,7 +510,9 @@ def measure(wl, args, dist, rank, world, exchange="sparse", lazy=False, steps=No
     out = {"value": round(steps * wl.qpi * world / med, 1), "unit": "queries/s", "ms_per_step": round(ms_per_step, 4), "timing": blocks}
     profiled = (wl.d, wl.B, wl.decoder, wl.inter, wl.zipf, len(wl.mix)) == ((256 if wl.name == "reddit-synth" else 128), 512, "bilinear-diag", "min", None, 9)
     out.update(kernel_block(eng, prepared, used, ms_per_step, lazy=lazy, world=world if sparse else 1, d=wl.d,
-                            tag=wl.name if (profiled and world == 1) else None, deferred=deferred))
+                            tag=wl.name if (profiled and world == 1) else None, deferred=deferred, train_step=train_step))
+    out["step_form"] = ("split" if eng.split_steps() > 0 else "two-call sequence inside gqe_train_step") if train_step else "two calls"
+    eng.sync()
     out["longest_gradient_list"] = int(max(p["longest_list"] for p in used))
     out["rows_with_over_32_contributions"] = int(max(p["rows_over_32"] for p in used))
     eng.timing_enable(0)
@@ -618,7 +694,7 @@ def slim(res):
     """A secondary measurement as it appears in the JSON line: the headline figures + per-kernel launch times."""
     k = res["kernels"]
     out = {"value": res["value"], "unit": "queries/s", "ms_per_step": res["ms_per_step"], "timing": res["timing"],
-           "final_loss": res["final_loss"],
+           "final_loss": res["final_loss"], "step_form": res.get("step_form"),
            "kernels_ms": {("matrix_step (pair GEMM / loss finalize ride in the optimiser launch)" if "matrix_step_launch" in v else name):
                           ((v["matrix_step_launch"] or {"avg_launch_ms": None}) if "matrix_step_launch" in v else v)["avg_launch_ms"]
                           for name, v in k.items() if isinstance(v, dict)},
@@ -715,7 +791,8 @@ def main():
     sparse = world > 1 and args.exchange == "sparse"
     sharded = world > 1 and args.exchange == "sharded"
     res["roofline"]["traffic"] = None if (world > 1 or args.lazy_adam or (d, B, args.decoder, args.inter_decoder) != ((256 if reddit else 128), 512, "bilinear-diag", "min")) \
-        else pmc_traffic("gqe_opt_gemm_kernel" if res["roofline"]["kernel"].startswith("gqe_opt_gemm_kernel") else "gqe_opt_kernel", args.workload)
+        else pmc_traffic("gqe_fused_kernel" if res["roofline"]["kernel"].startswith("gqe_fused_kernel") else
+                         "gqe_opt_gemm_kernel" if res["roofline"]["kernel"].startswith("gqe_opt_gemm_kernel") else "gqe_opt_kernel", args.workload)
     label = "Reddit" if reddit else "Bio"
     out = {
         "metric": "queries/sec, %s full conjunctive mix d=%d, at 1/2/4/8 MI355X" % (label, d),
@@ -728,7 +805,11 @@ def main():
                    "graph": wl.describe(), "queries_per_step_per_gpu": wl.qpi, "parallelism": "dp%d" % world,
                    "backend": None if world == 1 else backend,
                    "optimizer": "lazy (deferred, bit-exact) Adam — NON-DEFAULT mode" if args.lazy_adam else "eager dense Adam",
-                   "step_launches": ("fused forward/backward | Adam pass with the pair-GEMM units and the loss finalize in front of its chunks "
+                   "step_call": "gqe_train_step (one library call per iteration)" if res.get("step_form", "two calls") != "two calls" else "gqe_margin_fwd_bwd + gqe_adam_step",
+                   "step_launches": ("previous step's matrices + row stamps | fused forward/backward tiles WITH Adam over the rows the batches do not name "
+                                     "(rider workgroups) | loss finalize + pair-GEMM units + Adam over the named rows and the vectors  (the split step of "
+                                     "gqe_train_step, csrc/gqe_split.h)" if res["roofline"]["kernel"].startswith("gqe_fused_kernel") else
+                                     "fused forward/backward | Adam pass with the pair-GEMM units and the loss finalize in front of its chunks "
                                      "(gqe_set_deferred_gemm) | Adam on the d x d matrices" if res["roofline"]["kernel"].startswith("gqe_opt_gemm_kernel")
                                      else "fused forward/backward | pair GEMM + loss finalize | [exchange] | Adam pass"),
                    "gradient_exchange": "none" if world == 1 else
@@ -835,6 +916,14 @@ def main():
         out["cpu_baseline"] = cpu_baseline(eng, args.decoder, args.inter_decoder, wl.item_sets[:8], args.cpu_seconds, wl.qpi)
     elif rank == 0:
         out["cpu_baseline"] = None
+    # the keys the driver's record keeps verbatim are the contract's + roofline + cpu_baseline: what a reader of that record should
+    # not have to dig for rides in `roofline` as well
+    out["roofline"]["step"] = dict(out["step_roofline"], ms_per_step=out["ms_per_step"], note="whole step: bytes the step has to move / ms_per_step")
+    if out.get("host_fed"):
+        hf = out["host_fed"]
+        out["roofline"]["host_fed"] = {"resident_feed_value": out["value"], "pinned_host_memory_read_by_the_kernels": hf.get("value"),
+                                       "pinned_hipMemcpyAsync": (hf.get("pinned_hipMemcpyAsync") or {}).get("value"), "unit": "queries/s",
+                                       "note": "the same schedule with sampling + packing + the feed's transport inside the timed region (gqe_feeder_run)"}
     if rank == 0:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:

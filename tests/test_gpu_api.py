@@ -177,6 +177,13 @@ def test_run_train_reproduces_the_reference_run(dec, inter, d):
         seen.append((items, out[0]))
         return out
     model.margin_step = spy
+    orig_step = model.train_step       # (run_train with a FusedAdam runs the iteration as ONE call: margin_step + optimizer.step)
+
+    def spy_step(items, optimizer, **kw):
+        out = orig_step(items, optimizer)
+        seen.append((items, out))
+        return out
+    model.train_step = spy_step
 
     class Log(object):
         lines = []
