@@ -893,7 +893,82 @@ def test_lazy_adam_with_a_bag_mode():
         e.close()
 
 
-def _full_size_vs_oracle(workload, d, dec, inter, min_params, n_relations, zipf=None, min_longest_list=0):
+def _second_step_vs_oracle(eng, wl, items, descs, didx, n, keys, dec, inter, mode):
+    """One more iteration on the same batches, stepped the way ``mode`` says ("two-call": gqe_margin_fwd_bwd + gqe_adam_step;
+    "deferred": the same with gqe_set_deferred_gemm — the pair-GEMM units ride in the Adam pass; "train-step": gqe_train_step —
+    the split step where it applies), and the PARAMETERS AFTER IT against the oracle: O.adam_step (fp64) on the oracle's gradient at
+    the device's parameters / moments of the moment.  Rows the iteration names, vectors, matrices: elements whose gradient is
+    signal (|g| > 1e-4 max|g|, or exactly 0) within 2e-3 of the lr-sized move, at most 0.2 % of them on the other side of a relu /
+    arg-min decision; rows it does not name: the zero-gradient Adam formula to 1e-4 of the move (v_sqrt_f32 / v_rcp_f32 are 1 ulp)."""
+    import torch
+    entries = eng.layout.entries
+    # (the caller folded the lists with gqe_materialize_grads: until a pass consumes them the tables' DENSE gradients are
+    # authoritative, and a step that has to read them neither splits nor carries riding units — consume them)
+    eng.zero_grads(list(entries))
+    torch.cuda.synchronize()
+
+    def host(flat):
+        h = flat.cpu().numpy()
+        return {k: h[off:off + int(np.prod(shape))].reshape(shape).astype(np.float64) for k, (off, shape) in entries.items()}
+    before, m0, v0 = host(eng.params), host(eng.exp_avg), host(eng.exp_avg_sq)
+    oparams = dict(before)
+    oparams[O.BAGS_KEY] = {m: csr for m, csr in wl.g.bags.items()}
+    ograds = {k: np.zeros(v.shape, dtype=np.float64) for k, v in before.items()}
+    ograds[O.BAGS_KEY] = oparams[O.BAGS_KEY]
+    want_l = []
+    for (f, t, ng, a, w, m) in items:
+        l, _, _, _ = O.margin_fwd_bwd(oparams, O.make_plan(f.query_type, f.rels), dec, inter, t, ng, a, margin=m, weight=w, grads=ograds)
+        want_l.append(l)
+    steps = {k: int(eng.steps[k]) for k in keys}
+    ostate = {k: {"step": steps[k], "m": m0[k].copy(), "v": v0[k].copy()} for k in keys}
+    expect = {k: before[k].copy() for k in keys}
+    O.adam_step(expect, ograds, ostate, keys)
+    rides0, splits0 = eng.gemm_rides(), eng.split_steps()
+    if mode == "deferred":
+        eng.set_deferred_gemm(True)
+    if mode == "train-step":
+        losses = eng.train_step(descs, didx, keys)
+    else:
+        losses, _, _ = eng.margin_fwd_bwd(descs, didx, n)
+        eng.adam_step(keys)
+    np.testing.assert_allclose(losses.cpu().numpy()[:-1], want_l, rtol=LOSS_RTOL, err_msg=mode)
+    after = host(eng.params)
+    for k in sorted(keys):
+        g = np.abs(ograds[k])
+        move = np.abs(expect[k] - before[k])
+        diff = np.abs(after[k] - expect[k])
+        if k.startswith("enc.") and k not in eng.bag_keys:
+            named = g.reshape(g.shape[0], -1).max(axis=1) > 0
+            quiet = ~named
+            assert quiet.sum() > 100 and named.sum() > 100, k
+            # (a named row whose contributions cancel to an exact 0 in the oracle keeps ~1e-13 of cancellation noise on the
+            # device, and Adam turns g / (|g| + eps) into a visible fraction of lr: 1e-5 absolute covers it; rows the feed does
+            # not name at all are held BIT-equal to the eager pass in tests/test_gpu_split.py)
+            assert (diff[quiet] <= 1e-4 * move[quiet] + 1e-5).all(), (mode, k, float(diff[quiet].max()))
+            assert np.median(diff[quiet]) <= 1e-9, (mode, k, float(np.median(diff[quiet])))
+            g, move, diff = g[named], move[named], diff[named]
+        signal = (g == 0) | (g > 1e-4 * g.max())
+        bad = signal & (diff > 2e-3 * move + 2e-7)
+        assert bad.sum() <= max(2, 2e-3 * signal.sum()), (mode, k, int(bad.sum()), int(signal.sum()), float(diff[signal].max()))
+    for k in set(after) - set(keys):
+        assert np.array_equal(after[k], before[k]), (mode, k)
+    eng.materialize()
+    assert float(eng.grads.abs().max()) == 0.0
+    if mode == "deferred" and d_rides(eng):
+        assert eng.gemm_rides() == rides0 + 1, "the pair GEMM was expected to ride in the Adam pass"
+    if mode == "train-step" and not eng.bag_keys and eng.dim % 64 == 0:
+        assert eng.split_steps() == splits0 + 1, "gqe_train_step was expected to run as a split step"
+    if mode == "deferred":
+        eng.set_deferred_gemm(False)
+
+
+def d_rides(eng):
+    """can this engine's Adam pass carry the pair-GEMM units?  (d % 64 == 0, tables inside the Infinity Cache: include/gqe.h)"""
+    stream = 12 * sum(int(np.prod(shape)) for k, (off, shape) in eng.layout.entries.items() if k.startswith("enc."))
+    return eng.dim % 64 == 0 and stream <= (192 << 20)
+
+
+def _full_size_vs_oracle(workload, d, dec, inter, min_params, n_relations, zipf=None, min_longest_list=0, mode="two-call"):
     """One full-mix iteration (9 x 512 queries, ONE grouped launch, index feed resident in HBM) of a BASELINE workload at its
     REAL table sizes against the fp64 oracle (the oracle only gathers the rows a batch names, so it stays cheap):
       * scores and losses;
@@ -978,6 +1053,8 @@ def _full_size_vs_oracle(workload, d, dec, inter, min_params, n_relations, zipf=
         bad = torch.nonzero(touched & ~m_k).flatten()[:4].tolist()
         assert not bad, (k, bad, [float(gmax[r]) for r in bad], float(gmax.max()))
     assert bool(torch.isfinite(eng.params).all())
+    # ... and the VALUES of a step: one more iteration, stepped as `mode` says, against the oracle's Adam step
+    _second_step_vs_oracle(eng, wl, items, descs, didx, n, keys, dec, inter, mode)
     if zipf:
         # The Adam pass above walked the hub rows' long lists and PROMOTED them (include/gqe.h, gqe_hot_rows): from now on their
         # contributions are added into dense accumulators with float atomics instead of being linked.  Two more steps through
@@ -1020,23 +1097,31 @@ def _full_size_vs_oracle(workload, d, dec, inter, min_params, n_relations, zipf=
     eng.close()
 
 
-def test_reddit_synth_config5_full_size():
+STEP_MODES = ["two-call", "deferred", "train-step"]   # gqe_margin_fwd_bwd + gqe_adam_step | with gqe_set_deferred_gemm | gqe_train_step
+
+
+@pytest.mark.parametrize("mode", ["two-call", "train-step"])
+def test_reddit_synth_config5_full_size(mode):
     """BASELINE config 5 at its real size: reddit-synth (500 k users / 400 k posts / 2 k communities, the 12 directed
-    relations of reddit/data_utils_new.py:193-197, posts = EmbeddingBag mean over 5..30 of 50 k words), d=256."""
-    _full_size_vs_oracle("reddit-synth", 256, "bilinear-diag", "min", 141 * 10 ** 6, 12)
+    relations of reddit/data_utils_new.py:193-197, posts = EmbeddingBag mean over 5..30 of 50 k words), d=256.
+    (gqe_train_step runs the two-call sequence here: bag tables, tables beyond the Infinity Cache.)"""
+    _full_size_vs_oracle("reddit-synth", 256, "bilinear-diag", "min", 141 * 10 ** 6, 12, mode=mode)
 
 
+@pytest.mark.parametrize("mode", STEP_MODES)
 @pytest.mark.parametrize("dec,inter,P", [("bilinear-diag", "min", 12582912), ("bilinear", "mean", 12810496)])
-def test_bio_synth_configs_full_size(dec, inter, P):
+def test_bio_synth_configs_full_size(dec, inter, P, mode):
     """BASELINE configs 2-4 at their real size: bio-synth (97 000 nodes in 5 modes, 14 directed relations), d=128,
-    P = 12 582 912 (bilinear-diag + SetIntersection) / 12 810 496 (full Bilinear) parameters — the workload bench.py times."""
-    _full_size_vs_oracle("bio-synth", 128, dec, inter, P, 14)
+    P = 12 582 912 (bilinear-diag + SetIntersection) / 12 810 496 (full Bilinear) parameters — the workload bench.py times,
+    stepped every way the library offers: the timed path (gqe_train_step's split step) is pinned to the oracle here."""
+    _full_size_vs_oracle("bio-synth", 128, dec, inter, P, 14, mode=mode)
 
 
-def test_bio_synth_zipf_full_size():
+@pytest.mark.parametrize("mode", ["two-call", "train-step"])
+def test_bio_synth_zipf_full_size(mode):
     """The full mix on a HEAVY-TAILED bio-synth graph (node degrees ~ 1 / rank: the data shape the reference was written for,
     graph.py:108-122): hub rows collect 100+ gradient contributions in one step.  Same checks as the uniform case."""
-    _full_size_vs_oracle("bio-synth", 128, "bilinear-diag", "min", 12582912, 14, zipf=1.0, min_longest_list=100)
+    _full_size_vs_oracle("bio-synth", 128, "bilinear-diag", "min", 12582912, 14, zipf=1.0, min_longest_list=100, mode=mode)
 
 
 def test_reddit_synth_zipf_full_size():
