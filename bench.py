@@ -631,6 +631,97 @@ def host_fed(wl, args):
     return out
 
 
+def api_path(args, d, decoder, inter, B, iterations=120):
+    """The DROP-IN path itself, timed: ``train_helpers.run_train`` (the reference's loop, train_helpers.py:40-107) with a
+    ``FusedAdam`` on ``Query`` objects — a bio-synth-sized graph built through the reference-shaped ``Graph`` /
+    ``QueryEncoderDecoder`` classes, query lists sampled by the native sampler and converted ONCE to ``Query`` objects.  Per
+    iteration the loop draws a formula per batch (np.random.multinomial), takes its window of the formula's list, draws the
+    negatives exactly as the reference does (``random.choice`` per query, replayed natively), packs the index feed and runs the
+    iteration as one library call (model.train_step -> gqe_train_step); like the reference it reads the loss every iteration
+    (``.item()``: a device synchronisation).  Reported: queries/s of the steady state and the host's share per iteration."""
+    import random
+    import torch
+    from graphqembed_amd import data_utils, train_helpers, utils
+    from graphqembed_amd import model as model_mod
+    from graphqembed_amd.graph import Graph, Query
+    from graphqembed_amd.model import FusedAdam, QueryEncoderDecoder
+    from graphqembed_amd.sampler import NativeSampler
+    t_build = time.perf_counter()
+    rel, adj, ids = data_utils.make_synthetic_graph(data_utils.BIO_SYNTH_SIZES, seed=0)
+    node_maps = data_utils.make_node_maps(ids)
+    dims = {m: d for m in rel}
+    graph = Graph(None, dims, rel, adj)
+    feats = {m: torch.nn.Embedding(len(node_maps[m]) + 1, d) for m in rel}
+    for f in feats.values():
+        f.weight.data.normal_(0, 1.0 / d)
+    enc = utils.get_encoder(0, graph, dims, feats, True, node_maps=node_maps)
+    model = QueryEncoderDecoder(graph, enc, utils.get_metapath_decoder(graph, dims, decoder), utils.get_intersection_decoder(graph, dims, inter),
+                                max_queries=9 * B, max_batches=9)
+    sampler = NativeSampler(graph, node_maps)
+    train = {}
+    edges = graph.get_all_edges(seed=0)[:60000]
+    train["1-chain"] = dict(data_utils.group_by_formula([Query(("1-chain", e), None, None) for e in edges])["1-chain"])
+    for k, t in enumerate(["2-chain", "3-chain", "2-inter", "3-inter", "3-inter_chain"]):
+        by = data_utils.group_by_formula(sampler.sample(40000, q_type=t, neg_sample_max=20, seed=k, threads=8).to_queries(keep_graph=False))[t]
+        keep = sorted(by, key=lambda f: -len(by[f]))[:6]          # the six most frequent formulas: lists of >= one batch
+        train[t] = {f: by[f] for f in keep}
+    small = {f: qs[:24] for f, qs in list(train["2-chain"].items())[:1]}
+    test = {"one_neg": {"2-chain": small}, "full_neg": {"2-chain": small}}
+    t_build = time.perf_counter() - t_build
+    opt = FusedAdam(model, lr=0.01)
+    clock = {"lookup": 0.0, "pack": 0.0, "launch": 0.0, "n": 0, "queries": 0, "stamps": []}
+
+    def timed(owner, name, key, count=None):
+        fn = getattr(owner, name)
+
+        def wrapper(*a, **kw):
+            t0 = time.perf_counter()
+            out = fn(*a, **kw)
+            clock[key] += time.perf_counter() - t0
+            if count:
+                count(a, out)
+            return out
+        setattr(owner, name, wrapper)
+        return fn
+    undo = [(train_helpers.FusedExecutor, "add_window", timed(train_helpers.FusedExecutor, "add_window", "lookup",
+                                                             lambda a, out: clock.__setitem__("queries", clock["queries"] + (a[4] - a[3])))),
+            (model_mod, "pack_margin_batches", timed(model_mod, "pack_margin_batches", "pack")),
+            (model.engine, "train_step", timed(model.engine, "train_step", "launch"))]
+    step0 = opt.step
+
+    def step():
+        step0()
+        clock["stamps"].append((time.perf_counter(), clock["lookup"], clock["pack"], clock["launch"], clock["queries"]))
+    opt.step = step
+
+    class Quiet(object):
+        def info(self, m):
+            pass
+    random.seed(0); np.random.seed(0)
+    try:
+        train_helpers.run_train(model, opt, train, test, test, Quiet(), max_burn_in=2, batch_size=B, log_every=10 ** 9, val_every=10 ** 9,
+                                max_iter=iterations)
+    finally:
+        for owner, name, fn in undo:
+            setattr(owner, name, fn)
+    st = clock["stamps"]
+    a, b = st[len(st) // 3], st[-1]                                 # steady state: the last two thirds (all query types)
+    n = len(st) - 1 - len(st) // 3
+    dt = b[0] - a[0]
+    q = b[4] - a[4]
+    out = {"value": round(q / dt, 1), "unit": "queries/s", "iterations": n, "ms_per_iteration": round(dt / n * 1e3, 4),
+           "queries_per_iteration": round(q / n, 1), "split_steps": model.engine.split_steps(),
+           "host_us_per_iteration": {"row_lookup_and_negative_draw": round((b[1] - a[1]) / n * 1e6, 1), "packing": round((b[2] - a[2]) / n * 1e6, 1),
+                                     "library_call": round((b[3] - a[3]) / n * 1e6, 1),
+                                     "rest (formula draw, loss .item() = waiting for the device, loop)": round((dt - (b[1] - a[1]) - (b[2] - a[2]) - (b[3] - a[3])) / n * 1e6, 1)},
+           "setup_seconds": round(t_build, 1),
+           "note": ("train_helpers.run_train + FusedAdam on Query objects (the reference's loop and signatures): formula draw, window, "
+                    "reference negatives (random.choice per query, replayed natively), packing, gqe_train_step, loss.item() every "
+                    "iteration; row arrays of each formula's list are looked up once (train_helpers._PoolRows)")}
+    model.engine.close()
+    return out
+
+
 def cpu_baseline(eng, decoder, inter, item_sets, budget_s, queries_per_iter):
     """Time the torch-CPU port on the same parameters / batches (bounded sample).  torch's default
     (one thread per hardware thread) is far from its best on a 2x64-core host, so a short sweep over
@@ -752,13 +843,14 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the other SURVEY §8d configurations (N=1)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the gqe_feeder_run measurement (N=1)")
     ap.add_argument("--no-reddit", action="store_true", help="skip the secondary reddit-synth d=256 measurement")
+    ap.add_argument("--no-api-path", action="store_true", help="skip the measurement of the reference-shaped API (run_train on Query objects, N=1)")
     ap.add_argument("--only-main", action="store_true", help="main measurement only (profiling runs)")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="timed blocks of --steps steps repeat until this much time was "
                     "measured (profiling runs: 0 = one block)")
     ap.add_argument("--check-replicas", action="store_true", help="kept for compatibility: replicas are always compared for --gpus > 1")
     args = ap.parse_args()
     if args.only_main:
-        args.no_lazy = args.no_configs = args.no_host_fed = args.no_reddit = args.no_cpu_baseline = True
+        args.no_lazy = args.no_configs = args.no_host_fed = args.no_reddit = args.no_cpu_baseline = args.no_api_path = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, sys.argv[1:]))
@@ -859,6 +951,8 @@ def main():
         out["lazy_exact_adam"] = lz
     if world == 1 and not args.no_host_fed and not args.lazy_adam:
         out["host_fed"] = host_fed(wl, args)
+    if world == 1 and not args.no_api_path and not reddit:
+        out["api_path"] = api_path(args, d, args.decoder, args.inter_decoder, B)
     if world == 1 and not args.no_configs and not reddit:
         cfgs = {}
         M = synth.FULL_MIX

@@ -396,6 +396,48 @@ int fail(int code, const std::string& msg) {
 
 extern "C" {
 
+// ---- Python's random.choice on a batch of lists (include/gqe_sampler.h) ------------------------------------------------
+// MT19937 as CPython's _randommodule.c runs it: genrand_uint32 with the standard tempering; getrandbits(k <= 32) = one output
+// word >> (32 - k); lists longer than 2^32 do not occur (k <= 32 is checked).
+namespace {
+inline uint32_t mt_next(uint32_t* mt, uint32_t& pos) {
+  constexpr uint32_t N = 624, M = 397;
+  if (pos >= N) {
+    auto twist = [](uint32_t u, uint32_t v) { return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u); };
+    uint32_t kk = 0;
+    for (; kk < N - M; ++kk) mt[kk] = mt[kk + M] ^ twist(mt[kk], mt[kk + 1]);
+    for (; kk < N - 1; ++kk) mt[kk] = mt[kk + M - N] ^ twist(mt[kk], mt[kk + 1]);
+    mt[N - 1] = mt[M - 1] ^ twist(mt[N - 1], mt[0]);
+    pos = 0;
+  }
+  uint32_t y = mt[pos++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+}  // namespace
+
+int gqe_py_random_choices(uint32_t* state625, const int64_t* counts, int64_t n, int64_t* choice) {
+  if (!state625 || !counts || !choice || n < 0) return GQE_SAMPLER_ARG;
+  uint32_t pos = state625[624];
+  if (pos > 624) return GQE_SAMPLER_ARG;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t c = counts[i];
+    if (c < 1 || c > 0xffffffffll) return GQE_SAMPLER_ARG;
+    int k = 0;
+    for (int64_t x = c; x; x >>= 1) ++k;          // c.bit_length()
+    uint32_t r;
+    do {
+      r = mt_next(state625, pos) >> (32 - k);
+    } while ((int64_t)r >= c);
+    choice[i] = (int64_t)r;
+  }
+  state625[624] = pos;
+  return GQE_SAMPLER_OK;
+}
+
 const char* gqe_sampler_last_error(void) { return g_err.c_str(); }
 
 int gqe_sampler_create(const gqe_graph_desc* d, gqe_sampler** out) {

@@ -40,6 +40,7 @@ SAMPLER_SYMBOLS = {
     "gqe_query_batch_free": (C.c_int, [C.POINTER(_QueryBatch)]),
     "gqe_sampler_check": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "gqe_sampler_last_error": (C.c_char_p, []),
+    "gqe_py_random_choices": (C.c_int, [_P, _P, C.c_int64, _P]),
 }
 
 
@@ -51,6 +52,23 @@ def _lib():
             fn.restype, fn.argtypes = res, args
         lib._sampler_typed = True
     return lib
+
+
+def py_random_choices(counts):
+    """``[random.choice(range(c)) for c in counts]`` — the SAME values and the same consumption of the ``random`` module's
+    generator, drawn by one native call (include/gqe_sampler.h, gqe_py_random_choices).  int64 array."""
+    import random
+    counts = np.ascontiguousarray(counts, dtype=np.int64)
+    out = np.empty(len(counts), dtype=np.int64)
+    if len(counts) == 0:
+        return out
+    version, words, gauss = random.getstate()
+    state = np.array(words, dtype=np.uint32)
+    rc = _lib().gqe_py_random_choices(state.ctypes.data, counts.ctypes.data, len(counts), out.ctypes.data)
+    if rc != 0:
+        raise ValueError("gqe_py_random_choices: a list without entries cannot be chosen from")
+    random.setstate((version, tuple(state.tolist()), gauss))
+    return out
 
 
 class SampledQueries(object):

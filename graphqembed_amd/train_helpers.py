@@ -49,10 +49,10 @@ def iteration_plan(query_types, all_types, path_weight, inter_weight):
             yield BatchSpec(qt, path_weight, False)
 
 
-def draw_batch(queries_by_formula, iteration, batch_size):
-    """(formula, queries) of one batch: the formula is drawn with probability proportional to its query count (one
-    ``np.random.multinomial`` call, as train_helpers.py:96-99 consumes it), the queries are the iteration's window of
-    that formula's list, restarting at the list's end."""
+def draw_window(queries_by_formula, iteration, batch_size):
+    """(formula, its query list, lo, hi) of one batch: the formula is drawn with probability proportional to its query count
+    (one ``np.random.multinomial`` call, as train_helpers.py:96-99 consumes it), [lo, hi) is the iteration's window of that
+    formula's list, restarting at the list's end."""
     formulas = list(queries_by_formula)
     sizes = [float(len(queries_by_formula[f])) for f in formulas]
     pick = np.random.multinomial(1, np.array(sizes) / float(sum(sizes)))    # the same probability vector, bit for bit
@@ -62,6 +62,12 @@ def draw_batch(queries_by_formula, iteration, batch_size):
     hi = ((iteration + 1) * batch_size) % len(pool)
     if hi <= lo or hi > len(pool):
         hi = len(pool)
+    return formula, pool, lo, hi
+
+
+def draw_batch(queries_by_formula, iteration, batch_size):
+    """(formula, queries) of one batch (draw_window with the window taken out of the list)."""
+    formula, pool, lo, hi = draw_window(queries_by_formula, iteration, batch_size)
     return formula, pool[lo:hi]
 
 
@@ -102,6 +108,32 @@ class LossAverage(object):
 
 
 # ---- executors --------------------------------------------------------------------------------------------------
+class _PoolRows(object):
+    """The table rows of ONE formula's query list, looked up once (the tensorize step): target rows [n],
+    anchor rows [k, n], and — built when first asked for — the negative / hard-negative lists as CSR arrays of rows.  The
+    list is kept alive so that its identity stays a valid cache key; it is assumed not to change."""
+
+    def __init__(self, model, formula, pool):
+        enc = model.enc
+        self.pool, self.formula = pool, formula
+        self.target = enc.rows([q.target_node for q in pool], formula.target_mode)
+        self.anchors = np.stack([enc.rows([q.anchor_nodes[i] for q in pool], m) for i, m in enumerate(formula.anchor_modes)])
+        self._csr = {}
+
+    def lists(self, model, hard):
+        """(ptr[n + 1], rows) of every query's negative (hard-negative) list, or None if some query has none."""
+        if hard not in self._csr:
+            lists = [(q.hard_neg_samples if hard else q.neg_samples) for q in self.pool]
+            if any(l is None or len(l) == 0 for l in lists):
+                self._csr[hard] = None
+            else:
+                ptr = np.zeros(len(lists) + 1, dtype=np.int64)
+                ptr[1:] = np.cumsum([len(l) for l in lists])
+                rows = model.enc.rows([n for l in lists for n in l], self.formula.target_mode)
+                self._csr[hard] = (ptr, rows)
+        return self._csr[hard]
+
+
 class FusedExecutor(object):
     """The iteration's batches become index arrays; ``finish`` runs them in one grouped launch."""
 
@@ -111,9 +143,38 @@ class FusedExecutor(object):
         self.model = model
         self.optimizer = optimizer if isinstance(optimizer, FusedAdam) else None
         self.items = []
+        self._pools = {}          # id(query list) -> _PoolRows
+        self._full = {}           # mode -> rows of graph.full_lists[mode] (1-chain negatives)
 
     def begin(self):
         self.items = []
+
+    def add_window(self, formula, pool, lo, hi, weight, hard):
+        """``add(formula, pool[lo:hi], ...)`` without one interpreter step per query: the rows of the list come from a cache
+        built on first use, and the negatives are the reference's draw — ``random.choice`` per query, model.py:113-120 —
+        replayed on the ``random`` module's own generator by one native call (sampler.py_random_choices): the same values, the
+        same state afterwards."""
+        from .sampler import py_random_choices
+        m = self.model
+        if "inter" not in formula.query_type and hard:
+            raise Exception("Hard negative examples can only be used with intersection queries")
+        rows = self._pools.get(id(pool))
+        if rows is None or rows.pool is not pool:
+            rows = self._pools[id(pool)] = _PoolRows(m, formula, pool)
+        n = hi - lo
+        if formula.query_type == "1-chain" and not hard:
+            mode = formula.target_mode
+            if mode not in self._full:
+                self._full[mode] = m.enc.rows(m.graph.full_lists[mode], mode)
+            full = self._full[mode]
+            neg = full[py_random_choices(np.full(n, len(full), dtype=np.int64))]
+        else:
+            csr = rows.lists(m, hard)
+            if csr is None:       # (a query without negatives: the reference's own exception, from its own code path)
+                return self.add(formula, pool[lo:hi], weight, hard)
+            ptr, flat = csr
+            neg = flat[ptr[lo:hi] + py_random_choices(ptr[lo + 1:hi + 1] - ptr[lo:hi])]
+        self.items.append((formula, rows.target[lo:hi], neg, rows.anchors[:, lo:hi], weight, 1.0))
 
     def add(self, formula, queries, weight, hard):
         m = self.model
@@ -180,6 +241,13 @@ def run_train(model, optimizer, train_queries, val_queries, test_queries, logger
               max_burn_in=100000, batch_size=512, log_every=100, val_every=1000, tol=1e-6,
               max_iter=int(10e7), inter_weight=0.005, path_weight=0.01, model_file=None):
     executor = FusedExecutor(model, optimizer) if isinstance(optimizer, _FusedOptimizer) else EagerExecutor(model)
+
+    def add(window, weight, hard):
+        formula, pool, lo, hi = window
+        if hasattr(executor, "add_window"):
+            executor.add_window(formula, pool, lo, hi, weight, hard)
+        else:
+            executor.add(formula, pool[lo:hi], weight, hard)
     plateau = Plateau()        # ``tol`` is accepted but, as in the reference (its convergence test is called with the
                                # defaults, train_helpers.py:52,73), not used
     average = LossAverage()
@@ -189,7 +257,7 @@ def run_train(model, optimizer, train_queries, val_queries, test_queries, logger
     for iteration in range(max_iter):
         optimizer.zero_grad()
         executor.begin()
-        executor.add(*draw_batch(train_queries["1-chain"], iteration, batch_size), 1.0, False)
+        add(draw_window(train_queries["1-chain"], iteration, batch_size), 1.0, False)
         if not all_types and (plateau.reached() or average.count >= max_burn_in):
             logger.info("Edge converged at iteration {:d}".format(iteration - 1))
             logger.info("Testing at edge conv...")
@@ -200,7 +268,7 @@ def run_train(model, optimizer, train_queries, val_queries, test_queries, logger
             if model_file is not None:
                 torch.save(model.state_dict(), model_file + "-edge_conv")
         for spec in iteration_plan(train_queries, all_types, path_weight, inter_weight):
-            executor.add(*draw_batch(train_queries[spec.query_type], iteration, batch_size), spec.weight, spec.hard)
+            add(draw_window(train_queries[spec.query_type], iteration, batch_size), spec.weight, spec.hard)
         if all_types and plateau.reached():
             logger.info("Fully converged at iteration {:d}".format(iteration))
             break

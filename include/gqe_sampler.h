@@ -85,6 +85,14 @@ int gqe_query_batch_free(gqe_query_batch* b);
  * (_is_subgraph); bit 1 = `node` is a negative (_is_negative(.., False)); bit 2 = `node` is a hard negative. */
 int gqe_sampler_check(const gqe_sampler* s, int32_t qtype, const int32_t* edges9, int32_t node);
 
+/* The reference draws ONE negative per query with Python's `random.choice(list)` (model.py:113-120): for a list of n entries
+ * that is `_randbelow(n)` — k = n.bit_length(); r = getrandbits(k) until r < n — on the Mersenne Twister behind the `random` module.
+ * This replays exactly that consumption of the generator for a whole batch: `state` = the 624 words + position of
+ * `random.getstate()[1]` (updated in place: hand it back with `random.setstate`), counts[i] = len(list i) >= 1,
+ * choice[i] = the index `random.choice` would have picked.  A run seeded like the reference's reproduces its negatives without
+ * one interpreter call per query (train_helpers.FusedExecutor).  Returns GQE_SAMPLER_ARG for a count < 1 or a bad position. */
+int gqe_py_random_choices(uint32_t* state625, const int64_t* counts, int64_t n, int64_t* choice);
+
 const char* gqe_sampler_last_error(void);
 
 #define GQE_SAMPLER_OK 0
