@@ -78,8 +78,9 @@ def test_golden_adam_three_steps(path, dec, inter, d):
     same batches) — at rtol 1e-3 (+ 2e-6) for all but 5 % of them (2 elements of a small tensor; an arg-min that flips for a few
     elements moves those by a fraction of lr without showing in the loss) and 2e-3 absolute for all (the loose bound is 4e-2), whenever the three losses show that no discrete decision (arg-min / relu /
     hinge) flipped on the way (loss of steps 2-3 within 1e-4 of the reference's).  A trajectory that did flip — the fp32
-    numpy oracle does so on 2 of the 132 recorded cases — is held to the loose bound only, and at most 3 cases per model
-    may take that route."""
+    numpy oracle does so on 2 of the 132 recorded cases — is held to the per-case bound only (3 x the deviation of the fp32 oracle's
+    own trajectory on that case and tensor from the recorded one, + 2e-3; losses: 3 x the fp32 oracle's loss deviation), and at most 3
+    cases per model may take that route."""
     from gpu_utils import engine_from_params, load_params as put, plan_for, read_arena
     from graphqembed_amd.tensorize import pack_margin_batches
     z = np.load(path)
@@ -96,13 +97,20 @@ def test_golden_adam_three_steps(path, dec, inter, d):
         plan = plan_for(eng, c["type"], c["rels"])
         oplan = O.make_plan(c["type"], c["rels"])
         oparams, ostate = {k: v.astype(np.float64) for k, v in p0.items()}, {}
+        # the SAME trajectory through the oracle in fp32: how far fp32 arithmetic alone lands from what the reference recorded
+        # on THIS case is the yardstick for the device (x 3), instead of one blanket bound for all cases
+        o32, s32, loss32 = {k: v.astype(np.float32) for k, v in p0.items()}, {}, []
         signal = {k: np.ones(p0[k].shape, dtype=bool) for k in plan.touched}
         loss_err = 0.0
         for step in range(3):
+            l32, _, _, g32 = O.margin_fwd_bwd(o32, oplan, dec, inter, c["target"], c["adam_neg"][step], c["anchors"], margin=c["margin"])
+            O.adam_step(o32, g32, s32, plan.touched)
+            loss32.append(abs(float(l32) - float(c["adam_loss"][step])))
             descs, idx, n = pack_margin_batches([(plan, c["target"], c["adam_neg"][step], c["anchors"], 1.0, c["margin"])])
             losses, _, _ = eng.margin_fwd_bwd(descs, idx, n)
             got_loss = float(losses.cpu().numpy()[0])
-            np.testing.assert_allclose(got_loss, c["adam_loss"][step], rtol=LOSS_RTOL if step == 0 else 6e-2, err_msg=case)
+            np.testing.assert_allclose(got_loss, c["adam_loss"][step], rtol=LOSS_RTOL, atol=3.0 * loss32[-1] + (0.0 if step == 0 else 2e-4 * abs(float(c["adam_loss"][step]))),
+                                       err_msg="%s step %d (fp32 oracle off by %.3g)" % (case, step, loss32[-1]))
             loss_err = max(loss_err, abs(got_loss - c["adam_loss"][step]) / max(abs(c["adam_loss"][step]), 1e-12))
             eng.adam_step(plan.touched)
             _, _, _, og = O.margin_fwd_bwd(oparams, oplan, dec, inter, c["target"], c["adam_neg"][step], c["anchors"], margin=c["margin"])
@@ -115,8 +123,11 @@ def test_golden_adam_three_steps(path, dec, inter, d):
         flipped = loss_err > 1e-4
         for k, delta in c["adam_delta"].items():
             diff = np.abs(got[k].astype(np.float64) - p0[k] - delta)
-            # the loose bound every trajectory has to meet (tests/test_oracle_golden.py: Adam amplifies rounding noise on ~zero gradients)
-            assert diff.max() < 4e-2 and np.median(diff) < 5e-4, (case, k, diff.max(), np.median(diff))
+            # the bound every trajectory has to meet: three times what the fp32 oracle itself is off by on this case and tensor
+            # (Adam amplifies rounding noise on ~zero gradients: tests/test_oracle_golden.py), never more than the old blanket 4e-2
+            dev32 = np.abs(o32[k].astype(np.float64) - p0[k] - delta)
+            allow = min(4e-2, 3.0 * float(dev32.max()) + 2e-3)
+            assert diff.max() < allow and np.median(diff) < max(5e-5, 3.0 * float(np.median(dev32))), (case, k, diff.max(), allow, np.median(diff), float(np.median(dev32)))
             if not flipped and signal[k].any():
                 sg = signal[k]
                 bad = int((diff[sg] > 1e-3 * np.abs(delta[sg]) + 2e-6).sum())
