@@ -94,13 +94,18 @@ TOY_FORMULAS = {
 }
 
 
-def toy_batch(rng, qtype, B, hub=False):
+# ... and sizes whose tables (n + 2 rows: 91 / 71 / 53) leave a remainder when sharded over 2, 3 or 4 ranks
+TOY_SIZES_ODD = {"a": 89, "b": 69, "c": 51}
+
+
+def toy_batch(rng, qtype, B, hub=False, sizes=None):
     """Random row indices (1..n) for a TOY_FORMULAS batch: (target, neg, anchors[k,B])."""
+    sizes = sizes or TOY_SIZES
     plan = O.make_plan(qtype, TOY_FORMULAS[qtype])
-    nt = TOY_SIZES[plan["target_mode"]]
+    nt = sizes[plan["target_mode"]]
     target = rng.randint(1, nt + 1, B).astype(np.int32)
     neg = rng.randint(1, nt + 1, B).astype(np.int32)
-    anchors = np.stack([rng.randint(1, TOY_SIZES[m] + 1, B) for m in plan["anchor_modes"]]).astype(np.int32)
+    anchors = np.stack([rng.randint(1, sizes[m] + 1, B) for m in plan["anchor_modes"]]).astype(np.int32)
     if hub:                       # many queries hit the same rows -> atomics collide
         target[: B // 2] = target[0]
         anchors[:, : B // 2] = anchors[:, :1]

@@ -21,18 +21,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_dir, dec, inter, d, bag_modes=()):
+def _worker(rank, world, port, out_dir, dec, inter, d, bag_modes=(), odd=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from graphqembed_amd import parallel
     from graphqembed_amd.engine import ArenaLayout, Engine, GqeError
     from graphqembed_amd.tensorize import pack_forward_batches, pack_margin_batches
-    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, read_arena, toy_batch
+    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, TOY_SIZES_ODD, engine_from_params, plan_for, random_params, read_arena, toy_batch
     from oracle import netquery_numpy as O
     r, w, _, dist = parallel.init_from_env("gloo")
     rng = np.random.RandomState(21)
-    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS, bag_modes=bag_modes)
+    SIZES = TOY_SIZES_ODD if odd else TOY_SIZES      # odd: 91 / 71 / 53 table rows — ceil(rows / W) leaves a short last shard
+    params = random_params(rng, d, dec, inter, SIZES, TOY_KINDS, bag_modes=bag_modes)
     bag_keys = [O.table_key(m) for m in bag_modes]                     # EmbeddingBag tables stay replicated
     bags = {O.table_key(m): csr for m, csr in params.get(O.BAGS_KEY, {}).items()}
     params_only = {k: v for k, v in params.items() if k != O.BAGS_KEY}
@@ -76,7 +77,10 @@ def _worker(rank, world, port, out_dir, dec, inter, d, bag_modes=()):
         cur = gather_full(runs[0])                                     # what the sharded ranks hold together right now
         want_loss = 0.0
         for qtype, wgt in mix:
-            t, g, a = toy_batch(rng, qtype, n_pool, hub=(qtype == "2-inter" and step == 0))   # hub rows: long lists at one owner
+            t, g, a = toy_batch(rng, qtype, n_pool, hub=(qtype == "2-inter" and step == 0), sizes=SIZES)   # hub rows: long lists at one owner
+            if qtype == "2-inter" and step == 0 and w > 2:              # ... and that owner is the LAST rank (its shard is the short one)
+                nt = SIZES[O.make_plan(qtype, TOY_FORMULAS[qtype])["target_mode"]]
+                t[: n_pool // 2] = max(x for x in range(1, nt + 1) if x % w == w - 1)
             s, e = parallel.rank_slice(n_pool, B, step + 5, r, w)      # step 6 wraps around the pool: unequal slices
             cat = np.concatenate([np.arange(*parallel.rank_slice(n_pool, B, step + 5, rr, w)) for rr in range(w)])
             items.append((qtype, t[s:e], g[s:e], a[:, s:e], wgt * (e - s) / float(len(cat))))
@@ -169,7 +173,7 @@ def _worker(rank, world, port, out_dir, dec, inter, d, bag_modes=()):
     for k, v in sync.items():
         single.layout.view(single.params, k).copy_(v)
     for qtype in ("2-chain", "3-inter", "3-chain_inter"):
-        t, g, a = toy_batch(rng, qtype, 40 + 7 * r)
+        t, g, a = toy_batch(rng, qtype, 40 + 7 * r, sizes=SIZES)
         descs, idx, n = pack_forward_batches([(plan_for(runs[0], qtype, TOY_FORMULAS[qtype]), t, a)])
         ps = parallel.shard_prepare(runs[0], dist, descs, idx, with_negatives=False)
         got = parallel.shard_forward(runs[0], dist, ps, n)
@@ -192,6 +196,17 @@ def test_row_sharded_two_ranks(tmp_path, dec, inter, d, bag_modes):
     port = 29400 + os.getpid() % 150
     mp.spawn(_worker, args=(2, port, str(tmp_path), dec, inter, d, bag_modes), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+@pytest.mark.parametrize("world,dec,inter,d,bag_modes", [(3, "bilinear-diag", "min", 32, ()), (4, "bilinear-diag", "min", 32, ()),
+                                                         (3, "bilinear-diag", "min", 64, ("b",)), (4, "bilinear", "mean", 32, ())])
+def test_row_sharded_more_ranks_with_remainders(tmp_path, world, dec, inter, d, bag_modes):
+    """The same protocol on 3 and 4 ranks sharing the GPU, with tables of 91 / 71 / 53 rows: ceil(rows / W) does not divide,
+    the last ranks' shards are short (their padding rows must never be named, served or stepped into the result), the owner
+    counting sort has W buckets, a hub row lives on the LAST rank."""
+    port = 29700 + os.getpid() % 150
+    mp.spawn(_worker, args=(world, port, str(tmp_path), dec, inter, d, bag_modes, True), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % k)) for k in range(world))
 
 
 def _trainer_worker(rank, world, port, out_dir):
@@ -281,7 +296,7 @@ def test_row_sharded_trainer_two_ranks(tmp_path):
     assert os.path.exists(tmp_path / "tr_ok0") and os.path.exists(tmp_path / "tr_ok1")
 
 
-def _session_worker(rank, world, port, out_dir, dec, inter, d):
+def _session_worker(rank, world, port, out_dir, dec, inter, d, odd=False):
     """gqe_shard_open / post / step (the row-sharded step as one library call, planning through the shared-memory plan board)
     on 2 gloo ranks sharing cuda:0, the transport being callbacks over torch.distributed:
       * == the phases driven by hand (plan / serve / link + Python collectives) BIT FOR BIT on shards, moments and the
@@ -296,10 +311,11 @@ def _session_worker(rank, world, port, out_dir, dec, inter, d):
     from graphqembed_amd import parallel
     from graphqembed_amd.engine import ArenaLayout, Engine
     from graphqembed_amd.tensorize import pack_forward_batches, pack_margin_batches
-    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, read_arena, toy_batch
+    from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, TOY_SIZES_ODD, engine_from_params, plan_for, random_params, read_arena, toy_batch
     r, w, _, dist = parallel.init_from_env("gloo")
     rng = np.random.RandomState(33)
-    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
+    SIZES = TOY_SIZES_ODD if odd else TOY_SIZES
+    params = random_params(rng, d, dec, inter, SIZES, TOY_KINDS)
     tables = [k for k in params if k.startswith("enc.")]
 
     def sharded_engine(lazy=False):
@@ -336,9 +352,9 @@ def _session_worker(rank, world, port, out_dir, dec, inter, d):
     # branch gradients into Pre, two ranks into the all-reduce, row lists summed order-independently) and two engines agree
     # BIT FOR BIT — or differ because of the protocol.  No 3-inter: its three branches add into the Pre gradient in atomic order.
     types = ["1-chain", "2-inter", "2-chain", "3-inter_chain", "3-chain", "3-chain_inter", "2-inter", "1-chain", "3-inter_chain"]
-    sizes = [12, 9]                                                    # unequal slices
+    sizes = [12, 9, 7, 5][:w]                                          # unequal slices
     for step, qtype in enumerate(types):
-        t, g, a = toy_batch(rng, qtype, sum(sizes), hub=(step == 1))   # hub rows: long lists at one owner
+        t, g, a = toy_batch(rng, qtype, sum(sizes), hub=(step == 1), sizes=SIZES)   # hub rows: long lists at one owner
         hi = 25 + 12 * step                                            # most rows untouched at first: they lag in lazy mode
         t[:], g[:] = np.minimum(t, hi), np.minimum(g, hi)
         s0 = sum(sizes[:r])
@@ -369,8 +385,10 @@ def _session_worker(rank, world, port, out_dir, dec, inter, d):
     het = sharded_engine()
     keep.append(parallel.shard_session(het, dist, r, w))
     single = engine_from_params(params, d, dec, inter)
-    per_rank = [[(q,) + toy_batch(np.random.RandomState(100 + 10 * rr + j), q, 40) + (wgt,) for j, (q, wgt) in enumerate(lst)]
-                for rr, lst in enumerate(([("2-chain", 0.5), ("1-chain", 1.0)], [("3-inter", 0.5), ("1-chain", 1.0)]))]
+    # (with more than two ranks some rank names no row of table c at all: its requests to c's owners are empty)
+    mixes = ([("2-chain", 0.5), ("1-chain", 1.0)], [("3-inter", 0.5), ("1-chain", 1.0)], [("1-chain", 1.0)], [("2-inter", 0.5), ("3-chain", 0.2)])[:w]
+    per_rank = [[(q,) + toy_batch(np.random.RandomState(100 + 10 * rr + j), q, 40, sizes=SIZES) + (wgt,) for j, (q, wgt) in enumerate(lst)]
+                for rr, lst in enumerate(mixes)]
     packed = [(plan_for(het, q, TOY_FORMULAS[q]), t, g, a, wgt, 1.0) for (q, t, g, a, wgt) in per_rank[r]]
     descs, idx, _ = pack_margin_batches(packed)
     p1 = het.prepare_shard(descs, idx, set().union(*[p[0].touched for p in packed]))
@@ -399,7 +417,7 @@ def _session_worker(rank, world, port, out_dir, dec, inter, d):
     for k, v in got.items():
         single.layout.view(single.params, k).copy_(torch.from_numpy(v))
     for qtype in ("2-chain", "3-inter"):
-        t, g, a = toy_batch(rng, qtype, 30 + 5 * r)
+        t, g, a = toy_batch(rng, qtype, 30 + 5 * r, sizes=SIZES)
         descs, idx, n = pack_forward_batches([(plan_for(session, qtype, TOY_FORMULAS[qtype]), t, a)])
         pf = session.prepare_shard(descs, idx, with_negatives=False)
         session.shard_post(pf)
@@ -409,11 +427,10 @@ def _session_worker(rank, world, port, out_dir, dec, inter, d):
     # ---- candidate lists through the session (fused evaluation on row-sharded tables): the candidates are fetched from
     # their owners like any other row; ragged lists (one of them empty), a different number of queries per rank ----
     from graphqembed_amd.tensorize import pack_candidate_batches
-    from gpu_utils import TOY_SIZES as SIZES
     import oracle.netquery_numpy as O
     for qtype in ("1-chain", "3-chain", "2-inter", "3-inter_chain"):
         nq = 9 + 4 * r
-        t, g, a = toy_batch(rng, qtype, nq)
+        t, g, a = toy_batch(rng, qtype, nq, sizes=SIZES)
         mode = O.make_plan(qtype, TOY_FORMULAS[qtype])["target_mode"]
         lens = rng.randint(1, 40, nq)
         lens[nq // 2] = 0
@@ -439,3 +456,13 @@ def test_shard_step_session_two_ranks(tmp_path, dec, inter, d):
     port = 29300 + os.getpid() % 90
     mp.spawn(_session_worker, args=(2, port, str(tmp_path), dec, inter, d), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "s_ok0") and os.path.exists(tmp_path / "s_ok1")
+
+
+@pytest.mark.parametrize("world,dec,inter,d", [(3, "bilinear-diag", "min", 32), (4, "bilinear-diag", "min", 32), (4, "transe", "min-simple", 64)])
+def test_shard_step_session_more_ranks_with_remainders(tmp_path, world, dec, inter, d):
+    """gqe_shard_open / post / step on 3 and 4 ranks (plan board with W slots, W-way owner sort, W blocks per all-to-all) over
+    tables whose row counts W does not divide: one call == the phases by hand bit for bit, lazy == eager, ranks with different
+    formulas (one of them names no row of a table), forward and candidate lists through the session."""
+    port = 29850 + os.getpid() % 90
+    mp.spawn(_session_worker, args=(world, port, str(tmp_path), dec, inter, d, True), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("s_ok%d" % k)) for k in range(world))
