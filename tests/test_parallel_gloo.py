@@ -1,5 +1,5 @@
-"""world_size-2 gloo test of the data-parallel protocol (graphqembed_amd/parallel.py) on CPU:
-2 ranks x half batch, loss weights / 2, one sum all-reduce of the flat gradient arena
+"""world_size 2 / 3 / 4 (/ 8) gloo tests of the data-parallel protocol (graphqembed_amd/parallel.py) on CPU:
+W ranks x their slice of the batch, loss weights n_rank / n_all, one sum all-reduce of the flat gradient arena
 == 1 rank x full batch.  The per-rank compute is the numpy oracle (no GPU here); what is
 under test is the sharding rule, the weight scaling and the collective on the arena layout."""
 import os
@@ -41,14 +41,17 @@ def _worker(rank, world, port, out_dir):
         plan = O.make_plan(qtype, TOY_FORMULAS[qtype])
         grads = O.zero_grads_like(params)
         s, e = parallel.rank_slice(n_pool, B, step=1, rank=rank, world=world)
-        l, _, _, _ = O.margin_fwd_bwd(params, plan, dec, inter, t[s:e], g[s:e], a[:, s:e],
-                                      weight=parallel.dp_weight(wgt, world), grads=grads)
-        loss_local += parallel.dp_weight(wgt, world) * l
-        for k, gk in grads.items():
-            layout.view(flat, k).add_(torch.from_numpy(gk))
-        # the single-rank reference: the concatenation of both ranks' slices, full weight
+        # the single-rank reference: the concatenation of the ranks' slices, full weight
         sl = [parallel.rank_slice(n_pool, B, 1, rr, world) for rr in range(world)]
         cat = np.concatenate([np.arange(s0, e0) for s0, e0 in sl])
+        # a rank's weight is n_rank / n_all of the batch's (equal slices: dp_weight = 1 / W; a window that ends at the pool's end is shorter)
+        w_local = wgt * (e - s) / float(len(cat))
+        if all(e0 - s0 == B for s0, e0 in sl):
+            assert abs(w_local - parallel.dp_weight(wgt, world)) < 1e-15
+        l, _, _, _ = O.margin_fwd_bwd(params, plan, dec, inter, t[s:e], g[s:e], a[:, s:e], weight=w_local, grads=grads)
+        loss_local += w_local * l
+        for k, gk in grads.items():
+            layout.view(flat, k).add_(torch.from_numpy(gk))
         lf, _, _, _ = O.margin_fwd_bwd(params, plan, dec, inter, t[cat], g[cat], a[:, cat], weight=wgt, grads=full)
         loss_full += wgt * lf
     parallel.exchange_gradients(flat, d_)
@@ -59,19 +62,23 @@ def _worker(rank, world, port, out_dir):
         np.testing.assert_allclose(got[k], full[k], rtol=1e-9, atol=1e-12, err_msg=k)
     np.testing.assert_allclose(tl.item(), loss_full, rtol=1e-10)
     # slices of one step are consecutive and disjoint
-    s0, e0 = parallel.rank_slice(n_pool, B, 1, 0, world)
-    s1, e1 = parallel.rank_slice(n_pool, B, 1, 1, world)
-    assert e0 == s1 and e1 - s1 == B
+    bounds = [parallel.rank_slice(n_pool, B, 1, rr, world) for rr in range(world)]
+    for (s0, e0), (s1, e1) in zip(bounds[:-1], bounds[1:]):
+        assert e0 == s1 or e0 == n_pool     # (a window that reaches the pool's end is cut there; the next one starts at (it B) mod n: train_helpers.py:100-105)
+    assert all(0 < e - s <= B for s, e in bounds)
     with open(os.path.join(out_dir, "ok%d" % rank), "w") as f:
         f.write("ok")
     d_.barrier()
     d_.destroy_process_group()
 
 
-def test_two_rank_data_parallel_matches_single_rank(tmp_path):
-    port = 29600 + os.getpid() % 200
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_data_parallel_ranks_match_single_rank(tmp_path, world):
+    """W ranks x their slice, weights scaled by n_rank / n_all, one sum all-reduce == one rank x the concatenated batch
+    (W = 3: the third rank's window wraps around the 200-query pool)."""
+    port = 29600 + os.getpid() % 200 + 7 * world
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % k)) for k in range(world))
 
 
 def test_rank_slice_matches_reference_rule():
@@ -167,7 +174,10 @@ def _shard_worker(rank, world, port, out_dir):
     d_.destroy_process_group()
 
 
-def test_two_rank_row_sharded_protocol(tmp_path):
-    port = 29300 + os.getpid() % 90
-    mp.spawn(_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert os.path.exists(tmp_path / "shard_ok0") and os.path.exists(tmp_path / "shard_ok1")
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+def test_row_sharded_protocol_ranks(tmp_path, world):
+    """Tables of 53 / 20 / 31 rows over 2, 3, 4 and 8 ranks: ceil(rows / W) leaves short last shards (at W = 8 the 20-row table
+    gives ranks 4 .. 7 two rows and the others three), the owner sort has W buckets, every all-to-all W blocks."""
+    port = 29300 + os.getpid() % 90 + 11 * world
+    mp.spawn(_shard_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("shard_ok%d" % k)) for k in range(world))
