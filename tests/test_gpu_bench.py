@@ -41,6 +41,19 @@ def test_bench_two_ranks_self_launch():
     assert out["scaling"] == "weak" and out["cpu_baseline"] is None
 
 
+def test_bench_eight_ranks_gloo_smoke():
+    """What the driver's 8-GPU run executes, with the 8 ranks sharing this box's GPU over gloo: the plan board with 8 slots, the
+    8-way owner sort, every exchange form with 8 blocks per collective, tables of 10 002 / 40 002 / 27 002 rows sharded 8 ways
+    (remainders of 2) — functional, not a measurement."""
+    out = _run(["--gpus", "8", "--backend", "gloo", "--steps", "5", "--warmup", "2", "--no-reddit"], 1500)
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["replicas_identical"] is True
+    assert set(out["exchange"]) == {"sharded", "sparse", "dense"}
+    for form in out["exchange"].values():
+        assert form["replicas_identical"] is True and form["exchange_ms_per_step"] > 0 and form["value"] > 0
+    assert out["exchange"]["sharded"]["optimiser_bytes_per_launch"] < 0.2 * out["exchange"]["dense"]["optimiser_bytes_per_launch"]
+    assert out["config"]["queries_per_step_per_gpu"] == 4608 and "row-sharded" in out["config"]["gradient_exchange"]
+
+
 def test_bench_falls_back_to_the_sparse_exchange_when_the_sharded_session_fails():
     """A node on which the row-sharded session cannot be brought up (plan board, the library's RCCL communicator): every
     rank agrees on the failure and the line reports the replicated sparse exchange instead, saying so."""
