@@ -924,7 +924,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
       prof[prow * GQE_PROF_SLOTS + 0] = (long long)wall_clock64();
       prof[prow * GQE_PROF_SLOTS + 1] = ((long long)(xcc & 15) << 32) | (unsigned)hw;
     }
-    split_rider<GQE_FW>(ride, 64 * NC, tile_id < 0 ? (int)blockIdx.x : (int)blockIdx.x - plan.tiles);
+    split_rider<GQE_FW>(ride, 64 * NC, tile_id < 0 ? (int)blockIdx.x : (int)blockIdx.x - plan.tiles, reinterpret_cast<int*>(smem));
     if (prof && threadIdx.x == 0) prof[prow * GQE_PROF_SLOTS + 8] = (long long)wall_clock64();
     return;
   }

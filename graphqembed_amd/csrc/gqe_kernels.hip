@@ -1038,6 +1038,9 @@ __global__ __launch_bounds__(GQE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     split_leftover(sr, d, ((int)blockIdx.x - front - row_blocks) * GQE_WAVES + (int)(threadIdx.x >> 6));
     return;
   }
+  // (Finding the named rows by their stamps instead of through the feed — a wave per wave block of 8 rows, no index indirection,
+  // no claim, no duplicate entries — measured 20.1 us for this launch against 18.6: four sequential passes of dependent loads
+  // per wave outlast one lane group per entry; experiment 68)
   const int tpr = d >> 2;  // lanes per row: a divisor of 64 (checked by the launcher), the group never straddles a wave
   const int e = (int)((((long long)blockIdx.x - front) * GQE_THREADS + threadIdx.x) / tpr);
   if (e >= rsegs.total) return;

@@ -14,7 +14,8 @@ __device__ unsigned long long g_first = ~0ull, g_last = 0ull;
 template <int T>
 __global__ __launch_bounds__(T) void k_rider(const GqeSplitRide r, int d) {
   if (threadIdx.x == 0) atomicMin(&g_first, (unsigned long long)wall_clock64());
-  split_rider<T / 64>(r, d, blockIdx.x);
+  __shared__ int flag;
+  split_rider<T / 64>(r, d, blockIdx.x, &flag);
   __syncthreads();
   if (threadIdx.x == 0) atomicMax(&g_last, (unsigned long long)wall_clock64());
 }
