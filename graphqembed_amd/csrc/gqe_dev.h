@@ -387,6 +387,15 @@ hipError_t gqe_launch_prestep(const GqeMatStep& ms, float* p, float* g, float* m
 // a pass over non-table, non-matrix tensors)
 hipError_t gqe_launch_split_rows(const GqeOptArgs& a, const GqeGemmRide& r, const GqeSplitSegs& segs, const GqeSplitRide& ride, const int32_t* idx,
                                  int32_t* stamp);
+// the reference's decoder / encoder extension points on [d, B] tensors (gqe_encode_rows / gqe_decoder_project / gqe_decoder_forward /
+// gqe_set_intersection, include/gqe.h)
+hipError_t gqe_launch_x_encode(const float* table, const int32_t* rows, int B, int d, const int32_t* bag_ptr, const int32_t* bag_ids, float* out,
+                               hipStream_t stream);
+hipError_t gqe_launch_x_project(int dec, const float* w, const float* e, int B, int d, float* out, hipStream_t stream);
+hipError_t gqe_launch_x_forward(int dec, const float* params, const long long* rel_params, int n_rels, const float* e1, const float* e2, int B, int d,
+                                float* scores, hipStream_t stream);
+hipError_t gqe_launch_x_intersect(const float* pre, const float* post, int agg_min, const float* e1, const float* e2, const float* e3, int B, int d,
+                                  float* out, hipStream_t stream);
 // non-table floats of the arena (dense gradients that travel with the exchanged slab)
 struct GqeSpans {
   int n;  // < 0: more than 8 spans (unsupported)

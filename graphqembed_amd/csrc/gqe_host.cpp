@@ -2649,6 +2649,82 @@ int gqe_adam_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, float l
   return run_opt(ctx, GQE_OPT_ADAM, segs, n_segs, lr, beta1, beta2, eps, stream);
 }
 
+// ---- the decoder / encoder extension points on [d, B] tensors (include/gqe.h) ----
+namespace {
+int x_settle(gqe_ctx* ctx, void* stream) {   // whatever a split step / deferred launch / lazy rows still owe the parameters
+  if (!ctx->params) return fail(ctx, GQE_ERR_STATE, "gqe_bind_arena has not been called");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (ctx->ws) {
+    int rc = flush_ride(ctx, st);
+    if (rc == GQE_OK) rc = flush_split(ctx, st);
+    if (rc != GQE_OK) return rc;
+  }
+  if (ctx->lazy && ctx->ws) return run_opt(ctx, GQE_OPT_FLUSH, nullptr, 0, 0.f, 0.f, 0.f, 0.f, stream);
+  return GQE_OK;
+}
+bool x_param_ok(const gqe_ctx* ctx, int64_t off, int64_t numel) { return off >= 0 && off + numel <= ctx->n_arena; }
+}  // namespace
+
+int gqe_encode_rows(gqe_ctx* ctx, int64_t table_offset, const int32_t* rows, int32_t B, float* out, void* stream) {
+  if (!ctx) return GQE_ERR_ARG;
+  if (!rows || !out || B < 0) return fail(ctx, GQE_ERR_ARG, "gqe_encode_rows: bad arguments");
+  const int t = table_of(ctx, table_offset);
+  if (t < 0) return fail(ctx, GQE_ERR_ARG, "gqe_encode_rows: no table at offset %lld", (long long)table_offset);
+  int rc = x_settle(ctx, stream);
+  if (rc != GQE_OK) return rc;
+  const int32_t *bp = nullptr, *bi = nullptr;
+  for (const Bag& bg : ctx->bags)
+    if (bg.table == t) {
+      bp = bg.ptr;
+      bi = bg.ids;
+    }
+  HIP_TRY(ctx, gqe_launch_x_encode(ctx->params + table_offset, rows, B, ctx->cfg.dim, bp, bi, out, reinterpret_cast<hipStream_t>(stream)));
+  return GQE_OK;
+}
+
+int gqe_decoder_project(gqe_ctx* ctx, int64_t rel_param, const float* embeds, int32_t B, float* out, void* stream) {
+  if (!ctx) return GQE_ERR_ARG;
+  const int64_t d = ctx->cfg.dim, numel = ctx->cfg.decoder == GQE_DEC_BILINEAR ? d * d : d;
+  if (!embeds || !out || B < 0 || !x_param_ok(ctx, rel_param, numel)) return fail(ctx, GQE_ERR_ARG, "gqe_decoder_project: bad arguments");
+  int rc = x_settle(ctx, stream);
+  if (rc != GQE_OK) return rc;
+  HIP_TRY(ctx, gqe_launch_x_project(ctx->cfg.decoder, ctx->params + rel_param, embeds, B, (int)d, out, reinterpret_cast<hipStream_t>(stream)));
+  return GQE_OK;
+}
+
+int gqe_decoder_forward(gqe_ctx* ctx, const int64_t* rel_params, int32_t n_rels, const float* embeds1, const float* embeds2, int32_t B,
+                        float* scores, void* stream) {
+  if (!ctx) return GQE_ERR_ARG;
+  const int64_t d = ctx->cfg.dim, numel = ctx->cfg.decoder == GQE_DEC_BILINEAR ? d * d : d;
+  if (!embeds1 || !embeds2 || !scores || B < 0 || n_rels < 0 || n_rels > GQE_MAX_HOPS || (n_rels && !rel_params))
+    return fail(ctx, GQE_ERR_ARG, "gqe_decoder_forward: bad arguments (at most %d relations)", GQE_MAX_HOPS);
+  long long rp[GQE_MAX_HOPS] = {0, 0, 0};
+  for (int k = 0; k < n_rels; ++k) {
+    if (!x_param_ok(ctx, rel_params[k], numel)) return fail(ctx, GQE_ERR_ARG, "gqe_decoder_forward: relation %d outside the arena", k);
+    rp[k] = rel_params[k];
+  }
+  int rc = x_settle(ctx, stream);
+  if (rc != GQE_OK) return rc;
+  HIP_TRY(ctx, gqe_launch_x_forward(ctx->cfg.decoder, ctx->params, rp, n_rels, embeds1, embeds2, B, (int)d, scores, reinterpret_cast<hipStream_t>(stream)));
+  return GQE_OK;
+}
+
+int gqe_set_intersection(gqe_ctx* ctx, int64_t pre_param, int64_t post_param, const float* embeds1, const float* embeds2,
+                         const float* embeds3, int32_t B, float* out, void* stream) {
+  if (!ctx) return GQE_ERR_ARG;
+  const int64_t d = ctx->cfg.dim;
+  if (!embeds1 || !embeds2 || !out || B < 0) return fail(ctx, GQE_ERR_ARG, "gqe_set_intersection: bad arguments");
+  if (is_mlp(ctx) != (pre_param >= 0) || (pre_param >= 0) != (post_param >= 0))
+    return fail(ctx, GQE_ERR_ARG, "gqe_set_intersection: Pre / Post are given exactly for the MLP intersections");
+  if (pre_param >= 0 && (!x_param_ok(ctx, pre_param, d * d) || !x_param_ok(ctx, post_param, d * d)))
+    return fail(ctx, GQE_ERR_ARG, "gqe_set_intersection: Pre / Post outside the arena");
+  int rc = x_settle(ctx, stream);
+  if (rc != GQE_OK) return rc;
+  HIP_TRY(ctx, gqe_launch_x_intersect(pre_param >= 0 ? ctx->params + pre_param : nullptr, post_param >= 0 ? ctx->params + post_param : nullptr,
+                                      is_min(ctx) ? 1 : 0, embeds1, embeds2, embeds3, B, (int)d, out, reinterpret_cast<hipStream_t>(stream)));
+  return GQE_OK;
+}
+
 int64_t gqe_split_steps(gqe_ctx* ctx) { return ctx ? ctx->split_steps : -1; }
 
 int gqe_train_step(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx, int32_t idx_on_device,

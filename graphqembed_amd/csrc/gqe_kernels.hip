@@ -1105,6 +1105,207 @@ hipError_t gqe_launch_split_rows(const GqeOptArgs& a, const GqeGemmRide& r, cons
 }
 
 // ------------------------------------------------------------------------------------------
+// The reference's decoder / encoder extension points on [d, B] tensors (decoders.py:142-150, 200-208, 228-236, 288-300,
+// 311-319; encoders.py:40-43): the phases of the fused kernel as small forward-only launches for callers that score one hop
+// or one intersection on their own.  Element (i, b) of an embedding batch sits at i * B + b (a contiguous torch [d, B]).
+// One wave per query column; a lane owns elements lane, lane + 64, ... (d <= GQE_MAX_DIM = 256: four per lane); the d x d
+// contractions run through an LDS copy of the wave's vector.  Not a hot path: no tiling over queries, no MFMA.
+// ------------------------------------------------------------------------------------------
+#define GQE_XNC 4   // elements per lane (GQE_MAX_DIM / 64)
+struct XVec {
+  float v[GQE_XNC];
+};
+__device__ __forceinline__ XVec x_load(const float* __restrict__ e, int d, int B, int b, int lane) {
+  XVec r;
+#pragma unroll
+  for (int c = 0; c < GQE_XNC; ++c) {
+    const int j = lane + 64 * c;
+    r.v[c] = j < d ? e[(size_t)j * B + b] : 0.f;
+  }
+  return r;
+}
+__device__ __forceinline__ void x_store(float* __restrict__ e, const XVec& x, int d, int B, int b, int lane) {
+#pragma unroll
+  for (int c = 0; c < GQE_XNC; ++c) {
+    const int j = lane + 64 * c;
+    if (j < d) e[(size_t)j * B + b] = x.v[c];
+  }
+}
+__device__ __forceinline__ float x_dot(const XVec& a, const XVec& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < GQE_XNC; ++c) s += a.v[c] * b.v[c];
+  return wave_sum(s);
+}
+// y = M x (TRANS: y = M^T x, i.e. the row vector x^T M) for the wave's vector; `buf`: d floats of LDS owned by the wave
+template <bool TRANS>
+__device__ __forceinline__ XVec x_matvec(const float* __restrict__ M, const XVec& x, int d, float* buf, int lane) {
+#pragma unroll
+  for (int c = 0; c < GQE_XNC; ++c) {
+    const int j = lane + 64 * c;
+    if (j < d) buf[j] = x.v[c];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the wave's own LDS writes before its reads (no barrier: the buffer is the wave's)
+  XVec y;
+#pragma unroll
+  for (int c = 0; c < GQE_XNC; ++c) {
+    const int j = lane + 64 * c;
+    float acc = 0.f;
+    if (j < d)
+      for (int k = 0; k < d; ++k) acc += (TRANS ? M[(size_t)k * d + j] : M[(size_t)j * d + k]) * buf[k];
+    y.v[c] = acc;
+  }
+  return y;
+}
+
+// DirectEncoder.forward(nodes, mode) (encoders.py:40-43): rows of the table (a bag mode: the mean of the bag's word rows),
+// L2-normalised without eps, as columns of out[d, B]
+__global__ __launch_bounds__(GQE_THREADS) void gqe_x_encode_kernel(const float* __restrict__ table, const int32_t* __restrict__ rows, int B, int d,
+                                                                  const int32_t* __restrict__ bag_ptr, const int32_t* __restrict__ bag_ids,
+                                                                  float* __restrict__ out) {
+  const int b = blockIdx.x * GQE_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const int r = rows[b];
+  XVec x;
+#pragma unroll
+  for (int c = 0; c < GQE_XNC; ++c) x.v[c] = 0.f;
+  if (bag_ptr) {
+    const int lo = bag_ptr[r], hi = bag_ptr[r + 1];
+    for (int k = lo; k < hi; ++k) {
+      const float* w = table + (size_t)bag_ids[k] * d;
+#pragma unroll
+      for (int c = 0; c < GQE_XNC; ++c) {
+        const int j = lane + 64 * c;
+        if (j < d) x.v[c] += w[j];
+      }
+    }
+    const float inv = 1.f / (float)(hi - lo);
+#pragma unroll
+    for (int c = 0; c < GQE_XNC; ++c) x.v[c] *= inv;
+  } else {
+    const float* w = table + (size_t)r * d;
+#pragma unroll
+    for (int c = 0; c < GQE_XNC; ++c) {
+      const int j = lane + 64 * c;
+      if (j < d) x.v[c] = w[j];
+    }
+  }
+  const float inv = 1.f / sqrtf(x_dot(x, x));
+#pragma unroll
+  for (int c = 0; c < GQE_XNC; ++c) x.v[c] *= inv;
+  x_store(out, x, d, B, b, lane);
+}
+
+// path_dec.project(embeds, rel): M . e (bilinear), e + w (TransE), e * w (bilinear-diag)
+__global__ __launch_bounds__(GQE_THREADS) void gqe_x_project_kernel(int dec, const float* __restrict__ w, const float* __restrict__ e, int B, int d,
+                                                                   float* __restrict__ out) {
+  __shared__ float s_buf[GQE_WAVES][GQE_MAX_DIM];
+  const int b = blockIdx.x * GQE_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  XVec x = x_load(e, d, B, b, lane);
+  if (dec == DEC_BILINEAR) {
+    x = x_matvec<false>(w, x, d, s_buf[threadIdx.x >> 6], lane);
+  } else {
+#pragma unroll
+    for (int c = 0; c < GQE_XNC; ++c) {
+      const int j = lane + 64 * c;
+      if (j < d) x.v[c] = dec == DEC_TRANSE ? x.v[c] + w[j] : x.v[c] * w[j];
+    }
+  }
+  x_store(out, x, d, B, b, lane);
+}
+
+struct GqeXRels {
+  int n;
+  long long param[GQE_MAX_HOPS];
+};
+// path_dec.forward(embeds1, embeds2, rels): the relation chain applied to embeds1 (row vector times M_r for bilinear), then the
+// cosine with embeds2 (per-norm clamp 1e-8) — bilinear-diag: the plain dot product (decoders.py:232)
+__global__ __launch_bounds__(GQE_THREADS) void gqe_x_forward_kernel(int dec, const float* __restrict__ params, const GqeXRels rels,
+                                                                   const float* __restrict__ e1, const float* __restrict__ e2, int B, int d,
+                                                                   float* __restrict__ scores) {
+  __shared__ float s_buf[GQE_WAVES][GQE_MAX_DIM];
+  const int b = blockIdx.x * GQE_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  XVec x = x_load(e1, d, B, b, lane);
+  const XVec y = x_load(e2, d, B, b, lane);
+  for (int r = 0; r < rels.n; ++r) {
+    const float* w = params + rels.param[r];
+    if (dec == DEC_BILINEAR) {
+      x = x_matvec<true>(w, x, d, s_buf[threadIdx.x >> 6], lane);
+    } else {
+#pragma unroll
+      for (int c = 0; c < GQE_XNC; ++c) {
+        const int j = lane + 64 * c;
+        if (j < d) x.v[c] = dec == DEC_TRANSE ? x.v[c] + w[j] : x.v[c] * w[j];
+      }
+    }
+  }
+  float s = x_dot(x, y);
+  if (dec != DEC_DIAG) s /= fmaxf(sqrtf(x_dot(x, x)), COS_EPS) * fmaxf(sqrtf(x_dot(y, y)), COS_EPS);
+  if (lane == 0) scores[b] = s;
+}
+
+// inter_dec(embeds1, embeds2, mode[, embeds3]): Post . agg_i relu(Pre . e_i) (pre == NULL: agg_i e_i); agg = first-arg-min / mean
+__global__ __launch_bounds__(GQE_THREADS) void gqe_x_intersect_kernel(const float* __restrict__ pre, const float* __restrict__ post, int agg_min,
+                                                                     const float* __restrict__ e1, const float* __restrict__ e2,
+                                                                     const float* __restrict__ e3, int B, int d, float* __restrict__ out) {
+  __shared__ float s_buf[GQE_WAVES][GQE_MAX_DIM];
+  const int b = blockIdx.x * GQE_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const float* es[3] = {e1, e2, e3};
+  const int n = e3 ? 3 : 2;
+  XVec h;
+  for (int i = 0; i < n; ++i) {
+    XVec z = x_load(es[i], d, B, b, lane);
+    if (pre) {
+      z = x_matvec<false>(pre, z, d, s_buf[threadIdx.x >> 6], lane);
+#pragma unroll
+      for (int c = 0; c < GQE_XNC; ++c) z.v[c] = fmaxf(z.v[c], 0.f);
+    }
+#pragma unroll
+    for (int c = 0; c < GQE_XNC; ++c) h.v[c] = i == 0 ? z.v[c] : (agg_min ? fminf(h.v[c], z.v[c]) : h.v[c] + z.v[c]);
+  }
+  if (!agg_min) {
+    const float inv = 1.f / (float)n;
+#pragma unroll
+    for (int c = 0; c < GQE_XNC; ++c) h.v[c] *= inv;
+  }
+  if (post) h = x_matvec<false>(post, h, d, s_buf[threadIdx.x >> 6], lane);
+  x_store(out, h, d, B, b, lane);
+}
+
+hipError_t gqe_launch_x_encode(const float* table, const int32_t* rows, int B, int d, const int32_t* bag_ptr, const int32_t* bag_ids, float* out,
+                               hipStream_t stream) {
+  if (B < 1) return hipSuccess;
+  hipLaunchKernelGGL(gqe_x_encode_kernel, dim3((unsigned)((B + GQE_WAVES - 1) / GQE_WAVES)), dim3(GQE_THREADS), 0, stream, table, rows, B, d, bag_ptr,
+                     bag_ids, out);
+  return hipGetLastError();
+}
+hipError_t gqe_launch_x_project(int dec, const float* w, const float* e, int B, int d, float* out, hipStream_t stream) {
+  if (B < 1) return hipSuccess;
+  hipLaunchKernelGGL(gqe_x_project_kernel, dim3((unsigned)((B + GQE_WAVES - 1) / GQE_WAVES)), dim3(GQE_THREADS), 0, stream, dec, w, e, B, d, out);
+  return hipGetLastError();
+}
+hipError_t gqe_launch_x_forward(int dec, const float* params, const long long* rel_params, int n_rels, const float* e1, const float* e2, int B, int d,
+                                float* scores, hipStream_t stream) {
+  if (B < 1) return hipSuccess;
+  GqeXRels r;
+  r.n = n_rels;
+  for (int k = 0; k < GQE_MAX_HOPS; ++k) r.param[k] = k < n_rels ? rel_params[k] : 0;
+  hipLaunchKernelGGL(gqe_x_forward_kernel, dim3((unsigned)((B + GQE_WAVES - 1) / GQE_WAVES)), dim3(GQE_THREADS), 0, stream, dec, params, r, e1, e2, B, d,
+                     scores);
+  return hipGetLastError();
+}
+hipError_t gqe_launch_x_intersect(const float* pre, const float* post, int agg_min, const float* e1, const float* e2, const float* e3, int B, int d,
+                                  float* out, hipStream_t stream) {
+  if (B < 1) return hipSuccess;
+  hipLaunchKernelGGL(gqe_x_intersect_kernel, dim3((unsigned)((B + GQE_WAVES - 1) / GQE_WAVES)), dim3(GQE_THREADS), 0, stream, pre, post, agg_min, e1, e2,
+                     e3, B, d, out);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // data-parallel exchange.  Entry space = world slabs of S entries (d floats each); slab k:
 //   [0, n)            contribution vectors of rank k (written by its fused kernel)
 //   [n, n + R)        int32 list head of each contribution (-1: not pushed), R = ceil(n / d)

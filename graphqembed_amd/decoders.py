@@ -8,7 +8,9 @@ shapes and initialisers as the reference, so ``state_dict`` interchanges with it
   SetIntersection              netquery/decoders.py:270-300   Pre_m/Post_m [d,d] per mode
   SimpleSetIntersection        netquery/decoders.py:302-319   no parameters
 The arithmetic (projection chains, relu/min/mean, Pre/Post contractions) runs inside the
-fused HIP kernel; ``kind`` tells the engine which specialisation to launch.
+fused HIP kernel; ``kind`` tells the engine which specialisation to launch.  The reference's
+per-decoder entry points (``forward`` / ``project`` / the intersection's ``forward`` on [d, B]
+tensors) are served by small forward-only HIP launches once the decoder belongs to a model.
 """
 from __future__ import annotations
 
@@ -40,11 +42,25 @@ class _MetapathDecoder(nn.Module):
     def param_name(rel):
         return "_".join(rel)
 
+    # The reference's extension point (decoders.py:142-150, 200-208, 228-236) on [d, B] tensors.  QueryEncoderDecoder never calls
+    # it — queries run through the fused kernel — but a caller that scores one hop on its own gets the same arithmetic from small
+    # forward-only HIP launches (gqe_decoder_forward / gqe_decoder_project, include/gqe.h) once the decoder belongs to a model
+    # (the model's engine owns the parameters).  No gradient flows through these calls.
+    _engine = None            # set by QueryEncoderDecoder; (key prefix, engine)
+
+    def _attached(self):
+        if self._engine is None:
+            raise NotImplementedError("this decoder is not part of a QueryEncoderDecoder yet: its arithmetic runs on the model's "
+                                      "HIP engine (there is no torch fallback)")
+        return self._engine
+
     def forward(self, embeds1, embeds2, rels):
-        raise NotImplementedError("relation decoders are evaluated inside the fused HIP kernel")
+        prefix, eng = self._attached()
+        return eng.decoder_forward([prefix + self.param_name(r) for r in rels], embeds1, embeds2)
 
     def project(self, embeds, rel):
-        raise NotImplementedError("relation decoders are evaluated inside the fused HIP kernel")
+        prefix, eng = self._attached()
+        return eng.decoder_project(prefix + self.param_name(rel), embeds)
 
 
 class BilinearMetapathDecoder(_MetapathDecoder):
@@ -94,8 +110,14 @@ class SetIntersection(nn.Module):
             init.xavier_uniform_(post)
             self.register_parameter(mode + "_postmat", nn.Parameter(post))
 
+    _engine = None            # set by QueryEncoderDecoder; (key prefix, engine)
+
     def forward(self, embeds1, embeds2, mode, embeds3=[]):
-        raise NotImplementedError("set intersection is evaluated inside the fused HIP kernel")
+        """decoders.py:288-300 on [d, B] tensors, as a small forward-only HIP launch (gqe_set_intersection)."""
+        if self._engine is None:
+            raise NotImplementedError("this intersection decoder is not part of a QueryEncoderDecoder yet (no torch fallback)")
+        prefix, eng = self._engine
+        return eng.set_intersection(prefix + mode + "_premat", prefix + mode + "_postmat", embeds1, embeds2, embeds3 if len(embeds3) > 0 else None)
 
 
 class SimpleSetIntersection(nn.Module):
@@ -108,5 +130,10 @@ class SimpleSetIntersection(nn.Module):
         self.agg_func = agg_func
         self.kind = "min-simple" if agg_func is torch.min else "mean-simple"
 
+    _engine = None
+
     def forward(self, embeds1, embeds2, mode, embeds3=[]):
-        raise NotImplementedError("set intersection is evaluated inside the fused HIP kernel")
+        """decoders.py:311-319 on [d, B] tensors (gqe_set_intersection without Pre / Post)."""
+        if self._engine is None:
+            raise NotImplementedError("this intersection decoder is not part of a QueryEncoderDecoder yet (no torch fallback)")
+        return self._engine[1].set_intersection(None, None, embeds1, embeds2, embeds3 if len(embeds3) > 0 else None)

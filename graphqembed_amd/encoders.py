@@ -85,6 +85,12 @@ class DirectEncoder(nn.Module):
             out[real] = got
         return out
 
+    _engine = None            # set by QueryEncoderDecoder; (key prefix, engine)
+
     def forward(self, nodes, mode, offset=None, **kwargs):
-        raise NotImplementedError("DirectEncoder is evaluated inside the fused HIP kernel; call "
-                                  "QueryEncoderDecoder.forward / margin_loss")
+        """encoders.py:40-43: the L2-normalised feature rows of ``nodes`` as columns, [d, B] — a small forward-only HIP launch
+        (gqe_encode_rows) once the encoder belongs to a model; inside queries the fused kernel does the gather itself."""
+        if self._engine is None:
+            raise NotImplementedError("DirectEncoder is evaluated on the model's HIP engine; build a QueryEncoderDecoder first")
+        prefix, eng = self._engine
+        return eng.encode_rows(prefix + "feat-%s.weight" % mode, self.rows(nodes, mode))

@@ -117,6 +117,10 @@ SYMBOLS = OrderedDict([
     ("gqe_margin_fwd_bwd", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P, _P, _P])),
     ("gqe_allreduce_grads", (C.c_int, [_P, _P, _P])),
     ("gqe_adam_step", (C.c_int, [_P, C.POINTER(gqe_segment), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P])),
+    ("gqe_encode_rows", (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P, _P])),
+    ("gqe_decoder_project", (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P, _P])),
+    ("gqe_decoder_forward", (C.c_int, [_P, C.POINTER(C.c_int64), C.c_int32, _P, _P, C.c_int32, _P, _P])),
+    ("gqe_set_intersection", (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int32, _P, _P])),
     ("gqe_train_step", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, C.POINTER(gqe_segment), C.c_int32,
                                   C.c_float, C.c_float, C.c_float, C.c_float, _P, _P])),
     ("gqe_split_steps", (C.c_int64, [_P])),
@@ -642,6 +646,50 @@ class Engine(object):
                                             losses.data_ptr(), self._stream()))
         self._held_losses = losses
         return losses
+
+    # -- the reference's decoder / encoder extension points on [d, B] tensors (include/gqe.h) --------------------------
+    def _embeds(self, x, what):
+        t = self.torch
+        if not (isinstance(x, t.Tensor) and x.dim() == 2 and x.shape[0] == self.dim):
+            raise Exception("%s: expected a [%d, B] tensor" % (what, self.dim))
+        return x.to(device=self.device, dtype=t.float32).contiguous()
+
+    def encode_rows(self, table_key, rows):
+        """DirectEncoder.forward: the L2-normalised table rows as columns, [d, B] (gqe_encode_rows)."""
+        t = self.torch
+        rows = t.as_tensor(np.ascontiguousarray(rows, dtype=np.int32)).to(self.device)
+        out = t.empty((self.dim, len(rows)), dtype=t.float32, device=self.device)
+        self.params_changed()
+        self._check(self.lib.gqe_encode_rows(self.ctx, self.layout.offset(table_key), rows.data_ptr(), len(rows), out.data_ptr(), self._stream()))
+        return out
+
+    def decoder_project(self, rel_key, embeds):
+        e = self._embeds(embeds, "project")
+        out = self.torch.empty_like(e)
+        self.params_changed()
+        self._check(self.lib.gqe_decoder_project(self.ctx, self.layout.offset(rel_key), e.data_ptr(), e.shape[1], out.data_ptr(), self._stream()))
+        return out
+
+    def decoder_forward(self, rel_keys, embeds1, embeds2):
+        e1, e2 = self._embeds(embeds1, "forward"), self._embeds(embeds2, "forward")
+        if e1.shape != e2.shape:
+            raise Exception("forward: embeds1 and embeds2 differ in shape")
+        offs = (C.c_int64 * max(len(rel_keys), 1))(*[self.layout.offset(k) for k in rel_keys])
+        out = self.torch.empty(e1.shape[1], dtype=self.torch.float32, device=self.device)
+        self.params_changed()
+        self._check(self.lib.gqe_decoder_forward(self.ctx, offs, len(rel_keys), e1.data_ptr(), e2.data_ptr(), e1.shape[1], out.data_ptr(), self._stream()))
+        return out
+
+    def set_intersection(self, pre_key, post_key, embeds1, embeds2, embeds3=None):
+        es = [self._embeds(x, "intersection") for x in (embeds1, embeds2) + ((embeds3,) if embeds3 is not None else ())]
+        if any(e.shape != es[0].shape for e in es):
+            raise Exception("intersection: the embedding batches differ in shape")
+        out = self.torch.empty_like(es[0])
+        self.params_changed()
+        self._check(self.lib.gqe_set_intersection(self.ctx, -1 if pre_key is None else self.layout.offset(pre_key),
+                                                  -1 if post_key is None else self.layout.offset(post_key), es[0].data_ptr(), es[1].data_ptr(),
+                                                  es[2].data_ptr() if len(es) == 3 else None, es[0].shape[1], out.data_ptr(), self._stream()))
+        return out
 
     def split_steps(self):
         """How many train_step calls ran as split steps so far (gqe_split_steps)."""

@@ -79,6 +79,9 @@ class QueryEncoderDecoder(nn.Module):
             view = layout.view(self.engine.params, name)
             view.copy_(p.data)
             p.data = view
+        # the reference's per-module entry points (enc.forward, path_dec.forward / project, inter_dec.forward on [d, B] tensors)
+        # are served by the engine too (include/gqe.h: the extension points)
+        enc._engine, path_dec._engine, inter_dec._engine = ("enc.", self.engine), ("path_dec.", self.engine), ("inter_dec.", self.engine)
         self._plans = {}
         self._touched = set()      # tensors with a gradient since the last optimiser step
         self._dirty = set()        # tensors whose grad-arena segment may be non-zero

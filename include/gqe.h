@@ -404,6 +404,23 @@ int gqe_allreduce_grads(gqe_ctx* ctx, void* nccl_comm, void* stream);
  * over the listed segments only. */
 int gqe_adam_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs,
                   float lr, float beta1, float beta2, float eps, void* stream);
+/* The reference's decoder / encoder EXTENSION POINTS on [d, B] tensors — what model.py composes a query out of, for callers that
+ * score one hop or one intersection on their own (the fused path above never calls them).  Device pointers; element (i, b) of an
+ * embedding batch at i * B + b (a contiguous torch [d, B]); forward only; the decoder kind / aggregation are the ctx's.
+ *   gqe_encode_rows        replaces DirectEncoder.forward(nodes, mode) (encoders.py:40-43): out[:, b] = the L2-normalised row
+ *                          rows[b] of the table at table_offset (a bag table: the mean of the bag's word rows, normalised)
+ *   gqe_decoder_project    replaces path_dec.project(embeds, rel) (decoders.py:149-150, 207-208, 235-236): M_rel . e | e + w | e * w
+ *   gqe_decoder_forward    replaces path_dec.forward(embeds1, embeds2, rels) (decoders.py:142-147, 200-205, 228-233): the chain
+ *                          rels[0 .. n_rels) applied to embeds1, then cos(., embeds2) — bilinear-diag: the plain dot product
+ *   gqe_set_intersection   replaces inter_dec(embeds1, embeds2, mode, embeds3) (decoders.py:288-300, 311-319): Post . agg_i
+ *                          relu(Pre . e_i); pre_param = post_param = -1 for the Simple intersection; embeds3 may be NULL */
+int gqe_encode_rows(gqe_ctx* ctx, int64_t table_offset, const int32_t* rows, int32_t B, float* out, void* stream);
+int gqe_decoder_project(gqe_ctx* ctx, int64_t rel_param, const float* embeds, int32_t B, float* out, void* stream);
+int gqe_decoder_forward(gqe_ctx* ctx, const int64_t* rel_params, int32_t n_rels, const float* embeds1, const float* embeds2, int32_t B,
+                        float* scores, void* stream);
+int gqe_set_intersection(gqe_ctx* ctx, int64_t pre_param, int64_t post_param, const float* embeds1, const float* embeds2,
+                         const float* embeds3, int32_t B, float* out, void* stream);
+
 /* replaces: one whole iteration of run_train's loop body — optimizer.zero_grad(); loss = run_batch(...) [model.margin_loss];
  * loss.backward(); optimizer.step() (train_helpers.py:76-79 with torch.optim.Adam, bio/train.py:62) — as ONE call:
  * gqe_margin_fwd_bwd(batches, idx, losses) followed by gqe_adam_step(segs, lr, beta1, beta2, eps), same arguments, same result.

@@ -322,3 +322,46 @@ def test_native_sampler_to_trainer_to_eval():
     after = {t: utils.eval_auc_queries(by_type[t], model)[0] for t in by_type}
     assert np.isfinite(last) and last < 0.95 * first, (first, last)
     assert np.mean(list(after.values())) > np.mean(list(before.values())) + 0.02, (before, after)
+
+
+@pytest.mark.parametrize("dec,inter,d", [("bilinear-diag", "min", 32), ("bilinear", "mean", 32), ("transe", "min-simple", 32), ("bilinear-diag", "min", 128)])
+def test_decoder_extension_points_match_the_oracle(dec, inter, d):
+    """The reference's per-module entry points on [d, B] tensors — enc.forward(nodes, mode), path_dec.project(embeds, rel),
+    path_dec.forward(embeds1, embeds2, rels), inter_dec(embeds1, embeds2, mode[, embeds3]) (encoders.py:40-43,
+    decoders.py:142-150, 200-208, 228-236, 288-300, 311-319) — served by small HIP launches, against the oracle's statements of
+    the same formulas."""
+    import torch
+    from oracle import netquery_numpy as O
+    fixture = {("bilinear-diag", "min", 32): "train_bilinear-diag_min_d32.npz", ("bilinear", "mean", 32): "train_bilinear_mean_d32.npz",
+               ("transe", "min-simple", 32): "train_transe_min-simple_d32.npz", ("bilinear-diag", "min", 128): "train_bilinear-diag_min_d128.npz"}[(dec, inter, d)]
+    model, _ = build_world(dec, inter, d, fixture)
+    params = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in model.state_dict().items()}
+    rng = np.random.RandomState(4)
+    graph = model.graph
+    rels = list(model.path_dec.rels)
+    r1 = rels[0]
+    r2 = next(r for r in rels if r[0] == r1[2])               # hooks onto r1's far end
+    B = 37
+    mode = r1[0]
+    nodes = [graph.full_lists[mode][i] for i in rng.randint(0, len(graph.full_lists[mode]), B)]
+    e = model.enc.forward(nodes, mode)
+    assert tuple(e.shape) == (d, B)
+    want, _ = O._encode(params, mode, model.enc.rows(nodes, mode), np.float64)
+    np.testing.assert_allclose(e.cpu().numpy().T, want, rtol=1e-5, atol=1e-7)
+    # project / forward
+    p = model.path_dec.project(e, r1)
+    np.testing.assert_allclose(p.cpu().numpy().T, O._project(dec, params, r1, want), rtol=1e-5, atol=1e-6)
+    m2 = r2[2]
+    nodes2 = [graph.full_lists[m2][i] for i in rng.randint(0, len(graph.full_lists[m2]), B)]
+    e2 = model.enc.forward(nodes2, m2)
+    want2, _ = O._encode(params, m2, model.enc.rows(nodes2, m2), np.float64)
+    s = model.path_dec.forward(e, e2, [r1, r2])
+    np.testing.assert_allclose(s.cpu().numpy(), O._chain_score(dec, params, [r1, r2], want, want2)[0], rtol=1e-4, atol=2e-6)
+    # the intersection operator: two and three inputs, in the mode of e
+    a, b_, c = e, torch.flip(e, dims=[1]), 0.5 * e + 0.5 * torch.flip(e, dims=[1])
+    for es in ((a, b_), (a, b_, c)):
+        got = model.inter_dec(es[0], es[1], mode, es[2] if len(es) == 3 else [])
+        q, _ = O._intersect(inter, params, mode, [x.cpu().numpy().T.astype(np.float64) for x in es])
+        np.testing.assert_allclose(got.cpu().numpy().T, q, rtol=1e-4, atol=2e-6)
+    with pytest.raises(Exception):
+        model.path_dec.project(torch.zeros(d + 1, 3), r1)
