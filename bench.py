@@ -386,6 +386,10 @@ def kernel_block(eng, prepared, used, ms_per_step, lazy=False, world=1, d=128, t
         for k, nm in ((3, "optimiser_other_tables"), (4, "catch_up_before_read")):
             ms, n = eng.timing_read(k)
             out["kernels"][nm] = {"avg_launch_ms": round(ms, 5), "launches": n}
+        if eng.gemm_rides() > 0:
+            out["kernels"]["pair_gemm"]["note"] = ("gqe_set_deferred_gemm: the pair-GEMM units and the loss finalize ride in the step's row launch "
+                                                   "(gqe_rows_ride_kernel); this bracket is the small launch that steps the d x d matrices behind it "
+                                                   "(and the separate pair GEMM in front of the periodic full passes)")
     return out
 
 
@@ -496,8 +500,8 @@ def measure(wl, args, dist, rank, world, exchange="sparse", lazy=False, steps=No
     # the fused launch (the split step, csrc/gqe_split.h) wherever that applies, and the two-call sequence elsewhere.
     # GQE_BENCH_TWO_CALLS=1 measures gqe_margin_fwd_bwd + gqe_adam_step (round 4's headline step).
     train_step = deferred and os.environ.get("GQE_BENCH_TWO_CALLS") is None
-    if deferred:
-        eng.set_deferred_gemm(True)
+    if deferred or (lazy and world == 1 and os.environ.get("GQE_BENCH_NO_DEFERRED_GEMM") is None):
+        eng.set_deferred_gemm(True)                                # (lazy Adam: the units ride in the step's row launch)
     prepared = wl.prepare(eng, dist)
     session = parallel.shard_session(eng, dist, rank, world) if sharded else None
     ex_events = [] if (dist is not None and not sharded) else None
@@ -591,7 +595,7 @@ def host_fed(wl, args):
     out = None
     for feed in ("zero-copy", "copy", "lazy"):
         eng = wl.engine(lazy=(feed == "lazy"))
-        if feed != "lazy" and os.environ.get("GQE_BENCH_NO_DEFERRED_GEMM") is None:
+        if os.environ.get("GQE_BENCH_NO_DEFERRED_GEMM") is None:
             eng.set_deferred_gemm(True)                            # (losses are read behind feeder_run)
         plist = []
         for t in wl.types:

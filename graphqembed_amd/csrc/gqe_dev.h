@@ -214,6 +214,13 @@ struct GqeRowSegs {       // the table rows named by an index feed: segment k = 
   long long idx_begin[GQE_LAZY_SEGS];  // int32 offset from the launch's idx pointer (64-bit: a launch may span two feeds)
   int8_t tid[GQE_LAZY_SEGS];
 };
+struct GqeRowSegs32 {     // the same with 32-bit feed offsets: the form the row launch takes when it also carries riding pair-GEMM
+                          // units (their plan is 1.4 KB of kernel arguments; the launch has to stay inside the 4 KB it may pass)
+  int n, total;
+  int begin[GQE_LAZY_SEGS + 1];
+  int idx_begin[GQE_LAZY_SEGS];
+  int8_t tid[GQE_LAZY_SEGS];
+};
 struct GqeRowsArgs {
   GqeRowSegs segs;
   GqeLazyTabs t;
@@ -379,6 +386,10 @@ struct GqeMatStep {
 };
 hipError_t gqe_launch_matstep(const GqeMatStep& a, float* p, float* g, float* m, float* v, int d, float b1, float b2, float eps, hipStream_t stream);
 hipError_t gqe_launch_rows(const GqeRowsArgs& a);
+// lazy Adam's row launch (with gradient) carrying a deferred pair GEMM: workgroup 0 finalizes the losses, workgroups 1 .. units are
+// the GEMM units, then the row groups, then the chunks of a.dsegs (which must not contain the d x d matrices: they are stepped by
+// gqe_launch_matstep behind this launch).  hipErrorInvalidValue if a feed offset does not fit 32 bits.
+hipError_t gqe_launch_rows_ride(const GqeRowsArgs& a, const GqeGemmRide& r);
 // the split step's launch M: Adam on the pending d x d matrices (ms.n may be 0) + stamp[row] := 1 for the rows `segs` names
 hipError_t gqe_launch_prestep(const GqeMatStep& ms, float* p, float* g, float* m, float* v, int d, float b1, float b2, float eps,
                               const GqeSplitSegs& segs, const GqeSplitRide& ride, const int32_t* idx, int32_t* stamp, hipStream_t stream);

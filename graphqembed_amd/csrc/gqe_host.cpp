@@ -1206,7 +1206,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     bool any_candidates = false;
     // gqe_set_deferred_gemm: may this launch's pair GEMM wait for the Adam pass (decided below, once its units are counted)?
     const bool ride_candidate = bwd && (ctx->defer_gemm || ctx->split_active) && n_batches <= GQE_LAUNCH_BATCHES && !shard && ctx->world == 1 && d % 64 == 0 &&
-                                !ctx->lazy && !ctx->ordered_sums && (!ctx->prof || ctx->split_active);
+                                !ctx->ordered_sums && (!ctx->prof || ctx->split_active);   // (lazy Adam: the units ride in the step's row launch)
     // pair-GEMM units cover kmul x GQE_GEMM_KCHUNK queries: with thousands of units (large batches) a unit walks several
     // chunks before its one atomic pass over the 64 x 64 block — the units of a block all add into the same lines
     int kmul = 1;
@@ -1383,6 +1383,27 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
 
 #define GQE_OPT_FLUSH 4  // internal: lazy Adam, bring every lagging row of the dirty tables to its table's step
 
+// the lazy step's row launch with the pending pair GEMM in front of its row groups (gqe_rows_ride_kernel)
+int lazy_rows_ride(gqe_ctx* ctx, const GqeRowsArgs& ra) {
+  GqeGemmRide r;
+  r.plan = ctx->ride_fa.plan;
+  r.formulas = ctx->ride_fa.formulas;
+  r.ws = ctx->ride_fa.ws;
+  r.tile_loss = ctx->ride_fa.tile_loss;
+  r.losses = ctx->ride_losses;
+  const hipError_t e = gqe_launch_rows_ride(ra, r);
+  if (e == hipErrorInvalidValue) {   // (a feed offset beyond 32 bits: the two launches instead — the caller's ride flag stays harmless)
+    const int rc = flush_ride(ctx, ra.stream);
+    if (rc != GQE_OK) return rc;
+    HIP_TRY(ctx, gqe_launch_rows(ra));
+    return GQE_OK;
+  }
+  HIP_TRY(ctx, e);
+  ctx->ride_pending = false;
+  ++ctx->rides;
+  return GQE_OK;
+}
+
 int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, float lr, float b1, float b2, float eps,
             void* stream) {
   if (!ctx) return GQE_ERR_ARG;
@@ -1395,7 +1416,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
   const int d = ctx->cfg.dim;
   // a deferred pair GEMM rides in this pass if it is a plain eager Adam pass (decided at the launch below); everything else
   // needs the matrix gradients in place first
-  const bool may_ride = ctx->ride_pending && mode_in == GQE_OPT_ADAM && !ctx->lazy && !ctx->ordered_sums && ctx->world == 1;
+  const bool may_ride = ctx->ride_pending && mode_in == GQE_OPT_ADAM && !ctx->ordered_sums && ctx->world == 1;   // (lazy: decided where the sparse launch is)
   if (ctx->ride_pending && !may_ride) {
     const int rcf = flush_ride(ctx, st);
     if (rcf != GQE_OK) return rcf;
@@ -1711,10 +1732,21 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       GqeOptArgs ob = oa;
       ob.total_chunks = emit([&](size_t ui) { return ctx->universe[ui].is_table && !lazy_table_ok(ctx, ctx->universe[ui].table_index); },
                              ob.active, ob.coef, &ob.act, &ob.n_act);
+      // A deferred pair GEMM (gqe_set_deferred_gemm) rides in the row launch — the row groups do not read the matrix gradients —
+      // when ONE launch covers the step (the usual case: one feed, or this feed + the prefetched next one); the d x d matrices
+      // then leave the launch's dense chunks and are stepped by gqe_matstep_kernel behind it, as in the eager deferred step.
+      auto is_matrix = [&](size_t ui) { return ctx->universe[ui].tile != nullptr; };
+      const bool one_launch = feeds.size() == 1 && (!ctx->next_idx || (ctx->next_feed.size() == 1 && feeds[0].segs.n + ctx->next_feed[0].segs.n <= GQE_LAZY_SEGS));
+      const bool ride = ctx->ride_pending && may_ride && one_launch && !ra.sorted && !merged_matrix && (64 % (d / 4)) == 0;
+      if (ctx->ride_pending && !ride) {
+        rc = flush_ride(ctx, st);
+        if (rc != GQE_OK) return rc;
+      }
       // the small dense tensors ride in extra workgroups of the (first) row launch: the ordinary pass, tables masked out
       ra.dsegs = oa.segs;
       ra.n_dsegs = oa.n_segs;
-      ra.dense_chunks = emit(dense_only, ra.dactive, ra.dcoef, &ra.dact, &ra.n_dact);
+      ra.dense_chunks = ride ? emit([&](size_t ui) { return dense_only(ui) && !is_matrix(ui); }, ra.dactive, ra.dcoef, &ra.dact, &ra.n_dact)
+                             : emit(dense_only, ra.dactive, ra.dcoef, &ra.dact, &ra.n_dact);
       if (prefix_overflow) return fail(ctx, GQE_ERR_ARG, "optimiser pass over more than 2^31 chunks");
       rc = upload_staging();
       if (rc != GQE_OK) return rc;
@@ -1736,7 +1768,12 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
           both.begin[++both.n] = both.total;
         }
         ra.segs = both;
-        HIP_TRY(ctx, gqe_launch_rows(ra));
+        if (ride) {
+          rc = lazy_rows_ride(ctx, ra);
+          if (rc != GQE_OK) return rc;
+        } else {
+          HIP_TRY(ctx, gqe_launch_rows(ra));
+        }
         ra.dense_chunks = 0;
         merged = true;
         ctx->caught_idx = ctx->next_idx;
@@ -1746,7 +1783,12 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       for (const SavedFeed& sf : feeds) {
         if (merged) break;
         ra.segs = sf.segs;
-        HIP_TRY(ctx, gqe_launch_rows(ra));
+        if (ride) {   // (one_launch: this loop runs once and nothing follows it)
+          rc = lazy_rows_ride(ctx, ra);
+          if (rc != GQE_OK) return rc;
+        } else {
+          HIP_TRY(ctx, gqe_launch_rows(ra));
+        }
         ra.dense_chunks = 0;
       }
       if (ctx->next_idx && !merged) {
@@ -1764,6 +1806,33 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       }
       rc = timing_end(ctx, 2, st);
       if (rc != GQE_OK) return rc;
+      if (ride) {   // the d x d matrices, behind the kernel boundary that completes the units' sums
+        GqeMatStep ms;
+        memset(&ms, 0, sizeof ms);
+        ms.tile_t = ctx->lay.tile_floats;
+        bool any = false;
+        for (size_t ui = 0; ui < nu; ++ui) any = any || (ustep[ui] && is_matrix(ui));
+        if (any) {
+          rc = timing_begin(ctx, 1, st);
+          if (rc != GQE_OK) return rc;
+        }
+        for (size_t ui = 0; ui < nu; ++ui) {
+          if (!ustep[ui] || !is_matrix(ui)) continue;
+          ms.off[ms.n] = ctx->universe[ui].offset;
+          ms.tile[ms.n] = ctx->universe[ui].tile;
+          ms.step_size[ms.n] = uss[ui];
+          ms.bc2_sqrt[ms.n] = ubc[ui];
+          if (++ms.n == GQE_MATSTEP_MAX) {
+            HIP_TRY(ctx, gqe_launch_matstep(ms, oa.p, oa.g, oa.m, oa.v, d, b1, b2, eps, st));
+            ms.n = 0;
+          }
+        }
+        HIP_TRY(ctx, gqe_launch_matstep(ms, oa.p, oa.g, oa.m, oa.v, d, b1, b2, eps, st));
+        if (any) {
+          rc = timing_end(ctx, 1, st);
+          if (rc != GQE_OK) return rc;
+        }
+      }
       if (ctx->feed_buf >= 0) HIP_TRY(ctx, hipEventRecord(ctx->plan_free[ctx->feed_buf], st));  // the staged feed may go now
       if (ob.total_chunks > 0) {
         ob.lazy = false;
@@ -1782,6 +1851,10 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
           }
         }
     } else {
+      if (ctx->ride_pending) {   // the full pass reads the matrix gradients in its dense chunks: the deferred GEMM first
+        rc = flush_ride(ctx, st);
+        if (rc != GQE_OK) return rc;
+      }
       oa.lazy = true;
       oa.lz.last = reinterpret_cast<int32_t*>(ctx->ws + L.last_off);
       oa.lz.ring = reinterpret_cast<float2*>(ctx->ws + L.ring_off);

@@ -2,6 +2,7 @@
 // the fused query kernel (gqe_fused.h, instantiated per decoder variant in gqe_fused_inst.hip).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include "gqe_common.h"
 #include "gqe_adam.h"
 #define GQE_SPLIT_U 1   // the riders of the second launch live in the optimiser kernels' budget (<= 64 VGPRs, eight waves per SIMD: two slices in flight spilled 9 registers there)
@@ -849,26 +850,27 @@ static void launch_opt_mode(const GqeOptArgs& a, unsigned blocks) {
 // list — the launch that replaces the full-table pass after a fused forward/backward; without: replay only —
 // the launch that makes the rows current before a forward reads them.
 // ------------------------------------------------------------------------------------------
-template <bool WITH_GRAD, bool SORTED>
-__global__ __launch_bounds__(GQE_THREADS) void gqe_rows_kernel(const GqeRowSegs segs, const GqeLazyTabs t,
+template <bool WITH_GRAD, bool SORTED, typename SEGS>
+__device__ __forceinline__ void rows_body(const int row_block, const int n_row_blocks, const int dense_block, const int n_dense_blocks,
+                                          const SEGS& segs, const GqeLazyTabs& t,
                                                               const int32_t* __restrict__ idx, int32_t* __restrict__ last,
                                                               float2* __restrict__ ring, float* __restrict__ p,
                                                               float* __restrict__ g, float* __restrict__ m,
                                                               float* __restrict__ v, int32_t* __restrict__ head,
                                                               const int32_t* __restrict__ next,
                                                               const float* __restrict__ contrib, int max_entries, int d,
-                                                              float lr, float b1, float b2, float eps, int n_row_blocks,
+                                                              float lr, float b1, float b2, float eps,
                                                               const GqeDevSeg* __restrict__ dsegs, int n_dsegs,
-                                                              long long dense_chunks, GqeStepCoef dcoef, GqeOptActive dactive,
-                                                              const GqeActSeg* __restrict__ dact, int n_dact, GqeHot hot) {
-  if ((int)blockIdx.x >= n_row_blocks) {
+                                                              long long dense_chunks, const GqeStepCoef& dcoef, const GqeOptActive& dactive,
+                                                              const GqeActSeg* __restrict__ dact, int n_dact, const GqeHot& hot) {
+  if (row_block >= n_row_blocks) {
     // the step's small dense tensors (relation vectors / matrices, Pre / Post): the ordinary chunk loop
     GqeLazyArgs none;
     none.last = nullptr;
     none.ring = nullptr;
     GqeHot no_hot;
     no_hot.slot = nullptr;
-    opt_body<GQE_OPT_ADAM, false, false, false, false>((long long)blockIdx.x - n_row_blocks, (long long)gridDim.x - n_row_blocks,
+    opt_body<GQE_OPT_ADAM, false, false, false, false>((long long)dense_block, (long long)n_dense_blocks,
                                                        dsegs, n_dsegs, dense_chunks, p, g, m, v, head, next, contrib, nullptr,
                                                        max_entries, d, lr, b1, b2, eps, dcoef, dactive, dact, n_dact, none, no_hot);
     return;
@@ -877,11 +879,11 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_rows_kernel(const GqeRowSegs 
   __shared__ float2 s_ring[GQE_LAZY_TABLES * GQE_LAZY_RING];
   for (int i = threadIdx.x; i < GQE_LAZY_TABLES * GQE_LAZY_RING; i += GQE_THREADS) s_ring[i] = ring[i];
   __syncthreads();
-  if (WITH_GRAD && blockIdx.x == 0 && threadIdx.x < GQE_LAZY_TABLES && t.grad_step[threadIdx.x] > 0)
+  if (WITH_GRAD && row_block == 0 && threadIdx.x < GQE_LAZY_TABLES && t.grad_step[threadIdx.x] > 0)
     ring[threadIdx.x * GQE_LAZY_RING + (t.grad_step[threadIdx.x] & (GQE_LAZY_RING - 1))] =
         make_float2(t.step_size[threadIdx.x], t.bc2_sqrt[threadIdx.x]);
   const int tpr = d >> 2;  // threads per row (a divisor of 64: the group never straddles a wave)
-  const int e = (int)(((long long)blockIdx.x * GQE_THREADS + threadIdx.x) / tpr);
+  const int e = (int)(((long long)row_block * GQE_THREADS + threadIdx.x) / tpr);
   if (e >= segs.total) return;
   const int c4 = (threadIdx.x % tpr) * 4;
   int k = 0;  // segment of entry e: begin[k] <= e < begin[k+1]; a scan with uniform (scalar) loads of the kernel
@@ -930,6 +932,64 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_rows_kernel(const GqeRowSegs 
   *reinterpret_cast<float4*>(m + off) = mm;
   *reinterpret_cast<float4*>(v + off) = vv;
   *reinterpret_cast<float4*>(p + off) = pp;
+}
+
+template <bool WITH_GRAD, bool SORTED>
+__global__ __launch_bounds__(GQE_THREADS) void gqe_rows_kernel(const GqeRowSegs segs, const GqeLazyTabs t,
+                                                              const int32_t* __restrict__ idx, int32_t* __restrict__ last,
+                                                              float2* __restrict__ ring, float* __restrict__ p,
+                                                              float* __restrict__ g, float* __restrict__ m,
+                                                              float* __restrict__ v, int32_t* __restrict__ head,
+                                                              const int32_t* __restrict__ next,
+                                                              const float* __restrict__ contrib, int max_entries, int d,
+                                                              float lr, float b1, float b2, float eps, int n_row_blocks,
+                                                              const GqeDevSeg* __restrict__ dsegs, int n_dsegs,
+                                                              long long dense_chunks, GqeStepCoef dcoef, GqeOptActive dactive,
+                                                              const GqeActSeg* __restrict__ dact, int n_dact, GqeHot hot) {
+  rows_body<WITH_GRAD, SORTED>((int)blockIdx.x, n_row_blocks, (int)blockIdx.x - n_row_blocks, (int)gridDim.x - n_row_blocks, segs, t, idx, last, ring, p, g,
+                               m, v, head, next, contrib, max_entries, d, lr, b1, b2, eps, dsegs, n_dsegs, dense_chunks, dcoef, dactive, dact, n_dact,
+                               hot);
+}
+
+// The row launch that closes a lazy-Adam step carrying the step's deferred pair GEMM (gqe_set_deferred_gemm): the row groups do
+// not read the matrix gradients, so the units and the loss finalize run in front of them in the same launch — as they do in
+// front of the eager pass's chunks (gqe_opt_gemm_kernel) — and the d x d matrices are stepped by gqe_matstep_kernel behind it.
+__global__ __launch_bounds__(GQE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void gqe_rows_ride_kernel(
+    const GqeRowSegs32 segs, const GqeLazyTabs t, const int32_t* __restrict__ idx, int32_t* __restrict__ last, float2* __restrict__ ring,
+    float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int32_t* __restrict__ head,
+    const int32_t* __restrict__ next, const float* __restrict__ contrib, int max_entries, int d, float lr, float b1, float b2, float eps,
+    int n_row_blocks, const GqeDevSeg* __restrict__ dsegs, int n_dsegs, long long dense_chunks, GqeStepCoef dcoef, GqeOptActive dactive,
+    const GqeActSeg* __restrict__ dact, int n_dact, GqeHot hot, GqeGemmRide ride) {
+  const int front = ride.plan.units + 1;
+  if ((int)blockIdx.x < front) {
+    if (blockIdx.x == 0) finalize_losses(ride.plan, ride.tile_loss, ride.losses);
+    else gemm_ride_unit(ride.plan, ride.formulas, ride.ws, g, d, (int)blockIdx.x - 1);
+    return;
+  }
+  const int rb = (int)blockIdx.x - front;
+  rows_body<true, false>(rb, n_row_blocks, rb - n_row_blocks, (int)gridDim.x - front - n_row_blocks, segs, t, idx, last, ring, p, g, m, v, head, next,
+                         contrib, max_entries, d, lr, b1, b2, eps, dsegs, n_dsegs, dense_chunks, dcoef, dactive, dact, n_dact, hot);
+}
+
+hipError_t gqe_launch_rows_ride(const GqeRowsArgs& a, const GqeGemmRide& r) {
+  if (a.d < 4 || (64 % (a.d >> 2)) != 0 || !a.with_grad || a.sorted) return hipErrorInvalidValue;
+  GqeRowSegs32 s32;
+  memset(&s32, 0, sizeof s32);
+  s32.n = a.segs.n;
+  s32.total = a.segs.total;
+  for (int k = 0; k <= a.segs.n; ++k) s32.begin[k] = a.segs.begin[k];
+  for (int k = 0; k < a.segs.n; ++k) {
+    if (a.segs.idx_begin[k] < -0x7fffffffll || a.segs.idx_begin[k] > 0x7fffffffll) return hipErrorInvalidValue;
+    s32.idx_begin[k] = (int)a.segs.idx_begin[k];
+    s32.tid[k] = a.segs.tid[k];
+  }
+  const long long threads = (long long)a.segs.total * (a.d >> 2);
+  const unsigned row_blocks = (unsigned)((threads + GQE_THREADS - 1) / GQE_THREADS);
+  const unsigned dense_blocks = (unsigned)(a.dense_chunks < 512 ? a.dense_chunks : 512);
+  hipLaunchKernelGGL(gqe_rows_ride_kernel, dim3((unsigned)(r.plan.units + 1) + row_blocks + dense_blocks), dim3(GQE_THREADS), 0, a.stream, s32, a.t, a.idx,
+                     a.last, a.ring, a.p, a.g, a.m, a.v, a.head, a.next, a.contrib, a.max_entries, a.d, a.lr, a.b1, a.b2, a.eps, (int)row_blocks, a.dsegs,
+                     a.n_dsegs, a.dense_chunks, a.dcoef, a.dactive, a.dact, a.n_dact, a.hot, r);
+  return hipGetLastError();
 }
 
 hipError_t gqe_launch_rows(const GqeRowsArgs& a) {

@@ -248,3 +248,45 @@ def test_train_step_through_the_reference_api():
     for k in got:
         diff = np.abs(got[k].astype(np.float64) - p0[k] - z["delta/" + k])
         assert diff.max() < 6e-2 and np.median(diff) < 1e-3, (k, diff.max(), np.median(diff))
+
+
+@pytest.mark.parametrize("dec,inter,d", [("bilinear-diag", "min", 128), ("bilinear", "mean", 64)])
+def test_lazy_adam_row_launch_carries_the_deferred_pair_gemm(dec, inter, d):
+    """Lazy (deferred, bit-exact) Adam with gqe_set_deferred_gemm: the matrix-gradient units and the loss finalize ride in the step's
+    ROW launch (gqe_rows_ride_kernel), the d x d matrices are stepped by gqe_matstep_kernel behind it.  Against an eager engine
+    without the switch on the same batches — with and without the next feed declared (gqe_lazy_prefetch: one launch covers
+    rows(t) and rows(t+1)) — losses, parameters and moments agree to float-atomic reordering once the lazy engine is synchronised."""
+    import torch
+    from gpu_utils import read_arena
+    from graphqembed_amd.tensorize import pack_margin_batches
+    rng = np.random.RandomState(8)
+    params, make = _world(rng, d, dec, inter)
+    eager, lazy = make(), make(lazy_adam=True)
+    lazy.set_deferred_gemm(True)
+    mixes = [["2-inter", "1-chain"], ["3-inter", "2-chain"], ["3-inter_chain", "2-inter", "3-chain"], ["2-inter"], ["3-chain_inter", "1-chain"], ["3-inter", "2-inter"]]
+    batches = [_batches(eager, rng, types, 200 + 16 * it) for it, types in enumerate(mixes)]
+    prepared = []
+    for items in batches:
+        descs, idx, n = pack_margin_batches(items)
+        prepared.append((descs, idx, n, set().union(*[p[0].touched for p in items]),
+                         lazy.prepare_margin(descs, torch.from_numpy(idx).to(lazy.device))))
+    for it, (descs, idx, n, keys, ps) in enumerate(prepared):
+        le, _, _ = eager.margin_fwd_bwd(descs, idx, n)
+        eager.adam_step(keys)
+        lazy.run_margin(ps)
+        if it % 2 == 0 and it + 1 < len(prepared):
+            lazy.lazy_prefetch(prepared[it + 1][4])                     # rows(t) and rows(t+1) in one launch
+        lazy.adam_step(keys)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(ps["losses"].cpu().numpy(), le.cpu().numpy(), rtol=2e-5, atol=1e-7, err_msg="iteration %d" % it)
+    assert lazy.gemm_rides() == len(prepared), lazy.gemm_rides()
+    for name, fa, fb in (("p", eager.params, lazy.params), ("m", eager.exp_avg, lazy.exp_avg), ("v", eager.exp_avg_sq, lazy.exp_avg_sq)):
+        xa, xb = read_arena(eager, fa), read_arena(lazy, fb)
+        for k in xa:
+            diff = np.abs(xa[k].astype(np.float64) - xb[k])
+            scale = max(float(np.abs(xa[k]).max()), 1e-30)
+            bad = diff > 1e-4 * scale + (1e-5 if name == "p" else 1e-9)
+            assert bad.mean() <= 2e-3, (name, k, int(bad.sum()), bad.size, float(diff.max()))
+    assert float(lazy.grads.abs().max()) == 0.0
+    eager.close()
+    lazy.close()

@@ -16,10 +16,11 @@ ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--workload", default="bio-synth")
 ap.add_argument("--mix", default="full", help="full | 1-chain (the edge-only burn-in step, SURVEY C1)")
 ap.add_argument("--defer", action="store_true", help="gqe_set_deferred_gemm: the pair GEMM rides in the Adam pass's launch")
+ap.add_argument("--lazy", action="store_true", help="gqe_set_lazy_adam (with the next feed declared every step: gqe_lazy_prefetch)")
 ap.add_argument("--train-step", action="store_true", help="gqe_train_step: one call per iteration (the split step where it applies)")
 a = ap.parse_args()
 wl = bench.Workload(a.workload, a.dim, a.decoder, "min", synth.FULL_MIX if a.mix == "full" else (synth.FULL_MIX[0],), a.batch)
-eng = wl.engine()
+eng = wl.engine(lazy=a.lazy)
 prep = wl.prepare(eng)
 if a.defer:
     eng.set_deferred_gemm(True)
@@ -33,6 +34,8 @@ def run(k0, k):
             eng.run_train_step(ps, ps["adam"])
             continue
         eng.run_margin(ps)
+        if a.lazy:
+            eng.lazy_prefetch(prep[(i + 1) % n])
         eng.run_adam(ps["adam"])
 
 
@@ -46,5 +49,5 @@ for rep in range(20):
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) / 100)
 loss = float(prep[(50 + 2000 - 1) % n]["losses"][-1].item())
-print(("train_step (%d split) " % eng.split_steps() if a.train_step else "") + ("deferred GEMM " if a.defer else "") + "%s d=%d %s B=%d: %.1f us/step (median of 20 x 100), final loss %.6f, params checksum %.6f"
+print(("lazy (%d rides) " % eng.gemm_rides() if a.lazy else "") + ("train_step (%d split) " % eng.split_steps() if a.train_step else "") + ("deferred GEMM " if a.defer else "") + "%s d=%d %s B=%d: %.1f us/step (median of 20 x 100), final loss %.6f, params checksum %.6f"
       % (a.workload, a.dim, a.decoder, a.batch, np.median(ts) * 1e6, loss, float(eng._params.double().abs().sum())), flush=True)
