@@ -945,7 +945,8 @@ int split_first_launch(gqe_ctx* ctx, const gqe_batch* batches, int n_batches, co
   fa.split.waves = (waves_env > 0 && waves_env <= fa.force_fw) ? waves_env : fa.force_fw;
   const int total_blocks = ctx->split_t.blk_begin[ctx->split_t.n];
   fa.split.lead = std::max(0, std::min(lead_env >= 0 ? lead_env : 96, GQE_SPLIT_MAX_RIDERS / 2));
-  const int tail = std::max(0, std::min(tail_env >= 0 ? tail_env : 64, GQE_SPLIT_MAX_RIDERS / 2));
+  // (one tail rider per CU: full Bilinear 99 -> 92 us, B = 256 69 -> 62 us against 64 of them; the headline is indifferent)
+  const int tail = std::max(0, std::min(tail_env >= 0 ? tail_env : 256, GQE_SPLIT_MAX_RIDERS / 2));
   fa.split.blocks = std::max(1, fa.split.lead + tail);
   fa.split.lead = std::min(fa.split.lead, fa.split.blocks);
   // a lead rider streams for the whole launch (~35 us), a tail rider for what is left of it when its CU becomes free: ranges 4 : 1
@@ -2862,7 +2863,11 @@ int gqe_train_step(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
     st.blk_begin[k + 1] = st.blk_begin[k] + (int)((ctx->tables[(size_t)t].rows + GQE_SPLIT_WROWS - 1) / GQE_SPLIT_WROWS);
     stream_bytes += 12ll * s.numel;
   }
-  split = split && st.n > 0 && stream_bytes <= GQE_NT_STREAM_BYTES;
+  static const long long max_stream = [] {   // GQE_SPLIT_MAX_STREAM_MB: tuning runs only
+    const char* e = getenv("GQE_SPLIT_MAX_STREAM_MB");
+    return e ? (long long)atoll(e) << 20 : 2 * (long long)GQE_NT_STREAM_BYTES;   // (d = 256 bio-synth, 298 MB of p + m + v: 179 -> 160 us per step)
+  }();
+  split = split && st.n > 0 && stream_bytes <= max_stream;
   // every table the batches name has to be among the stepped ones (the second launch owns their stamped rows)
   for (int bi = 0; bi < n_batches && split; ++bi) {
     const gqe_batch& b = batches[bi];
