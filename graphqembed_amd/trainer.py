@@ -81,6 +81,9 @@ class TensorizedTrainer(object):
         from .model import _FusedOptimizer
         if self.engine is not None and self.world == 1 and not self.sharded and isinstance(optimizer, _FusedOptimizer):
             self.engine.set_deferred_gemm(True)
+        from .model import FusedAdam
+        self._one_call = (self.world == 1 and not self.sharded and isinstance(optimizer, FusedAdam) and hasattr(model_or_engine, "train_step")
+                          and getattr(optimizer, "model", None) is model_or_engine and not getattr(self.engine, "lazy_adam", False))
         if self.sharded and plan_of is None:
             raise Exception("row-sharded training needs plan_of(formula) -> FormulaPlan on the engine's layout")
         if self.sharded:
@@ -126,6 +129,11 @@ class TensorizedTrainer(object):
             if slab != self._slab:
                 self.engine.exchange_reserve(slab)
                 self._slab = slab
+        if self._one_call:     # one GPU, the model's own FusedAdam: the iteration as ONE library call (gqe_train_step)
+            losses = self.model.train_step(items, self.opt)
+            self.iterations += 1
+            self.queries_seen += sum(len(x[1]) for x in items)
+            return losses
         losses, _, _ = self.model.margin_step(items)
         if self.world > 1:
             if self.engine.sparse_exchange:
