@@ -1230,6 +1230,22 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       if (forced == 1 || forced == 2 || forced == 4 || forced == 8) kmul = forced;
     }
     P.pad[0] = kmul;
+    // a split step's units (gqe_split_rows_kernel) are their launch's critical chain: 64 queries per unit when that keeps the
+    // launch under GQE_RIDE_MAX_UNITS (GQE_SPLIT_UNIT_Q: tuning runs)
+    int unit_q = 0;
+    if (bwd && ride_candidate && ctx->split_active) {
+      static const int uq = [] {
+        const char* e = getenv("GQE_SPLIT_UNIT_Q");
+        return e ? atoi(e) : 0;
+      }();
+      if (uq >= 16 && uq % 16 == 0) {
+        long long u = 0;
+        for (int k = 0; k < nb; ++k)
+          u += (long long)ctx->formulas[fid[b0 + k]].n_jobs * ((align_up(batches[b0 + k].n_queries, GQE_TQ) + uq - 1) / uq) * macros_sq;
+        if (u <= GQE_RIDE_MAX_UNITS) unit_q = uq;
+      }
+    }
+    P.pad[2] = unit_q;
     GqeDynBatch tmp[GQE_LAUNCH_BATCHES];
     int tiles_of[GQE_LAUNCH_BATCHES], units_of[GQE_LAUNCH_BATCHES], cost[GQE_LAUNCH_BATCHES], order[GQE_LAUNCH_BATCHES];
     for (int k = 0; k < nb; ++k) {
@@ -1264,7 +1280,8 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       if (bwd) {
         entry += (int64_t)(2 + f.n_anchors) * s.n_queries;
         scratch += (int64_t)f.n_slots * b.Bpad * d;
-        units_of[k] = f.n_jobs * ((b.Bpad + GQE_GEMM_KCHUNK * kmul - 1) / (GQE_GEMM_KCHUNK * kmul)) * macros_sq;
+        const int cq = unit_q ? unit_q : GQE_GEMM_KCHUNK * kmul;
+        units_of[k] = f.n_jobs * ((b.Bpad + cq - 1) / cq) * macros_sq;
       } else if (s.n_candidates > 0 && bil && chain) {
         // candidate lists of a full-Bilinear chain: the projection runs on the candidate side, so the batch's tiles cover its
         // candidates (16 per tile, one [16 x d] . [d x d] contraction per hop on the matrix cores); the query of every

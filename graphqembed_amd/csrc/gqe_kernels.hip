@@ -695,16 +695,18 @@ __device__ __forceinline__ void gemm_ride_unit(const GqeDynPlan& plan, const Gqe
   const GqeDevFormula* __restrict__ f = formulas + b.formula;
   constexpr int MT = GQE_GEMM_MT;
   const int mper = d / MT, macros = mper * mper;   // (d % 64 == 0: the host only lets such launches ride)
-  const int kmul = plan.pad[0];
-  const int chunks = (b.Bpad + GQE_GEMM_KCHUNK * kmul - 1) / (GQE_GEMM_KCHUNK * kmul);
+  // queries per unit: pad[0] chunks of GQE_GEMM_KCHUNK — or pad[2] queries (a split step's units are the critical chain of their
+  // launch: shorter units, more of them)
+  const int cq = plan.pad[2] ? plan.pad[2] : GQE_GEMM_KCHUNK * plan.pad[0];
+  const int chunks = (b.Bpad + cq - 1) / cq;
   int u = unit - b.unit_begin;
   const int job = u / (chunks * macros);
   u -= job * chunks * macros;
   const int chunk = u / macros;
   const int mt = u - chunk * macros;
   const int i0 = (mt / mper) * MT, j0 = (mt % mper) * MT;
-  const int k_first = chunk * GQE_GEMM_KCHUNK * kmul;
-  const int k_end = min(k_first + GQE_GEMM_KCHUNK * kmul, b.Bpad);   // Bpad % 16 == 0: whole steps of four queries
+  const int k_first = chunk * cq;
+  const int k_end = min(k_first + cq, b.Bpad);   // Bpad % 16 == 0: whole steps of four queries
   const size_t slot_floats = (size_t)b.Bpad * d;
   const float* L = ws + b.scratch_base + (size_t)f->job_L[job] * slot_floats + (size_t)lk * d + i0 + 4 * il;
   const float* R = ws + b.scratch_base + (size_t)f->job_R[job] * slot_floats + (size_t)lk * d + j0 + 16 * wave + il;

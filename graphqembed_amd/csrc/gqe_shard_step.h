@@ -441,6 +441,11 @@ int shard_run_consumed(gqe_ctx* ctx, ShardSession* S, uint64_t t, int s, int kin
   float* fetched = reinterpret_cast<float*>(ctx->ws + L.shard_fetch);
   float* csend = reinterpret_cast<float*>(ctx->ws + L.shard_csend);
   float* crecv = reinterpret_cast<float*>(ctx->ws + L.contrib_off);
+  // The serve kernel of a margin step pushes this step's entries onto the gradient lists (below): that must not happen on top of
+  // contributions an earlier call left linked — checked HERE, before anything is launched (gqe_shard_link's own check comes
+  // after the serve kernel and would leave head / next inconsistent behind its error).
+  if (kind == 1 && (ctx->entries_used != 0 || ctx->shard_sent))
+    return fail(ctx, GQE_ERR_STATE, "row-sharded step: contributions of an earlier call are still pending (step or materialize first)");
   ctx->shard_internal = true;
   // a margin step links while it serves: which entry answers which request is known now, so no link launch is needed between
   // the contributions' all-to-all and the optimiser pass (GQE_SHARD_LINK_LATE=1 keeps the separate launch: A / B runs)
