@@ -610,3 +610,70 @@ def test_deferred_pair_gemm_under_random_call_sequences(seed):
         assert rides_seen > 0, "the sequence never let a pair GEMM ride"
     for e in engines:
         e.close()
+
+
+def test_merged_dense_segment_over_matrices_keeps_copies_and_rides_consistent():
+    """The C ABI accepts ANY dense segment: one flat segment over all relation / Pre / Post parameters moves the matrices
+    without being their own d x d universe entries.  (1) the operand-ordered copies must follow (GQE_CHECK_TILES=1: every
+    forward / backward call verifies them): the pass marks them dirty and the next launch rebuilds them; (2) with
+    gqe_set_deferred_gemm such a pass must NOT carry the riding GEMM units (its chunks would read and zero a matrix gradient the
+    units are still adding to): the deferred launch is flushed first; (3) gqe_train_step takes the two-call sequence.  Results ==
+    an engine stepped tensor by tensor."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+from gpu_utils import TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, read_arena, toy_batch
+from graphqembed_amd.engine import gqe_segment
+from graphqembed_amd.tensorize import pack_margin_batches
+rng = np.random.RandomState(0)
+d, dec, inter = 64, "bilinear", "min"
+params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS)
+ref, eng = engine_from_params(params, d, dec, inter), engine_from_params(params, d, dec, inter)
+eng.set_deferred_gemm(True)
+lay = eng.layout
+tables = [k for k in lay.entries if k.startswith("enc.")]
+dense = [k for k in lay.entries if not k.startswith("enc.")]
+lo = min(lay.offset(k) for k in dense)
+hi = max(lay.offset(k) + lay.numel(k) for k in dense)
+
+def merged_segments(step):
+    arr = (gqe_segment * (len(tables) + 1))()
+    for i, k in enumerate(tables):
+        arr[i].offset, arr[i].numel, arr[i].step = lay.offset(k), lay.numel(k), step
+    arr[len(tables)].offset, arr[len(tables)].numel, arr[len(tables)].step = lo, hi - lo, step
+    return arr
+
+for step in range(1, 4):
+    items = [(q,) + toy_batch(rng, q, 96) for q in ("3-inter", "2-inter", "2-chain", "3-inter_chain", "1-chain", "3-chain_inter")]
+    keys = list(lay.entries)                      # both engines step EVERY tensor (a flat segment cannot leave one out): same step counts
+    for e in (ref, eng):
+        packed = [(plan_for(e, q, TOY_FORMULAS[q]), t, g, a, 1.0, 1.0) for (q, t, g, a) in items]
+        descs, idx, n = pack_margin_batches(packed)
+        if e is ref:
+            e.margin_fwd_bwd(descs, idx, n)
+            e.adam_step(keys)
+        elif step < 3:
+            e.margin_fwd_bwd(descs, idx, n)       # the pair GEMM is deferred ...
+            segs = merged_segments(step)          # ... and the pass that follows covers the matrices inside ONE flat segment
+            e._check(e.lib.gqe_adam_step(e.ctx, segs, len(segs), 0.01, 0.9, 0.999, 1e-8, e._stream()))
+        else:                                     # the same through gqe_train_step
+            arr = e.make_batches(descs)
+            keep, ptr, n_idx, on_dev = e._idx_arg(idx)
+            losses = torch.empty(len(descs) + 1, device=e.device)
+            segs = merged_segments(step)
+            e._check(e.lib.gqe_train_step(e.ctx, arr, len(descs), ptr, n_idx, on_dev, segs, len(segs), 0.01, 0.9, 0.999, 1e-8, losses.data_ptr(), e._stream()))
+    a, b = read_arena(ref, ref.params), read_arena(eng, eng.params)
+    for k in a:
+        diff = np.abs(a[k].astype(np.float64) - b[k])
+        assert (diff > 1e-4 * max(float(np.abs(a[k]).max()), 1e-30) + 1e-5).mean() <= 2e-3, (step, k, float(diff.max()))
+assert eng.gemm_rides() == 0 and eng.split_steps() == 0, (eng.gemm_rides(), eng.split_steps())
+print("MERGED OK")
+""" % (root, os.path.join(root, "tests"))
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, GQE_CHECK_TILES="1"), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert "MERGED OK" in p.stdout, p.stdout[-3000:]
