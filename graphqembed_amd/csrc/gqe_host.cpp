@@ -120,6 +120,7 @@ struct gqe_ctx {
   GqeSplitTabs split_t;
   GqeSplitRide split_ride;   // the rider description of the fused launch (its second launch continues the same ticket counter)
   GqeSplitSegs split_segs;
+  int split_buf = -1;        // staging buffer that holds the step's (host) index feed: free once the second launch has read it
   const int32_t* split_idx = nullptr;
   float split_b1 = 0.f, split_b2 = 0.f, split_eps = 0.f;
   std::vector<GqeMatStep> mat_pending;
@@ -1357,6 +1358,7 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     HIP_TRY(ctx, hipEventRecord(ctx->plan_free[buf], st));
     ctx->plan_free_set[buf] = true;
   }
+  ctx->split_buf = ctx->split_launched ? buf : -1;   // (a split step's second launch reads the staged feed again: it re-records the event)
   return GQE_OK;
 }
 
@@ -1946,6 +1948,8 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
                                          reinterpret_cast<int32_t*>(ctx->ws + ctx->lay.stamp_off)));
       rc = timing_end(ctx, 2, st);
       if (rc != GQE_OK) return rc;
+      if (ctx->split_buf >= 0) HIP_TRY(ctx, hipEventRecord(ctx->plan_free[ctx->split_buf], st));   // the staged feed may go NOW (not behind the fused launch)
+      ctx->split_buf = -1;
       ctx->split_launched = false;
       ++ctx->split_steps;
       // the d x d matrices wait for the next step's first launch (split_first_launch) or for flush_split
