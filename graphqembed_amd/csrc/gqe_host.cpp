@@ -1918,14 +1918,18 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
         return fail(ctx, GQE_ERR_STATE, "internal: split step reached a pass it cannot finish");
       auto is_matrix = [&](size_t ui) { return ctx->universe[ui].tile != nullptr; };
       for (size_t ui = 0; ui < nu; ++ui) {   // the tables: exactly the ones the riders stepped, with the same coefficients
-        if (!ustep[ui] || !ctx->universe[ui].is_table) continue;
+        if (!ustep[ui] || !ctx->universe[ui].is_table || is_bag_table(ctx, ctx->universe[ui].table_index)) continue;
         int slot = -1;
         for (int k = 0; k < ctx->split_t.n; ++k)
           if (ctx->split_t.offset[k] == ctx->universe[ui].offset) slot = k;
         if (slot < 0 || ctx->split_t.step_size[slot] != uss[ui] || ctx->split_t.bc2_sqrt[slot] != ubc[ui])
           return fail(ctx, GQE_ERR_STATE, "internal: split step: the second launch disagrees with the riders about table %lld", (long long)ctx->universe[ui].offset);
       }
-      oa.total_chunks = emit([&](size_t ui) { return !ctx->universe[ui].is_table && !is_matrix(ui); }, oa.active, oa.coef, &oa.act, &oa.n_act);
+      // the launch's ordinary chunk loop: the vectors, and bag tables in full (their lists hang on rows no feed names)
+      oa.total_chunks = emit([&](size_t ui) {
+        const GqeDevSeg& u = ctx->universe[ui];
+        return u.is_table ? is_bag_table(ctx, u.table_index) : !is_matrix(ui);
+      }, oa.active, oa.coef, &oa.act, &oa.n_act);
       if (prefix_overflow) return fail(ctx, GQE_ERR_ARG, "optimiser pass over more than 2^31 chunks");
       rc = upload_staging();
       if (rc != GQE_OK) return rc;
@@ -2835,7 +2839,9 @@ int gqe_train_step(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
   const int d = ctx->cfg.dim;
   // ---- may this step run split?  Everything the second launch will check is checked here, before anything is enqueued ----
   static const bool prof_ok = getenv("GQE_SPLIT_PROF") != nullptr;   // (debug profile of a split step: tools/probes/split_timeline.py)
-  bool split = !env_off && !ctx->lazy && !ctx->ordered_sums && ctx->world == 1 && !ctx->shard_on && (!ctx->prof || prof_ok) && ctx->bags.empty() &&
+  // (bag tables — nn.EmbeddingBag word tables: their gradient lists hang on word rows no feed names — are stepped in full by the
+  // second launch; the riders cover the plain tables)
+  bool split = !env_off && !ctx->lazy && !ctx->ordered_sums && ctx->world == 1 && !ctx->shard_on && (!ctx->prof || prof_ok) &&
                n_batches <= GQE_LAUNCH_BATCHES && n_segs <= ctx->cap_tensors && ctx->entries_used == 0 && !any_dense(ctx) &&
                gqe_fused_can_ride(ctx->cfg.decoder, is_mlp(ctx) ? 1 : 0, d, 0);
   for (const Table& t : ctx->tables) split = split && !t.pending;
@@ -2850,6 +2856,7 @@ int gqe_train_step(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
   std::vector<gqe_segment> resolved(segs, segs + n_segs);
   GqeSplitTabs st;
   memset(&st, 0, sizeof st);
+  std::vector<int64_t> bag_offsets;
   long long stream_bytes = 0;
   for (int i = 0; i < n_segs && split; ++i) {
     gqe_segment& s = resolved[(size_t)i];
@@ -2871,7 +2878,15 @@ int gqe_train_step(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
       if (covers && tile_of(ctx, s.offset) < 0) split = false;
       continue;
     }
-    if (s.numel != ctx->tables[(size_t)t].rows * d || st.n == GQE_SPLIT_TABLES) {
+    if (s.numel != ctx->tables[(size_t)t].rows * d) {
+      split = false;
+      break;
+    }
+    if (is_bag_table(ctx, t)) {   // stepped by the second launch's ordinary chunk loop (lists + link nodes), not by riders
+      bag_offsets.push_back(s.offset);
+      continue;
+    }
+    if (st.n == GQE_SPLIT_TABLES) {
       split = false;
       break;
     }
@@ -2895,7 +2910,7 @@ int gqe_train_step(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
     auto stepped = [&](int64_t off) {
       for (int k = 0; k < st.n; ++k)
         if (st.offset[k] == off) return true;
-      return false;
+      return std::find(bag_offsets.begin(), bag_offsets.end(), off) != bag_offsets.end();
     };
     split = stepped(b.target_table) && b.n_candidates == 0 && b.n_anchors >= 1 && b.n_anchors <= GQE_MAX_BRANCH;
     for (int i = 0; i < b.n_anchors && i < GQE_MAX_BRANCH && split; ++i) split = stepped(b.anchor_table[i]);

@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(GQE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     float* __restrict__ v, int32_t* __restrict__ head, const int32_t* __restrict__ next, const float* __restrict__ contrib, int max_entries, int d,
     float lr, float b1, float b2, float eps, GqeStepCoef coef, GqeOptActive active, const GqeActSeg* __restrict__ act, int n_act, GqeHot hot,
     GqeGemmRide ride, const GqeSplitSegs rsegs, const GqeSplitRide sr, const int32_t* __restrict__ idx, int32_t* __restrict__ stamp, int row_blocks,
-    int rider_blocks) {
+    int rider_blocks, const int32_t* __restrict__ link_contrib) {
   const GqeSplitTabs& t = sr.t;
   const int front = ride.plan.units + 1;   // (units == -1: the pair GEMM and the finalize block ran as a launch of their own)
   if ((int)blockIdx.x < front) {
@@ -1087,13 +1087,22 @@ __global__ __launch_bounds__(GQE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     return;
   }
   if ((int)blockIdx.x >= front + row_blocks + rider_blocks) {
+    // the ordinary chunk loop over the step's vectors — and over bag tables (link_contrib != NULL: word tables, stepped in full:
+    // their gradient lists and hot accumulators hang on rows no feed names)
     GqeLazyArgs lazy;   // (never read: LAZY = false)
-    GqeHot no_hot;
-    no_hot.slot = nullptr;
-    opt_body<GQE_OPT_ADAM, false, false, false, false>((long long)blockIdx.x - front - row_blocks - rider_blocks,
-                                                       (long long)gridDim.x - front - row_blocks - rider_blocks, segs,
-                                                       n_segs, total_chunks, p, g, m, v, head, next, contrib, nullptr, max_entries, d, lr, b1, b2,
-                                                       eps, coef, active, act, n_act, lazy, no_hot);
+    if (link_contrib) {
+      opt_body<GQE_OPT_ADAM, true, false, false, false>((long long)blockIdx.x - front - row_blocks - rider_blocks,
+                                                        (long long)gridDim.x - front - row_blocks - rider_blocks, segs, n_segs, total_chunks, p, g, m,
+                                                        v, head, next, contrib, link_contrib, max_entries, d, lr, b1, b2, eps, coef, active, act, n_act,
+                                                        lazy, hot);
+    } else {
+      GqeHot no_hot;
+      no_hot.slot = nullptr;
+      opt_body<GQE_OPT_ADAM, false, false, false, false>((long long)blockIdx.x - front - row_blocks - rider_blocks,
+                                                         (long long)gridDim.x - front - row_blocks - rider_blocks, segs, n_segs, total_chunks, p, g,
+                                                         m, v, head, next, contrib, nullptr, max_entries, d, lr, b1, b2, eps, coef, active, act, n_act,
+                                                         lazy, no_hot);
+    }
     return;
   }
   if ((int)blockIdx.x >= front + row_blocks) {   // what the fused launch's riders left of the untouched rows
@@ -1148,7 +1157,8 @@ hipError_t gqe_launch_split_rows(const GqeOptArgs& a, const GqeGemmRide& r, cons
   if (a.d < 4 || (64 % (a.d >> 2)) != 0) return hipErrorInvalidValue;
   const long long threads = (long long)segs.total * (a.d >> 2);
   const int row_blocks = (int)((threads + GQE_THREADS - 1) / GQE_THREADS);
-  const unsigned dense_blocks = (unsigned)(a.total_chunks < 512 ? a.total_chunks : 512);
+  // (bag tables in the chunk loop: tens of thousands of chunks — as many workgroups as the plain optimiser launch would take)
+  const unsigned dense_blocks = (unsigned)(a.total_chunks < 262144 ? a.total_chunks : 262144);
   static const int dbg = [] {   // GQE_SPLIT_DEBUG_B (timing experiments, WRONG results): 1 = without the GEMM units, 2 = without the named rows
     const char* e = getenv("GQE_SPLIT_DEBUG_B");
     return e ? atoi(e) : 0;
@@ -1162,7 +1172,7 @@ hipError_t gqe_launch_split_rows(const GqeOptArgs& a, const GqeGemmRide& r, cons
   const unsigned blocks = (unsigned)(r2.plan.units + 1) + (unsigned)rb + (unsigned)riders + dense_blocks;
   hipLaunchKernelGGL(gqe_split_rows_kernel, dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.n_segs, a.total_chunks, a.p, a.g, a.m, a.v, a.head,
                      a.next, a.contrib, a.max_entries, a.d, a.lr, a.b1, a.b2, a.eps, a.coef, a.active, a.act, a.n_act, a.hot, r2, segs, ride, idx, stamp,
-                     rb, riders);
+                     rb, riders, a.lists ? a.link_contrib : nullptr);
   return hipGetLastError();
 }
 

@@ -439,7 +439,7 @@ int gqe_set_intersection(gqe_ctx* ctx, int64_t pre_param, int64_t post_param, co
  * settles it: gqe_forward, gqe_margin_fwd_bwd, the optimiser calls, gqe_materialize_grads, gqe_optimizer_sync, ...).  A caller
  * that reads the parameter or moment arenas itself — a checkpoint, an evaluation of its own — calls gqe_optimizer_sync first.
  * Where the split does not apply the call runs the two-call sequence (with the matrix-gradient units riding in the Adam pass as
- * under gqe_set_deferred_gemm when that applies): lazy Adam, gqe_set_exchange / gqe_set_shard, ordered sums, bag tables, tables
+ * under gqe_set_deferred_gemm when that applies): lazy Adam, gqe_set_exchange / gqe_set_shard, ordered sums, tables
  * far beyond the Infinity Cache (p + m + v of the stepped tables above 384 MB), gradients already pending from an earlier gqe_margin_fwd_bwd, dims whose kernels are not the
  * straight-line ones (d % 64 != 0), more than GQE_LAUNCH_BATCHES batches or 8 stepped tables.  GQE_SPLIT=0 in the environment
  * forces that sequence.  gqe_split_steps: how many calls ran as split steps (diagnostics, tests). */

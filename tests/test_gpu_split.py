@@ -327,6 +327,48 @@ def test_train_step_host_feeds_without_synchronisation():
     # step rows with another iteration's stamps: lr-sized errors everywhere.)
     for k in a:
         diff = np.abs(a[k].astype(np.float64) - b[k])
-        assert np.median(diff) < 1e-3 and (diff > 2e-2).mean() <= 1e-3, (k, float(diff.max()), float(np.median(diff)), float((diff > 2e-2).mean()))
+        assert np.isfinite(b[k]).all() and float(diff.max()) < 0.1, (k, float(diff.max()))
+        if k.startswith("enc."):      # (a relation vector whose gradient is rounding noise moves by +- lr per step either way)
+            assert np.median(diff) < 1e-3 and (diff > 2e-2).mean() <= 1e-3, (k, float(diff.max()), float(np.median(diff)), float((diff > 2e-2).mean()))
     host.close()
     dev.close()
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_train_step_with_a_bag_table(d):
+    """A world with an nn.EmbeddingBag mode (Reddit posts: mode b = bags over a word table): the word table's gradient lists hang
+    on word rows no feed names, so a split step leaves that table to its second launch's ordinary chunk loop (lists, link nodes,
+    hot accumulators) while the riders cover the plain tables.  Against the two-call step, iteration by iteration from the same
+    state: losses, plain tables' unnamed rows bit-equal, everything else to float-atomic reordering."""
+    import torch
+    from gpu_utils import TOY_KINDS, TOY_SIZES, engine_from_params, random_params, read_arena
+    from graphqembed_amd.tensorize import pack_margin_batches
+    rng = np.random.RandomState(31)
+    dec, inter = "bilinear-diag", "min"
+    params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS, bag_modes=("b",))
+    a, b = engine_from_params(params, d, dec, inter), engine_from_params(params, d, dec, inter)
+    bag_key = O.table_key("b")
+    for it, types in enumerate([["1-chain", "2-inter"], ["3-inter", "2-chain", "3-inter_chain"], ["2-inter", "3-chain_inter"], ["1-chain"]]):
+        items = _batches(a, rng, types, 60 + 11 * it)
+        descs, idx, n = pack_margin_batches(items)
+        keys = set().union(*[p[0].touched for p in items])
+        b.params.copy_(a.params); b.exp_avg.copy_(a.exp_avg); b.exp_avg_sq.copy_(a.exp_avg_sq)
+        la, _, _ = a.margin_fwd_bwd(descs, idx, n)
+        a.adam_step(keys)
+        lb = b.train_step(descs, idx, keys)
+        np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=2e-5, atol=1e-7, err_msg="iteration %d" % it)
+        named = _named_rows(items, a.layout)
+        xa, xb = read_arena(a, a.params), read_arena(b, b.params)
+        for k in xa:
+            if k.startswith("enc.") and k != bag_key:
+                rows = np.ones(xa[k].shape[0], dtype=bool)
+                rows[sorted(named.get(k, ()))] = False
+                assert np.array_equal(xa[k][rows], xb[k][rows]), (it, k)
+            diff = np.abs(xa[k].astype(np.float64) - xb[k])
+            scale = max(float(np.abs(xa[k]).max()), 1e-30)
+            assert (diff > 1e-4 * scale + 1e-5).mean() <= 2e-3, (it, k, float(diff.max()))
+    assert b.split_steps() == 4
+    b.materialize()                                   # nothing left on a list, a link node or in an accumulator
+    assert float(b.grads.abs().max()) == 0.0
+    a.close()
+    b.close()
