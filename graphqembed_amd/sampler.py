@@ -71,6 +71,48 @@ def py_random_choices(counts):
     return out
 
 
+class PyRandomStream(object):
+    """The ``random`` module's generator held as a native array for a run of ``choices`` calls: ``random.getstate()`` /
+    ``setstate()`` move 625 words through a Python tuple (~60 us a round trip) — once per training iteration instead of once per
+    batch.  Between ``__enter__`` and ``__exit__`` nothing else may draw from ``random`` except between ``give()`` and ``take()``."""
+
+    def __init__(self):
+        self.state = None
+
+    def __enter__(self):
+        import random
+        self.version, words, self.gauss = random.getstate()
+        self.state = np.array(words, dtype=np.uint32)
+        return self
+
+    def choices(self, counts):
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        out = np.empty(len(counts), dtype=np.int64)
+        if len(counts) and _lib().gqe_py_random_choices(self.state.ctypes.data, counts.ctypes.data, len(counts), out.ctypes.data) != 0:
+            raise ValueError("gqe_py_random_choices: a list without entries cannot be chosen from")
+        return out
+
+    def give(self):
+        """Hand the state back to ``random``: something else is about to draw from it ..."""
+        import random
+        if self.state is not None:
+            random.setstate((self.version, tuple(self.state.tolist()), self.gauss))
+
+    def take(self):
+        """... and continue from wherever that left the generator."""
+        import random
+        if self.state is not None:
+            self.version, words, self.gauss = random.getstate()
+            self.state = np.array(words, dtype=np.uint32)
+
+    def __exit__(self, *exc):
+        import random
+        if self.state is not None:
+            random.setstate((self.version, tuple(self.state.tolist()), self.gauss))
+        self.state = None
+        return False
+
+
 class SampledQueries(object):
     """One ``sample`` call: ``qtype[n]``, ``edges[n,3,3]`` ((src, rel id, dst) local indices, -1 padding) and the CSR
     negative / hard-negative lists (local indices in the target mode)."""

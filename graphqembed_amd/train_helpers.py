@@ -148,14 +148,27 @@ class FusedExecutor(object):
 
     def begin(self):
         self.items = []
+        # the reference's negatives are drawn on the ``random`` module's generator: held natively for the iteration's batches
+        # (sampler.PyRandomStream), handed back in ``finish``
+        from .sampler import PyRandomStream
+        self._stream = PyRandomStream().__enter__()
+
+    def _close_stream(self):
+        st, self._stream = getattr(self, "_stream", None), None
+        if st is not None:
+            st.__exit__()
 
     def add_window(self, formula, pool, lo, hi, weight, hard):
         """``add(formula, pool[lo:hi], ...)`` without one interpreter step per query: the rows of the list come from a cache
         built on first use, and the negatives are the reference's draw — ``random.choice`` per query, model.py:113-120 —
         replayed on the ``random`` module's own generator by one native call (sampler.py_random_choices): the same values, the
         same state afterwards."""
-        from .sampler import py_random_choices
         m = self.model
+        stream = getattr(self, "_stream", None)
+        if stream is None:                       # (add_window outside begin / finish)
+            from .sampler import py_random_choices
+        else:
+            py_random_choices = stream.choices
         if "inter" not in formula.query_type and hard:
             raise Exception("Hard negative examples can only be used with intersection queries")
         rows = self._pools.get(id(pool))
@@ -176,13 +189,29 @@ class FusedExecutor(object):
             neg = flat[ptr[lo:hi] + py_random_choices(ptr[lo + 1:hi + 1] - ptr[lo:hi])]
         self.items.append((formula, rows.target[lo:hi], neg, rows.anchors[:, lo:hi], weight, 1.0))
 
+    def give_random(self):
+        """Whatever else draws from ``random`` inside an iteration (an evaluation, this class's own ``add``) has to see the generator
+        where the batches so far left it ..."""
+        st = getattr(self, "_stream", None)
+        if st is not None:
+            st.give()
+
+    def take_random(self):
+        """... and the batches after it continue from where IT left the generator."""
+        st = getattr(self, "_stream", None)
+        if st is not None:
+            st.take()
+
     def add(self, formula, queries, weight, hard):
         m = self.model
+        self.give_random()
         negatives = reference_negative_nodes(m.graph, formula, queries, hard)     # the reference's draw, call for call
+        self.take_random()
         target, anchors = m._rows(formula, queries, [q.target_node for q in queries])
         self.items.append((formula, target, m.enc.rows(negatives, formula.target_mode), anchors, weight, 1.0))
 
     def finish(self):
+        self._close_stream()
         if self.optimizer is not None:
             losses = self.model.train_step(self.items, self.optimizer)
         else:
@@ -242,6 +271,9 @@ def run_train(model, optimizer, train_queries, val_queries, test_queries, logger
               max_iter=int(10e7), inter_weight=0.005, path_weight=0.01, model_file=None):
     executor = FusedExecutor(model, optimizer) if isinstance(optimizer, _FusedOptimizer) else EagerExecutor(model)
 
+    give_random = getattr(executor, "give_random", lambda: None)
+    take_random = getattr(executor, "take_random", lambda: None)
+
     def add(window, weight, hard):
         formula, pool, lo, hi = window
         if hasattr(executor, "add_window"):
@@ -261,7 +293,9 @@ def run_train(model, optimizer, train_queries, val_queries, test_queries, logger
         if not all_types and (plateau.reached() or average.count >= max_burn_in):
             logger.info("Edge converged at iteration {:d}".format(iteration - 1))
             logger.info("Testing at edge conv...")
+            give_random()
             score_at_switch = _macro(evaluate(model, test_queries, iteration, logger))
+            take_random()
             all_types = True
             plateau.reset()
             average.reset()
@@ -271,6 +305,7 @@ def run_train(model, optimizer, train_queries, val_queries, test_queries, logger
             add(draw_window(train_queries[spec.query_type], iteration, batch_size), spec.weight, spec.hard)
         if all_types and plateau.reached():
             logger.info("Fully converged at iteration {:d}".format(iteration))
+            getattr(executor, "_close_stream", lambda: None)()
             break
         smoothed = average.add(executor.finish())
         optimizer.step()
