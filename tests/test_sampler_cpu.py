@@ -267,3 +267,35 @@ def test_samplers_against_the_reference_samplers_own_outputs(world):
             p_ref, p_nat = c / n_ref, got[t] / 40000.0
             sigma = np.sqrt(p_ref * (1 - p_ref) / n_ref)
             assert abs(p_ref - p_nat) < 4 * sigma + 0.004, (arity, t, p_ref, p_nat)
+
+
+def test_py_random_choices_replays_the_random_module():
+    """gqe_py_random_choices (include/gqe_sampler.h): ``random.choice`` per query — the reference's negative draw, model.py:113-120 —
+    as one native call: the same indices, the same generator state afterwards; across state regenerations (624 words), for list
+    lengths 1, 2, powers of two and their neighbours; PyRandomStream holds the state across calls and lends it out."""
+    import random
+    from graphqembed_amd.sampler import PyRandomStream, py_random_choices
+    rng = np.random.RandomState(1)
+    counts = np.concatenate([rng.randint(1, 400, 3000), [1, 2, 3, 4, 5, 255, 256, 257, 65535, 65536, 97002, (1 << 31) - 1, 1 << 31, (1 << 32) - 1]]).astype(np.int64)
+    random.seed(77)
+    want = [random.choice(range(int(c))) for c in counts]
+    after = [random.random() for _ in range(3)]
+    random.seed(77)
+    got = py_random_choices(counts)
+    assert np.array_equal(got, np.array(want, dtype=np.int64))
+    assert [random.random() for _ in range(3)] == after
+    # the stream: three native batches with a Python draw lent out in between == the same sequence drawn in Python
+    random.seed(5)
+    want = [random.randrange(9) for _ in range(50)] + [random.random()] + [random.randrange(1000) for _ in range(700)] + [random.randrange(7) for _ in range(5)]
+    tail = random.getrandbits(32)
+    random.seed(5)
+    with PyRandomStream() as st:
+        a = st.choices(np.full(50, 9))
+        st.give()
+        x = random.random()
+        st.take()
+        b = st.choices(np.full(700, 1000))
+        c = st.choices(np.full(5, 7))
+    assert list(a) + [x] + list(b) + list(c) == want and random.getrandbits(32) == tail
+    with pytest.raises(ValueError):
+        py_random_choices([3, 0, 2])
