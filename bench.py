@@ -889,6 +889,11 @@ def main():
     res["roofline"]["traffic"] = None if (world > 1 or args.lazy_adam or (d, B, args.decoder, args.inter_decoder) != ((256 if reddit else 128), 512, "bilinear-diag", "min")) \
         else pmc_traffic("gqe_fused_kernel" if res["roofline"]["kernel"].startswith("gqe_fused_kernel") else
                          "gqe_opt_gemm_kernel" if res["roofline"]["kernel"].startswith("gqe_opt_gemm_kernel") else "gqe_opt_kernel", args.workload)
+    if res["roofline"].get("traffic") and res["roofline"].get("avg_launch_ms"):
+        # what the memory system actually carried during the launch (PMC bytes of the last profiled run / this run's launch time)
+        tr = res["roofline"]["traffic"] / (res["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
+        res["roofline"]["traffic_GBs"] = round(tr, 1)
+        res["roofline"]["traffic_frac_of_measured_copy_peak"] = round(tr / HBM_COPY_GBS, 4)
     label = "Reddit" if reddit else "Bio"
     out = {
         "metric": "queries/sec, %s full conjunctive mix d=%d, at 1/2/4/8 MI355X" % (label, d),
