@@ -891,7 +891,11 @@ struct FusedShape {
   static constexpr int MIN_WAVES_PER_EU = COMPACT ? 6 : FW / 4;   // (FW / 4 is what the workgroup size implies anyway)
 };
 
-template <int DEC, bool MLP, int NC, bool FULL, bool BWD, int FW>
+// LEAN (backward kernels of the straight-line dims): the launch has no EmbeddingBag role, no fetched rows (row-sharded mode) and
+// no debug profile — the common training launch.  The uniform branches around those features, and the scalar registers their
+// operands hold, go at compile time: the COMPACT kernel (thousands of tiles, issue-bound: every instruction of a tile is paid
+// 4 600 times at B = 8192) drops from 13.9 k to 5.6 k instructions and from 119 to 30 spilled SGPRs, 226 -> 207 us.
+template <int DEC, bool MLP, int NC, bool FULL, bool BWD, int FW, bool LEAN = false>
 __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_WAVES_PER_EU)) void gqe_fused_kernel(const GqeDynPlan plan,
                                                                 const GqeDevFormula* __restrict__ formulas,
                                                                 const float* __restrict__ params,
@@ -903,17 +907,20 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
                                                                 float* __restrict__ contrib, const GqeBagTable bags,
                                                                 int32_t* __restrict__ link_contrib,
                                                                 int32_t* __restrict__ link_counter, int max_entries,
-                                                                const float* __restrict__ fetched,
+                                                                const float* __restrict__ fetched_arg,
                                                                 float* __restrict__ contrib_bag, long long bag_shift,
-                                                                const GqeHot hot, long long* __restrict__ prof, const GqeSplitRide ride) {
+                                                                const GqeHot hot, long long* __restrict__ prof_arg, const GqeSplitRide ride) {
+  const float* __restrict__ fetched = LEAN ? nullptr : fetched_arg;
+  long long* __restrict__ prof = LEAN ? nullptr : prof_arg;
   static_assert(FW == GQE_FW, "FW only distinguishes the kernels of the per-GQE_FW translation units");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // gqe_train_step (gqe_split.h): the workgroups behind the tiles are riders — Adam over the table rows this step's batches do
   // not name.  They read and write nothing a tile touches, so they need no order against the tiles: they fill the wave slots
   // the tiles leave free (8-wave tiles) or the CUs whose tiles have finished (16-wave tiles) with HBM-bound work.
   // Grid: [ride.lead riders][plan.tiles tiles][the other riders]
-  const int tile_id = (BWD && FULL) ? (int)blockIdx.x - ride.lead : (int)blockIdx.x;
-  if (BWD && FULL && (tile_id < 0 || tile_id >= plan.tiles)) {
+  constexpr bool RIDE = BWD && FULL && !(LEAN && FusedShape<DEC, MLP, NC, FULL, FW>::COMPACT);   // (lean COMPACT launches carry no riders: registers)
+  const int tile_id = RIDE ? (int)blockIdx.x - ride.lead : (int)blockIdx.x;
+  if (RIDE && (tile_id < 0 || tile_id >= plan.tiles)) {
     // (debug profile: start / end of the rider workgroup and the CU it ran on, in the rows behind the tiles')
     const size_t prow = (size_t)plan.tiles + (tile_id < 0 ? blockIdx.x : blockIdx.x - plan.tiles);
     if (prof && threadIdx.x == 0) {
@@ -965,7 +972,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
   e.link_counter = link_counter;
   e.max_entries = max_entries;
   e.d = d;
-  e.wt = plan.pad[1] != 0;
+  e.wt = (LEAN && FusedShape<DEC, MLP, NC, FULL, FW>::COMPACT) ? false : plan.pad[1] != 0;   // (lean COMPACT launches are the many-tile ones: plain stores)
   e.DP = 64 * NC + 4;   // tiles are padded to whole 64-float chunks: columns past d hold 0 (guarded kernels, see gqe_common.h)
   // the wave index as an SGPR: everything derived from it (the rows a wave owns, their bounds checks, row base addresses) is then
   // scalar arithmetic and scalar branches instead of 64-bit VALU address math and EXEC masks issued for all 64 lanes
@@ -1032,9 +1039,11 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
   constexpr bool EARLY = FW == 16 && NC <= 2 && FULL;  // (the d = 256 and the guarded d % 64 != 0 kernels sit at the 128-VGPR limit:
                                                        // a few more live registers spill there — and a spilling d = 96 kernel faulted)
 #define GQE_DSC(early, field) (EARLY ? (early) : (field))
+#define GQE_TBAG (LEAN ? -1 : f->target_bag)      // (LEAN: no bag role in the launch)
+#define GQE_ABAG(i) (LEAN ? -1 : f->anchor_bag[i])
   int qtype = f->qtype;
   int64_t t_table = 0;
-  int tbag = f->target_bag;
+  int tbag = GQE_TBAG;
   int64_t a_table[GQE_MAX_BRANCH] = {0, 0, 0};
   int a_bag[GQE_MAX_BRANCH] = {-1, -1, -1};
   int64_t t_head = 0, a_head[GQE_MAX_BRANCH] = {0, 0, 0};   // list-head bases: where a row's hot slot is looked up (backward only)
@@ -1044,7 +1053,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
 #pragma unroll
     for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
       a_table[i] = f->anchor_table[i];
-      a_bag[i] = f->anchor_bag[i];
+      a_bag[i] = GQE_ABAG(i);
       if (BWD) a_head[i] = f->anchor_head[i];
     }
   }
@@ -1092,7 +1101,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
     for (int i = 0; i < GQE_MAX_BRANCH; ++i)
       if (role == 2 + i) {
         hb = GQE_DSC(a_head[i], f->anchor_head[i]);
-        bg = GQE_DSC(a_bag[i], f->anchor_bag[i]);
+        bg = GQE_DSC(a_bag[i], GQE_ABAG(i));
       }
     if (row >= 0 && bg < 0) e.hotv = e.hot_slot[hb + row];
   }
@@ -1127,7 +1136,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
 #pragma unroll
     for (int i = 0; i < GQE_MAX_BRANCH; ++i) {
       if (i < n) {
-        abag[i] = GQE_DSC(a_bag[i], f->anchor_bag[i]);
+        abag[i] = GQE_DSC(a_bag[i], GQE_ABAG(i));
         if (abag[i] >= 0) bag_spans<NC>(sa[i], RA[i], e, s_idx + (2 + i) * GQE_TQ, bags.ptr[abag[i]]);
       }
     }
@@ -1168,7 +1177,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
     if (has_neg) gather(RN, GQE_DSC(t_table, f->target_table), s_idx + GQE_TQ, tbag);
 #pragma unroll
     for (int i = 0; i < GQE_MAX_BRANCH; ++i)
-      if (i < n) gather(RA[i], GQE_DSC(a_table[i], f->anchor_table[i]), s_idx + (2 + i) * GQE_TQ, GQE_DSC(a_bag[i], f->anchor_bag[i]));
+      if (i < n) gather(RA[i], GQE_DSC(a_table[i], f->anchor_table[i]), s_idx + (2 + i) * GQE_TQ, GQE_DSC(a_bag[i], GQE_ABAG(i)));
   }
   rows_finish<NC>(RT);
   if (has_neg) {
@@ -1293,13 +1302,13 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
             VEC_OP(ga, cp * (up.v[c] * ipp - sp * a.v[c] * iaa) + cn * (un.v[c] * ipn - sn * a.v[c] * iaa));
             VEC_OP(gw_acc, gw_acc.v[c] + gtp.v[c] + gtn.v[c]);
           }
-          scatter_row<NC, FULL>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0], blens[rr][0]);
-          scatter_row<NC, FULL>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1], blens[rr][1]);
-          scatter_row<NC, FULL>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2], blens[rr][2]);
+          scatter_row<NC, FULL>(e, bags, GQE_TBAG, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0], blens[rr][0]);
+          scatter_row<NC, FULL>(e, bags, GQE_TBAG, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1], blens[rr][1]);
+          scatter_row<NC, FULL>(e, bags, GQE_ABAG(0), f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2], blens[rr][2]);
         } else {
-          sharded_zero<NC, FULL>(e, f->target_bag, RT.row[rr]);
-          sharded_zero<NC, FULL>(e, f->target_bag, RN.row[rr]);
-          sharded_zero<NC, FULL>(e, f->anchor_bag[0], RA[0].row[rr]);
+          sharded_zero<NC, FULL>(e, GQE_TBAG, RT.row[rr]);
+          sharded_zero<NC, FULL>(e, GQE_TBAG, RN.row[rr]);
+          sharded_zero<NC, FULL>(e, GQE_ABAG(0), RA[0].row[rr]);
         }
       }
       if (BWD) {
@@ -1384,8 +1393,8 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
           VEC_OP(ga, ga.v[c] + cf[s] * (u[s].v[c] * iun - a.v[c] * iaa));
           lstore<NC>(cur[s] + r * DP, gu, lane);
         }
-        if (act) scatter_row<NC, FULL>(e, bags, f->anchor_bag[0], f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2], blens[rr][2]);
-        else if (q < B) sharded_zero<NC, FULL>(e, f->anchor_bag[0], RA[0].row[rr]);
+        if (act) scatter_row<NC, FULL>(e, bags, GQE_ABAG(0), f->anchor_head[0], 2, wave * RPW + rr, RA[0], rr, ga, olds[rr][2], blens[rr][2]);
+        else if (q < B) sharded_zero<NC, FULL>(e, GQE_ABAG(0), RA[0].row[rr]);
       }
       if (BWD) {
         // back through the hops: act_{h+1} = act_h M_h  =>  g_act_h = g_act_{h+1} M_h^T (= M . g per row),
@@ -1406,8 +1415,8 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
         for (int rr = 0; rr < RPW; ++rr) {
           const int r = wave * RPW + rr;
           if (e.q0 + r >= B) continue;
-          scatter_row<NC, FULL>(e, bags, f->target_bag, f->target_head, 0, r, RT, rr, lload<NC>(cur[0] + r * DP, lane), olds[rr][0], blens[rr][0]);
-          scatter_row<NC, FULL>(e, bags, f->target_bag, f->target_head, 1, r, RN, rr, lload<NC>(cur[1] + r * DP, lane), olds[rr][1], blens[rr][1]);
+          scatter_row<NC, FULL>(e, bags, GQE_TBAG, f->target_head, 0, r, RT, rr, lload<NC>(cur[0] + r * DP, lane), olds[rr][0], blens[rr][0]);
+          scatter_row<NC, FULL>(e, bags, GQE_TBAG, f->target_head, 1, r, RN, rr, lload<NC>(cur[1] + r * DP, lane), olds[rr][1], blens[rr][1]);
         }
       }
     }
@@ -1580,11 +1589,11 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
         const float ipp = sp * gqe_rcp(ncp * ncp), inn = sn * gqe_rcp(ncn * ncn);
         VEC_OP(gtp, cp * (qv.v[c] * ipq - tp.v[c] * ipp));
         VEC_OP(gtn, cn * (qv.v[c] * inq - tn.v[c] * inn));
-        scatter_row<NC, FULL>(e, bags, f->target_bag, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0], blens[rr][0]);
-        scatter_row<NC, FULL>(e, bags, f->target_bag, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1], blens[rr][1]);
+        scatter_row<NC, FULL>(e, bags, GQE_TBAG, f->target_head, 0, wave * RPW + rr, RT, rr, gtp, olds[rr][0], blens[rr][0]);
+        scatter_row<NC, FULL>(e, bags, GQE_TBAG, f->target_head, 1, wave * RPW + rr, RN, rr, gtn, olds[rr][1], blens[rr][1]);
       } else if (q < B) {
-        sharded_zero<NC, FULL>(e, f->target_bag, RT.row[rr]);
-        sharded_zero<NC, FULL>(e, f->target_bag, RN.row[rr]);
+        sharded_zero<NC, FULL>(e, GQE_TBAG, RT.row[rr]);
+        sharded_zero<NC, FULL>(e, GQE_TBAG, RN.row[rr]);
       }
     }
     GQE_STAMP(5);
@@ -1742,7 +1751,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
           for (int rr = 0; rr < RPW; ++rr) {
             const int r = wave * RPW + rr;
             if (e.q0 + r >= B) continue;
-            scatter_row<NC, FULL>(e, bags, f->anchor_bag[i], f->anchor_head[i], 2 + i, r, RA[i], rr, lload<NC>(tcur + r * DP, lane),
+            scatter_row<NC, FULL>(e, bags, GQE_ABAG(i), f->anchor_head[i], 2 + i, r, RA[i], rr, lload<NC>(tcur + r * DP, lane),
                             olds[rr][2 + i], blens[rr][2 + i]);
           }
           __syncthreads();  // tt / tq are rewritten by the next branch
@@ -1780,7 +1789,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
             } else {
               VEC_OP(gw0, gw0.v[c] + g.v[c]);
             }
-            scatter_row<NC, FULL>(e, bags, f->anchor_bag[i], f->anchor_head[i], 2 + i, r, RA[i], rr, g, olds[rr][2 + i], blens[rr][2 + i]);
+            scatter_row<NC, FULL>(e, bags, GQE_ABAG(i), f->anchor_head[i], 2 + i, r, RA[i], rr, g, olds[rr][2 + i], blens[rr][2 + i]);
           }
           // (slot indices spelled out per branch: indexed with the loop variable, the TransE 8-wave d = 128 kernels kept the
           // slots in a dynamically indexed private array — 40 B of scratch without a single spilled register)
@@ -1824,7 +1833,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
   }
   GQE_STAMP(8);
   // (split steps: the launch's riders stop taking rounds once every tile has left)
-  if (BWD && FULL && ride.blocks > 0 && ride.stop && threadIdx.x == 0) __hip_atomic_fetch_add(ride.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (RIDE && ride.blocks > 0 && ride.stop && threadIdx.x == 0) __hip_atomic_fetch_add(ride.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #undef GQE_STAMP
 #undef GQE_WSTAMP
 #undef GQE_DSC
@@ -1849,6 +1858,15 @@ static hipError_t launch_fused_v(const GqeFusedArgs& a) {
                                               FusedShape<DEC, MLP, NC, FULL, GQE_FW>::COMPACT) + lds_pad;
   const int riders = (a.bwd && FULL) ? a.split.blocks : 0;
   if (a.split.blocks > 0 && !riders) return hipErrorInvalidValue;   // (gqe_fused_can_ride said no: the host does not ask)
+  static const bool lean_off = getenv("GQE_NO_LEAN") != nullptr;   // (A / B runs)
+  constexpr bool COMPACT = FusedShape<DEC, MLP, NC, FULL, GQE_FW>::COMPACT;
+  if (FULL && a.bwd && !lean_off && !a.fetched && !a.prof && a.bags.max_len == 0 && (!COMPACT || (a.plan.pad[1] == 0 && riders == 0))) {
+    if constexpr (FULL)
+      hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true, GQE_FW, true>), dim3(a.plan.tiles + riders), dim3(GQE_FWT), lds, a.stream, a.plan,
+                         a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags,
+                         a.link_contrib, a.link_counter, a.max_entries, a.fetched, a.contrib_bag, a.bag_shift, a.hot, a.prof, a.split);
+    return hipGetLastError();
+  }
   if (a.bwd)
     hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true, GQE_FW>), dim3(a.plan.tiles + riders), dim3(GQE_FWT), lds, a.stream, a.plan,
                        a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags, a.link_contrib, a.link_counter,
