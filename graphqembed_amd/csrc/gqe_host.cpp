@@ -1946,6 +1946,10 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
         memset(&r, 0, sizeof r);
         r.plan.units = -1;
       }
+      // (the chunk loop walks gradient lists only for a bag table: the launch without one runs the kernel compiled without them)
+      oa.lists = false;
+      for (size_t ui = 0; ui < nu; ++ui)
+        if (ustep[ui] && ctx->universe[ui].is_table && is_bag_table(ctx, ctx->universe[ui].table_index)) oa.lists = true;
       rc = timing_begin(ctx, 2, st);
       if (rc != GQE_OK) return rc;
       HIP_TRY(ctx, gqe_launch_split_rows(oa, r, ctx->split_segs, ctx->split_ride, ctx->split_idx,

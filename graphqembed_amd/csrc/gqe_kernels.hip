@@ -1073,6 +1073,9 @@ hipError_t gqe_launch_prestep(const GqeMatStep& ms, float* p, float* g, float* m
 // (a row named twice is stepped once), sums its gradient list and hot accumulators and applies Adam with exactly the eager pass's
 // arithmetic — and the rest are the ordinary chunk loop over the step's vectors (relation vectors: dense gradients the fused
 // tiles accumulated with atomics, complete since the kernel boundary).
+// (EXTRAS: the launch has leftover riders or a bag table in its chunk loop — the common launch has neither, and its instantiation
+// is compiled without them: fewer scalar registers to spill in front of every row's dependent chain)
+template <bool EXTRAS>
 __global__ __launch_bounds__(GQE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void gqe_split_rows_kernel(
     const GqeDevSeg* __restrict__ segs, int n_segs, long long total_chunks, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
     float* __restrict__ v, int32_t* __restrict__ head, const int32_t* __restrict__ next, const float* __restrict__ contrib, int max_entries, int d,
@@ -1090,7 +1093,7 @@ __global__ __launch_bounds__(GQE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     // the ordinary chunk loop over the step's vectors — and over bag tables (link_contrib != NULL: word tables, stepped in full:
     // their gradient lists and hot accumulators hang on rows no feed names)
     GqeLazyArgs lazy;   // (never read: LAZY = false)
-    if (link_contrib) {
+    if (EXTRAS && link_contrib) {
       opt_body<GQE_OPT_ADAM, true, false, false, false>((long long)blockIdx.x - front - row_blocks - rider_blocks,
                                                         (long long)gridDim.x - front - row_blocks - rider_blocks, segs, n_segs, total_chunks, p, g, m,
                                                         v, head, next, contrib, link_contrib, max_entries, d, lr, b1, b2, eps, coef, active, act, n_act,
@@ -1105,7 +1108,7 @@ __global__ __launch_bounds__(GQE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     }
     return;
   }
-  if ((int)blockIdx.x >= front + row_blocks) {   // what the fused launch's riders left of the untouched rows
+  if (EXTRAS && (int)blockIdx.x >= front + row_blocks) {   // what the fused launch's riders left of the untouched rows
     split_leftover(sr, d, ((int)blockIdx.x - front - row_blocks) * GQE_WAVES + (int)(threadIdx.x >> 6));
     return;
   }
@@ -1170,9 +1173,14 @@ hipError_t gqe_launch_split_rows(const GqeOptArgs& a, const GqeGemmRide& r, cons
   // one wave per (rider, wave) pair of the fused launch: it continues where that wave stopped
   const int riders = (ride.blocks > 0 && ride.stop) ? (ride.blocks * ride.waves + GQE_WAVES - 1) / GQE_WAVES : 0;   // (riders that do not stop leave nothing)
   const unsigned blocks = (unsigned)(r2.plan.units + 1) + (unsigned)rb + (unsigned)riders + dense_blocks;
-  hipLaunchKernelGGL(gqe_split_rows_kernel, dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.n_segs, a.total_chunks, a.p, a.g, a.m, a.v, a.head,
-                     a.next, a.contrib, a.max_entries, a.d, a.lr, a.b1, a.b2, a.eps, a.coef, a.active, a.act, a.n_act, a.hot, r2, segs, ride, idx, stamp,
-                     rb, riders, a.lists ? a.link_contrib : nullptr);
+  if (riders > 0 || a.lists)
+    hipLaunchKernelGGL(gqe_split_rows_kernel<true>, dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.n_segs, a.total_chunks, a.p, a.g, a.m, a.v, a.head,
+                       a.next, a.contrib, a.max_entries, a.d, a.lr, a.b1, a.b2, a.eps, a.coef, a.active, a.act, a.n_act, a.hot, r2, segs, ride, idx, stamp,
+                       rb, riders, a.lists ? a.link_contrib : nullptr);
+  else
+    hipLaunchKernelGGL(gqe_split_rows_kernel<false>, dim3(blocks), dim3(GQE_THREADS), 0, a.stream, a.segs, a.n_segs, a.total_chunks, a.p, a.g, a.m, a.v, a.head,
+                       a.next, a.contrib, a.max_entries, a.d, a.lr, a.b1, a.b2, a.eps, a.coef, a.active, a.act, a.n_act, a.hot, r2, segs, ride, idx, stamp,
+                       rb, 0, nullptr);
   return hipGetLastError();
 }
 
