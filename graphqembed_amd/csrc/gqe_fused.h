@@ -770,7 +770,9 @@ __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t h
       while (todo) {
         const int l = __builtin_ctzll(todo);
         todo &= todo - 1;
+#ifndef GQE_DEBUG_SKIP_BAG_HOT   // (timing experiments, WRONG results: what the hot words' atomic rows cost a bag launch)
         hot_add<NC, FULL>(e, __builtin_amdgcn_readlane(hs, l), gx);
+#endif
       }
     }
   }
@@ -911,7 +913,11 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
                                                                 float* __restrict__ contrib_bag, long long bag_shift,
                                                                 const GqeHot hot, long long* __restrict__ prof_arg, const GqeSplitRide ride) {
   const float* __restrict__ fetched = LEAN ? nullptr : fetched_arg;
+#ifdef GQE_LEAN_PROF   // (debug builds: the profile stamps stay in the lean kernels — tools/probes/split_timeline.py on the production code path)
+  long long* __restrict__ prof = prof_arg;
+#else
   long long* __restrict__ prof = LEAN ? nullptr : prof_arg;
+#endif
   static_assert(FW == GQE_FW, "FW only distinguishes the kernels of the per-GQE_FW translation units");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // gqe_train_step (gqe_split.h): the workgroups behind the tiles are riders — Adam over the table rows this step's batches do
@@ -949,6 +955,14 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
       prof[(size_t)tile_id * GQE_PROF_SLOTS + 16 + (p) * 4 + (threadIdx.x >> 8)] = (long long)wall_clock64();    \
   } while (0)
   GQE_STAMP(0);
+#ifdef GQE_LEAN_PROF   // (where the tile ran: slot 63)
+  if (prof && threadIdx.x == 0) {
+    int hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    prof[(size_t)tile_id * GQE_PROF_SLOTS + 63] = ((long long)(xcc & 15) << 32) | (unsigned)hw;
+  }
+#endif
   const int d = FULL ? 64 * NC : d_arg;
   int bi = 0;  // which batch owns this tile: the plan is a kernel argument (SGPRs), 16 scalar compares
 #pragma unroll
@@ -1860,7 +1874,12 @@ static hipError_t launch_fused_v(const GqeFusedArgs& a) {
   if (a.split.blocks > 0 && !riders) return hipErrorInvalidValue;   // (gqe_fused_can_ride said no: the host does not ask)
   static const bool lean_off = getenv("GQE_NO_LEAN") != nullptr;   // (A / B runs)
   constexpr bool COMPACT = FusedShape<DEC, MLP, NC, FULL, GQE_FW>::COMPACT;
-  if (FULL && a.bwd && !lean_off && !a.fetched && !a.prof && a.bags.max_len == 0 && (!COMPACT || (a.plan.pad[1] == 0 && riders == 0))) {
+#ifdef GQE_LEAN_PROF
+  const bool prof_ok = true;
+#else
+  const bool prof_ok = !a.prof;
+#endif
+  if (FULL && a.bwd && !lean_off && !a.fetched && prof_ok && a.bags.max_len == 0 && (!COMPACT || (a.plan.pad[1] == 0 && riders == 0))) {
     if constexpr (FULL)
       hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true, GQE_FW, true>), dim3(a.plan.tiles + riders), dim3(GQE_FWT), lds, a.stream, a.plan,
                          a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags,

@@ -59,3 +59,21 @@ if len(R):
         print("  %5.0f  %6d  %6d  %6d" % (e, int(((rs <= e) & (re > e)).sum()), int((re <= e).sum()), int(((us(st[T, 0]) <= e) & (us(st[T, 8]) > e)).sum())))
     cu = st[R, 1]
     print("distinct (xcc, hw_id>>8 & 0xf cu, se) of riders:", len(set((int(c >> 32), int(c & 0xffffffff) >> 8 & 0xf, int(c & 0xffffffff) >> 13 & 0x7) for c in cu)))
+
+if len(R) and st[T, 63].any():   # (debug build with GQE_LEAN_PROF: where every tile ran)
+    key = lambda c: (int(c >> 32), int(c & 0xffffffff) >> 8 & 0xf, int(c & 0xffffffff) >> 13 & 0x7)
+    lead = R[us(st[R, 0]) < 5.0]
+    lead_cus = {}
+    for r in lead:
+        lead_cus[key(st[r, 1])] = us(st[r, 8])
+    late = T[us(st[T, 0]) > 5.0]
+    on_lead = [t for t in late if key(st[t, 63]) in lead_cus]
+    print("second-round tiles: %d, of which on a lead rider's CU: %d" % (len(late), len(on_lead)))
+    if on_lead:
+        gap = [us(st[t, 0]) - lead_cus[key(st[t, 63])] for t in on_lead]
+        print("   start of those tiles: min/med/max %.1f %.1f %.1f; gap after the rider's end stamp: min/med/max %.1f %.1f %.1f" % (
+            min(us(st[on_lead, 0])), np.median(us(st[on_lead, 0])), max(us(st[on_lead, 0])), min(gap), np.median(gap), max(gap)))
+    off = [t for t in late if key(st[t, 63]) not in lead_cus]
+    if off:
+        print("   the others start: min/med/max %.1f %.1f %.1f" % (min(us(st[off, 0])), np.median(us(st[off, 0])), max(us(st[off, 0]))))
+    print("   lead riders end: min/med/max %.1f %.1f %.1f" % (min(lead_cus.values()), np.median(list(lead_cus.values())), max(lead_cus.values())))

@@ -18,8 +18,9 @@ ap.add_argument("--mix", default="full", help="full | 1-chain (the edge-only bur
 ap.add_argument("--defer", action="store_true", help="gqe_set_deferred_gemm: the pair GEMM rides in the Adam pass's launch")
 ap.add_argument("--lazy", action="store_true", help="gqe_set_lazy_adam (with the next feed declared every step: gqe_lazy_prefetch)")
 ap.add_argument("--train-step", action="store_true", help="gqe_train_step: one call per iteration (the split step where it applies)")
+ap.add_argument("--zipf", type=float, default=None, help="heavy-tailed degrees / word frequencies: 1 / rank^zipf")
 a = ap.parse_args()
-wl = bench.Workload(a.workload, a.dim, a.decoder, "min", synth.FULL_MIX if a.mix == "full" else (synth.FULL_MIX[0],), a.batch)
+wl = bench.Workload(a.workload, a.dim, a.decoder, "min", synth.FULL_MIX if a.mix == "full" else (synth.FULL_MIX[0],), a.batch, zipf=a.zipf)
 eng = wl.engine(lazy=a.lazy)
 prep = wl.prepare(eng)
 if a.defer:
