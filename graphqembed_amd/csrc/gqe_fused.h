@@ -986,7 +986,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
   e.link_counter = link_counter;
   e.max_entries = max_entries;
   e.d = d;
-  e.wt = (LEAN && FusedShape<DEC, MLP, NC, FULL, FW>::COMPACT) ? false : plan.pad[1] != 0;   // (lean COMPACT launches are the many-tile ones: plain stores)
+  e.wt = plan.pad[1] != 0;
   e.DP = 64 * NC + 4;   // tiles are padded to whole 64-float chunks: columns past d hold 0 (guarded kernels, see gqe_common.h)
   // the wave index as an SGPR: everything derived from it (the rows a wave owns, their bounds checks, row base addresses) is then
   // scalar arithmetic and scalar branches instead of 64-bit VALU address math and EXEC masks issued for all 64 lanes
@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
   }
   const int DP = e.DP, lane = e.lane, wave = e.wave;
   const int B = b.B;
-  const bool has_neg = b.has_neg != 0;
+  const bool has_neg = BWD;   // (== b.has_neg: the host sets it for exactly the backward launches — a compile-time fact here)
   const int n = b.n_anchors;  // == f->n_anchors, without the descriptor round trip in front of the index load
   // evaluation against candidate lists (forward only): index layout anchors[n][B] | cand_ptr[B+1] | cand_rows[..];
   // every query is scored against its own list, the query side being computed once (the reference re-encodes
@@ -1879,7 +1879,7 @@ static hipError_t launch_fused_v(const GqeFusedArgs& a) {
 #else
   const bool prof_ok = !a.prof;
 #endif
-  if (FULL && a.bwd && !lean_off && !a.fetched && prof_ok && a.bags.max_len == 0 && (!COMPACT || (a.plan.pad[1] == 0 && riders == 0))) {
+  if (FULL && a.bwd && !lean_off && !a.fetched && prof_ok && a.bags.max_len == 0 && (!COMPACT || riders == 0)) {
     if constexpr (FULL)
       hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true, GQE_FW, true>), dim3(a.plan.tiles + riders), dim3(GQE_FWT), lds, a.stream, a.plan,
                          a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags,

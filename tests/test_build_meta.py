@@ -81,14 +81,17 @@ def test_no_unreachable_fused_kernels_are_built(kernels, lib):
 
 def test_every_selectable_fused_kernel_is_free_of_spills(kernels, lib):
     from kernel_meta import fused_variant
-    built = {fused_variant(k["name"]): k for k in kernels if fused_variant(k["name"])}
+    built = {}
+    for k in kernels:       # (a variant may exist twice: the plain and the LEAN instantiation — both have to be clean)
+        if fused_variant(k["name"]):
+            built.setdefault(fused_variant(k["name"]), []).append(k)
     sel = selectable(lib)
     assert len(sel) >= 60, len(sel)
     for v, cfgs in sorted(sel.items()):
         assert v in built, "the dispatcher selects %r (%r) but the library does not contain it" % (v, cfgs[0])
-        k = built[v]
-        assert k["vgpr_spill"] == 0, "gqe_fused_kernel<DEC=%d, MLP=%d, NC=%d, FULL=%d, BWD=%d, FW=%d> spills %d VGPRs; reached by %r" % (v + (k["vgpr_spill"], cfgs[0]))
-        assert k["vgpr"] <= (128 if v[5] == 16 else 256), (v, k["vgpr"])
+        for k in built[v]:
+            assert k["vgpr_spill"] == 0, "gqe_fused_kernel<DEC=%d, MLP=%d, NC=%d, FULL=%d, BWD=%d, FW=%d> spills %d VGPRs; reached by %r" % (v + (k["vgpr_spill"], cfgs[0]))
+            assert k["vgpr"] <= (128 if v[5] == 16 else 256), (v, k["vgpr"])
 
 
 def test_fused_kernels_use_no_scratch(kernels, lib):
@@ -105,7 +108,18 @@ def test_fused_kernels_use_no_scratch(kernels, lib):
         seen += 1
         assert k["scratch"] == 0 and k["vgpr_spill"] == 0, "%s: %d B scratch, %d spilled VGPRs" % (k["name"][:60], k["scratch"], k["vgpr_spill"])
         assert k["vgpr"] <= (128 if v[5] == 16 else 256), k
-    assert seen == len(sel) and seen >= 3 * 2 * (7 + 1) * 2, seen     # DEC x MLP x (16-wave NC / FULL variants + the 8-wave shape) x {fwd, bwd}
+    # DEC x MLP x (16-wave NC / FULL variants + the 8-wave shape) x {fwd, bwd} + the LEAN instantiations of the FULL backward kernels
+    assert seen >= len(sel) and seen >= 3 * 2 * (7 + 1) * 2, seen
+
+
+def test_lean_instantiations_exist_where_the_launcher_picks_them(kernels):
+    """gqe_fused_kernel<..., LEAN = true> (no EmbeddingBag role, no fetched rows, no profile: gqe_fused.h) is built for exactly
+    the backward kernels of the straight-line dims (FULL), next to the plain instantiation."""
+    from kernel_meta import fused_lean, fused_variant
+    lean = set(fused_variant(k["name"]) for k in kernels if fused_lean(k["name"]) == 1)
+    plain = set(fused_variant(k["name"]) for k in kernels if fused_lean(k["name"]) == 0)
+    assert lean and lean <= plain
+    assert lean == set(v for v in plain if v[3] == 1 and v[4] == 1), sorted(lean ^ set(v for v in plain if v[3] == 1 and v[4] == 1))
 
 
 def test_streaming_and_gemm_kernels_use_no_scratch(kernels):
