@@ -897,7 +897,9 @@ struct FusedShape {
 // no debug profile — the common training launch.  The uniform branches around those features, and the scalar registers their
 // operands hold, go at compile time: the COMPACT kernel (thousands of tiles, issue-bound: every instruction of a tile is paid
 // 4 600 times at B = 8192) drops from 13.9 k to 5.6 k instructions and from 119 to 30 spilled SGPRs, 226 -> 207 us.
-template <int DEC, bool MLP, int NC, bool FULL, bool BWD, int FW, bool LEAN = false>
+// LEAN == 2 (16-wave kernels): the row-sharded step's launch — every row comes from the fetched buffer or this rank's own shard,
+// no bag role, no profile, no riders.
+template <int DEC, bool MLP, int NC, bool FULL, bool BWD, int FW, int LEAN = 0>
 __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_WAVES_PER_EU)) void gqe_fused_kernel(const GqeDynPlan plan,
                                                                 const GqeDevFormula* __restrict__ formulas,
                                                                 const float* __restrict__ params,
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
                                                                 const float* __restrict__ fetched_arg,
                                                                 float* __restrict__ contrib_bag, long long bag_shift,
                                                                 const GqeHot hot, long long* __restrict__ prof_arg, const GqeSplitRide ride) {
-  const float* __restrict__ fetched = LEAN ? nullptr : fetched_arg;
+  const float* __restrict__ fetched = LEAN == 1 ? nullptr : fetched_arg;   // (LEAN == 2: the row-sharded launch — fetched rows, and that is a compile-time fact)
 #ifdef GQE_LEAN_PROF   // (debug builds: the profile stamps stay in the lean kernels — tools/probes/split_timeline.py on the production code path)
   long long* __restrict__ prof = prof_arg;
 #else
@@ -924,7 +926,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
   // not name.  They read and write nothing a tile touches, so they need no order against the tiles: they fill the wave slots
   // the tiles leave free (8-wave tiles) or the CUs whose tiles have finished (16-wave tiles) with HBM-bound work.
   // Grid: [ride.lead riders][plan.tiles tiles][the other riders]
-  constexpr bool RIDE = BWD && FULL && !(LEAN && FusedShape<DEC, MLP, NC, FULL, FW>::COMPACT);   // (lean COMPACT launches carry no riders: registers)
+  constexpr bool RIDE = BWD && FULL && !(LEAN && FusedShape<DEC, MLP, NC, FULL, FW>::COMPACT) && LEAN != 2;   // (lean COMPACT and row-sharded launches carry no riders: registers)
   const int tile_id = RIDE ? (int)blockIdx.x - ride.lead : (int)blockIdx.x;
   if (RIDE && (tile_id < 0 || tile_id >= plan.tiles)) {
     // (debug profile: start / end of the rider workgroup and the CU it ran on, in the rows behind the tiles')
@@ -974,7 +976,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
   e.f = f;
   e.params = params;
   e.rows = fetched ? fetched : params;
-  e.sharded = fetched != nullptr;
+  e.sharded = LEAN == 2 ? true : fetched != nullptr;
   e.contrib_bag = contrib_bag;
   e.bag_shift = bag_shift;
   e.grads = grads;
@@ -1881,7 +1883,14 @@ static hipError_t launch_fused_v(const GqeFusedArgs& a) {
 #endif
   if (FULL && a.bwd && !lean_off && !a.fetched && prof_ok && a.bags.max_len == 0 && (!COMPACT || riders == 0)) {
     if constexpr (FULL)
-      hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true, GQE_FW, true>), dim3(a.plan.tiles + riders), dim3(GQE_FWT), lds, a.stream, a.plan,
+      hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true, GQE_FW, 1>), dim3(a.plan.tiles + riders), dim3(GQE_FWT), lds, a.stream, a.plan,
+                         a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags,
+                         a.link_contrib, a.link_counter, a.max_entries, a.fetched, a.contrib_bag, a.bag_shift, a.hot, a.prof, a.split);
+    return hipGetLastError();
+  }
+  if (FULL && GQE_FW == 16 && a.bwd && !lean_off && a.fetched && prof_ok && a.bags.max_len == 0 && riders == 0) {
+    if constexpr (FULL && GQE_FW == 16)
+      hipLaunchKernelGGL((gqe_fused_kernel<DEC, MLP, NC, FULL, true, GQE_FW, 2>), dim3(a.plan.tiles), dim3(GQE_FWT), lds, a.stream, a.plan,
                          a.formulas, a.params, a.grads, a.ws, a.idx, a.d, a.tile_loss, a.pos, a.neg, a.inter_min, a.head, a.next, a.contrib, a.bags,
                          a.link_contrib, a.link_counter, a.max_entries, a.fetched, a.contrib_bag, a.bag_shift, a.hot, a.prof, a.split);
     return hipGetLastError();

@@ -120,6 +120,9 @@ def test_lean_instantiations_exist_where_the_launcher_picks_them(kernels):
     plain = set(fused_variant(k["name"]) for k in kernels if fused_lean(k["name"]) == 0)
     assert lean and lean <= plain
     assert lean == set(v for v in plain if v[3] == 1 and v[4] == 1), sorted(lean ^ set(v for v in plain if v[3] == 1 and v[4] == 1))
+    # LEAN == 2: the row-sharded launch (fetched rows as a compile-time fact) — the 16-wave kernels of the same set
+    sharded = set(fused_variant(k["name"]) for k in kernels if fused_lean(k["name"]) == 2)
+    assert sharded == set(v for v in lean if v[5] == 16), sorted(sharded ^ set(v for v in lean if v[5] == 16))
 
 
 def test_streaming_and_gemm_kernels_use_no_scratch(kernels):

@@ -63,13 +63,13 @@ def fused_variant(name):
     """(DEC, MLP, NC, FULL, BWD, FW) of a mangled gqe_fused_kernel name, or None.  (The LEAN instantiations — the seventh
     template argument, fused_lean — are variants of the same dispatcher choice: the launcher picks them by what the launch
     carries, not by the configuration.)"""
-    m = re.match(r"_Z16gqe_fused_kernelILi(\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d+)ELb\dEE", name)
+    m = re.match(r"_Z16gqe_fused_kernelILi(\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d+)EL[bi]\dEE", name)
     return tuple(int(x) for x in m.groups()) if m else None
 
 
 def fused_lean(name):
-    """1 / 0: the LEAN template argument of a mangled gqe_fused_kernel name (None: not one)."""
-    m = re.match(r"_Z16gqe_fused_kernelILi\dELb\dELi\dELb\dELb\dELi\d+ELb(\d)EE", name)
+    """The LEAN template argument of a mangled gqe_fused_kernel name — 0 plain, 1 lean, 2 lean row-sharded (None: not one)."""
+    m = re.match(r"_Z16gqe_fused_kernelILi\dELb\dELi\dELb\dELb\dELi\d+EL[bi](\d)EE", name)
     return int(m.group(1)) if m else None
 
 
@@ -80,5 +80,5 @@ if __name__ == "__main__":
     print("%-78s %5s %7s %6s %6s" % ("kernel", "VGPR", "scratch", "vspill", "sspill"))
     for k in sorted(ks, key=lambda k: k["name"]):
         v = fused_variant(k["name"])
-        label = ("gqe_fused_kernel<DEC=%d, MLP=%d, NC=%d, FULL=%d, BWD=%d, FW=%d%s>" % (v + (", LEAN" if fused_lean(k["name"]) else "",))) if v else k["name"][:78]
+        label = ("gqe_fused_kernel<DEC=%d, MLP=%d, NC=%d, FULL=%d, BWD=%d, FW=%d%s>" % (v + (", LEAN=%d" % fused_lean(k["name"]) if fused_lean(k["name"]) else "",))) if v else k["name"][:78]
         print("%-78s %5s %7s %6s %6s" % (label, k["vgpr"], k["scratch"], k["vgpr_spill"], k["sgpr_spill"]))
