@@ -916,10 +916,11 @@ def main():
                    "gradient_exchange": "none" if world == 1 else
                    ("row-sharded tables (rank k owns rows r %% %d == k and their Adam moments), one library call per step "
                     "(gqe_shard_step over RCCL): all-to-all of the %d rows the batch reads (%d floats each), all-to-all of their "
-                    "gradient contributions back to the owners, all-reduce of the relation/Pre/Post gradients; the fused Adam pass "
+                    "gradient contributions back to the owners WITH every rank's relation/Pre/Post gradient as further sends / "
+                    "receives of the same ncclGroup (summed in rank order by each rank: no all-reduce); the fused Adam pass "
                     "streams 1/%d of the tables per rank.  INSIDE the timed region: the host planning of every step (owner sort of "
-                    "its index feed + publication on the shared-memory plan board, gqe_shard_post), the serve / link kernels, all "
-                    "three collectives, the optimiser" % (world, prepared[0]["n_entries"], d, world)) if sharded else
+                    "its index feed + publication on the shared-memory plan board, gqe_shard_post), the serve / link kernels, both "
+                    "exchanges, the optimiser" % (world, prepared[0]["n_entries"], d, world)) if sharded else
                    ("one all-gather per step of per-rank slabs: %d contribution entries x (%d floats + row id) + the dense "
                     "relation/Pre/Post gradients" % (prepared[0]["n_entries"], d)) if sparse else
                    "all-reduce of the %d-float gradient arena" % wl.layout.total},

@@ -412,6 +412,12 @@ struct GqeSpans {
   int n;  // < 0: more than 8 spans (unsupported)
   long long off[8], len[8], total;
 };
+// row-sharded step: the relation / Pre / Post gradients of the ranks travel with the contributions (one exchange instead of an
+// all-to-all and an all-reduce).  gqe_launch_dense_stage: `world` copies of this rank's dense gradient (the spans, packed) for a
+// transport that needs one send block per peer; gqe_launch_dense_sum: grads[span j] = sum over the ranks IN RANK ORDER (this
+// rank's own term read from the arena, the others from block p of `recv`, `stride` floats apart): the same bits on every rank.
+hipError_t gqe_launch_dense_stage(const GqeSpans& sp, const float* grads, float* send, long long stride, int world, hipStream_t stream);
+hipError_t gqe_launch_dense_sum(const GqeSpans& sp, float* grads, const float* recv, long long stride, int rank, int world, hipStream_t stream);
 // row-sharded data parallelism: serve rows of the local shards / link received contributions onto the local lists
 struct GqeShardTabs {
   int n;

@@ -71,6 +71,8 @@ struct Bag {
 struct Layout {  // byte offsets inside the bound workspace
   size_t idx_cap, tloss_off, scratch_off, scratch_cap;  // [staged indices x kStageBufs | tile losses | pair scratch]
   size_t shard_req_send, shard_req_recv, shard_fetch, shard_csend;  // row-sharded mode (0 otherwise)
+  size_t shard_dense;          // ... the ranks' relation / Pre / Post gradients, exchanged with the contributions: world blocks of
+  int64_t shard_dense_floats;  //     shard_dense_floats received + as many staged for a callback transport (0: no such region)
   int64_t shard_cap_send, shard_cap_recv;                          // entries
   size_t seg_off, act_off, formula_off, head_off, rows_off, next_off, contrib_off, linkc_off, counter_off, last_off, ring_off, total;
   // operand-ordered copies of the d x d matrices (gqe_dev.h, GQE_TILE_INDEX): a mirror of the arena's non-table spans for M,
@@ -394,13 +396,20 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
   L.stamp_off = L.tile_off + align_up(sizeof(float) * 2 * (size_t)L.tile_floats, 256);
   L.progress_off = L.stamp_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
   L.total = L.progress_off + align_up(sizeof(int32_t) * (size_t)GQE_SPLIT_MAX_RIDERS * GQE_SPLIT_PWAVES, 256);
-  L.shard_req_send = L.shard_req_recv = L.shard_fetch = L.shard_csend = 0;
+  L.shard_req_send = L.shard_req_recv = L.shard_fetch = L.shard_csend = L.shard_dense = 0;
+  L.shard_dense_floats = 0;
   if (ctx->shard_on) {
     L.shard_req_send = L.total;
     L.shard_req_recv = L.shard_req_send + align_up(sizeof(int32_t) * (size_t)L.shard_cap_send, 256);
     L.shard_fetch = L.shard_req_recv + align_up(sizeof(int32_t) * (size_t)L.shard_cap_recv, 256);
     L.shard_csend = L.contrib_off + sizeof(float) * (size_t)L.shard_cap_recv * ctx->cfg.dim;   // entries [cap_recv, cap_recv + cap_send)
     L.total = L.shard_fetch + align_up(sizeof(float) * (size_t)L.shard_cap_send * ctx->cfg.dim, 256);
+    const GqeSpans sp = dense_spans(ctx);
+    if (sp.n > 0) {   // (also at one rank: GQE_SHARD_SELF_VIA_RCCL sends the own block through the transport — tests, overhead bench)
+      L.shard_dense_floats = (int64_t)align_up((size_t)sp.total, 64);
+      L.shard_dense = L.total;
+      L.total += align_up(sizeof(float) * 2 * (size_t)L.shard_dense_floats * (size_t)ctx->shard_world, 256);
+    }
   }
   return L;
 }

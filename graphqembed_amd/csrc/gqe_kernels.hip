@@ -1405,6 +1405,40 @@ __device__ __forceinline__ long long span_address(const GqeSpans& sp, long long 
   return sp.off[k] + j;
 }
 
+// the row-sharded step's dense gradients (gqe_dev.h): stage `world` packed copies / sum the ranks' blocks in rank order
+__global__ __launch_bounds__(GQE_THREADS) void gqe_dense_stage_kernel(const GqeSpans sp, const float* __restrict__ grads, float* __restrict__ send,
+                                                                     long long stride, int world) {
+  const long long j = (long long)blockIdx.x * GQE_THREADS + threadIdx.x;
+  if (j >= sp.total) return;
+  const float x = grads[span_address(sp, j)];
+  for (int p = 0; p < world; ++p) send[(long long)p * stride + j] = x;
+}
+
+__global__ __launch_bounds__(GQE_THREADS) void gqe_dense_sum_kernel(const GqeSpans sp, float* __restrict__ grads, const float* __restrict__ recv,
+                                                                   long long stride, int rank, int world) {
+  const long long j = (long long)blockIdx.x * GQE_THREADS + threadIdx.x;
+  if (j >= sp.total) return;
+  const long long a = span_address(sp, j);
+  const float own = grads[a];
+  float sum = 0.f;
+  for (int p = 0; p < world; ++p) sum += (p == rank) ? own : recv[(long long)p * stride + j];
+  grads[a] = sum;
+}
+
+hipError_t gqe_launch_dense_stage(const GqeSpans& sp, const float* grads, float* send, long long stride, int world, hipStream_t stream) {
+  if (sp.total < 1) return hipSuccess;
+  hipLaunchKernelGGL(gqe_dense_stage_kernel, dim3((unsigned)((sp.total + GQE_THREADS - 1) / GQE_THREADS)), dim3(GQE_THREADS), 0, stream, sp, grads, send,
+                     stride, world);
+  return hipGetLastError();
+}
+
+hipError_t gqe_launch_dense_sum(const GqeSpans& sp, float* grads, const float* recv, long long stride, int rank, int world, hipStream_t stream) {
+  if (sp.total < 1) return hipSuccess;
+  hipLaunchKernelGGL(gqe_dense_sum_kernel, dim3((unsigned)((sp.total + GQE_THREADS - 1) / GQE_THREADS)), dim3(GQE_THREADS), 0, stream, sp, grads, recv, stride,
+                     rank, world);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(GQE_THREADS) void gqe_export_kernel(float* __restrict__ contrib, const int32_t* __restrict__ rows,
                                                                 const float* __restrict__ grads, int d, long long slab_base,
                                                                 int32_t n, const GqeSpans sp) {

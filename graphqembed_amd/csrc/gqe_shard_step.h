@@ -269,12 +269,31 @@ void shard_planner_main(ShardSession* S) {
 // ---- transports -------------------------------------------------------------------------------------------
 // all-to-all of variable blocks (elem_bytes each), blocks contiguous in peer order on both sides
 // own_in_place: this rank's own block is not moved (the caller arranged for producer and consumer to meet in place)
+// `dense` (the contributions' exchange of a margin step): every rank's relation / Pre / Post gradient goes to every peer in the
+// SAME exchange — with RCCL as further sends / receives of the one group (the spans straight out of the gradient arena, block p
+// of the receive region for peer p), with a callback transport as a second all-to-all of staged copies.  The caller sums the
+// blocks in rank order (gqe_launch_dense_sum): what the all-reduce did, without a third collective.
+struct ShardDense {
+  const GqeSpans* sp = nullptr;
+  float* grads = nullptr;
+  float* recv = nullptr;    // [world][stride]
+  float* stage = nullptr;   // [world][stride] (callback transports)
+  int64_t stride = 0;
+};
+
 int shard_all_to_all(gqe_ctx* ctx, const void* send, const int64_t* send_counts, void* recv, const int64_t* recv_counts, int64_t elem_bytes,
-                     bool own_in_place, hipStream_t st) {
+                     bool own_in_place, hipStream_t st, const ShardDense* dense = nullptr) {
   ShardSession* S = ctx->shard_sess;
   if (S->custom) {
-    const int rc = S->tr.all_to_all(S->tr.user, send, send_counts, recv, recv_counts, elem_bytes, st);
+    int rc = S->tr.all_to_all(S->tr.user, send, send_counts, recv, recv_counts, elem_bytes, st);
     if (rc != 0) return fail(ctx, GQE_ERR_HIP, "transport all_to_all failed with %d", rc);
+    if (dense && S->world > 1) {
+      HIP_TRY(ctx, gqe_launch_dense_stage(*dense->sp, dense->grads, dense->stage, dense->stride, S->world, st));
+      int64_t ones[GQE_SHARD_MAX_WORLD];
+      for (int p = 0; p < S->world; ++p) ones[p] = 1;
+      rc = S->tr.all_to_all(S->tr.user, dense->stage, ones, dense->recv, ones, dense->stride * 4, st);
+      if (rc != 0) return fail(ctx, GQE_ERR_HIP, "transport all_to_all (dense gradients) failed with %d", rc);
+    }
     return GQE_OK;
   }
   if (!S->comm) {  // world = 1 without a communicator: the block goes from the send to the receive buffer
@@ -287,7 +306,7 @@ int shard_all_to_all(gqe_ctx* ctx, const void* send, const int64_t* send_counts,
   // when world = 1); the other blocks travel as one ncclSend / ncclRecv group
   int64_t so = 0, ro = 0, others = 0;
   for (int p = 0; p < S->world; ++p)
-    if (p != S->rank || S->self_rccl) others += send_counts[p] + recv_counts[p];
+    if (p != S->rank || S->self_rccl) others += send_counts[p] + recv_counts[p] + (dense ? 1 : 0);
   int nr = 0, ne = 0;
   if (others > 0) nr = S->group_start();
   for (int p = 0; p < S->world && nr == 0; ++p) {
@@ -304,6 +323,14 @@ int shard_all_to_all(gqe_ctx* ctx, const void* send, const int64_t* send_counts,
     }
     so += send_counts[p];
     ro += recv_counts[p];
+    if (dense && nr == 0 && (p != S->rank || S->self_rccl)) {   // (this rank's own term is read from the arena by the sum)
+      int64_t at = 0;
+      for (int k = 0; k < dense->sp->n && nr == 0; ++k) {
+        nr = S->send(dense->grads + dense->sp->off[k], (size_t)dense->sp->len[k], nccl_float32, p, S->comm, st);
+        if (nr == 0) nr = S->recv(dense->recv + (int64_t)p * dense->stride + at, (size_t)dense->sp->len[k], nccl_float32, p, S->comm, st);
+        at += dense->sp->len[k];
+      }
+    }
   }
   if (others > 0) ne = S->group_end();
   if (nr != 0 || ne != 0) return fail(ctx, GQE_ERR_HIP, "ncclSend / ncclRecv group failed with ncclResult_t %d / %d", nr, ne);
@@ -501,8 +528,23 @@ int shard_run_consumed(gqe_ctx* ctx, ShardSession* S, uint64_t t, int s, int kin
     // ---- contributions to the owners, the small gradients summed over the ranks, Adam on the own shards ----
     rc = timing_begin(ctx, 6, st);
     if (rc != GQE_OK) return rc;
-    rc = shard_all_to_all(ctx, csend, sl.send_counts, crecv, col.recv_counts, (int64_t)d * 4, in_place, st);
+    // the relation / Pre / Post gradients of the ranks ride in the same exchange (GQE_SHARD_DENSE_ALLREDUCE=1: the all-reduce
+    // behind it instead, as before round 5)
+    static const bool dense_allreduce = getenv("GQE_SHARD_DENSE_ALLREDUCE") != nullptr;
+    const GqeSpans dsp = dense_spans(ctx);
+    if (dsp.n < 0) return fail(ctx, GQE_ERR_STATE, "row-sharded step: the non-table parameters form more than 8 spans of the arena");
+    ShardDense dn;
+    const bool dense_rides = !dense_allreduce && (S->world > 1 || (S->self_rccl && S->comm)) && dsp.total > 0 && L.shard_dense_floats >= dsp.total;
+    if (dense_rides) {
+      dn.sp = &dsp;
+      dn.grads = ctx->grads;
+      dn.recv = reinterpret_cast<float*>(ctx->ws + L.shard_dense);
+      dn.stride = L.shard_dense_floats;
+      dn.stage = dn.recv + (size_t)L.shard_dense_floats * (size_t)S->world;
+    }
+    rc = shard_all_to_all(ctx, csend, sl.send_counts, crecv, col.recv_counts, (int64_t)d * 4, in_place, st, dense_rides ? &dn : nullptr);
     if (rc != GQE_OK) return rc;
+    if (dense_rides) HIP_TRY(ctx, gqe_launch_dense_sum(dsp, ctx->grads, dn.recv, dn.stride, S->rank, S->world, st));
     clk.mark(6);
     // the tables the UNION of the ranks' batches names may receive lists (whatever this rank's own batches named)
     ctx->shard_tables.clear();
@@ -524,10 +566,8 @@ int shard_run_consumed(gqe_ctx* ctx, ShardSession* S, uint64_t t, int s, int kin
           if (rc != GQE_OK) return rc;
         }
       }
-      const GqeSpans sp = dense_spans(ctx);
-      if (sp.n < 0) return fail(ctx, GQE_ERR_STATE, "row-sharded step: the non-table parameters form more than 8 spans of the arena");
-      for (int k = 0; k < sp.n; ++k) {
-        rc = shard_all_reduce(ctx, ctx->grads + sp.off[k], sp.len[k], st);
+      for (int k = 0; k < dsp.n && !dense_rides; ++k) {
+        rc = shard_all_reduce(ctx, ctx->grads + dsp.off[k], dsp.len[k], st);
         if (rc != GQE_OK) return rc;
       }
     }

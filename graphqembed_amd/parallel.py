@@ -331,8 +331,34 @@ def shard_exchange(engine, dist, ps):
         engine.materialize_tables(ps["bag_keys"])
         for g in ps["bag_grads"]:
             dist.all_reduce(g)
-    for span in ps["dense"]:
-        dist.all_reduce(span)
+    _ordered_sum(dist, ps["dense"])
+
+
+def _ordered_sum(dist, spans):
+    """Sum of the ranks' copies of ``spans`` (the relation / Pre / Post gradients) IN RANK ORDER, written back in place: what
+    gqe_shard_step does with the blocks that ride in its contribution exchange (csrc/gqe_shard_step.h, gqe_launch_dense_sum) —
+    an all-reduce sums in an order of the transport's choosing, and from three ranks on that is a different float."""
+    import torch
+    world = dist.get_world_size()
+    if world == 1 or not spans:
+        return
+    flat = torch.cat([s.reshape(-1) for s in spans])
+    if flat.is_cuda and dist.get_backend() == "gloo":
+        host = flat.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host)
+        parts = [x.to(flat.device) for x in parts]
+    else:
+        parts = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(parts, flat)
+    acc = torch.zeros_like(flat)
+    for x in parts:
+        acc += x
+    at = 0
+    for s in spans:
+        n = s.numel()
+        s.copy_(acc[at:at + n].view_as(s))
+        at += n
 
 
 def shard_margin_step(engine, dist, ps, adam=None, lr=0.01, betas=(0.9, 0.999), eps=1e-8):

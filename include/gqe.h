@@ -285,7 +285,10 @@ int gqe_import_entries(gqe_ctx* ctx, int64_t slab_entries, void* stream);
  *                              row at position p is written to workspace + contrib_send at p; nothing is linked here
  *   [all-to-all: contributions]  -> the owners' workspace + contrib_recv, in the order of the requests they received
  *   gqe_shard_link(...)        link the received contributions onto my rows' gradient lists
- *   [all-reduce of the relation / Pre / Post gradients: the non-table spans of the gradient arena]
+ *   [sum of the ranks' relation / Pre / Post gradients: the non-table spans of the gradient arena — an all-reduce in the
+ *    phase API; gqe_shard_step moves every rank's copy to every peer INSIDE the contributions' exchange (further sends /
+ *    receives of the same ncclGroup, or a second all_to_all of a callback transport) and sums them in rank order: two
+ *    collectives per step, the same bits on every rank.  GQE_SHARD_DENSE_ALLREDUCE=1 keeps the all-reduce]
  *   gqe_adam_step(local segments)   the ordinary fused pass over MY shards (24 B per OWNED parameter) + the small tensors
  *
  * Per rank and step the optimiser streams 1/world of the tables and the inbound traffic is (rows + contributions of one
