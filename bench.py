@@ -1015,6 +1015,19 @@ def main():
             zs["rows_with_over_32_contributions"] = rz["rows_with_over_32_contributions"]
             zs["optimiser_vs_uniform"] = round(zs["optimiser"]["avg_launch_ms"] / rs["optimiser"]["avg_launch_ms"], 3)
             zs["fused_vs_uniform"] = round(zs["kernels_ms"]["fused_fwd_bwd"] / rs["kernels_ms"]["fused_fwd_bwd"], 3)
+            # The ratio above is the FIRST steps of training, where every hinge is active and every hot word collects a gradient
+            # from every query that holds it; both workloads run again behind 300 training steps (tools/probes/hot_settle_probe.py:
+            # the fused launch settles over ~250 steps at a constant hot set), same engines' parameters, same feeds.
+            settled = dict(short, warmup=300, min_seconds=0.1)
+            ru, eu, _ = measure(wr, args, None, 0, 1, **settled)
+            eu.close()
+            rz2, ez2, _ = measure(wz, args, None, 0, 1, **settled)
+            ez2.close()
+            fu, fz = slim(ru)["kernels_ms"]["fused_fwd_bwd"], slim(rz2)["kernels_ms"]["fused_fwd_bwd"]
+            zs["after_300_steps"] = {"fused_fwd_bwd_ms": fz, "uniform_fused_fwd_bwd_ms": fu, "fused_vs_uniform": round(fz / fu, 3),
+                                     "value": rz2["value"], "uniform_value": ru["value"], "unit": "queries/s",
+                                     "note": "the same two workloads measured behind 300 training steps instead of 10: fewer active hinges, "
+                                             "so fewer contributions to the hot words' accumulators (DESIGN.md section 3, Hot rows; experiment 81)"}
             out["reddit_synth_zipf"] = zs
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not reddit:
         out["cpu_baseline"] = cpu_baseline(eng, args.decoder, args.inter_decoder, wl.item_sets[:8], args.cpu_seconds, wl.qpi)

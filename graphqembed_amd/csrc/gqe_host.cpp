@@ -120,6 +120,7 @@ struct gqe_ctx {
   bool split_active = false, split_launched = false;
   int split_epoch = -1;   // stamp value of the current split step's named rows (odd; += 2 per step)
   GqeSplitTabs split_t;
+  long long split_stream_bytes = 0;   // 12 B per parameter of the tables the riders stream (p, m, v): sizes the lead riders
   GqeSplitRide split_ride;   // the rider description of the fused launch (its second launch continues the same ticket counter)
   GqeSplitSegs split_segs;
   int split_buf = -1;        // staging buffer that holds the step's (host) index feed: free once the second launch has read it
@@ -954,7 +955,10 @@ int split_first_launch(gqe_ctx* ctx, const gqe_batch* batches, int n_batches, co
   }();
   fa.split.waves = (waves_env > 0 && waves_env <= fa.force_fw) ? waves_env : fa.force_fw;
   const int total_blocks = ctx->split_t.blk_begin[ctx->split_t.n];
-  fa.split.lead = std::max(0, std::min(lead_env >= 0 ? lead_env : 96, GQE_SPLIT_MAX_RIDERS / 2));
+  // (a stream of more than ~220 MB of p + m + v outlasts the tiles by far — bio-synth d = 256, 298 MB: lead 96 / 128 / 160 / 192:
+  // 161.5 / 158.5 / 160.5 / 153.4 us per step — so more CUs stream from the first microsecond; at 150 MB 64-128 are equal)
+  const int lead_default = ctx->split_stream_bytes > (220ll << 20) ? 192 : 96;
+  fa.split.lead = std::max(0, std::min(lead_env >= 0 ? lead_env : lead_default, GQE_SPLIT_MAX_RIDERS / 2));
   // (one tail rider per CU: full Bilinear 99 -> 92 us, B = 256 69 -> 62 us against 64 of them; the headline is indifferent)
   const int tail = std::max(0, std::min(tail_env >= 0 ? tail_env : 256, GQE_SPLIT_MAX_RIDERS / 2));
   fa.split.blocks = std::max(1, fa.split.lead + tail);
@@ -2864,7 +2868,8 @@ int gqe_train_step(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
     // the tiles' latency chains far more than they gain (tools/probes/split_timeline.py): the two-call sequence
     long long tiles = 0;
     for (int bi = 0; bi < n_batches; ++bi) tiles += (batches[bi].n_queries + GQE_TQ - 1) / GQE_TQ;
-    split = split && tiles <= GQE_FW8_MIN_TILES;
+    static const bool many_ok = getenv("GQE_SPLIT_MANY_TILES") != nullptr;   // (experiment 85: the split step on launches of thousands of tiles)
+    split = split && (tiles <= GQE_FW8_MIN_TILES || many_ok);
   }
   std::vector<gqe_segment> resolved(segs, segs + n_segs);
   GqeSplitTabs st;
@@ -2940,6 +2945,7 @@ int gqe_train_step(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
     return flush_ride(ctx, reinterpret_cast<hipStream_t>(stream));   // (a pass that could not carry them: losses[] as documented)
   }
   ctx->split_t = st;
+  ctx->split_stream_bytes = stream_bytes;
   ctx->split_b1 = beta1;
   ctx->split_b2 = beta2;
   ctx->split_eps = eps;
