@@ -672,6 +672,45 @@ def api_path(args, d, decoder, inter, B, iterations=120):
     small = {f: qs[:24] for f, qs in list(train["2-chain"].items())[:1]}
     test = {"one_neg": {"2-chain": small}, "full_neg": {"2-chain": small}}
     t_build = time.perf_counter() - t_build
+    class Quiet(object):
+        def info(self, m):
+            pass
+
+    # ---- (1) the loop as run_train runs it: its iterations between two events executed natively (train_helpers._NativeLoop) ----
+    opt = FusedAdam(model, lr=0.01)
+    runs = []
+    orig_run = train_helpers._NativeLoop.run
+
+    def spy_run(self, first, n, all_types):
+        q0 = self.model.engine.feeder_queries(self.feeder)
+        t0 = time.perf_counter()
+        res = orig_run(self, first, n, all_types)             # (returns behind the copy of the run's loss history: the device is idle)
+        runs.append((n, all_types, time.perf_counter() - t0, self.model.engine.feeder_queries(self.feeder) - q0))
+        return res
+    train_helpers._NativeLoop.run = spy_run
+    random.seed(0); np.random.seed(0)
+    t_run = time.perf_counter()
+    try:
+        train_helpers.run_train(model, opt, train, test, test, Quiet(), max_burn_in=2, batch_size=B, log_every=100, val_every=500,
+                                max_iter=2001)
+    finally:
+        train_helpers._NativeLoop.run = orig_run
+    t_run = time.perf_counter() - t_run
+    full = [r for r in runs if r[1]][1:]                       # steady state: every query type, behind the first such run
+    n_it, dt, q = sum(r[0] for r in full), sum(r[2] for r in full), sum(r[3] for r in full)
+    out = {"value": round(q / dt, 1), "unit": "queries/s", "iterations": n_it, "ms_per_iteration": round(dt / n_it * 1e3, 4),
+           "queries_per_iteration": round(q / n_it, 1), "split_steps": model.engine.split_steps(),
+           "native_runs": [{"iterations": r[0], "all_types": bool(r[1]), "ms": round(r[2] * 1e3, 3)} for r in runs],
+           "run_train_seconds": round(t_run, 2), "setup_seconds": round(t_build, 1),
+           "note": ("train_helpers.run_train + FusedAdam on Query objects (the reference's loop and signatures; 2 001 iterations, log lines "
+                    "every 100, validation every 500): the iterations between two events of the schedule run as ONE library call "
+                    "(gqe_feeder_run with reference streams: formula draws replayed on np.random's generator, negatives on random's, "
+                    "packing, gqe_train_step) - the same batches as the reference's loop under the same seeds "
+                    "(tests/test_gpu_api.py::test_run_train_native_runs_reproduce_the_reference_run); the phase switch, validation, "
+                    "moving average and log lines stay in Python; value = queries / wall time of the native runs behind the first "
+                    "(each ends with the copy of its loss history: the device is idle at both ends)")}
+
+    # ---- (2) the same loop batch by batch from Python (GQE_RUN_TRAIN_NATIVE=0; what round 5's first half measured) ----
     opt = FusedAdam(model, lr=0.01)
     clock = {"lookup": 0.0, "pack": 0.0, "launch": 0.0, "n": 0, "queries": 0, "stamps": []}
 
@@ -697,15 +736,13 @@ def api_path(args, d, decoder, inter, B, iterations=120):
         step0()
         clock["stamps"].append((time.perf_counter(), clock["lookup"], clock["pack"], clock["launch"], clock["queries"]))
     opt.step = step
-
-    class Quiet(object):
-        def info(self, m):
-            pass
     random.seed(0); np.random.seed(0)
+    os.environ["GQE_RUN_TRAIN_NATIVE"] = "0"
     try:
         train_helpers.run_train(model, opt, train, test, test, Quiet(), max_burn_in=2, batch_size=B, log_every=10 ** 9, val_every=10 ** 9,
                                 max_iter=iterations)
     finally:
+        os.environ.pop("GQE_RUN_TRAIN_NATIVE", None)
         for owner, name, fn in undo:
             setattr(owner, name, fn)
     st = clock["stamps"]
@@ -713,15 +750,12 @@ def api_path(args, d, decoder, inter, B, iterations=120):
     n = len(st) - 1 - len(st) // 3
     dt = b[0] - a[0]
     q = b[4] - a[4]
-    out = {"value": round(q / dt, 1), "unit": "queries/s", "iterations": n, "ms_per_iteration": round(dt / n * 1e3, 4),
-           "queries_per_iteration": round(q / n, 1), "split_steps": model.engine.split_steps(),
-           "host_us_per_iteration": {"row_lookup_and_negative_draw": round((b[1] - a[1]) / n * 1e6, 1), "packing": round((b[2] - a[2]) / n * 1e6, 1),
-                                     "library_call": round((b[3] - a[3]) / n * 1e6, 1),
-                                     "rest (formula draw, loss .item() = waiting for the device, loop)": round((dt - (b[1] - a[1]) - (b[2] - a[2]) - (b[3] - a[3])) / n * 1e6, 1)},
-           "setup_seconds": round(t_build, 1),
-           "note": ("train_helpers.run_train + FusedAdam on Query objects (the reference's loop and signatures): formula draw, window, "
-                    "reference negatives (random.choice per query, replayed natively), packing, gqe_train_step, loss.item() every "
-                    "iteration; row arrays of each formula's list are looked up once (train_helpers._PoolRows)")}
+    out["per_batch_python_path"] = {
+        "value": round(q / dt, 1), "unit": "queries/s", "iterations": n, "ms_per_iteration": round(dt / n * 1e3, 4),
+        "host_us_per_iteration": {"row_lookup_and_negative_draw": round((b[1] - a[1]) / n * 1e6, 1), "packing": round((b[2] - a[2]) / n * 1e6, 1),
+                                  "library_call": round((b[3] - a[3]) / n * 1e6, 1),
+                                  "rest (formula draw, loss .item() = waiting for the device, loop)": round((dt - (b[1] - a[1]) - (b[2] - a[2]) - (b[3] - a[3])) / n * 1e6, 1)},
+        "note": "GQE_RUN_TRAIN_NATIVE=0: every batch drawn and packed from Python, one gqe_train_step and one loss.item() per iteration"}
     model.engine.close()
     return out
 

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "gqe_dev.h"
+#include "gqe_mt.h"
 
 namespace {
 
@@ -217,6 +218,10 @@ struct FeederPool {
   gqe_batch proto;  // static fields of the formula
   int64_t n;
   std::vector<int32_t> target, anchors /*[k][n]*/, neg, hard;
+  // reference streams (gqe_feeder_add_pool_lists): every query's negative / hard-negative LIST as the reference's files hold
+  // them (rows; CSR), one of which random.choice picks per query and batch (model.py:113-120)
+  std::vector<int64_t> neg_ptr, hard_ptr;
+  std::vector<int32_t> neg_rows, hard_rows;
 };
 
 struct gqe_feeder {
@@ -240,6 +245,7 @@ struct gqe_feeder {
     std::vector<gqe_segment> segs;
     std::vector<int32_t> host_idx;     // row-sharded mode: the host feed gqe_shard_post takes
     const int32_t* dev_idx = nullptr;  // where the kernels read the feed (device buffer or pinned host slot)
+    const int32_t* host_src = nullptr; // the packed feed in pinned host memory (gqe_feeder_debug_feed)
     int64_t n_idx = 0;
   };
   Prepared prep[2 * kFeedGroup];
@@ -263,6 +269,17 @@ struct gqe_feeder {
   // where the previous one ended (or changes burn_in) starts from a clean ring
   int64_t next_it = -1;
   int32_t last_burn_in = -1;
+  // reference streams (gqe_feeder_set_reference_streams): the formula of a batch is np.random.multinomial's draw and the
+  // negatives are random.choice's, replayed on the caller's two MT19937 states (gqe_mt.h) — a run seeded like the reference's
+  // trains on the reference's batches (train_helpers.run_train).  pvals[type]: the probability vector as the caller computed it;
+  // type_order: the query types behind 1-chain in the order of the caller's training dictionary.
+  uint32_t* np_state = nullptr;
+  uint32_t* py_state = nullptr;
+  std::vector<double> pvals[7];
+  std::vector<int> type_order;
+  int64_t loss_stride = 0;   // > 0: iteration i of a run writes its losses at losses + (i - first_iteration) * loss_stride
+  int64_t run_end = 0;       // (copy mode samples a group of iterations together: never past the end of the run)
+  int64_t queries_fed = 0;   // queries of every batch packed so far (gqe_feeder_queries)
 };
 
 namespace {
@@ -2962,6 +2979,13 @@ int gqe_train_step(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
   return GQE_OK;
 }
 
+int gqe_adam_step_count(gqe_ctx* ctx, int64_t offset, int32_t* count) {
+  if (!ctx || !count) return GQE_ERR_ARG;
+  auto it = ctx->adam_steps.find(offset);
+  *count = it == ctx->adam_steps.end() ? 0 : it->second;
+  return GQE_OK;
+}
+
 int gqe_sgd_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, float lr, void* stream) {
   return run_opt(ctx, GQE_OPT_SGD, segs, n_segs, lr, 0.f, 0.f, 0.f, stream);
 }
@@ -3085,19 +3109,97 @@ int gqe_feeder_set_mode_rows(gqe_feeder* f, int64_t table_offset, const int32_t*
   return GQE_OK;
 }
 
+int gqe_feeder_add_pool_lists(gqe_feeder* f, const gqe_batch* formula, int64_t n, const int32_t* target, const int32_t* anchors,
+                              const int64_t* neg_ptr, const int32_t* neg_rows, const int64_t* hard_ptr, const int32_t* hard_rows) {
+  if (!f) return GQE_ERR_ARG;
+  gqe_ctx* ctx = f->ctx;
+  if (!formula || n < 1) return fail(ctx, GQE_ERR_ARG, "bad pool");
+  if (formula->qtype != GQE_Q_1CHAIN && (!neg_ptr || !neg_rows)) return fail(ctx, GQE_ERR_ARG, "pool: negative lists are required except for 1-chain");
+  auto check = [&](const int64_t* ptr) {
+    if (!ptr) return true;
+    if (ptr[0] != 0) return false;
+    for (int64_t q = 0; q < n; ++q)
+      if (ptr[q + 1] <= ptr[q] || ptr[q + 1] - ptr[q] > 0xffffffffll) return false;   // random.choice of an empty list raises
+    return true;
+  };
+  if (!check(neg_ptr) || !check(hard_ptr)) return fail(ctx, GQE_ERR_ARG, "pool: every query needs a non-empty negative list");
+  // (the stored-negative arrays of the pool stay empty: with lists, a batch's negatives are drawn)
+  std::vector<int32_t> one((size_t)n, 0);
+  int rc = gqe_feeder_add_pool(f, formula, n, target, anchors, formula->qtype == GQE_Q_1CHAIN ? nullptr : one.data(), nullptr);
+  if (rc != GQE_OK) return rc;
+  FeederPool& p = f->pools.back();
+  p.neg.clear();
+  if (neg_ptr) {
+    p.neg_ptr.assign(neg_ptr, neg_ptr + n + 1);
+    p.neg_rows.assign(neg_rows, neg_rows + neg_ptr[n]);
+  }
+  if (hard_ptr && hard_rows) {
+    p.hard_ptr.assign(hard_ptr, hard_ptr + n + 1);
+    p.hard_rows.assign(hard_rows, hard_rows + hard_ptr[n]);
+  }
+  return GQE_OK;
+}
+
+int gqe_feeder_set_reference_streams(gqe_feeder* f, uint32_t* np_state625, uint32_t* py_state625) {
+  if (!f) return GQE_ERR_ARG;
+  if ((np_state625 == nullptr) != (py_state625 == nullptr)) return fail(f->ctx, GQE_ERR_ARG, "reference streams: both states or neither");
+  if (np_state625 && (np_state625[624] > 624 || py_state625[624] > 624)) return fail(f->ctx, GQE_ERR_ARG, "reference streams: bad generator position");
+  f->np_state = np_state625;
+  f->py_state = py_state625;
+  return GQE_OK;
+}
+
+int gqe_feeder_set_type_order(gqe_feeder* f, const int32_t* qtypes, int32_t n) {
+  if (!f) return GQE_ERR_ARG;
+  if (n < 0 || (n > 0 && !qtypes)) return fail(f->ctx, GQE_ERR_ARG, "bad type order");
+  std::vector<int> order;
+  for (int i = 0; i < n; ++i) {
+    if (qtypes[i] <= GQE_Q_1CHAIN || qtypes[i] > GQE_Q_3CHAIN_INTER) return fail(f->ctx, GQE_ERR_ARG, "type order: query types behind 1-chain only");
+    if (std::find(order.begin(), order.end(), qtypes[i]) != order.end()) return fail(f->ctx, GQE_ERR_ARG, "type order: a type twice");
+    order.push_back(qtypes[i]);
+  }
+  f->type_order = order;
+  return GQE_OK;
+}
+
+int gqe_feeder_set_pvals(gqe_feeder* f, int32_t qtype, const double* pvals, int32_t n) {
+  if (!f) return GQE_ERR_ARG;
+  if (qtype < 0 || qtype > GQE_Q_3CHAIN_INTER || !pvals || n != (int32_t)f->by_type[qtype].size())
+    return fail(f->ctx, GQE_ERR_ARG, "pvals: one probability per pool of the type");
+  f->pvals[qtype].assign(pvals, pvals + n);
+  return GQE_OK;
+}
+
+int gqe_feeder_set_loss_stride(gqe_feeder* f, int64_t stride) {
+  if (!f) return GQE_ERR_ARG;
+  if (stride != 0 && stride < GQE_LAUNCH_BATCHES + 1) return fail(f->ctx, GQE_ERR_ARG, "loss stride: 0 or at least %d floats", GQE_LAUNCH_BATCHES + 1);
+  f->loss_stride = stride;
+  return GQE_OK;
+}
+
 // one (formula, slice) batch appended to f->batches / f->idx
 static int feeder_batch(gqe_feeder* f, int qtype, int64_t it, float weight, bool hard) {
   gqe_ctx* ctx = f->ctx;
   const std::vector<int>& cand = f->by_type[qtype];
   if (cand.empty()) return GQE_OK;
   size_t pick = 0;
-  if (cand.size() > 1) {
+  const bool ref = f->np_state != nullptr;
+  if (ref) {
+    // np.random.multinomial(1, sizes / sum).argmax() on the caller's generator (train_helpers.py:96-99; one pool: no draw, as in numpy)
+    if (f->pvals[qtype].size() != cand.size()) return fail(ctx, GQE_ERR_STATE, "reference streams: gqe_feeder_set_pvals missing for query type %d", qtype);
+    uint32_t pos = f->np_state[624];
+    pick = (size_t)gqe_mt::np_multinomial_one(f->np_state, pos, f->pvals[qtype].data(), (int64_t)cand.size());
+    f->np_state[624] = pos;
+  } else if (cand.size() > 1) {
     const double u = (double)(feeder_next(f) >> 11) * (1.0 / 9007199254740992.0) * f->cum[qtype].back();
     pick = std::lower_bound(f->cum[qtype].begin(), f->cum[qtype].end(), u) - f->cum[qtype].begin();
     if (pick >= cand.size()) pick = cand.size() - 1;
   }
   const FeederPool& p = f->pools[cand[pick]];
-  if (hard && p.hard.empty()) return fail(ctx, GQE_ERR_ARG, "pool of query type %d has no hard negatives", qtype);
+  if (ref && qtype != GQE_Q_1CHAIN && (hard ? p.hard_ptr.empty() : p.neg_ptr.empty()))
+    return fail(ctx, GQE_ERR_ARG, "reference streams: pool of query type %d has no %snegative lists", qtype, hard ? "hard-" : "");
+  if (!ref && qtype != GQE_Q_1CHAIN && p.neg.empty()) return fail(ctx, GQE_ERR_ARG, "pool of query type %d holds negative lists: reference streams only", qtype);
+  if (!ref && hard && p.hard.empty()) return fail(ctx, GQE_ERR_ARG, "pool of query type %d has no hard negatives", qtype);
   const int64_t n = p.n, B = f->batch_size;
   // row-sharded data parallelism: the W ranks of iteration `it` train the W consecutive slices it * W + rank of the same
   // formula draw (the reference's wrap-around rule, train_helpers.py:102-105) and weight their mean losses by n_rank / n_all
@@ -3131,8 +3233,20 @@ static int feeder_batch(gqe_feeder* f, int qtype, int64_t it, float weight, bool
     auto it_rows = f->mode_rows.find(p.proto.target_table);
     if (it_rows == f->mode_rows.end()) return fail(ctx, GQE_ERR_STATE, "gqe_feeder_set_mode_rows missing for the 1-chain target table");
     const std::vector<int32_t>& rows = it_rows->second;
-    // (several ranks: the negatives come from a per-rank stream, the formula draws stay on the shared one)
-    for (int64_t k = 0; k < m; ++k) f->idx.push_back(rows[(W > 1 ? feeder_next_neg(f) : feeder_next(f)) % rows.size()]);
+    if (ref) {   // random.choice(graph.full_lists[mode]) per query (model.py:113-114)
+      uint32_t pos = f->py_state[624];
+      for (int64_t k = 0; k < m; ++k) f->idx.push_back(rows[(size_t)gqe_mt::py_randbelow(f->py_state, pos, (int64_t)rows.size())]);
+      f->py_state[624] = pos;
+    } else {
+      // (several ranks: the negatives come from a per-rank stream, the formula draws stay on the shared one)
+      for (int64_t k = 0; k < m; ++k) f->idx.push_back(rows[(W > 1 ? feeder_next_neg(f) : feeder_next(f)) % rows.size()]);
+    }
+  } else if (ref) {   // random.choice(query.neg_samples / hard_neg_samples) per query (model.py:115-120)
+    const std::vector<int64_t>& ptr = hard ? p.hard_ptr : p.neg_ptr;
+    const std::vector<int32_t>& rows = hard ? p.hard_rows : p.neg_rows;
+    uint32_t pos = f->py_state[624];
+    for (int64_t q = start; q < end; ++q) f->idx.push_back(rows[(size_t)(ptr[q] + gqe_mt::py_randbelow(f->py_state, pos, ptr[q + 1] - ptr[q]))]);
+    f->py_state[624] = pos;
   } else {
     const std::vector<int32_t>& src = hard ? p.hard : p.neg;
     f->idx.insert(f->idx.end(), src.begin() + start, src.begin() + end);
@@ -3140,6 +3254,7 @@ static int feeder_batch(gqe_feeder* f, int qtype, int64_t it, float weight, bool
   for (int a = 0; a < p.proto.n_anchors; ++a)
     f->idx.insert(f->idx.end(), p.anchors.begin() + (size_t)a * n + start, p.anchors.begin() + (size_t)a * n + end);
   f->batches.push_back(b);
+  f->queries_fed += m;
   return GQE_OK;
 }
 
@@ -3169,7 +3284,10 @@ static int feeder_build(gqe_feeder* f, int64_t it, int32_t burn_in) {
   int rc = feeder_batch(f, GQE_Q_1CHAIN, it, 1.f, false);
   if (rc != GQE_OK) return rc;
   if (it >= burn_in) {
-    for (int t = GQE_Q_2CHAIN; t <= GQE_Q_3CHAIN_INTER; ++t) {
+    std::vector<int> order = f->type_order;   // (gqe_feeder_set_type_order: the caller's dictionary order; else the enum's)
+    if (order.empty())
+      for (int t = GQE_Q_2CHAIN; t <= GQE_Q_3CHAIN_INTER; ++t) order.push_back(t);
+    for (int t : order) {
       if (f->by_type[t].empty()) continue;
       const bool inter = t >= GQE_Q_2INTER;
       rc = feeder_batch(f, t, it, inter ? f->inter_weight : f->path_weight, false);
@@ -3261,6 +3379,7 @@ static int feeder_ensure(gqe_feeder* f, int64_t it, int32_t burn_in, hipStream_t
     memcpy(slot, f->idx.data(), f->idx.size() * sizeof(int32_t));
     stash(P, it);
     P.dev_idx = slot;
+    P.host_src = slot;
     return GQE_OK;
   }
   // ---- copy mode: the rest of this iteration's group in one upload ----
@@ -3276,7 +3395,9 @@ static int feeder_ensure(gqe_feeder* f, int64_t it, int32_t burn_in, hipStream_t
   if (!f->grp_pin[g]) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&f->grp_pin[g]), (size_t)kFeedGroup * L.idx_cap, hipHostMallocDefault));
   HIP_TRY(ctx, hipEventSynchronize(f->grp_ready[g]));   // the previous upload out of this pinned buffer (two groups ago) is long done
   const int k0 = (int)(it % kFeedGroup);
-  for (int k = k0; k < kFeedGroup; ++k) {
+  int k1 = kFeedGroup;   // (never past the end of the run: the samples of a later run are drawn by it — reference streams stop where the run stops)
+  if (group * kFeedGroup + k1 > f->run_end) k1 = (int)(f->run_end - group * kFeedGroup);
+  for (int k = k0; k < k1; ++k) {
     const int64_t i = group * kFeedGroup + k;
     rc = feeder_build(f, i, burn_in);
     if (rc != GQE_OK) return rc;
@@ -3285,10 +3406,11 @@ static int feeder_ensure(gqe_feeder* f, int64_t it, int32_t burn_in, hipStream_t
     gqe_feeder::Prepared& Q = f->prep[i % (2 * kFeedGroup)];
     stash(Q, i);
     Q.dev_idx = reinterpret_cast<const int32_t*>(ctx->ws + (size_t)(2 + g * kFeedGroup + k) * L.idx_cap);
+    Q.host_src = f->grp_pin[g] + (size_t)k * slot_ints;
   }
   char* dev = ctx->ws + (size_t)(2 + g * kFeedGroup + k0) * L.idx_cap;
   if (f->grp_free_set[g]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->up, f->grp_free[g], 0));   // the kernels of group - 2 have read the buffers
-  HIP_TRY(ctx, hipMemcpyAsync(dev, f->grp_pin[g] + (size_t)k0 * slot_ints, (size_t)(kFeedGroup - k0) * L.idx_cap, hipMemcpyHostToDevice, ctx->up));
+  HIP_TRY(ctx, hipMemcpyAsync(dev, f->grp_pin[g] + (size_t)k0 * slot_ints, (size_t)(k1 - k0) * L.idx_cap, hipMemcpyHostToDevice, ctx->up));
   HIP_TRY(ctx, hipEventRecord(f->grp_ready[g], ctx->up));
   HIP_TRY(ctx, hipStreamWaitEvent(st, f->grp_ready[g], 0));
   return GQE_OK;
@@ -3314,9 +3436,14 @@ int gqe_feeder_run(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations,
   }
   f->next_it = end;
   f->last_burn_in = burn_in;
+  f->run_end = end;
+  float* const losses0 = losses;
   for (int64_t it = first_iteration; it < end; ++it) {
+    losses = losses0 + (it - first_iteration) * f->loss_stride;   // (gqe_feeder_set_loss_stride: a history of the run's losses)
     int rc = feeder_ensure(f, it, burn_in, st);
     if (rc != GQE_OK) return rc;
+    if (f->loss_stride > 0 && (int64_t)f->prep[it % (2 * kFeedGroup)].batches.size() + 1 > f->loss_stride)
+      return fail(ctx, GQE_ERR_ARG, "iteration of %zu batches: its losses do not fit the loss stride", f->prep[it % (2 * kFeedGroup)].batches.size());
     // one iteration of look-ahead where it pays: lazy Adam (the step's row launch also brings the next feed's rows up to
     // date: one launch instead of two) and row-sharded runs (the next plan is posted before this step runs)
     const bool ahead = (ctx->lazy || shard) && it + 1 < end;
@@ -3366,6 +3493,20 @@ int gqe_feeder_run(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations,
       f->grp_free_set[g] = true;
     }
   }
+  return GQE_OK;
+}
+
+int64_t gqe_feeder_queries(gqe_feeder* f) { return f ? f->queries_fed : 0; }
+
+int gqe_feeder_debug_feed(gqe_feeder* f, int64_t iteration, gqe_batch* batches, int32_t max_batches, int32_t* n_batches, int32_t* idx,
+                          int64_t max_idx, int64_t* n_idx) {
+  if (!f || !n_batches || !n_idx) return GQE_ERR_ARG;
+  const gqe_feeder::Prepared& P = f->prep[((iteration % (2 * kFeedGroup)) + 2 * kFeedGroup) % (2 * kFeedGroup)];
+  if (P.it != iteration || !P.host_src) return fail(f->ctx, GQE_ERR_STATE, "iteration %lld is not among the prepared ones", (long long)iteration);
+  *n_batches = (int32_t)P.batches.size();
+  *n_idx = P.n_idx;
+  if (batches && max_batches >= *n_batches) std::copy(P.batches.begin(), P.batches.end(), batches);
+  if (idx && max_idx >= P.n_idx) memcpy(idx, P.host_src, sizeof(int32_t) * (size_t)P.n_idx);
   return GQE_OK;
 }
 

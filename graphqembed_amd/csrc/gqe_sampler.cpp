@@ -397,27 +397,10 @@ int fail(int code, const std::string& msg) {
 extern "C" {
 
 // ---- Python's random.choice on a batch of lists (include/gqe_sampler.h) ------------------------------------------------
-// MT19937 as CPython's _randommodule.c runs it: genrand_uint32 with the standard tempering; getrandbits(k <= 32) = one output
-// word >> (32 - k); lists longer than 2^32 do not occur (k <= 32 is checked).
-namespace {
-inline uint32_t mt_next(uint32_t* mt, uint32_t& pos) {
-  constexpr uint32_t N = 624, M = 397;
-  if (pos >= N) {
-    auto twist = [](uint32_t u, uint32_t v) { return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u); };
-    uint32_t kk = 0;
-    for (; kk < N - M; ++kk) mt[kk] = mt[kk + M] ^ twist(mt[kk], mt[kk + 1]);
-    for (; kk < N - 1; ++kk) mt[kk] = mt[kk + M - N] ^ twist(mt[kk], mt[kk + 1]);
-    mt[N - 1] = mt[M - 1] ^ twist(mt[N - 1], mt[0]);
-    pos = 0;
-  }
-  uint32_t y = mt[pos++];
-  y ^= y >> 11;
-  y ^= (y << 7) & 0x9d2c5680u;
-  y ^= (y << 15) & 0xefc60000u;
-  y ^= y >> 18;
-  return y;
-}
-}  // namespace
+// MT19937 as CPython's _randommodule.c runs it (gqe_mt.h): genrand_uint32 with the standard tempering; getrandbits(k <= 32) = one
+// output word >> (32 - k); lists longer than 2^32 do not occur (k <= 32 is checked).
+#include "gqe_mt.h"
+using gqe_mt::mt_next;
 
 int gqe_py_random_choices(uint32_t* state625, const int64_t* counts, int64_t n, int64_t* choice) {
   if (!state625 || !counts || !choice || n < 0) return GQE_SAMPLER_ARG;
@@ -434,6 +417,15 @@ int gqe_py_random_choices(uint32_t* state625, const int64_t* counts, int64_t n, 
     } while ((int64_t)r >= c);
     choice[i] = (int64_t)r;
   }
+  state625[624] = pos;
+  return GQE_SAMPLER_OK;
+}
+
+int gqe_np_multinomial_pick(uint32_t* state625, const double* pvals, int64_t d, int64_t* pick) {
+  if (!state625 || !pvals || !pick || d < 1) return GQE_SAMPLER_ARG;
+  uint32_t pos = state625[624];
+  if (pos > 624) return GQE_SAMPLER_ARG;
+  *pick = gqe_mt::np_multinomial_one(state625, pos, pvals, d);
   state625[624] = pos;
   return GQE_SAMPLER_OK;
 }

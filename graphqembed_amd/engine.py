@@ -131,6 +131,15 @@ SYMBOLS = OrderedDict([
     ("gqe_feeder_add_pool", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int64, _P, _P, _P, _P])),
     ("gqe_feeder_set_mode_rows", (C.c_int, [_P, C.c_int64, _P, C.c_int64])),
     ("gqe_feeder_set_feed", (C.c_int, [_P, C.c_int32])),
+    ("gqe_feeder_add_pool_lists", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int64, _P, _P, _P, _P, _P, _P])),
+    ("gqe_feeder_set_reference_streams", (C.c_int, [_P, _P, _P])),
+    ("gqe_feeder_set_pvals", (C.c_int, [_P, C.c_int32, _P, C.c_int32])),
+    ("gqe_feeder_set_type_order", (C.c_int, [_P, _P, C.c_int32])),
+    ("gqe_feeder_set_loss_stride", (C.c_int, [_P, C.c_int64])),
+    ("gqe_adam_step_count", (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int32)])),
+    ("gqe_feeder_queries", (C.c_int64, [_P])),
+    ("gqe_feeder_debug_feed", (C.c_int, [_P, C.c_int64, C.POINTER(gqe_batch), C.c_int32, C.POINTER(C.c_int32), _P, C.c_int64,
+                                         C.POINTER(C.c_int64)])),
     ("gqe_feeder_run", (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P])),
     ("gqe_timing_enable", (C.c_int, [_P, C.c_int32])),
     ("gqe_debug_profile", (C.c_int, [_P, _P])),
@@ -771,6 +780,82 @@ class Engine(object):
 
     def feeder_destroy(self, feeder):
         self.lib.gqe_feeder_destroy(feeder)
+
+    LOSS_STRIDE = 32    # floats per iteration of a reference feeder's loss history (>= GQE_LAUNCH_BATCHES + 1)
+
+    def make_reference_feeder(self, pools_by_type, mode_rows, batch_size, path_weight, inter_weight, feed="copy"):
+        """The reference's own training loop, natively (include/gqe.h "reference streams"; train_helpers.run_train):
+        pools_by_type = {query type name: [(FormulaPlan, target[n], anchors[k, n], (neg_ptr, neg_rows) | None,
+        (hard_ptr, hard_rows) | None)]} in the order of the training dictionary (1-chain pools carry no lists),
+        mode_rows = {table key: rows of graph.full_lists[mode]}.  The probability vector of a type is computed here exactly as
+        train_helpers.py:96-98 does."""
+        h = _P()
+        self._check(self.lib.gqe_feeder_create(self.ctx, 0, batch_size, path_weight, inter_weight, C.byref(h)))
+        try:
+            self._check(self.lib.gqe_feeder_set_feed(h, {"copy": 0, "zero-copy": 1}[feed]))
+            self._check(self.lib.gqe_feeder_set_loss_stride(h, self.LOSS_STRIDE))
+            i32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+            i64 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int64)
+            ptr = lambda x: None if x is None else C.c_void_p(x.ctypes.data)
+            order = []
+            for qt, pools in pools_by_type.items():
+                if qt != "1-chain":
+                    order.append(QTYPES[qt])
+                for plan, target, anchors, neg, hard in pools:
+                    arr = self.make_batches([plan.batch(1, 0, 0)])
+                    t, a = i32(target), i32(anchors)
+                    np_, nr = (i64(neg[0]), i32(neg[1])) if neg is not None else (None, None)
+                    hp, hr = (i64(hard[0]), i32(hard[1])) if hard is not None else (None, None)
+                    self._check(self.lib.gqe_feeder_add_pool_lists(h, arr, len(t), ptr(t), ptr(a), ptr(np_), ptr(nr), ptr(hp), ptr(hr)))
+                sizes = [float(len(p[1])) for p in pools]
+                pv = np.ascontiguousarray(np.array(sizes) / float(sum(sizes)), dtype=np.float64)
+                self._check(self.lib.gqe_feeder_set_pvals(h, QTYPES[qt], C.c_void_p(pv.ctypes.data), len(pv)))
+            od = np.ascontiguousarray(order, dtype=np.int32)
+            self._check(self.lib.gqe_feeder_set_type_order(h, C.c_void_p(od.ctypes.data), len(od)))
+            for key, rows in mode_rows.items():
+                rows = np.ascontiguousarray(rows, dtype=np.int32)
+                self._check(self.lib.gqe_feeder_set_mode_rows(h, self.layout.offset(key), C.c_void_p(rows.ctypes.data), len(rows)))
+        except Exception:
+            self.lib.gqe_feeder_destroy(h)
+            raise
+        return h
+
+    def reference_feeder_run(self, feeder, np_state, py_state, first_iteration, n_iterations, edges_only, lr, betas, eps):
+        """n_iterations of the reference's loop on the two generator states (625 uint32 words each, updated in place); returns the
+        loss history [n_iterations, LOSS_STRIDE] (device tensor; row i, column <number of batches of iteration i> = its total
+        loss).  The per-tensor Adam step counters of this engine follow the library's afterwards."""
+        t = self.torch
+        hist = t.zeros((n_iterations, self.LOSS_STRIDE), dtype=t.float32, device=self.device)
+        self._check(self.lib.gqe_feeder_set_reference_streams(feeder, C.c_void_p(np_state.ctypes.data), C.c_void_p(py_state.ctypes.data)))
+        try:
+            burn_in = first_iteration + n_iterations if edges_only else 0
+            self._check(self.lib.gqe_feeder_run(feeder, first_iteration, n_iterations, burn_in, lr, betas[0], betas[1], eps,
+                                                hist.data_ptr(), self._stream()))
+        finally:
+            self.lib.gqe_feeder_set_reference_streams(feeder, None, None)
+            self.sync_step_counts()
+        return hist
+
+    def feeder_queries(self, feeder):
+        return int(self.lib.gqe_feeder_queries(feeder))
+
+    def feeder_debug_feed(self, feeder, iteration):
+        """(batches, idx) of one of the feeder's last prepared iterations: [(qtype, n_queries, n_anchors, idx_offset, loss_weight)]
+        and the packed int32 feed (tests)."""
+        nb, ni = C.c_int32(0), C.c_int64(0)
+        self._check(self.lib.gqe_feeder_debug_feed(feeder, iteration, None, 0, C.byref(nb), None, 0, C.byref(ni)))
+        arr = (gqe_batch * nb.value)()
+        idx = np.empty(ni.value, dtype=np.int32)
+        self._check(self.lib.gqe_feeder_debug_feed(feeder, iteration, arr, nb.value, C.byref(nb), C.c_void_p(idx.ctypes.data), ni.value, C.byref(ni)))
+        return [(b.qtype, b.n_queries, b.n_anchors, b.idx_offset, b.loss_weight) for b in arr], idx
+
+    def sync_step_counts(self):
+        """This engine's per-tensor Adam step counters := the library's (gqe_adam_step_count), behind a native run."""
+        c = C.c_int32(0)
+        for k in self.layout.entries:
+            self._check(self.lib.gqe_adam_step_count(self.ctx, self.layout.offset(k), C.byref(c)))
+            if c.value > self.steps[k]:
+                self.steps[k] = int(c.value)
 
     # -- timing (bench.py roofline) ------------------------------------------------
     def timing_enable(self, stride):

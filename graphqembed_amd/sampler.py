@@ -41,6 +41,7 @@ SAMPLER_SYMBOLS = {
     "gqe_sampler_check": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "gqe_sampler_last_error": (C.c_char_p, []),
     "gqe_py_random_choices": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "gqe_np_multinomial_pick": (C.c_int, [_P, _P, C.c_int64, _P]),
 }
 
 
@@ -69,6 +70,34 @@ def py_random_choices(counts):
         raise ValueError("gqe_py_random_choices: a list without entries cannot be chosen from")
     random.setstate((version, tuple(state.tolist()), gauss))
     return out
+
+
+def np_state_words():
+    """``np.random``'s generator (the global RandomState, MT19937) as the 625-word array the native replays take: 624 key words +
+    the position; ``rest`` = what ``np.random.set_state`` needs back unchanged (the cached Gaussian)."""
+    name, key, pos, has_gauss, cached = np.random.get_state()
+    if name != "MT19937":
+        raise ValueError("np.random is not on MT19937")
+    state = np.empty(625, dtype=np.uint32)
+    state[:624] = key
+    state[624] = pos
+    return state, (has_gauss, cached)
+
+
+def np_state_restore(state, rest):
+    np.random.set_state(("MT19937", state[:624].copy(), int(state[624]), rest[0], rest[1]))
+
+
+def np_multinomial_pick(pvals):
+    """``np.random.multinomial(1, pvals).argmax()`` — the same value and the same consumption of ``np.random``'s generator, drawn
+    natively (include/gqe_sampler.h, gqe_np_multinomial_pick): the reference's formula draw, train_helpers.py:96-99."""
+    pvals = np.ascontiguousarray(pvals, dtype=np.float64)
+    state, rest = np_state_words()
+    pick = np.zeros(1, dtype=np.int64)
+    if _lib().gqe_np_multinomial_pick(state.ctypes.data, pvals.ctypes.data, len(pvals), pick.ctypes.data) != 0:
+        raise ValueError("gqe_np_multinomial_pick: bad arguments")
+    np_state_restore(state, rest)
+    return int(pick[0])
 
 
 class PyRandomStream(object):

@@ -21,6 +21,7 @@ optimisers.  Evaluation and logging (``evaluate``) are separate from the schedul
 """
 from __future__ import annotations
 
+import os
 from collections import namedtuple
 
 import numpy as np
@@ -218,6 +219,98 @@ class FusedExecutor(object):
             losses, _, _ = self.model.margin_step(self.items)
         return float(losses[-1].item())
 
+    # ---- the loop itself, natively: runs of iterations between two points where run_train has to look (include/gqe.h,
+    # "reference streams") ----
+    def native_loop(self, train_queries, batch_size, path_weight, inter_weight):
+        """A ``_NativeLoop`` over these training queries, or None where the native feeder cannot stand in for the loop: no
+        FusedAdam, a query without the negatives its type needs (the reference raises on it: that exception has to come from
+        the per-batch path), more batches per iteration than one launch carries.  Built once per (dictionary, batch size)."""
+        if self.optimizer is None or os.environ.get("GQE_RUN_TRAIN_NATIVE", "1") == "0":
+            return None
+        key = (id(train_queries), batch_size, path_weight, inter_weight)
+        if getattr(self, "_native_key", None) != key:
+            self._native_key = key
+            try:
+                self._native = _NativeLoop(self, train_queries, batch_size, path_weight, inter_weight)
+            except _NativeUnsupported:
+                self._native = None
+        return self._native
+
+
+class _NativeUnsupported(Exception):
+    pass
+
+
+class _NativeLoop(object):
+    """train_helpers.py:40-107 between two events (phase switch, validation, end) as ONE library call per run of iterations:
+    formula draws on ``np.random``'s generator, negatives on ``random``'s, packing, gqe_train_step — gqe_feeder_run with reference
+    streams.  What Python keeps: the schedule's decisions, the moving average and the log lines (made from the run's loss
+    history), validation."""
+
+    MAX_RUN = 4096
+
+    def __init__(self, executor, train_queries, batch_size, path_weight, inter_weight):
+        m = executor.model
+        pools_by_type, mode_rows = {}, {}
+        from .tensorize import table_key
+        # the loop draws a 1-chain batch first whatever the dictionary's order; the other types follow in its order
+        order = ["1-chain"] + [qt for qt in train_queries if qt != "1-chain"]
+        n_batches = 1 + sum(2 if "inter" in qt else 1 for qt in order[1:])
+        if n_batches > 16 or "1-chain" not in train_queries:
+            raise _NativeUnsupported()
+        for qt in order:
+            entries = []
+            for formula, pool in train_queries[qt].items():
+                if len(pool) == 0:
+                    raise _NativeUnsupported()
+                rows = executor._pools.get(id(pool))
+                if rows is None or rows.pool is not pool:
+                    rows = executor._pools[id(pool)] = _PoolRows(m, formula, pool)
+                neg = hard = None
+                if qt == "1-chain":
+                    mode = formula.target_mode
+                    if mode not in executor._full:
+                        executor._full[mode] = m.enc.rows(m.graph.full_lists[mode], mode)
+                    mode_rows[table_key(mode)] = executor._full[mode]
+                else:
+                    neg = rows.lists(m, False)
+                    if neg is None:
+                        raise _NativeUnsupported()
+                    if "inter" in qt:
+                        hard = rows.lists(m, True)
+                        if hard is None:
+                            raise _NativeUnsupported()
+                entries.append((m.plan(formula), rows.target, rows.anchors, neg, hard))
+            if not entries:
+                raise _NativeUnsupported()
+            pools_by_type[qt] = entries
+        self.executor, self.model = executor, m
+        self.batches_full = n_batches
+        self.feeder = m.engine.make_reference_feeder(pools_by_type, mode_rows, batch_size, path_weight, inter_weight)
+
+    def close(self):
+        if self.feeder is not None:
+            self.model.engine.feeder_destroy(self.feeder)
+            self.feeder = None
+
+    def run(self, first_iteration, n, all_types):
+        """Iterations [first_iteration, first_iteration + n): the list of their losses (floats)."""
+        import random
+        from .sampler import np_state_restore, np_state_words
+        m, opt = self.model, self.executor.optimizer
+        np_state, np_rest = np_state_words()
+        version, words, gauss = random.getstate()
+        py_state = np.array(words, dtype=np.uint32)
+        try:
+            hist = m.engine.reference_feeder_run(self.feeder, np_state, py_state, first_iteration, n, not all_types,
+                                                 opt.lr, opt.betas, opt.eps)
+            out = hist[:, self.batches_full if all_types else 1].cpu().numpy()
+        finally:
+            # (whatever the run consumed is consumed: the generators continue from where it left them)
+            np_state_restore(np_state, np_rest)
+            random.setstate((version, tuple(py_state.tolist()), gauss))
+        return [float(x) for x in out]
+
 
 class EagerExecutor(object):
     """torch.optim compatibility: one ``margin_loss`` per batch, one backward on the weighted sum."""
@@ -285,8 +378,35 @@ def run_train(model, optimizer, train_queries, val_queries, test_queries, logger
     average = LossAverage()
     all_types = False          # phase 2: every query type, not only edges
     score_at_switch = None
-    iteration = -1
-    for iteration in range(max_iter):
+    iteration, nxt = -1, 0
+    native_for = getattr(executor, "native_loop", lambda *a: None)
+    while nxt < max_iter:
+        iteration = nxt
+        # Runs of iterations in which nothing has to be decided here — no phase switch, no convergence stop, validation at most
+        # behind the last one — go to the native loop as ONE call (``_NativeLoop``: the same draws on the same generators, the
+        # same batches, the same steps); the moving average and the log lines are made from the run's loss history.
+        native = native_for(train_queries, batch_size, path_weight, inter_weight)
+        switching = (not all_types) and (plateau.reached() or average.count >= max_burn_in)
+        stopping = all_types and plateau.reached()
+        if native is not None and not switching and not stopping and not model._touched:
+            n = min(max_iter - nxt, native.MAX_RUN)
+            if not all_types:
+                n = min(n, max_burn_in - average.count)       # (the iteration that finds the count there switches phases)
+            if val_every > 0:
+                due = max(val_every, -(-nxt // val_every) * val_every)      # the next iteration behind which validation runs
+                n = min(n, due - nxt + 1)
+            optimizer.zero_grad()
+            for k, loss in enumerate(native.run(nxt, n, all_types)):
+                smoothed = average.add(loss)
+                if (nxt + k) % log_every == 0:
+                    logger.info("Iter: {:d}; ema_loss: {:f}".format(nxt + k, smoothed))
+            nxt += n
+            iteration = nxt - 1
+            if iteration >= val_every and iteration % val_every == 0:
+                scores = evaluate(model, val_queries, iteration, logger)
+                plateau.add(_macro(scores) if all_types else scores["1-chain"])
+            continue
+        nxt += 1
         optimizer.zero_grad()
         executor.begin()
         add(draw_window(train_queries["1-chain"], iteration, batch_size), 1.0, False)
@@ -314,6 +434,10 @@ def run_train(model, optimizer, train_queries, val_queries, test_queries, logger
         if iteration >= val_every and iteration % val_every == 0:
             scores = evaluate(model, val_queries, iteration, logger)
             plateau.add(_macro(scores) if all_types else scores["1-chain"])
+    native = getattr(executor, "_native", None)
+    if native is not None:      # (its pinned buffers and events go with the run)
+        native.close()
+        executor._native, executor._native_key = None, None
     final = evaluate(model, test_queries, iteration, logger)
     logger.info("Test macro-averaged val: {:f}".format(_macro(final)))
     if score_at_switch is not None:

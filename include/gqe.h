@@ -449,6 +449,10 @@ int gqe_set_intersection(gqe_ctx* ctx, int64_t pre_param, int64_t post_param, co
 int gqe_train_step(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx, int32_t idx_on_device,
                    const gqe_segment* segs, int32_t n_segs, float lr, float beta1, float beta2, float eps, float* losses, void* stream);
 int64_t gqe_split_steps(gqe_ctx* ctx);
+/* The library's Adam step counter of the tensor at `offset` (what a segment with step <= 0 continues from; a caller's explicit step
+ * count is committed to it): how a caller that keeps its own counters — torch.optim's state["step"] — catches up behind a native
+ * run (gqe_feeder_run). */
+int gqe_adam_step_count(gqe_ctx* ctx, int64_t offset, int32_t* count);
 /* replaces: torch.optim.SGD(momentum=0).step() + zero_grad (bio/train.py:60) */
 int gqe_sgd_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, float lr, void* stream);
 /* replaces: optimizer.zero_grad() alone */
@@ -468,6 +472,31 @@ int gqe_feeder_destroy(gqe_feeder* f);
 int gqe_feeder_add_pool(gqe_feeder* f, const gqe_batch* formula, int64_t n, const int32_t* target, const int32_t* anchors,
                         const int32_t* neg, const int32_t* hard);
 int gqe_feeder_set_mode_rows(gqe_feeder* f, int64_t table_offset, const int32_t* rows, int64_t n);
+/* ---- reference streams: run_train's own loop (train_helpers.py:40-107) executed natively, batch for batch ----
+ * The reference draws the formula of a batch with np.random.multinomial(1, sizes / sum) (train_helpers.py:96-99) and one negative
+ * per query with random.choice — of graph.full_lists[mode] for 1-chain queries, of the query's neg_samples / hard_neg_samples
+ * otherwise (model.py:113-120).  With gqe_feeder_set_reference_streams the feeder replays exactly those draws on the caller's two
+ * generators: np_state625 / py_state625 = 624 key words + position of np.random.get_state() / random.getstate(), updated in place
+ * (the caller hands them back with set_state / setstate after a run; nothing else may draw in between).  Pools then carry every
+ * query's negative LISTS (gqe_feeder_add_pool_lists: CSR over table rows; hard lists optional, 1-chain pools none),
+ * gqe_feeder_set_pvals the probability vector of each query type as the caller computed it (float64, one per pool in the
+ * order the pools were added), gqe_feeder_set_type_order the query types behind 1-chain in the order of the caller's training
+ * dictionary (train_helpers.py:63-71).  A run seeded like the reference's then trains on the reference's batches
+ * (graphqembed_amd/train_helpers.py, tests/test_gpu_api.py).  gqe_feeder_set_loss_stride(s > 0): iteration i of a run writes
+ * its losses at losses + (i - first_iteration) * s — the loss history the loop's moving average and log lines are made of.  NULL
+ * states switch back to the feeder's own generator. */
+int gqe_feeder_add_pool_lists(gqe_feeder* f, const gqe_batch* formula, int64_t n, const int32_t* target, const int32_t* anchors,
+                              const int64_t* neg_ptr, const int32_t* neg_rows, const int64_t* hard_ptr, const int32_t* hard_rows);
+int gqe_feeder_set_reference_streams(gqe_feeder* f, uint32_t* np_state625, uint32_t* py_state625);
+int gqe_feeder_set_pvals(gqe_feeder* f, int32_t qtype, const double* pvals, int32_t n);
+int gqe_feeder_set_type_order(gqe_feeder* f, const int32_t* qtypes, int32_t n);
+int gqe_feeder_set_loss_stride(gqe_feeder* f, int64_t stride);
+/* Queries of every batch the feeder has packed so far (throughput accounting: the windows at a list's end are shorter). */
+int64_t gqe_feeder_queries(gqe_feeder* f);
+/* Debug / tests: the batches and the packed index feed (target | negative | anchors per batch) of one of the last prepared
+ * iterations, as the kernels were given them; a NULL / too small output only reports the sizes. */
+int gqe_feeder_debug_feed(gqe_feeder* f, int64_t iteration, gqe_batch* batches, int32_t max_batches, int32_t* n_batches, int32_t* idx,
+                          int64_t max_idx, int64_t* n_idx);
 /* How an iteration's index feed reaches the kernels: 0 = pinned staging ring + hipMemcpyAsync on the library's upload
  * stream (as gqe_margin_fwd_bwd does for any host feed); 1 (default) = the kernels read the feed straight from pinned host
  * memory (16 slots, an event every 8 iterations guards their re-use).  In mode 0 the feeds of eight iterations are sampled together

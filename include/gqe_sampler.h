@@ -93,6 +93,12 @@ int gqe_sampler_check(const gqe_sampler* s, int32_t qtype, const int32_t* edges9
  * one interpreter call per query (train_helpers.FusedExecutor).  Returns GQE_SAMPLER_ARG for a count < 1 or a bad position. */
 int gqe_py_random_choices(uint32_t* state625, const int64_t* counts, int64_t n, int64_t* choice);
 
+/* The reference picks the formula of a batch with `np.random.multinomial(1, sizes / sum(sizes))` (train_helpers.py:96-99).  This
+ * replays that draw — numpy's legacy multinomial -> binomial inversion on the RandomState's MT19937 — on `state625` = the 624 key
+ * words + position of `np.random.get_state()` (updated in place: hand it back with `np.random.set_state`); pvals = the float64
+ * probability vector exactly as the caller would pass it; *pick = argmax of the draw.  Same value, same generator state after. */
+int gqe_np_multinomial_pick(uint32_t* state625, const double* pvals, int64_t d, int64_t* pick);
+
 const char* gqe_sampler_last_error(void);
 
 #define GQE_SAMPLER_OK 0

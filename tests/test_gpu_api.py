@@ -157,15 +157,17 @@ def test_margin_loss_backward_with_torch_optim(dec, inter):
 
 @pytest.mark.parametrize("dec,inter,d", [("bilinear-diag", "min", 32), ("bilinear", "mean", 32), ("transe", "min-simple", 32),
                                          ("bilinear-diag", "min", 128)])
-def test_run_train_reproduces_the_reference_run(dec, inter, d):
+def test_run_train_reproduces_the_reference_run(dec, inter, d, monkeypatch):
     """train_helpers.run_train with the fused optimiser, seeded like oracle/make_golden.py: the same
     (formula, slice, negatives) batches in the same order, the same per-iteration losses, per-tensor Adam
-    step counts and final parameters as the reference's own run_train (5 iterations, burn-in 2)."""
+    step counts and final parameters as the reference's own run_train (5 iterations, burn-in 2).  (The per-batch path:
+    GQE_RUN_TRAIN_NATIVE=0; the native runs of iterations are the next test.)"""
     import torch
     from graphqembed_amd import train_helpers
     from graphqembed_amd.model import FusedAdam
     if d != 32:
         pytest.skip("query objects are only shipped for the d=32 world")  # the d=128 train fixture is replayed below
+    monkeypatch.setenv("GQE_RUN_TRAIN_NATIVE", "0")
     model, z = build_world(dec, inter, d, "train_%s_%s_d%d.npz" % (dec, inter, d))
     train, test = rebuild_queries()
     p0 = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
@@ -213,6 +215,92 @@ def test_run_train_reproduces_the_reference_run(dec, inter, d):
     mine = Log.lines
     assert [l.split(";")[0] for l in mine if l.startswith("Iter")] == [l.split(";")[0] for l in ref_log if l.startswith("Iter")]
     assert any(l.startswith("Edge converged at iteration 1") for l in mine)
+
+
+@pytest.mark.parametrize("dec,inter,d", [("bilinear-diag", "min", 32), ("bilinear", "mean", 32), ("transe", "min-simple", 32)])
+def test_run_train_native_runs_reproduce_the_reference_run(dec, inter, d):
+    """The same run with run_train's iterations executed natively between its events (train_helpers._NativeLoop: gqe_feeder_run
+    with reference streams — the formula draws replayed on np.random's generator, the negatives on random's): iterations 0-1
+    (edges only) and 3-4 (every type) are two native runs, iteration 2 (the phase switch with its evaluation) goes batch by batch.
+    Checked against the REFERENCE's recorded run: every batch's formula type / rows / negatives bit for bit (the feeds the native
+    loop packed), every iteration's loss, the log lines, per-tensor Adam step counts, final parameters; and the two generators end
+    where the per-batch path leaves them."""
+    import torch
+    from graphqembed_amd import train_helpers
+    from graphqembed_amd.model import FusedAdam
+    from graphqembed_amd.engine import QTYPES
+
+    class Log(object):
+        def __init__(self):
+            self.lines = []
+
+        def info(self, m):
+            self.lines.append(m)
+
+    def run(native):
+        os.environ["GQE_RUN_TRAIN_NATIVE"] = "1" if native else "0"
+        try:
+            model, z = build_world(dec, inter, d, "train_%s_%s_d%d.npz" % (dec, inter, d))
+            train, test = rebuild_queries()
+            p0 = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+            feeds, python_its = {}, []
+            orig_run = train_helpers._NativeLoop.run
+
+            def spy_run(self, first, n, all_types):
+                out = orig_run(self, first, n, all_types)
+                for it in range(first, first + n):
+                    feeds[it] = self.model.engine.feeder_debug_feed(self.feeder, it) + (out[it - first],)
+                return out
+            orig_step = model.train_step
+
+            def spy_step(items, optimizer, **kw):
+                python_its.append(len(items))
+                return orig_step(items, optimizer)
+            model.train_step = spy_step
+            train_helpers._NativeLoop.run = spy_run
+            try:
+                random.seed(41); np.random.seed(41); torch.manual_seed(41)
+                log = Log()
+                train_helpers.run_train(model, FusedAdam(model, lr=0.01), train, test, test, log, max_burn_in=2, batch_size=23, log_every=1,
+                                        val_every=1000, max_iter=5)
+            finally:
+                train_helpers._NativeLoop.run = orig_run
+            got = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+            return model, z, p0, got, feeds, python_its, log.lines, random.getstate(), np.random.get_state()
+        finally:
+            os.environ.pop("GQE_RUN_TRAIN_NATIVE", None)
+
+    model, z, p0, got, feeds, python_its, lines, py_end, np_end = run(True)
+    assert sorted(feeds) == [0, 1, 3, 4] and len(python_its) == 1, (sorted(feeds), python_its)
+    for i, (batches, idx, loss) in feeds.items():
+        assert len(batches) == int(z["it%d/n" % i]), i
+        for j, (qtype, n, n_anchors, off, weight) in enumerate(batches):
+            meta = json.loads(str(z["it%d/b%d/meta" % (i, j)]))
+            t, ng, a = z["it%d/b%d/target" % (i, j)], z["it%d/b%d/neg" % (i, j)], z["it%d/b%d/anchors" % (i, j)]
+            assert qtype == QTYPES[meta["type"]] and n == len(t) and n_anchors == a.shape[0], (i, j)
+            assert np.array_equal(idx[off:off + n], t) and np.array_equal(idx[off + n:off + 2 * n], ng), (i, j)
+            assert np.array_equal(idx[off + 2 * n:off + (2 + n_anchors) * n].reshape(n_anchors, n), a), (i, j)
+        np.testing.assert_allclose(loss, float(z["it%d/loss" % i]), rtol=1e-4 if i == 0 else 3e-2, err_msg="iteration %d" % i)
+    for k in got:
+        diff = np.abs(got[k].astype(np.float64) - p0[k] - z["delta/" + k])
+        assert diff.max() < 6e-2 and np.median(diff) < 1e-3, (k, diff.max(), np.median(diff))
+        steps = int(z["touched/" + k]) if "touched/" + k in z.files else 0
+        assert model.engine.steps[k] == steps, (k, model.engine.steps[k], steps)
+    ref_log = json.loads(str(z["log"]))
+    assert [l.split(";")[0] for l in lines if l.startswith("Iter")] == [l.split(";")[0] for l in ref_log if l.startswith("Iter")]
+    assert any(l.startswith("Edge converged at iteration 1") for l in lines)
+    # the per-batch path on the same seeds: the same log lines (moving averages to float-atomics noise) and the same generator states
+    _, _, _, got2, feeds2, python_its2, lines2, py_end2, np_end2 = run(False)
+    assert not feeds2 and len(python_its2) == 5
+    assert py_end == py_end2
+    assert np_end[0] == np_end2[0] and np.array_equal(np_end[1], np_end2[1]) and np_end[2:] == np_end2[2:]
+    assert len(lines) == len(lines2)
+    for a, b in zip(lines, lines2):
+        if a.startswith("Iter"):
+            assert a.split(";")[0] == b.split(";")[0]
+            np.testing.assert_allclose(float(a.rsplit(" ", 1)[1]), float(b.rsplit(" ", 1)[1]), rtol=2e-2, atol=1e-4)
+    for k in got:
+        assert np.abs(got[k] - got2[k]).max() < 6e-2, k
 
 
 def test_train_fixture_replay_d128():

@@ -299,3 +299,36 @@ def test_py_random_choices_replays_the_random_module():
     assert list(a) + [x] + list(b) + list(c) == want and random.getrandbits(32) == tail
     with pytest.raises(ValueError):
         py_random_choices([3, 0, 2])
+
+
+def test_np_multinomial_pick_replays_np_random():
+    """gqe_np_multinomial_pick (include/gqe_sampler.h): ``np.random.multinomial(1, sizes / sum)`` — the reference's formula draw,
+    train_helpers.py:96-99 — natively: the same category and the same generator state afterwards (numpy's legacy multinomial ->
+    binomial inversion on the RandomState's MT19937), for one formula (no draw at all), a dominant formula (p > 0.5: the
+    mirrored branch), many formulas, positions across the generator's 624-word regeneration, and interleaved with other draws."""
+    from graphqembed_amd.sampler import np_multinomial_pick
+    rng = np.random.RandomState(5)
+    for trial in range(400):
+        d = int(rng.choice([1, 1, 2, 2, 3, 5, 8, 20, 100]))
+        sizes = rng.randint(1, 5000, size=d).astype(float)
+        if trial % 7 == 0:
+            sizes[rng.randint(d)] = 1e7
+        pv = np.array(sizes) / float(sum(sizes))
+        np.random.seed(trial)
+        for _ in range(int(rng.randint(1, 700))):
+            np.random.random()
+        st = np.random.get_state()
+        want = [int(np.random.multinomial(1, pv).argmax()) for _ in range(5)] + [np.random.randint(1 << 30)]
+        want_state = np.random.get_state()
+        np.random.set_state(st)
+        got = [np_multinomial_pick(pv) for _ in range(5)] + [np.random.randint(1 << 30)]
+        got_state = np.random.get_state()
+        assert got == want, (trial, d, want, got)
+        assert got_state[2] == want_state[2] and np.array_equal(got_state[1], want_state[1]) and got_state[3:] == want_state[3:]
+    # the cached Gaussian of the RandomState survives the round trip
+    np.random.seed(3)
+    np.random.standard_normal()
+    st = np.random.get_state()
+    assert st[3] == 1
+    np_multinomial_pick(np.array([0.25, 0.75]))
+    assert np.random.get_state()[3:] == st[3:]
