@@ -286,6 +286,7 @@ class _NativeLoop(object):
             pools_by_type[qt] = entries
         self.executor, self.model = executor, m
         self.batches_full = n_batches
+        m.engine.reserve(n_batches * batch_size, n_batches)       # (the per-batch path grows the workspace step by step)
         self.feeder = m.engine.make_reference_feeder(pools_by_type, mode_rows, batch_size, path_weight, inter_weight)
 
     def close(self):
