@@ -638,11 +638,11 @@ def host_fed(wl, args):
 def api_path(args, d, decoder, inter, B, iterations=120):
     """The DROP-IN path itself, timed: ``train_helpers.run_train`` (the reference's loop, train_helpers.py:40-107) with a
     ``FusedAdam`` on ``Query`` objects — a bio-synth-sized graph built through the reference-shaped ``Graph`` /
-    ``QueryEncoderDecoder`` classes, query lists sampled by the native sampler and converted ONCE to ``Query`` objects.  Per
-    iteration the loop draws a formula per batch (np.random.multinomial), takes its window of the formula's list, draws the
-    negatives exactly as the reference does (``random.choice`` per query, replayed natively), packs the index feed and runs the
-    iteration as one library call (model.train_step -> gqe_train_step); like the reference it reads the loss every iteration
-    (``.item()``: a device synchronisation).  Reported: queries/s of the steady state and the host's share per iteration."""
+    ``QueryEncoderDecoder`` classes, query lists sampled by the native sampler and converted ONCE to ``Query`` objects.
+    (1) as ``run_train`` runs it: the iterations between two events of its schedule are ONE native call each
+    (train_helpers._NativeLoop -> gqe_feeder_run with reference streams: the reference's formula draws and negatives replayed on
+    np.random's / random's generators); (2) ``per_batch_python_path``: GQE_RUN_TRAIN_NATIVE=0 — every batch drawn and packed from
+    Python, one gqe_train_step and one ``loss.item()`` per iteration — with the host's share per iteration."""
     import random
     import torch
     from graphqembed_amd import data_utils, train_helpers, utils
