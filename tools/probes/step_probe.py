@@ -35,13 +35,19 @@ def run(k0, k):
             eng.run_train_step(ps, ps["adam"])
             continue
         eng.run_margin(ps)
-        if a.lazy:
+        if a.lazy and os.environ.get("STEP_PROBE_NO_PREFETCH") is None:
             eng.lazy_prefetch(prep[(i + 1) % n])
         eng.run_adam(ps["adam"])
 
 
 run(0, 50)
 torch.cuda.synchronize()
+if os.environ.get("STEP_PROBE_TIMING"):      # the library's hipEvent brackets per launch kind (include/gqe.h, gqe_timing_read)
+    eng.timing_enable(8)
+    run(50, 400)
+    torch.cuda.synchronize()
+    print("event brackets (us): " + ", ".join("%d: %.1f x%d" % ((k,) + (lambda r: (r[0] * 1e3, r[1]))(eng.timing_read(k))) for k in range(7)), flush=True)
+    eng.timing_enable(0)
 ts = []
 for rep in range(20):
     t0 = time.perf_counter()
