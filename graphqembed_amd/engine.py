@@ -576,6 +576,16 @@ class Engine(object):
                                                  count.data_ptr(), self._stream()))
         return float(count.item()) / (2.0 * float(pos.numel()) * float(neg.numel()))
 
+    def auc_pair_count(self, pos, neg, counts, slot):
+        """The pair count behind ``auc`` written to counts[slot] (device int64) — no read-back: an evaluation over hundreds of
+        formulas reads all of its AUCs back at once (utils.eval_auc_queries).  AUC = count / (2 |pos| |neg|)."""
+        if pos.numel() == 0 or neg.numel() == 0:
+            raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
+        pos, neg = pos.contiguous(), neg.contiguous()
+        self._check(self.lib.gqe_auc_pair_counts(self.ctx, pos.data_ptr(), int(pos.numel()), neg.data_ptr(), int(neg.numel()),
+                                                 counts.data_ptr() + 8 * int(slot), self._stream()))
+        return 2.0 * float(pos.numel()) * float(neg.numel())
+
     def margin_fwd_bwd(self, descs, idx, n_scores=0, want_scores=False, losses=None):
         """gqe_margin_fwd_bwd: grads += d(sum_i w_i loss_i); returns (losses[n+1], pos, neg)."""
         total = sum(dsc["n"] for dsc in descs)

@@ -83,6 +83,7 @@ class QueryEncoderDecoder(nn.Module):
         # are served by the engine too (include/gqe.h: the extension points)
         enc._engine, path_dec._engine, inter_dec._engine = ("enc.", self.engine), ("path_dec.", self.engine), ("inter_dec.", self.engine)
         self._plans = {}
+        self._pool_rows = {}       # id(query list) -> tensorize.PoolRows
         self._touched = set()      # tensors with a gradient since the last optimiser step
         self._dirty = set()        # tensors whose grad-arena segment may be non-zero
         self._autograd_anchor = torch.zeros((), device=self.engine.device, requires_grad=True)
@@ -215,6 +216,30 @@ class QueryEncoderDecoder(nn.Module):
         query comes back.  Returns a device tensor[len(queries)]."""
         scores, ptr = self.forward_candidates(formula, queries, candidate_nodes)
         return self.engine.rank_candidates(scores, ptr)
+
+    def pool_rows(self, formula, pool):
+        """The table rows of ONE formula's query list, looked up once (``tensorize.PoolRows``: target rows, anchor rows, the
+        negative / hard-negative lists as CSR arrays of rows) and kept for as long as the list lives: training windows
+        (train_helpers) and every later validation (utils.eval_*) then work on arrays instead of Query objects.  The list is
+        assumed not to change (its length is checked)."""
+        from .tensorize import PoolRows
+        rows = self._pool_rows.get(id(pool))
+        if rows is None or rows.pool is not pool or rows.n != len(pool):
+            rows = self._pool_rows[id(pool)] = PoolRows(self, formula, pool)
+        return rows
+
+    def candidate_percentiles_rows(self, items):
+        """``candidate_percentiles`` on row arrays, several formulas per launch: items = [(formula, anchors[k, n], ptr[n + 1],
+        rows)] with the candidate rows of query i = rows[ptr[i]:ptr[i + 1]] (its target first).  Returns one device tensor of
+        percentiles in item order."""
+        descs, idx, n = pack_candidate_batches([(self.plan(f), a, p, r) for f, a, p, r in items])
+        self.engine.params_changed()
+        scores = self.engine.forward(descs, idx, n)
+        ptr, off = [np.zeros(1, dtype=np.int64)], 0
+        for _, _, p, r in items:
+            ptr.append(np.asarray(p[1:], dtype=np.int64) + off)
+            off += len(r)
+        return self.engine.rank_candidates(scores, np.concatenate(ptr).astype(np.int32))
 
     def score_batches(self, items):
         """items: [(formula, target_rows, anchor_rows)] -> one scores tensor (concatenated)."""

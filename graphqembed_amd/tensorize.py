@@ -177,3 +177,29 @@ def reference_negative_nodes(graph, formula, queries, hard_negatives):
         full = graph.full_lists[formula.target_mode]
         return [random.choice(full) for _ in queries]
     return [random.choice(q.neg_samples) for q in queries]
+
+
+class PoolRows(object):
+    """The table rows of ONE formula's query list, looked up once (the tensorize step): target rows [n],
+    anchor rows [k, n], and — built when first asked for — the negative / hard-negative lists as CSR arrays of rows.  The
+    list is kept alive so that its identity stays a valid cache key; it is assumed not to change."""
+
+    def __init__(self, model, formula, pool):
+        enc = model.enc
+        self.pool, self.formula, self.n = pool, formula, len(pool)
+        self.target = enc.rows([q.target_node for q in pool], formula.target_mode)
+        self.anchors = np.stack([enc.rows([q.anchor_nodes[i] for q in pool], m) for i, m in enumerate(formula.anchor_modes)])
+        self._csr = {}
+
+    def lists(self, model, hard):
+        """(ptr[n + 1], rows) of every query's negative (hard-negative) list, or None if some query has none."""
+        if hard not in self._csr:
+            lists = [(q.hard_neg_samples if hard else q.neg_samples) for q in self.pool]
+            if any(l is None or len(l) == 0 for l in lists):
+                self._csr[hard] = None
+            else:
+                ptr = np.zeros(len(lists) + 1, dtype=np.int64)
+                ptr[1:] = np.cumsum([len(l) for l in lists])
+                rows = model.enc.rows([n for l in lists for n in l], self.formula.target_mode)
+                self._csr[hard] = (ptr, rows)
+        return self._csr[hard]

@@ -109,32 +109,6 @@ class LossAverage(object):
 
 
 # ---- executors --------------------------------------------------------------------------------------------------
-class _PoolRows(object):
-    """The table rows of ONE formula's query list, looked up once (the tensorize step): target rows [n],
-    anchor rows [k, n], and — built when first asked for — the negative / hard-negative lists as CSR arrays of rows.  The
-    list is kept alive so that its identity stays a valid cache key; it is assumed not to change."""
-
-    def __init__(self, model, formula, pool):
-        enc = model.enc
-        self.pool, self.formula = pool, formula
-        self.target = enc.rows([q.target_node for q in pool], formula.target_mode)
-        self.anchors = np.stack([enc.rows([q.anchor_nodes[i] for q in pool], m) for i, m in enumerate(formula.anchor_modes)])
-        self._csr = {}
-
-    def lists(self, model, hard):
-        """(ptr[n + 1], rows) of every query's negative (hard-negative) list, or None if some query has none."""
-        if hard not in self._csr:
-            lists = [(q.hard_neg_samples if hard else q.neg_samples) for q in self.pool]
-            if any(l is None or len(l) == 0 for l in lists):
-                self._csr[hard] = None
-            else:
-                ptr = np.zeros(len(lists) + 1, dtype=np.int64)
-                ptr[1:] = np.cumsum([len(l) for l in lists])
-                rows = model.enc.rows([n for l in lists for n in l], self.formula.target_mode)
-                self._csr[hard] = (ptr, rows)
-        return self._csr[hard]
-
-
 class FusedExecutor(object):
     """The iteration's batches become index arrays; ``finish`` runs them in one grouped launch."""
 
@@ -144,7 +118,6 @@ class FusedExecutor(object):
         self.model = model
         self.optimizer = optimizer if isinstance(optimizer, FusedAdam) else None
         self.items = []
-        self._pools = {}          # id(query list) -> _PoolRows
         self._full = {}           # mode -> rows of graph.full_lists[mode] (1-chain negatives)
 
     def begin(self):
@@ -172,9 +145,7 @@ class FusedExecutor(object):
             py_random_choices = stream.choices
         if "inter" not in formula.query_type and hard:
             raise Exception("Hard negative examples can only be used with intersection queries")
-        rows = self._pools.get(id(pool))
-        if rows is None or rows.pool is not pool:
-            rows = self._pools[id(pool)] = _PoolRows(m, formula, pool)
+        rows = m.pool_rows(formula, pool)
         n = hi - lo
         if formula.query_type == "1-chain" and not hard:
             mode = formula.target_mode
@@ -263,9 +234,7 @@ class _NativeLoop(object):
             for formula, pool in train_queries[qt].items():
                 if len(pool) == 0:
                     raise _NativeUnsupported()
-                rows = executor._pools.get(id(pool))
-                if rows is None or rows.pool is not pool:
-                    rows = executor._pools[id(pool)] = _PoolRows(m, formula, pool)
+                rows = m.pool_rows(formula, pool)
                 neg = hard = None
                 if qt == "1-chain":
                     mode = formula.target_mode

@@ -12,6 +12,7 @@ through ``QueryEncoderDecoder.forward`` on the GPU.
 from __future__ import annotations
 
 import logging
+import os
 import random
 
 import numpy as np
@@ -101,8 +102,23 @@ def eval_auc_queries(test_queries, enc_dec, batch_size=1000, hard_negatives=Fals
     predictions, labels, formula_aucs = [], [], {}
     pos_all, neg_all = [], []
     random.seed(seed)
+    cached = on_device and hasattr(enc_dec, "pool_rows") and os.environ.get("GQE_EVAL_CACHED", "1") != "0"
+    deferred = []
     for formula in test_queries:
         f_labels, f_preds, f_pos, f_neg = [], [], [], []
+        if cached and len(test_queries[formula]):
+            # the rows of this list are looked up once (model.pool_rows) and every later validation works on arrays: the negatives
+            # are the reference's draw — random.choice per query, batch by batch — replayed natively on ``random``'s generator
+            # (sampler.py_random_choices: the same values, the same state afterwards); scored below, several formulas per launch
+            rows = enc_dec.pool_rows(formula, test_queries[formula])
+            csr = rows.lists(enc_dec, hard_negatives)
+            if csr is not None:
+                from .sampler import py_random_choices
+                ptr, flat = csr
+                pick = py_random_choices(ptr[1:] - ptr[:-1])       # (the chunks draw in order: one call over the whole list is the same sequence)
+                deferred.append((formula, rows, flat[ptr[:-1] + pick]))
+                formula_aucs[formula] = None                       # (keeps the dictionary's order)
+                continue
         for batch in _chunks(test_queries[formula], batch_size):
             if hard_negatives:
                 negatives = [random.choice(q.hard_neg_samples) for q in batch]
@@ -129,6 +145,34 @@ def eval_auc_queries(test_queries, enc_dec, batch_size=1000, hard_negatives=Fals
         predictions.extend(f_preds)
     if on_device:
         import torch
+        if deferred:
+            # up to 16 formulas (<= batch_size queries each) per forward launch; every AUC's pair count lands in ONE device array
+            # that is read back once
+            eng = enc_dec.engine
+            items, owner = [], []
+            for k, (formula, rows, neg) in enumerate(deferred):
+                for lo in range(0, rows.n, batch_size):
+                    hi = min(lo + batch_size, rows.n)
+                    items.append((formula, np.concatenate([rows.target[lo:hi], neg[lo:hi]]),
+                                  np.concatenate([rows.anchors[:, lo:hi], rows.anchors[:, lo:hi]], axis=1)))
+                    owner.append((k, hi - lo))
+            parts = [[[], []] for _ in deferred]
+            for g in range(0, len(items), 16):
+                scores = enc_dec.score_batches(items[g:g + 16])
+                off = 0
+                for k, n in owner[g:g + 16]:
+                    parts[k][0].append(scores[off:off + n])
+                    parts[k][1].append(scores[off + n:off + 2 * n])
+                    off += 2 * n
+            counts = torch.zeros(len(deferred), dtype=torch.int64, device=eng.device)
+            norms = []
+            for k, (formula, rows, neg) in enumerate(deferred):
+                p, n = torch.cat(parts[k][0]), torch.cat(parts[k][1])
+                norms.append(eng.auc_pair_count(p, n, counts, k))
+                pos_all.append(p)
+                neg_all.append(n)
+            for (formula, _, _), c, z in zip(deferred, counts.cpu().tolist(), norms):
+                formula_aucs[formula] = float(c) / z
         if not pos_all:
             raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
         return enc_dec.engine.auc(torch.cat(pos_all), torch.cat(neg_all)), formula_aucs
@@ -144,7 +188,37 @@ def eval_perc_queries(test_queries, enc_dec, batch_size=1000, hard_negatives=Fal
     perc_scores = []
     if fused is None:
         fused = hasattr(enc_dec, "candidate_percentiles")
+    cached = fused and hasattr(enc_dec, "pool_rows") and os.environ.get("GQE_EVAL_CACHED", "1") != "0"
+    pending, on_dev = [], []      # cached lists: candidate batches of several formulas share a launch, one read-back at the end
+
+    def flush():
+        if pending:
+            on_dev.append(enc_dec.candidate_percentiles_rows(pending))
+            del pending[:]
     for formula in test_queries:
+        if cached and len(test_queries[formula]):
+            rows = enc_dec.pool_rows(formula, test_queries[formula])
+            csr = rows.lists(enc_dec, hard_negatives)
+            if csr is not None:
+                nptr, flat = csr
+                for lo in range(0, rows.n, batch_size):
+                    hi = min(lo + batch_size, rows.n)
+                    # candidate list of query i: its target, then its negatives (CSR over table rows)
+                    ptr = (nptr[lo:hi + 1] - nptr[lo] + np.arange(hi - lo + 1)).astype(np.int32)
+                    cand = np.empty(int(ptr[-1]), dtype=np.int32)
+                    is_target = np.zeros(len(cand), dtype=bool)
+                    is_target[ptr[:-1]] = True
+                    cand[is_target] = rows.target[lo:hi]
+                    cand[~is_target] = flat[nptr[lo]:nptr[hi]]
+                    pending.append((formula, rows.anchors[:, lo:hi], ptr, cand))
+                    if len(pending) == 16 or sum(len(p[3]) for p in pending) > (1 << 20):
+                        flush()
+                continue
+        flush()                   # (the per-Query path below appends to perc_scores directly: keep the order)
+        if on_dev:
+            import torch
+            perc_scores.extend(torch.cat(on_dev).detach().cpu().tolist())
+            del on_dev[:]
         for batch in _chunks(test_queries[formula], batch_size):
             lists = [q.hard_neg_samples if hard_negatives else q.neg_samples for q in batch]
             lengths = [len(l) for l in lists]
@@ -160,6 +234,10 @@ def eval_perc_queries(test_queries, enc_dec, batch_size=1000, hard_negatives=Fal
             for i, k in enumerate(lengths):
                 perc_scores.append(_percentile_of_score(neg_scores[cum:cum + k], scores[i]))
                 cum += k
+    flush()
+    if on_dev:
+        import torch
+        perc_scores.extend(torch.cat(on_dev).detach().cpu().tolist())
     return np.mean(perc_scores)
 
 

@@ -66,7 +66,7 @@ def rebuild_queries():
 
 @pytest.mark.parametrize("dec,inter,d", [("bilinear-diag", "min", 32), ("bilinear", "mean", 32), ("transe", "min-simple", 32),
                                          ("bilinear-diag", "min", 128)])
-def test_forward_matches_reference_eval_calls_and_auc(dec, inter, d):
+def test_forward_matches_reference_eval_calls_and_auc(dec, inter, d, monkeypatch):
     """eval_auc_queries / eval_perc_queries (utils.py:35-91) for three decoder families at d=32 and at d=128: same negatives
     (seeded like the reference), the same scores call by call, AUC and percentile within 1e-4 / 1e-2 of what the reference
     logged — through the per-candidate forward AND through the fused candidate-list evaluation, whose scores are compared
@@ -77,6 +77,7 @@ def test_forward_matches_reference_eval_calls_and_auc(dec, inter, d):
     _, test = rebuild_queries()                      # the query sets do not depend on d (same graph, same sampler seeds)
     summary = json.loads(str(z["summary"]))
     assert len(summary) == 11
+    monkeypatch.setenv("GQE_EVAL_CACHED", "0")       # the calls are compared one by one: the per-Query path (the cached one follows)
     for tag, want in summary.items():
         qtype, hard = (tag[:-5], True) if tag.endswith(".hard") else (tag, False)
         calls, cand_calls = [], []
@@ -116,6 +117,13 @@ def test_forward_matches_reference_eval_calls_and_auc(dec, inter, d):
             n = len(ptr) - 1
             regrouped = np.concatenate([flat[ptr[:-1]]] + [flat[ptr[i] + 1:ptr[i + 1]] for i in range(n)])
             np.testing.assert_allclose(regrouped, ref, atol=2e-5, rtol=1e-4, err_msg=tag + " (fused candidates)")
+        # the evaluation on cached row arrays (model.pool_rows; formulas grouped per launch, one read-back): the same statistics
+        monkeypatch.setenv("GQE_EVAL_CACHED", "1")
+        auc_c, f_aucs_c = utils.eval_auc_queries(test["one_neg"][qtype], model, hard_negatives=hard)
+        perc_c = utils.eval_perc_queries(test["full_neg"][qtype], model, hard_negatives=hard)
+        monkeypatch.setenv("GQE_EVAL_CACHED", "0")
+        assert abs(auc_c - auc) < 1e-9 and list(f_aucs_c) == list(f_aucs) and all(abs(f_aucs_c[f] - f_aucs[f]) < 1e-9 for f in f_aucs), tag
+        assert abs(perc_c - perc_fused) < 1e-9, (tag, perc_c, perc_fused)
 
 
 @pytest.mark.parametrize("dec,inter", [("bilinear-diag", "min"), ("bilinear", "mean"), ("transe", "min-simple")])
@@ -453,3 +461,39 @@ def test_decoder_extension_points_match_the_oracle(dec, inter, d):
         np.testing.assert_allclose(got.cpu().numpy().T, q, rtol=1e-4, atol=2e-6)
     with pytest.raises(Exception):
         model.path_dec.project(torch.zeros(d + 1, 3), r1)
+
+
+def test_evaluation_on_cached_rows_is_the_same_evaluation(monkeypatch):
+    """utils.eval_auc_queries / eval_perc_queries look a query list's rows up once (model.pool_rows) and then evaluate on arrays —
+    negatives drawn by the native replay of ``random.choice``, candidate lists built from CSR rows.  Against the per-Query path
+    (GQE_EVAL_CACHED=0): the same AUCs (overall and per formula), the same percentiles, the same ``random`` state afterwards, for
+    regular and hard negatives; a second evaluation on the cache repeats the first."""
+    from graphqembed_amd import utils
+    model, _ = build_world("bilinear-diag", "min", 32, "train_bilinear-diag_min_d32.npz")
+    _, test = rebuild_queries()
+
+    def run():
+        out = []
+        for t in ("1-chain", "2-chain", "3-chain", "2-inter", "3-inter", "3-inter_chain", "3-chain_inter"):
+            for hard in ((False, True) if "inter" in t else (False,)):
+                if t not in test["one_neg"]:
+                    continue
+                random.seed(123)
+                auc, per = utils.eval_auc_queries(test["one_neg"][t], model, hard_negatives=hard, batch_size=7)
+                state = random.getstate()
+                perc = utils.eval_perc_queries(test["full_neg"][t], model, hard_negatives=hard, batch_size=5)
+                out.append((t, hard, auc, sorted((str(k), v) for k, v in per.items()), perc, state))
+        return out
+    cached = run()
+    again = run()
+    monkeypatch.setenv("GQE_EVAL_CACHED", "0")
+    plain = run()
+    assert len(cached) >= 7
+    for a, b, c in zip(cached, again, plain):
+        assert a[:2] == c[:2]
+        assert a[2] == b[2] and a[4] == b[4]
+        np.testing.assert_allclose(a[2], c[2], rtol=0, atol=1e-6)
+        assert [k for k, _ in a[3]] == [k for k, _ in c[3]]
+        np.testing.assert_allclose([v for _, v in a[3]], [v for _, v in c[3]], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(a[4], c[4], rtol=0, atol=1e-6)
+        assert a[5] == c[5]
