@@ -669,8 +669,9 @@ def api_path(args, d, decoder, inter, B, iterations=120):
         by = data_utils.group_by_formula(sampler.sample(40000, q_type=t, neg_sample_max=20, seed=k, threads=8).to_queries(keep_graph=False))[t]
         keep = sorted(by, key=lambda f: -len(by[f]))[:6]          # the six most frequent formulas: lists of >= one batch
         train[t] = {f: by[f] for f in keep}
-    small = {f: qs[:24] for f, qs in list(train["2-chain"].items())[:1]}
-    test = {"one_neg": {"2-chain": small}, "full_neg": {"2-chain": small}}
+    # validation sets: 250 queries of each of the four most frequent formulas of every sampled type (<= 20 negatives per query)
+    held = {t: {f: qs[:250] for f, qs in list(train[t].items())[:4]} for t in train if t != "1-chain"}
+    test = {"one_neg": held, "full_neg": held}
     t_build = time.perf_counter() - t_build
     class Quiet(object):
         def info(self, m):
@@ -688,6 +689,15 @@ def api_path(args, d, decoder, inter, B, iterations=120):
         runs.append((n, all_types, time.perf_counter() - t0, self.model.engine.feeder_queries(self.feeder) - q0))
         return res
     train_helpers._NativeLoop.run = spy_run
+    evals = []
+    orig_eval = train_helpers.evaluate
+
+    def spy_eval(*a, **kw):
+        t0 = time.perf_counter()
+        res = orig_eval(*a, **kw)
+        evals.append(time.perf_counter() - t0)
+        return res
+    train_helpers.evaluate = spy_eval
     random.seed(0); np.random.seed(0)
     t_run = time.perf_counter()
     try:
@@ -695,6 +705,7 @@ def api_path(args, d, decoder, inter, B, iterations=120):
                                 max_iter=2001)
     finally:
         train_helpers._NativeLoop.run = orig_run
+        train_helpers.evaluate = orig_eval
     t_run = time.perf_counter() - t_run
     full = [r for r in runs if r[1]][1:]                       # steady state: every query type, behind the first such run
     n_it, dt, q = sum(r[0] for r in full), sum(r[2] for r in full), sum(r[3] for r in full)
@@ -702,6 +713,12 @@ def api_path(args, d, decoder, inter, B, iterations=120):
            "queries_per_iteration": round(q / n_it, 1), "split_steps": model.engine.split_steps(),
            "native_runs": [{"iterations": r[0], "all_types": bool(r[1]), "ms": round(r[2] * 1e3, 3)} for r in runs],
            "run_train_seconds": round(t_run, 2), "setup_seconds": round(t_build, 1),
+           "validation": {"queries": sum(len(q) for by in held.values() for q in by.values()), "calls": len(evals),
+                          "first_call_ms": round(evals[0] * 1e3, 1) if evals else None,
+                          "later_calls_ms": round(float(np.median(evals[1:])) * 1e3, 1) if len(evals) > 1 else None,
+                          "note": "train_helpers.evaluate (AUC with one negative + percentile over all negatives per query type, hard "
+                                  "variants for intersections): the lists' rows are looked up at the first call (model.pool_rows), "
+                                  "later calls work on arrays - formulas grouped per launch, one read-back per statistic"},
            "note": ("train_helpers.run_train + FusedAdam on Query objects (the reference's loop and signatures; 2 001 iterations, log lines "
                     "every 100, validation every 500): the iterations between two events of the schedule run as ONE library call "
                     "(gqe_feeder_run with reference streams: formula draws replayed on np.random's generator, negatives on random's, "
