@@ -1092,6 +1092,11 @@ def main():
         out["roofline"]["host_fed"] = {"resident_feed_value": out["value"], "pinned_host_memory_read_by_the_kernels": hf.get("value"),
                                        "pinned_hipMemcpyAsync": (hf.get("pinned_hipMemcpyAsync") or {}).get("value"), "unit": "queries/s",
                                        "note": "the same schedule with sampling + packing + the feed's transport inside the timed region (gqe_feeder_run)"}
+    if out.get("api_path"):
+        ap_ = out["api_path"]
+        out["roofline"]["api_path"] = {"run_train_native_runs": ap_.get("value"), "run_train_batch_by_batch": (ap_.get("per_batch_python_path") or {}).get("value"),
+                                       "unit": "queries/s", "note": "the reference-shaped API (train_helpers.run_train + FusedAdam on Query objects), "
+                                       "same seeds = the reference's batches; see api_path"}
     if rank == 0:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
