@@ -727,6 +727,37 @@ def api_path(args, d, decoder, inter, B, iterations=120):
                     "moving average and log lines stay in Python; value = queries / wall time of the native runs behind the first "
                     "(each ends with the copy of its loss history: the device is idle at both ends)")}
 
+    # ---- (1b) the same call on a model built with lazy_adam=True (deferred, bit-exact Adam: NON-DEFAULT mode, as lazy_exact_adam) ----
+    if not args.no_lazy:
+        feats_l = {m: torch.nn.Embedding(len(node_maps[m]) + 1, d) for m in rel}
+        for f in feats_l.values():
+            f.weight.data.normal_(0, 1.0 / d)
+        enc_l = utils.get_encoder(0, graph, dims, feats_l, True, node_maps=node_maps)
+        model_l = QueryEncoderDecoder(graph, enc_l, utils.get_metapath_decoder(graph, dims, decoder), utils.get_intersection_decoder(graph, dims, inter),
+                                      max_queries=9 * B, max_batches=9, lazy_adam=True)
+        runs_l = []
+
+        def spy_run_l(self, first, n, all_types):
+            q0 = self.model.engine.feeder_queries(self.feeder)
+            t0 = time.perf_counter()
+            res = orig_run(self, first, n, all_types)
+            self.model.engine.sync()                            # (the deferred steps are settled inside the timed region)
+            torch.cuda.synchronize()
+            runs_l.append((n, all_types, time.perf_counter() - t0, self.model.engine.feeder_queries(self.feeder) - q0))
+            return res
+        train_helpers._NativeLoop.run = spy_run_l
+        random.seed(0); np.random.seed(0)
+        try:
+            train_helpers.run_train(model_l, FusedAdam(model_l, lr=0.01), train, test, test, Quiet(), max_burn_in=2, batch_size=B, log_every=100,
+                                    val_every=500, max_iter=2001)
+        finally:
+            train_helpers._NativeLoop.run = orig_run
+        full_l = [r for r in runs_l if r[1]][1:]
+        out["lazy_exact_adam"] = {"value": round(sum(r[3] for r in full_l) / sum(r[2] for r in full_l), 1), "unit": "queries/s",
+                                  "ms_per_iteration": round(sum(r[2] for r in full_l) / sum(r[0] for r in full_l) * 1e3, 4),
+                                  "note": "QueryEncoderDecoder(..., lazy_adam=True): the same run_train call, NON-DEFAULT mode"}
+        model_l.engine.close()
+
     # ---- (2) the same loop batch by batch from Python (GQE_RUN_TRAIN_NATIVE=0; what round 5's first half measured) ----
     opt = FusedAdam(model, lr=0.01)
     clock = {"lookup": 0.0, "pack": 0.0, "launch": 0.0, "n": 0, "queries": 0, "stamps": []}

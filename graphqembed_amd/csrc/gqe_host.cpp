@@ -3466,21 +3466,16 @@ int gqe_feeder_run(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations,
       if (rc != GQE_OK) return rc;
       continue;
     }
-    if (!ctx->lazy) {
-      // the iteration as one call: the split step where it applies (gqe_train_step), the two-call sequence elsewhere
-      rc = gqe_train_step(ctx, P.batches.data(), (int32_t)P.batches.size(), P.dev_idx, P.n_idx, 1, P.segs.data(), (int32_t)P.segs.size(), lr, beta1,
-                          beta2, eps, losses, stream);
-      if (rc != GQE_OK) return rc;
-    } else {
-    rc = run_queries(ctx, P.batches.data(), (int32_t)P.batches.size(), P.dev_idx, P.n_idx, 1, true, losses, nullptr, nullptr, stream);
-    if (rc != GQE_OK) return rc;
+    // the iteration as one call: the split step where it applies (gqe_train_step), the two-call sequence elsewhere — lazy Adam:
+    // with the next iteration's feed declared in front of it, so that the step's row launch (which also carries the pair-GEMM
+    // units) brings that feed's rows up to date
     if (ctx->lazy && ahead) {
       rc = gqe_lazy_prefetch(ctx, N.batches.data(), (int32_t)N.batches.size(), N.dev_idx, N.n_idx, 1);
       if (rc != GQE_OK) return rc;
     }
-    rc = run_opt(ctx, GQE_OPT_ADAM, P.segs.data(), (int32_t)P.segs.size(), lr, beta1, beta2, eps, stream);
+    rc = gqe_train_step(ctx, P.batches.data(), (int32_t)P.batches.size(), P.dev_idx, P.n_idx, 1, P.segs.data(), (int32_t)P.segs.size(), lr, beta1,
+                        beta2, eps, losses, stream);
     if (rc != GQE_OK) return rc;
-    }
     // everything that reads the feeds of this group (fused kernel, lazy row launches) is enqueued
     const bool group_done = (it % kFeedGroup) == kFeedGroup - 1 || it == end - 1;
     const int g = (int)((it / kFeedGroup) & 1);
