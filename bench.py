@@ -410,9 +410,11 @@ class Loop(object):
     def run(self, step, warmup, steps, min_seconds=0.5, max_blocks=400):
         import torch
         eng = self.eng
-        # hipEvent pairs around every 16th launch of each kernel (recycled).  Denser sampling perturbs what it measures:
-        # every 4th launch cost 4 us of a 88 us step (profiles/r02_experiment_event_stride.log)
-        eng.timing_enable(int(os.environ.get("GQE_BENCH_EVENT_STRIDE", "16")))
+        # hipEvent pairs around every 64th launch of each kernel (recycled; > 100 samples of the dominant launch in the 0.5 s that
+        # are timed).  Denser sampling perturbs what it measures: every 4th launch cost 4 us of a 88 us step
+        # (profiles/r02_experiment_event_stride.log), every 16th still 1.1 us of this round's 71 us step (stride 16 / 64 / 256:
+        # 71.6 / 70.5 / 70.2 us per step, two runs each on one box)
+        eng.timing_enable(int(os.environ.get("GQE_BENCH_EVENT_STRIDE", "64")))
         for i in range(warmup):
             step(i)
         self.fence()
