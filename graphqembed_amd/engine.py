@@ -838,7 +838,7 @@ class Engine(object):
         hist = t.zeros((n_iterations, self.LOSS_STRIDE), dtype=t.float32, device=self.device)
         self._check(self.lib.gqe_feeder_set_reference_streams(feeder, C.c_void_p(np_state.ctypes.data), C.c_void_p(py_state.ctypes.data)))
         try:
-            burn_in = first_iteration + n_iterations if edges_only else 0
+            burn_in = 0x7fffffff if edges_only else 0      # (a constant: the feeder starts from a clean ring when it changes)
             self._check(self.lib.gqe_feeder_run(feeder, first_iteration, n_iterations, burn_in, lr, betas[0], betas[1], eps,
                                                 hist.data_ptr(), self._stream()))
         finally:

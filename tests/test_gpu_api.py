@@ -497,3 +497,51 @@ def test_evaluation_on_cached_rows_is_the_same_evaluation(monkeypatch):
         np.testing.assert_allclose([v for _, v in a[3]], [v for _, v in c[3]], rtol=0, atol=1e-6)
         np.testing.assert_allclose(a[4], c[4], rtol=0, atol=1e-6)
         assert a[5] == c[5]
+
+
+@pytest.mark.parametrize("feed", ["copy", "zero-copy"])
+def test_native_runs_do_not_depend_on_where_they_are_cut(feed):
+    """The reference streams must not notice how run_train's native runs are cut: 20 iterations as ONE gqe_feeder_run against the same
+    20 as runs of 5 + 1 + 9 + 5 (boundaries inside and on the feeder's groups of eight; copy mode samples a group together — never
+    past the end of its run) give the same packed feeds for every iteration still in the ring, the same two generator states, and
+    — edges-only or every type — the same loss history to float-atomics noise."""
+    import torch
+    from graphqembed_amd import train_helpers
+    from graphqembed_amd.model import FusedAdam
+    from graphqembed_amd.sampler import np_state_words
+
+    def run(cuts, all_types):
+        model, _ = build_world("bilinear-diag", "min", 32, "train_bilinear-diag_min_d32.npz")
+        train, _ = rebuild_queries()
+        ex = train_helpers.FusedExecutor(model, FusedAdam(model, lr=0.01))
+        loop = train_helpers._NativeLoop(ex, train, 23, 0.01, 0.005)
+        model.engine.feeder_destroy(loop.feeder)
+        # (the same pools through the other transport)
+        loop2 = train_helpers._NativeLoop.__new__(train_helpers._NativeLoop)
+        loop2.__dict__.update(loop.__dict__)
+        orig = model.engine.make_reference_feeder
+        model.engine.make_reference_feeder = lambda *a, **kw: orig(*a, feed=feed, **kw)
+        try:
+            loop2 = train_helpers._NativeLoop(ex, train, 23, 0.01, 0.005)
+        finally:
+            model.engine.make_reference_feeder = orig
+        random.seed(9); np.random.seed(9); torch.manual_seed(9)
+        losses, it = [], 0
+        for n in cuts:
+            losses += loop2.run(it, n, all_types)
+            it += n
+        feeds = {i: model.engine.feeder_debug_feed(loop2.feeder, i) for i in range(max(0, it - 8), it)}
+        state = (random.getstate(), np_state_words()[0].copy())
+        loop2.close()
+        return losses, feeds, state
+
+    for all_types in (False, True):
+        one, feeds1, st1 = run([20], all_types)
+        cut, feeds2, st2 = run([5, 1, 9, 5], all_types)
+        assert st1[0] == st2[0] and np.array_equal(st1[1], st2[1])
+        assert sorted(feeds1) == sorted(feeds2) and len(feeds1) >= 5
+        for i in feeds1:
+            assert feeds1[i][0] == feeds2[i][0], i
+            assert np.array_equal(feeds1[i][1], feeds2[i][1]), i
+        np.testing.assert_allclose(one, cut, rtol=5e-2, atol=1e-4)
+        assert len(one) == 20 and np.isfinite(one).all()
