@@ -329,6 +329,20 @@ def _macro(scores):
 
 
 # ---- the loop ----------------------------------------------------------------------------------------------------
+def native_run_length(first, max_iter, all_types, losses_seen, max_burn_in, val_every, max_run):
+    """How many iterations from ``first`` on need nothing from ``run_train`` but their losses: up to (and including) the next
+    iteration behind which validation runs (``i >= val_every and i % val_every == 0``), not into the iteration that finds
+    ``max_burn_in`` losses of the edges-only phase (it switches phases), not past ``max_iter``, at most ``max_run``.  The caller has
+    checked that ``first`` itself neither switches nor stops."""
+    n = min(max_iter - first, max_run)
+    if not all_types:
+        n = min(n, max_burn_in - losses_seen)
+    if val_every > 0:
+        due = max(val_every, -(-first // val_every) * val_every)
+        n = min(n, due - first + 1)
+    return n
+
+
 def run_train(model, optimizer, train_queries, val_queries, test_queries, logger,
               max_burn_in=100000, batch_size=512, log_every=100, val_every=1000, tol=1e-6,
               max_iter=int(10e7), inter_weight=0.005, path_weight=0.01, model_file=None):
@@ -359,12 +373,7 @@ def run_train(model, optimizer, train_queries, val_queries, test_queries, logger
         switching = (not all_types) and (plateau.reached() or average.count >= max_burn_in)
         stopping = all_types and plateau.reached()
         if native is not None and not switching and not stopping and not model._touched:
-            n = min(max_iter - nxt, native.MAX_RUN)
-            if not all_types:
-                n = min(n, max_burn_in - average.count)       # (the iteration that finds the count there switches phases)
-            if val_every > 0:
-                due = max(val_every, -(-nxt // val_every) * val_every)      # the next iteration behind which validation runs
-                n = min(n, due - nxt + 1)
+            n = native_run_length(nxt, max_iter, all_types, average.count, max_burn_in, val_every, native.MAX_RUN)
             optimizer.zero_grad()
             for k, loss in enumerate(native.run(nxt, n, all_types)):
                 smoothed = average.add(loss)

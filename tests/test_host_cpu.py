@@ -294,3 +294,31 @@ def test_operand_ordered_matrix_layout_is_a_permutation_the_loader_reads_linearl
                     lq, lk = lane & 15, lane >> 4
                     off = (((i0 // 16) * (d // 16) + kb) * 1024 + 16 * lane) // 4
                     np.testing.assert_array_equal(copy[off:off + 4], m[i0 + lq, 16 * kb + 4 * lk: 16 * kb + 4 * lk + 4])
+
+
+def test_native_run_length_never_crosses_an_event_of_the_schedule():
+    """train_helpers.native_run_length against the reference's loop walked iteration by iteration (train_helpers.py:48-79): a run
+    handed to the native loop ends AT the next iteration behind which validation runs, before the iteration that finds max_burn_in
+    losses in the edges-only phase, at max_iter, or at the run cap — whichever comes first — and is never empty."""
+    from graphqembed_amd.train_helpers import native_run_length
+    rng = np.random.RandomState(0)
+    for _ in range(3000):
+        max_iter = int(rng.randint(1, 400))
+        val_every = int(rng.choice([1, 2, 3, 7, 50, 100, 1000]))
+        max_burn_in = int(rng.randint(1, 300))
+        max_run = int(rng.choice([1, 5, 64, 4096]))
+        all_types = bool(rng.randint(2))
+        first = int(rng.randint(0, max_iter))
+        seen = int(rng.randint(0, max_burn_in)) if not all_types else int(rng.randint(0, 1000))
+        n = native_run_length(first, max_iter, all_types, seen, max_burn_in, val_every, max_run)
+        # walk the loop: iteration i runs if it is inside max_iter and (edges-only) fewer than max_burn_in losses were seen at its
+        # start; it is the last of the run if validation follows it, or the cap is reached
+        want, count = 0, seen
+        for i in range(first, max_iter):
+            if not all_types and count >= max_burn_in:
+                break
+            want += 1
+            count += 1
+            if (i >= val_every and i % val_every == 0) or want == max_run:
+                break
+        assert n == want and n >= 1, (first, max_iter, all_types, seen, max_burn_in, val_every, max_run, n, want)
