@@ -280,6 +280,7 @@ struct gqe_feeder {
   int64_t loss_stride = 0;   // > 0: iteration i of a run writes its losses at losses + (i - first_iteration) * loss_stride
   int64_t run_end = 0;       // (copy mode samples a group of iterations together: never past the end of the run)
   int64_t queries_fed = 0;   // queries of every batch packed so far (gqe_feeder_queries)
+  bool sgd = false;          // gqe_feeder_set_sgd: the iteration closes with gqe_sgd_step(lr) instead of the Adam step
 };
 
 namespace {
@@ -3170,6 +3171,12 @@ int gqe_feeder_set_pvals(gqe_feeder* f, int32_t qtype, const double* pvals, int3
   return GQE_OK;
 }
 
+int gqe_feeder_set_sgd(gqe_feeder* f, int32_t enable) {
+  if (!f) return GQE_ERR_ARG;
+  f->sgd = enable != 0;
+  return GQE_OK;
+}
+
 int gqe_feeder_set_loss_stride(gqe_feeder* f, int64_t stride) {
   if (!f) return GQE_ERR_ARG;
   if (stride != 0 && stride < GQE_LAUNCH_BATCHES + 1) return fail(f->ctx, GQE_ERR_ARG, "loss stride: 0 or at least %d floats", GQE_LAUNCH_BATCHES + 1);
@@ -3473,8 +3480,13 @@ int gqe_feeder_run(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations,
       rc = gqe_lazy_prefetch(ctx, N.batches.data(), (int32_t)N.batches.size(), N.dev_idx, N.n_idx, 1);
       if (rc != GQE_OK) return rc;
     }
-    rc = gqe_train_step(ctx, P.batches.data(), (int32_t)P.batches.size(), P.dev_idx, P.n_idx, 1, P.segs.data(), (int32_t)P.segs.size(), lr, beta1,
-                        beta2, eps, losses, stream);
+    if (f->sgd) {   // --opt sgd (bio/train.py:59-60): forward / backward, then p -= lr g on what the batches touched
+      rc = run_queries(ctx, P.batches.data(), (int32_t)P.batches.size(), P.dev_idx, P.n_idx, 1, true, losses, nullptr, nullptr, stream);
+      if (rc == GQE_OK) rc = gqe_sgd_step(ctx, P.segs.data(), (int32_t)P.segs.size(), lr, stream);
+    } else {
+      rc = gqe_train_step(ctx, P.batches.data(), (int32_t)P.batches.size(), P.dev_idx, P.n_idx, 1, P.segs.data(), (int32_t)P.segs.size(), lr, beta1,
+                          beta2, eps, losses, stream);
+    }
     if (rc != GQE_OK) return rc;
     // everything that reads the feeds of this group (fused kernel, lazy row launches) is enqueued
     const bool group_done = (it % kFeedGroup) == kFeedGroup - 1 || it == end - 1;

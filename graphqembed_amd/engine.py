@@ -136,6 +136,7 @@ SYMBOLS = OrderedDict([
     ("gqe_feeder_set_pvals", (C.c_int, [_P, C.c_int32, _P, C.c_int32])),
     ("gqe_feeder_set_type_order", (C.c_int, [_P, _P, C.c_int32])),
     ("gqe_feeder_set_loss_stride", (C.c_int, [_P, C.c_int64])),
+    ("gqe_feeder_set_sgd", (C.c_int, [_P, C.c_int32])),
     ("gqe_adam_step_count", (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int32)])),
     ("gqe_feeder_queries", (C.c_int64, [_P])),
     ("gqe_feeder_debug_feed", (C.c_int, [_P, C.c_int64, C.POINTER(gqe_batch), C.c_int32, C.POINTER(C.c_int32), _P, C.c_int64,
@@ -793,7 +794,7 @@ class Engine(object):
 
     LOSS_STRIDE = 32    # floats per iteration of a reference feeder's loss history (>= GQE_LAUNCH_BATCHES + 1)
 
-    def make_reference_feeder(self, pools_by_type, mode_rows, batch_size, path_weight, inter_weight, feed="copy"):
+    def make_reference_feeder(self, pools_by_type, mode_rows, batch_size, path_weight, inter_weight, feed="copy", sgd=False):
         """The reference's own training loop, natively (include/gqe.h "reference streams"; train_helpers.run_train):
         pools_by_type = {query type name: [(FormulaPlan, target[n], anchors[k, n], (neg_ptr, neg_rows) | None,
         (hard_ptr, hard_rows) | None)]} in the order of the training dictionary (1-chain pools carry no lists),
@@ -804,6 +805,7 @@ class Engine(object):
         try:
             self._check(self.lib.gqe_feeder_set_feed(h, {"copy": 0, "zero-copy": 1}[feed]))
             self._check(self.lib.gqe_feeder_set_loss_stride(h, self.LOSS_STRIDE))
+            self._check(self.lib.gqe_feeder_set_sgd(h, 1 if sgd else 0))       # (--opt sgd: the iterations close with gqe_sgd_step)
             i32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
             i64 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int64)
             ptr = lambda x: None if x is None else C.c_void_p(x.ctypes.data)

@@ -27,7 +27,7 @@ from collections import namedtuple
 import numpy as np
 import torch
 
-from .model import FusedAdam, _FusedOptimizer
+from .model import FusedAdam, FusedSGD, _FusedOptimizer
 from .tensorize import reference_negative_nodes
 from .utils import eval_auc_queries, eval_perc_queries
 
@@ -117,6 +117,7 @@ class FusedExecutor(object):
         library call (model.train_step: gqe_train_step), and the loop's ``optimizer.step()`` finds nothing left to do."""
         self.model = model
         self.optimizer = optimizer if isinstance(optimizer, FusedAdam) else None
+        self.native_optimizer = optimizer if isinstance(optimizer, (FusedAdam, FusedSGD)) else None    # (what the native loop can step with)
         self.items = []
         self._full = {}           # mode -> rows of graph.full_lists[mode] (1-chain negatives)
 
@@ -196,7 +197,7 @@ class FusedExecutor(object):
         """A ``_NativeLoop`` over these training queries, or None where the native feeder cannot stand in for the loop: no
         FusedAdam, a query without the negatives its type needs (the reference raises on it: that exception has to come from
         the per-batch path), more batches per iteration than one launch carries.  Built once per (dictionary, batch size)."""
-        if self.optimizer is None or os.environ.get("GQE_RUN_TRAIN_NATIVE", "1") == "0":
+        if getattr(self, "native_optimizer", None) is None or os.environ.get("GQE_RUN_TRAIN_NATIVE", "1") == "0":
             return None
         key = (id(train_queries), batch_size, path_weight, inter_weight)
         if getattr(self, "_native_key", None) != key:
@@ -256,7 +257,8 @@ class _NativeLoop(object):
         self.executor, self.model = executor, m
         self.batches_full = n_batches
         m.engine.reserve(n_batches * batch_size, n_batches)       # (the per-batch path grows the workspace step by step)
-        self.feeder = m.engine.make_reference_feeder(pools_by_type, mode_rows, batch_size, path_weight, inter_weight)
+        self.sgd = isinstance(executor.native_optimizer, FusedSGD)
+        self.feeder = m.engine.make_reference_feeder(pools_by_type, mode_rows, batch_size, path_weight, inter_weight, sgd=self.sgd)
 
     def close(self):
         if self.feeder is not None:
@@ -267,13 +269,14 @@ class _NativeLoop(object):
         """Iterations [first_iteration, first_iteration + n): the list of their losses (floats)."""
         import random
         from .sampler import np_state_restore, np_state_words
-        m, opt = self.model, self.executor.optimizer
+        m, opt = self.model, self.executor.native_optimizer
+        betas, eps = (opt.betas, opt.eps) if not self.sgd else ((0.0, 0.0), 0.0)
         np_state, np_rest = np_state_words()
         version, words, gauss = random.getstate()
         py_state = np.array(words, dtype=np.uint32)
         try:
             hist = m.engine.reference_feeder_run(self.feeder, np_state, py_state, first_iteration, n, not all_types,
-                                                 opt.lr, opt.betas, opt.eps)
+                                                 opt.lr, betas, eps)
             out = hist[:, self.batches_full if all_types else 1].cpu().numpy()
         finally:
             # (whatever the run consumed is consumed: the generators continue from where it left them)

@@ -491,6 +491,9 @@ int gqe_feeder_set_reference_streams(gqe_feeder* f, uint32_t* np_state625, uint3
 int gqe_feeder_set_pvals(gqe_feeder* f, int32_t qtype, const double* pvals, int32_t n);
 int gqe_feeder_set_type_order(gqe_feeder* f, const int32_t* qtypes, int32_t n);
 int gqe_feeder_set_loss_stride(gqe_feeder* f, int64_t stride);
+/* --opt sgd (bio/train.py:59-60, torch.optim.SGD with momentum 0): the feeder's iterations close with gqe_sgd_step(lr) instead of
+ * the Adam step (gqe_feeder_run's betas / eps are then ignored). */
+int gqe_feeder_set_sgd(gqe_feeder* f, int32_t enable);
 /* Queries of every batch the feeder has packed so far (throughput accounting: the windows at a list's end are shorter). */
 int64_t gqe_feeder_queries(gqe_feeder* f);
 /* Debug / tests: the batches and the packed index feed (target | negative | anchors per batch) of one of the last prepared

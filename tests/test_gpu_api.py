@@ -545,3 +545,57 @@ def test_native_runs_do_not_depend_on_where_they_are_cut(feed):
             assert np.array_equal(feeds1[i][1], feeds2[i][1]), i
         np.testing.assert_allclose(one, cut, rtol=5e-2, atol=1e-4)
         assert len(one) == 20 and np.isfinite(one).all()
+
+
+def test_run_train_with_fused_sgd_runs_natively_too():
+    """--opt sgd (bio/train.py:59-60): run_train with a FusedSGD goes through the native runs as well (the feeder closes its iterations
+    with gqe_sgd_step).  Against the per-batch path under the same seeds: the same packed batches (formula draws and negatives come
+    from the same generators), the same log lines to float-atomics noise, the same generator states, the same parameters."""
+    import torch
+    from graphqembed_amd import train_helpers
+    from graphqembed_amd.model import FusedSGD
+
+    class Log(object):
+        def __init__(self):
+            self.lines = []
+
+        def info(self, m):
+            self.lines.append(m)
+
+    def run(native):
+        os.environ["GQE_RUN_TRAIN_NATIVE"] = "1" if native else "0"
+        try:
+            model, _ = build_world("bilinear-diag", "min", 32, "train_bilinear-diag_min_d32.npz")
+            train, test = rebuild_queries()
+            runs = []
+            orig_run = train_helpers._NativeLoop.run
+
+            def spy_run(self, first, n, all_types):
+                runs.append((first, n, all_types, self.sgd))
+                return orig_run(self, first, n, all_types)
+            train_helpers._NativeLoop.run = spy_run
+            try:
+                random.seed(17); np.random.seed(17); torch.manual_seed(17)
+                log = Log()
+                train_helpers.run_train(model, FusedSGD(model, lr=0.05), train, test, test, log, max_burn_in=4, batch_size=31, log_every=1,
+                                        val_every=1000, max_iter=12)
+            finally:
+                train_helpers._NativeLoop.run = orig_run
+            got = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+            return got, runs, log.lines, random.getstate(), np.random.get_state(), dict(model.engine.steps)
+        finally:
+            os.environ.pop("GQE_RUN_TRAIN_NATIVE", None)
+    nat, runs, lines, py1, np1, steps1 = run(True)
+    assert runs == [(0, 4, False, True), (5, 7, True, True)], runs
+    ref, runs0, lines0, py0, np0, steps0 = run(False)
+    assert not runs0 and py1 == py0 and np.array_equal(np1[1], np0[1]) and np1[2] == np0[2]
+    assert steps1 == steps0 and not any(steps1.values())      # SGD keeps no step counters
+    assert [l.split(";")[0] for l in lines] == [l.split(";")[0] for l in lines0]
+    for a, b in zip(lines, lines0):
+        if a.startswith("Iter"):
+            np.testing.assert_allclose(float(a.rsplit(" ", 1)[1]), float(b.rsplit(" ", 1)[1]), rtol=1e-3, atol=1e-5)
+    moved = 0
+    for k in nat:
+        np.testing.assert_allclose(nat[k], ref[k], rtol=1e-3, atol=2e-5, err_msg=k)
+        moved += int(np.abs(nat[k]).sum() > 0)
+    assert moved
