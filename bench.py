@@ -760,6 +760,29 @@ def api_path(args, d, decoder, inter, B, iterations=120):
                                   "note": "QueryEncoderDecoder(..., lazy_adam=True): the same run_train call, NON-DEFAULT mode"}
         model_l.engine.close()
 
+    # ---- (1c) --opt sgd (bio/train.py:59-60): the same call with a FusedSGD on the first model (its parameters keep training) ----
+    from graphqembed_amd.model import FusedSGD
+    runs_s = []
+
+    def spy_run_s(self, first, n, all_types):
+        q0 = self.model.engine.feeder_queries(self.feeder)
+        t0 = time.perf_counter()
+        res = orig_run(self, first, n, all_types)
+        runs_s.append((n, all_types, time.perf_counter() - t0, self.model.engine.feeder_queries(self.feeder) - q0))
+        return res
+    train_helpers._NativeLoop.run = spy_run_s
+    random.seed(0); np.random.seed(0)
+    try:
+        train_helpers.run_train(model, FusedSGD(model, lr=0.01), train, test, test, Quiet(), max_burn_in=2, batch_size=B, log_every=100,
+                                val_every=500, max_iter=1501)
+    finally:
+        train_helpers._NativeLoop.run = orig_run
+    full_s = [r for r in runs_s if r[1]][1:]
+    out["opt_sgd"] = {"value": round(sum(r[3] for r in full_s) / sum(r[2] for r in full_s), 1), "unit": "queries/s",
+                      "ms_per_iteration": round(sum(r[2] for r in full_s) / sum(r[0] for r in full_s) * 1e3, 4),
+                      "note": "run_train with FusedSGD (torch.optim.SGD, momentum 0: the reference's --opt sgd): fused forward / backward, pair GEMM, "
+                              "and a pass that touches only the rows with a gradient"}
+
     # ---- (2) the same loop batch by batch from Python (GQE_RUN_TRAIN_NATIVE=0; what round 5's first half measured) ----
     opt = FusedAdam(model, lr=0.01)
     clock = {"lookup": 0.0, "pack": 0.0, "launch": 0.0, "n": 0, "queries": 0, "stamps": []}
