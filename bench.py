@@ -414,7 +414,8 @@ class Loop(object):
         # are timed).  Denser sampling perturbs what it measures: every 4th launch cost 4 us of a 88 us step
         # (profiles/r02_experiment_event_stride.log), every 16th still 1.1 us of this round's 71 us step (stride 16 / 64 / 256:
         # 71.6 / 70.5 / 70.2 us per step, two runs each on one box)
-        eng.timing_enable(int(os.environ.get("GQE_BENCH_EVENT_STRIDE", "64")))
+        # (several ranks: every 16th — their steps are longer, their timed regions hold fewer of them)
+        eng.timing_enable(int(os.environ.get("GQE_BENCH_EVENT_STRIDE", "64" if self.world == 1 else "16")))
         for i in range(warmup):
             step(i)
         self.fence()
