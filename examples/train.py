@@ -45,9 +45,8 @@ random.seed(args.seed); np.random.seed(args.seed); torch.manual_seed(args.seed)
 clock = time.perf_counter
 t0 = clock()
 if args.data_dir:
-    rels, adj_lists, node_maps = data_utils.load_graph_data(args.data_dir)
-    node_ids = {m: sorted(n for n in ids if n != -1) for m, ids in node_maps.items()} if isinstance(next(iter(node_maps.values())), dict) else node_maps
-    node_maps = data_utils.make_node_maps(node_ids)
+    rels, adj_lists, node_ids = data_utils.load_graph_data(args.data_dir)        # (the pickle's third element: the id list of every mode)
+    node_maps = data_utils.make_node_maps(node_ids)                              # bio/data_utils.py:11-13
 else:
     rels, adj_lists, node_ids = data_utils.make_synthetic_graph(data_utils.BIO_SYNTH_SIZES, seed=args.seed)
     node_maps = data_utils.make_node_maps(node_ids)
