@@ -212,3 +212,70 @@ def convert_query_file(raw_infos, flat_graph):
         lut = luts[mode]
         return np.fromiter((lut[n] for n in nodes), dtype=np.int32, count=len(nodes))
     return pools_from_queries([Query.deserialize(info) for info in raw_infos], row_of)
+
+
+# ------------------------------------------------------------------------------------------------
+# flat query lists behind the reference's dictionaries: {type: {Formula: list}} for run_train / eval_* without one Python object
+# per query
+# ------------------------------------------------------------------------------------------------
+class PoolQueryList(object):
+    """One formula's queries as the list ``run_train`` / ``eval_auc_queries`` / ``eval_perc_queries`` expect — ``len``, indexing,
+    slicing, iteration — backed by a ``FormulaPool`` of row arrays.  ``QueryEncoderDecoder.pool_rows`` takes the arrays as they
+    are (no per-query lookups: the training windows, the native loop and the cached evaluation never build a ``Query``); anything
+    that does index the list (the per-Query fallback paths) gets ``Query`` objects with real node ids, built on first use
+    (``pools_to_queries``: needs the ``FlatGraph`` for the ids)."""
+
+    def __init__(self, pool, flat_graph=None):
+        self.flat_pool, self.flat_graph = pool, flat_graph
+        self._queries = None
+
+    def __len__(self):
+        return self.flat_pool.n
+
+    def queries(self):
+        if self._queries is None:
+            if self.flat_graph is None:
+                raise Exception("this query list is backed by row arrays only: pass the FlatGraph to its loader to get Query objects")
+            self._queries = pools_to_queries({self.flat_pool.formula.query_type: [self.flat_pool]}, self.flat_graph)
+        return self._queries
+
+    def __getitem__(self, i):
+        return self.queries()[i]
+
+    def __iter__(self):
+        return iter(self.queries())
+
+
+def _take(pool, mask):
+    """The sub-pool of the queries selected by a boolean mask (CSR lists re-based)."""
+    keep = np.flatnonzero(mask)
+
+    def csr(ptr, rows):
+        lens = (ptr[1:] - ptr[:-1])[keep]
+        out = np.zeros(len(keep) + 1, dtype=np.int64)
+        out[1:] = np.cumsum(lens)
+        src = np.repeat(ptr[:-1][keep] - out[:-1], lens) + np.arange(int(out[-1]))
+        return out, rows[src]
+    return FormulaPool(pool.formula, pool.target[keep], pool.anchors[:, keep], *csr(pool.neg_ptr, pool.neg_rows), *csr(pool.hard_ptr, pool.hard_rows))
+
+
+def load_queries_by_formula(path, flat_graph=None):
+    """``data_utils.load_queries_by_formula`` on a converted file: {query type: {Formula: PoolQueryList}} (netquery/data_utils.py:
+    37-44)."""
+    out = {}
+    for qt, pools in load_pools(path).items():
+        out[qt] = {p.formula: PoolQueryList(p, flat_graph) for p in pools}
+    return out
+
+
+def load_test_queries_by_formula(path, flat_graph=None):
+    """``data_utils.load_test_queries_by_formula`` on a converted file: a query with more than one stored negative goes to
+    "full_neg", the others to "one_neg" (netquery/data_utils.py:27-35)."""
+    out = {"full_neg": {}, "one_neg": {}}
+    for qt, pools in load_pools(path).items():
+        for p in pools:
+            many = (p.neg_ptr[1:] - p.neg_ptr[:-1]) > 1
+            for key, mask in (("full_neg", many), ("one_neg", ~many)):
+                if mask.any():
+                    out[key].setdefault(qt, {})[p.formula] = PoolQueryList(_take(p, mask) if not mask.all() else p, flat_graph)
+    return out

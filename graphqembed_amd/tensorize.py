@@ -187,9 +187,16 @@ class PoolRows(object):
     def __init__(self, model, formula, pool):
         enc = model.enc
         self.pool, self.formula, self.n = pool, formula, len(pool)
+        self._csr = {}
+        flat = getattr(pool, "flat_pool", None)
+        if flat is not None:        # flatdata.PoolQueryList: the arrays are the list (rows of the converted files = index + 1)
+            self.target, self.anchors = flat.target, flat.anchors
+            for hard, ptr, rows in ((False, flat.neg_ptr, flat.neg_rows), (True, flat.hard_ptr, flat.hard_rows)):
+                ptr = np.asarray(ptr, dtype=np.int64)
+                self._csr[hard] = (ptr, np.asarray(rows, dtype=np.int32)) if len(ptr) > 1 and (ptr[1:] > ptr[:-1]).all() else None
+            return
         self.target = enc.rows([q.target_node for q in pool], formula.target_mode)
         self.anchors = np.stack([enc.rows([q.anchor_nodes[i] for q in pool], m) for i, m in enumerate(formula.anchor_modes)])
-        self._csr = {}
 
     def lists(self, model, hard):
         """(ptr[n + 1], rows) of every query's negative (hard-negative) list, or None if some query has none."""

@@ -7,6 +7,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from graphqembed_amd import data_utils, flatdata, graph as G
 
@@ -99,3 +100,66 @@ def test_native_sampler_from_flat_graph():
         assert ref._is_subgraph(q.query_graph)
         negs, hard = ref.get_negative_samples(q.query_graph)
         assert set(q.neg_samples) == set(negs) and set(q.hard_neg_samples) == set(hard)
+
+
+def test_flat_query_lists_stand_in_for_query_lists(tmp_path):
+    """flatdata.load_queries_by_formula / load_test_queries_by_formula on converted files: the dictionaries run_train and eval_*
+    take, with PoolQueryList values — tensorize.PoolRows built from them (no Query object) equals PoolRows built from the
+    reference-format Query lists; the test split follows the reference's rule (more than one stored negative -> full_neg,
+    netquery/data_utils.py:27-35); indexing a list yields Query objects with the real node ids."""
+    from graphqembed_amd.encoders import DirectEncoder
+    from graphqembed_amd.tensorize import PoolRows
+    rel, adj, maps = _world()
+    g = flatdata.FlatGraph.from_reference(rel, adj, maps)
+    with open(os.path.join(GOLDEN, "queries_tiny.pkl"), "rb") as f:
+        data = pickle.load(f)
+
+    class M(object):
+        enc = DirectEncoder(None, {}, node_maps=maps)
+    # training file
+    raw = [info for infos in data["train"].values() for info in infos]
+    flatdata.save_pools(tmp_path / "train.npz", flatdata.convert_query_file(raw, g))
+    flat = flatdata.load_queries_by_formula(tmp_path / "train.npz", g)
+    objs = data_utils.group_by_formula([G.Query.deserialize(i) for i in raw])
+    assert set(flat) == set(objs)
+    n = 0
+    for qt in objs:
+        assert set(flat[qt]) == set(objs[qt])
+        for f in objs[qt]:
+            a, b = PoolRows(M, f, flat[qt][f]), PoolRows(M, f, objs[qt][f])
+            assert len(flat[qt][f]) == len(objs[qt][f]) == a.n == b.n
+            assert np.array_equal(a.target, b.target) and np.array_equal(a.anchors, b.anchors)
+            for hard in (False, True):
+                x, y = a.lists(M, hard), b.lists(M, hard)
+                assert (x is None) == (y is None), (qt, hard)
+                if x is not None:
+                    assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+            q0, r0 = flat[qt][f][0], objs[qt][f][0]
+            assert (q0.target_node, q0.anchor_nodes, q0.formula) == (r0.target_node, r0.anchor_nodes, r0.formula)
+            assert [q.target_node for q in flat[qt][f][1:3]] == [q.target_node for q in objs[qt][f][1:3]]
+            n += 1
+    assert n >= 10
+    # held-out file: the reference's split
+    raw_test = [info for infos in data["test"].values() for info in infos]
+    flatdata.save_pools(tmp_path / "test.npz", flatdata.convert_query_file(raw_test, g))
+    flat_t = flatdata.load_test_queries_by_formula(tmp_path / "test.npz", g)
+    objs_t = data_utils.split_test_queries(raw_test)
+    for key in ("one_neg", "full_neg"):
+        assert set(flat_t[key]) == set(objs_t[key])
+        for qt in objs_t[key]:
+            assert set(flat_t[key][qt]) == set(objs_t[key][qt])
+            for f in objs_t[key][qt]:
+                a, b = PoolRows(M, f, flat_t[key][qt][f]), PoolRows(M, f, objs_t[key][qt][f])
+                # (grouping by formula keeps the file's order inside a formula on both sides)
+                assert np.array_equal(a.target, b.target) and np.array_equal(a.anchors, b.anchors)
+                # (Query.deserialize hands a list of n negatives to random.sample(.., n), as the reference does, graph.py:99-100: every
+                # load draws a new order; the converted file keeps the one its conversion drew — the same SETS per query)
+                x, y = a.lists(M, False), b.lists(M, False)
+                assert np.array_equal(x[0], y[0])
+                for i in range(a.n):
+                    assert sorted(x[1][x[0][i]:x[0][i + 1]]) == sorted(y[1][y[0][i]:y[0][i + 1]])
+    # a list without its graph still trains (arrays only) but cannot hand out Query objects
+    bare = flatdata.load_queries_by_formula(tmp_path / "train.npz")
+    some = next(iter(next(iter(bare.values())).values()))
+    with pytest.raises(Exception, match="row arrays only"):
+        some[0]

@@ -599,3 +599,69 @@ def test_run_train_with_fused_sgd_runs_natively_too():
         np.testing.assert_allclose(nat[k], ref[k], rtol=1e-3, atol=2e-5, err_msg=k)
         moved += int(np.abs(nat[k]).sum() > 0)
     assert moved
+
+
+def test_run_train_on_flat_query_lists(tmp_path):
+    """The converted files' lists (flatdata.load_queries_by_formula / load_test_queries_by_formula: row arrays behind the reference's
+    dictionaries) through run_train and evaluate: no Query object is built on the way (the native runs, the phase-switch iteration
+    and the cached validation all work on model.pool_rows), and the run equals the run on the Query lists those files yield —
+    same log lines to float-atomics noise, same generator states."""
+    import torch
+    from graphqembed_amd import data_utils, flatdata, train_helpers
+    from graphqembed_amd.model import FusedAdam
+    with open(os.path.join(GOLDEN, "queries_tiny.pkl"), "rb") as f:
+        data = pickle.load(f)
+    model0, _ = build_world("bilinear-diag", "min", 32, "train_bilinear-diag_min_d32.npz")
+    maps = model0.enc.node_maps
+    rel, adj = model0.graph.relations, model0.graph.adj_lists
+    g = flatdata.FlatGraph.from_reference(rel, adj, maps)
+    random.seed(1)
+    flatdata.save_pools(tmp_path / "train.npz", flatdata.convert_query_file([i for v in data["train"].values() for i in v], g))
+    flatdata.save_pools(tmp_path / "test.npz", flatdata.convert_query_file([i for v in data["test"].values() for i in v], g))
+
+    class Log(object):
+        def __init__(self):
+            self.lines = []
+
+        def info(self, m):
+            self.lines.append(m)
+
+    def run(as_objects):
+        model, _ = build_world("bilinear-diag", "min", 32, "train_bilinear-diag_min_d32.npz")
+        train = flatdata.load_queries_by_formula(tmp_path / "train.npz", g)
+        test = flatdata.load_test_queries_by_formula(tmp_path / "test.npz", g)
+        order = ["1-chain"] + sorted(t for t in train if t != "1-chain")
+        train = {t: train[t] for t in order}
+        built = []
+        if as_objects:      # the same lists as plain Python lists of Query objects
+            train = {t: {f: list(l.queries()) for f, l in by.items()} for t, by in train.items()}
+            test = {k: {t: {f: list(l.queries()) for f, l in by.items()} for t, by in v.items()} for k, v in test.items()}
+        else:
+            orig = flatdata.PoolQueryList.queries
+
+            def spy(self):
+                built.append(self)
+                return orig(self)
+            flatdata.PoolQueryList.queries = spy
+        try:
+            random.seed(5); np.random.seed(5); torch.manual_seed(5)
+            log = Log()
+            train_helpers.run_train(model, FusedAdam(model, lr=0.01), train, test, test, log, max_burn_in=3, batch_size=19, log_every=1,
+                                    val_every=4, max_iter=11)
+        finally:
+            if not as_objects:
+                flatdata.PoolQueryList.queries = orig
+        return log.lines, random.getstate(), np.random.get_state(), built
+    flat_lines, py1, np1, built = run(False)
+    assert not built, "a flat list was turned into Query objects"
+    obj_lines, py0, np0, _ = run(True)
+    assert py1 == py0 and np.array_equal(np1[1], np0[1]) and np1[2] == np0[2]
+    assert len(flat_lines) == len(obj_lines) and any("val AUC" in l for l in flat_lines) and any(l.startswith("Edge converged") for l in flat_lines)
+    for a, b in zip(flat_lines, obj_lines):
+        ta, tb = a.split(), b.split()
+        assert len(ta) == len(tb)
+        for x, y in zip(ta, tb):
+            try:
+                np.testing.assert_allclose(float(x.strip(";")), float(y.strip(";")), rtol=3e-2, atol=2e-3)
+            except ValueError:
+                assert x == y, (a, b)
