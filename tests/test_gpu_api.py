@@ -665,3 +665,39 @@ def test_run_train_on_flat_query_lists(tmp_path):
                 np.testing.assert_allclose(float(x.strip(";")), float(y.strip(";")), rtol=3e-2, atol=2e-3)
             except ValueError:
                 assert x == y, (a, b)
+
+
+@pytest.mark.parametrize("batch_size", [1, 1000])
+def test_native_runs_at_the_batch_size_extremes(batch_size):
+    """Windows of one query, and a batch size beyond every list (each window is the whole list, train_helpers.py:102-105): the native
+    runs against the per-batch path under the same seeds — same log lines to float-atomics noise, same generator states."""
+    import torch
+    from graphqembed_amd import train_helpers
+    from graphqembed_amd.model import FusedAdam
+
+    class Log(object):
+        def __init__(self):
+            self.lines = []
+
+        def info(self, m):
+            self.lines.append(m)
+
+    def run(native):
+        os.environ["GQE_RUN_TRAIN_NATIVE"] = "1" if native else "0"
+        try:
+            model, _ = build_world("transe", "min-simple", 32, "train_transe_min-simple_d32.npz")
+            train, test = rebuild_queries()
+            random.seed(23); np.random.seed(23); torch.manual_seed(23)
+            log = Log()
+            train_helpers.run_train(model, FusedAdam(model, lr=0.01), train, test, test, log, max_burn_in=3, batch_size=batch_size, log_every=1,
+                                    val_every=1000, max_iter=9)
+            return log.lines, random.getstate(), np.random.get_state()
+        finally:
+            os.environ.pop("GQE_RUN_TRAIN_NATIVE", None)
+    a, py1, np1 = run(True)
+    b, py0, np0 = run(False)
+    assert py1 == py0 and np.array_equal(np1[1], np0[1]) and np1[2] == np0[2]
+    assert [l.split(";")[0] for l in a] == [l.split(";")[0] for l in b] and sum(l.startswith("Iter") for l in a) == 9
+    for x, y in zip(a, b):
+        if x.startswith("Iter"):
+            np.testing.assert_allclose(float(x.rsplit(" ", 1)[1]), float(y.rsplit(" ", 1)[1]), rtol=2e-2, atol=1e-4)
