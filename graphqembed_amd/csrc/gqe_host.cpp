@@ -3130,7 +3130,7 @@ int gqe_feeder_add_pool_lists(gqe_feeder* f, const gqe_batch* formula, int64_t n
   if (rc != GQE_OK) return rc;
   FeederPool& p = f->pools.back();
   p.neg.clear();
-  if (neg_ptr) {
+  if (neg_ptr && neg_rows) {
     p.neg_ptr.assign(neg_ptr, neg_ptr + n + 1);
     p.neg_rows.assign(neg_rows, neg_rows + neg_ptr[n]);
   }
