@@ -78,7 +78,8 @@ else:
     val_queries = {"one_neg": {}, "full_neg": {}}
     test_queries = {"one_neg": {}, "full_neg": {}}
     for k, t in enumerate(["2-chain", "3-chain", "2-inter", "3-inter", "3-inter_chain"]):
-        by = data_utils.group_by_formula(sampler.sample(n, q_type=t, neg_sample_max=20, seed=args.seed + k, threads=8).to_queries(keep_graph=False))[t]
+        # (query_lists: the sampled queries as lists that ARE row arrays — no Query object per sample; .to_queries() would build them)
+        by = sampler.sample(n, q_type=t, neg_sample_max=20, seed=args.seed + k, threads=8).query_lists()[t]
         keep = sorted(by, key=lambda f: -len(by[f]))[:8]
         train_queries[t] = {f: by[f][:-100] for f in keep if len(by[f]) > 200}
         val = {f: by[f][-100:-50] for f in train_queries[t]}

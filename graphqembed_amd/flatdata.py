@@ -240,6 +240,12 @@ class PoolQueryList(object):
         return self._queries
 
     def __getitem__(self, i):
+        if isinstance(i, slice):     # a slice of the list is again a list of row arrays (held-out splits, windows)
+            keep = np.zeros(self.flat_pool.n, dtype=bool)
+            keep[i] = True
+            if i.step not in (None, 1):
+                raise Exception("PoolQueryList slices keep the list's order: step 1 only")
+            return PoolQueryList(_take(self.flat_pool, keep), self.flat_graph)
         return self.queries()[i]
 
     def __iter__(self):

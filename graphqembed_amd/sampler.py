@@ -217,6 +217,16 @@ class SampledQueries(object):
         return out
 
 
+def _query_lists(self, flat_graph=None):
+    """{query type: {Formula: flatdata.PoolQueryList}}: the sampled queries as the dictionaries ``run_train`` / ``eval_*`` take, the
+    lists being row arrays — no ``Query`` object per sampled query (``to_queries`` builds them: seconds per 100 k)."""
+    from .flatdata import PoolQueryList
+    return {qt: {p.formula: PoolQueryList(p, flat_graph) for p in pools} for qt, pools in self.pools().items()}
+
+
+SampledQueries.query_lists = _query_lists
+
+
 def _take_csr(ptr, idx, rows):
     lens = ptr[rows + 1] - ptr[rows]
     new_ptr = np.zeros(len(rows) + 1, dtype=np.int64)

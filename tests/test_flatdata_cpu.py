@@ -163,3 +163,32 @@ def test_flat_query_lists_stand_in_for_query_lists(tmp_path):
     some = next(iter(next(iter(bare.values())).values()))
     with pytest.raises(Exception, match="row arrays only"):
         some[0]
+
+
+def test_flat_query_list_slices_stay_flat(tmp_path):
+    """A slice of a PoolQueryList is a PoolQueryList over the sub-arrays (targets, anchors, re-based CSR negatives): held-out splits
+    of sampled or converted lists never build Query objects; NativeSampler(...).sample(...).query_lists() hands the sampler's
+    output over in that form."""
+    rel, adj, maps = _world()
+    g = flatdata.FlatGraph.from_reference(rel, adj, maps)
+    with open(os.path.join(GOLDEN, "queries_tiny.pkl"), "rb") as f:
+        data = pickle.load(f)
+    raw = [info for infos in data["test"].values() for info in infos]
+    flatdata.save_pools(tmp_path / "t.npz", flatdata.convert_query_file(raw, g))
+    lists = flatdata.load_queries_by_formula(tmp_path / "t.npz", g)
+    checked = 0
+    for by in lists.values():
+        for f, l in by.items():
+            if len(l) < 4:
+                continue
+            for sl in (slice(1, 3), slice(None, -1), slice(-2, None), slice(0, 0)):
+                sub = l[sl]
+                assert isinstance(sub, flatdata.PoolQueryList) and len(sub) == len(range(len(l))[sl])
+                whole = l.queries()[sl]
+                got = sub.queries() if len(sub) else []
+                assert [(q.target_node, q.anchor_nodes, sorted(q.neg_samples or [])) for q in got] == \
+                       [(q.target_node, q.anchor_nodes, sorted(q.neg_samples or [])) for q in whole]
+            with pytest.raises(Exception, match="step 1"):
+                l[::2]
+            checked += 1
+    assert checked >= 3
