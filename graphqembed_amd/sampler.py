@@ -194,12 +194,25 @@ class SampledQueries(object):
     def pools(self):
         """{query_type: [FormulaPool]}: the queries grouped by formula as int32 TABLE-ROW arrays (row = local
         index + 1, the DirectEncoder convention), ready for ``trainer.TensorizedTrainer``."""
-        forms = self.formulas()
-        groups = {}
-        for i, f in enumerate(forms):
-            groups.setdefault(f, []).append(i)
+        # group by (query type, relation ids) as integers — one Formula object per GROUP, not per query
+        nrel = len(self.sampler.rels) + 1
+        two = np.isin(self.qtype, [k for k, name in QNAMES.items() if name.startswith("2")])
+        r = self.edges[:, :, 1].astype(np.int64) + 1
+        r[two, 2] = 0
+        key = ((self.qtype.astype(np.int64) * nrel + r[:, 0]) * nrel + r[:, 1]) * nrel + r[:, 2]
+        uniq, first, inverse = np.unique(key, return_index=True, return_inverse=True)
+        order = np.argsort(inverse, kind="stable")
+        bounds = np.concatenate([[0], np.cumsum(np.bincount(inverse, minlength=len(uniq)))])
+        s_ = self.sampler
+        groups = []
+        for g in np.argsort(first, kind="stable"):          # groups in order of first appearance (as a dictionary filled query by query)
+            i = int(first[g])
+            qt = QNAMES[int(self.qtype[i])]
+            rr = [s_.rels[int(self.edges[i, k, 1])] for k in range(2 if qt.startswith("2") else 3)]
+            rels = (rr[0], (rr[1], rr[2])) if qt in ("3-inter_chain", "3-chain_inter") else tuple(rr)
+            groups.append((Formula(qt, rels), order[bounds[g]:bounds[g + 1]]))
         out = {}
-        for f, rows in groups.items():
+        for f, rows in groups:
             rows = np.asarray(rows)
             qt = f.query_type
             e = self.edges[rows]
@@ -233,7 +246,7 @@ def _take_csr(ptr, idx, rows):
     new_ptr[1:] = np.cumsum(lens)
     if new_ptr[-1] == 0:
         return new_ptr, np.zeros(0, dtype=np.int32)
-    take = np.concatenate([np.arange(ptr[r], ptr[r + 1]) for r in rows])
+    take = np.repeat(ptr[rows] - new_ptr[:-1], lens) + np.arange(int(new_ptr[-1]))      # (no Python step per query)
     return new_ptr, (idx[take] + 1).astype(np.int32)
 
 
