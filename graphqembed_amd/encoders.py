@@ -30,6 +30,7 @@ class DirectEncoder(nn.Module):
         self.modes = list(feature_modules.keys())
         self.node_maps = node_maps
         self._lut = {}
+        self._flat_lut = {}
         self.bag_csr = {}       # mode -> (ptr int32[n+1], ids int32[nnz]); a node's "row" is its bag index
         self._bag_index = {}
         for mode, module in feature_modules.items():
@@ -83,6 +84,28 @@ class DirectEncoder(nn.Module):
             if (got < 0).any():
                 raise KeyError("node id not in mode %r" % mode)
             out[real] = got
+        return out
+
+    def flat_rows(self, rows, mode):
+        """Rows of the FLAT data convention (sampler / converted files: node_maps index + 1 in every mode) -> this encoder's table
+        rows: the same for ordinary tables; for an EmbeddingBag mode the bag index of the node (``rows`` above: the order of the
+        ``bags`` dictionary)."""
+        rows = np.asarray(rows, dtype=np.int32)
+        if mode not in self._bag_index:
+            return rows
+        lut = self._flat_lut.get(mode)
+        if lut is None:
+            if self.node_maps is None:
+                raise Exception("flat query lists on the EmbeddingBag mode %r need node_maps" % mode)
+            nm, idx = self.node_maps[mode], self._bag_index[mode]
+            lut = np.full(max(nm.values()) + 2, -1, dtype=np.int32)
+            for n, i in nm.items():
+                if n >= 0 and n in idx:
+                    lut[i + 1] = idx[n]
+            self._flat_lut[mode] = lut
+        out = lut[rows]
+        if (out < 0).any():
+            raise KeyError("a node of mode %r has no bag" % mode)
         return out
 
     _engine = None            # set by QueryEncoderDecoder; (key prefix, engine)

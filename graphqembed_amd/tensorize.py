@@ -190,10 +190,14 @@ class PoolRows(object):
         self._csr = {}
         flat = getattr(pool, "flat_pool", None)
         if flat is not None:        # flatdata.PoolQueryList: the arrays are the list (rows of the converted files = index + 1)
-            self.target, self.anchors = flat.target, flat.anchors
+            # (an EmbeddingBag mode's table rows are bag indices: DirectEncoder.flat_rows translates; identity elsewhere)
+            conv = getattr(enc, "flat_rows", lambda r, m: r)
+            self.target = conv(flat.target, formula.target_mode)
+            self.anchors = np.stack([conv(flat.anchors[i], m) for i, m in enumerate(formula.anchor_modes)])
             for hard, ptr, rows in ((False, flat.neg_ptr, flat.neg_rows), (True, flat.hard_ptr, flat.hard_rows)):
                 ptr = np.asarray(ptr, dtype=np.int64)
-                self._csr[hard] = (ptr, np.asarray(rows, dtype=np.int32)) if len(ptr) > 1 and (ptr[1:] > ptr[:-1]).all() else None
+                ok = len(ptr) > 1 and (ptr[1:] > ptr[:-1]).all()
+                self._csr[hard] = (ptr, conv(np.asarray(rows, dtype=np.int32), formula.target_mode)) if ok else None
             return
         self.target = enc.rows([q.target_node for q in pool], formula.target_mode)
         self.anchors = np.stack([enc.rows([q.anchor_nodes[i] for q in pool], m) for i, m in enumerate(formula.anchor_modes)])

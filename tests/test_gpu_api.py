@@ -701,3 +701,72 @@ def test_native_runs_at_the_batch_size_extremes(batch_size):
     for x, y in zip(a, b):
         if x.startswith("Iter"):
             np.testing.assert_allclose(float(x.rsplit(" ", 1)[1]), float(y.rsplit(" ", 1)[1]), rtol=2e-2, atol=1e-4)
+
+
+def test_run_train_with_an_embedding_bag_mode():
+    """A Reddit-shaped world through the Python API (reddit/data_utils_new.py:153-169: one mode's features are an nn.EmbeddingBag
+    over word rows): run_train's native runs against the per-batch path under the same seeds, lists handed over as sampled (flat)
+    lists — the same log lines to float-atomics noise, the same generator states; the word table trains."""
+    import torch
+    from graphqembed_amd import data_utils, train_helpers, utils
+    from graphqembed_amd.graph import Graph, Query
+    from graphqembed_amd.model import FusedAdam, QueryEncoderDecoder
+    from graphqembed_amd.sampler import NativeSampler
+    d, n_words = 32, 150
+    sizes = {"user": 400, "post": 300, "community": 120}
+    kinds = (("user", "make", "post"), ("post", "belong", "community"), ("user", "subscribe", "community"))
+    rel, adj, ids = data_utils.make_synthetic_graph(sizes, kinds=kinds, edges_per_kind=6000, seed=3)
+    node_maps = data_utils.make_node_maps(ids)
+    dims = {m: d for m in rel}
+    graph = Graph(None, dims, rel, adj)
+    rng = np.random.RandomState(4)
+    bags = {"post": {n: rng.randint(0, n_words, size=int(rng.randint(2, 9))).tolist() for n in ids["post"]}}
+    sampler = NativeSampler(graph, node_maps)
+    lists = {}
+    for k, t in enumerate(["2-chain", "2-inter"]):
+        by = sampler.sample(3000, q_type=t, neg_sample_max=8, seed=k, threads=2).query_lists()[t]
+        lists[t] = {f: l for f, l in sorted(by.items(), key=lambda kv: -len(kv[1]))[:5]}
+    edges = graph.get_all_edges(seed=0)[:2000]
+    train = {"1-chain": dict(data_utils.group_by_formula([Query(("1-chain", e), None, None) for e in edges])["1-chain"])}
+    train.update({t: {f: l[:-20] for f, l in by.items()} for t, by in lists.items()})
+    held = {t: {f: l[-20:] for f, l in by.items()} for t, by in lists.items()}
+    test = {"one_neg": held, "full_neg": held}
+
+    class Log(object):
+        def __init__(self):
+            self.lines = []
+
+        def info(self, m):
+            self.lines.append(m)
+
+    def run(native):
+        os.environ["GQE_RUN_TRAIN_NATIVE"] = "1" if native else "0"
+        try:
+            torch.manual_seed(11)
+            feats = {m: (torch.nn.EmbeddingBag(n_words, d, mode="mean") if m == "post" else torch.nn.Embedding(len(node_maps[m]) + 1, d)) for m in rel}
+            for f in feats.values():
+                f.weight.data.normal_(0, 1.0 / d)
+            enc = utils.get_encoder(0, graph, dims, feats, True, node_maps=node_maps, bags=bags)
+            model = QueryEncoderDecoder(graph, enc, utils.get_metapath_decoder(graph, dims, "bilinear-diag"), utils.get_intersection_decoder(graph, dims, "min"))
+            w0 = model.state_dict()["enc.feat-post.weight"].detach().cpu().numpy().copy()
+            random.seed(2); np.random.seed(2)
+            log = Log()
+            train_helpers.run_train(model, FusedAdam(model, lr=0.01), train, test, test, log, max_burn_in=3, batch_size=64, log_every=1,
+                                    val_every=6, max_iter=14)
+            w1 = model.state_dict()["enc.feat-post.weight"].detach().cpu().numpy()
+            return log.lines, random.getstate(), np.random.get_state(), float(np.abs(w1 - w0).max())
+        finally:
+            os.environ.pop("GQE_RUN_TRAIN_NATIVE", None)
+    a, py1, np1, moved1 = run(True)
+    b, py0, np0, moved0 = run(False)
+    assert moved1 > 1e-3 and moved0 > 1e-3
+    assert py1 == py0 and np.array_equal(np1[1], np0[1]) and np1[2] == np0[2]
+    assert len(a) == len(b) and sum(l.startswith("Iter") for l in a) == 14 and any("val AUC" in l for l in a)
+    for x, y in zip(a, b):
+        tx, ty = x.split(), y.split()
+        assert len(tx) == len(ty)
+        for u, v in zip(tx, ty):
+            try:
+                np.testing.assert_allclose(float(u.strip(";")), float(v.strip(";")), rtol=3e-2, atol=3e-3)
+            except ValueError:
+                assert u == v, (x, y)
