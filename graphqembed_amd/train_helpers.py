@@ -350,6 +350,11 @@ def run_train(model, optimizer, train_queries, val_queries, test_queries, logger
               max_burn_in=100000, batch_size=512, log_every=100, val_every=1000, tol=1e-6,
               max_iter=int(10e7), inter_weight=0.005, path_weight=0.01, model_file=None):
     executor = FusedExecutor(model, optimizer) if isinstance(optimizer, _FusedOptimizer) else EagerExecutor(model)
+    if isinstance(executor, EagerExecutor) and hasattr(model, "engine"):
+        import warnings
+        warnings.warn("run_train with a torch.optim optimiser keeps the reference's call sequence (margin_loss -> backward -> step: one "
+                      "launch per batch, dense gradients, torch's own Adam kernels); graphqembed_amd.model.FusedAdam(model, lr=...) / "
+                      "FusedSGD run the same schedule as one library call per iteration, natively between validations", stacklevel=2)
 
     give_random = getattr(executor, "give_random", lambda: None)
     take_random = getattr(executor, "take_random", lambda: None)
