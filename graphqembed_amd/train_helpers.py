@@ -18,6 +18,13 @@ How it is organised here: ``iteration_plan`` yields the batch specs of an iterat
 arrays and runs ONE grouped fused forward/backward launch (``QueryEncoderDecoder.margin_step``) followed by the fused
 optimiser pass; ``EagerExecutor`` keeps the reference's eager flow (``margin_loss`` -> ``backward``) for ``torch.optim``
 optimisers.  Evaluation and logging (``evaluate``) are separate from the schedule.
+
+With a fused optimiser the iterations BETWEEN two events of the schedule (phase switch, validation, convergence stop, end) do not go
+through Python at all: ``native_run_length`` says how many there are, ``_NativeLoop`` runs them as ONE library call
+(``gqe_feeder_run`` with reference streams, include/gqe.h: the formula draws replayed on ``np.random``'s generator, the negatives on
+``random``'s, packing, ``gqe_train_step`` / ``gqe_sgd_step``) and hands back the loss history the moving average and the log lines
+are made of — the same batches, steps and generator states as the per-batch path (tests/test_gpu_api.py).  ``GQE_RUN_TRAIN_NATIVE=0``
+keeps every iteration on the per-batch path.
 """
 from __future__ import annotations
 
