@@ -15,6 +15,6 @@ for GROUP in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_WAVE_CYC
   g=$((g+1))
   rocprofv3 --kernel-trace --pmc $GROUP -d "$OUT/sq_${TAG}_$g" -o bench -- python "$ROOTDIR/bench.py" $ARGS > /dev/null 2>> "$OUT/${TAG}_sq.err"
   DB=$(find "$OUT/sq_${TAG}_$g" -name '*.db' | head -1)
-  python "$ROOTDIR/tools/rocpd_summary.py" "$DB" 2>> "$OUT/${TAG}_sq.err" | sed -n '/PMC counters/,$p' | grep -E "gqe_fused|gqe_pair|counter" > "$OUT/${TAG}_sq_$g.txt"
+  python "$ROOTDIR/tools/rocpd_summary.py" "$DB" 2>> "$OUT/${TAG}_sq.err" | sed -n '/PMC counters/,$p' | grep -E "gqe_|counter" > "$OUT/${TAG}_sq_$g.txt"
 done
 cd "$ROOTDIR"; cat "$OUT"/${TAG}_sq_*.txt; tail -2 "$OUT/${TAG}_sq.err"
