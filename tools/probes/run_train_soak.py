@@ -27,7 +27,7 @@ def run(native, seed, dec, inter, B, opt, burn, val_every, iters):
 
 rng = np.random.RandomState(0)
 bad = 0
-for trial in range(24):
+for trial in range(int(os.environ.get("SOAK_TRIALS", "24"))):
     dec, inter = [("bilinear-diag", "min"), ("bilinear", "mean"), ("transe", "min-simple")][trial % 3]
     B = int(rng.choice([1, 3, 17, 23, 64, 500]))
     opt = "adam" if trial % 4 else "sgd"
