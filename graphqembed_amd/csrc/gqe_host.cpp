@@ -2987,6 +2987,16 @@ int gqe_adam_step_count(gqe_ctx* ctx, int64_t offset, int32_t* count) {
   return GQE_OK;
 }
 
+int gqe_set_adam_step_count(gqe_ctx* ctx, int64_t offset, int32_t count) {
+  if (!ctx || count < 0) return GQE_ERR_ARG;
+  if (offset < 0 || offset >= ctx->n_arena) return fail(ctx, GQE_ERR_ARG, "gqe_set_adam_step_count: offset %lld is outside the arena", (long long)offset);
+  if (ctx->split_launched || !ctx->mat_pending.empty())
+    return fail(ctx, GQE_ERR_STATE, "gqe_set_adam_step_count: a split step is still pending (gqe_optimizer_sync comes first)");
+  if (count == 0) ctx->adam_steps.erase(offset);
+  else ctx->adam_steps[offset] = count;
+  return GQE_OK;
+}
+
 int gqe_sgd_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, float lr, void* stream) {
   return run_opt(ctx, GQE_OPT_SGD, segs, n_segs, lr, 0.f, 0.f, 0.f, stream);
 }

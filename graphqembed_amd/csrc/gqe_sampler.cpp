@@ -13,6 +13,9 @@
 #include <thread>
 #include <vector>
 
+#include "gqe_mt.h"   // MT19937 as numpy / CPython run it (C++ helpers: outside the extern "C" block below)
+using gqe_mt::mt_next;
+
 namespace {
 
 enum { Q2C = 1, Q3C = 2, Q2I = 3, Q3I = 4, Q3IC = 5, Q3CI = 6 };
@@ -399,9 +402,6 @@ extern "C" {
 // ---- Python's random.choice on a batch of lists (include/gqe_sampler.h) ------------------------------------------------
 // MT19937 as CPython's _randommodule.c runs it (gqe_mt.h): genrand_uint32 with the standard tempering; getrandbits(k <= 32) = one
 // output word >> (32 - k); lists longer than 2^32 do not occur (k <= 32 is checked).
-#include "gqe_mt.h"
-using gqe_mt::mt_next;
-
 int gqe_py_random_choices(uint32_t* state625, const int64_t* counts, int64_t n, int64_t* choice) {
   if (!state625 || !counts || !choice || n < 0) return GQE_SAMPLER_ARG;
   uint32_t pos = state625[624];

@@ -138,6 +138,7 @@ SYMBOLS = OrderedDict([
     ("gqe_feeder_set_loss_stride", (C.c_int, [_P, C.c_int64])),
     ("gqe_feeder_set_sgd", (C.c_int, [_P, C.c_int32])),
     ("gqe_adam_step_count", (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int32)])),
+    ("gqe_set_adam_step_count", (C.c_int, [_P, C.c_int64, C.c_int32])),
     ("gqe_feeder_queries", (C.c_int64, [_P])),
     ("gqe_feeder_debug_feed", (C.c_int, [_P, C.c_int64, C.POINTER(gqe_batch), C.c_int32, C.POINTER(C.c_int32), _P, C.c_int64,
                                          C.POINTER(C.c_int64)])),
@@ -662,8 +663,13 @@ class Engine(object):
             losses = t.empty(len(descs) + 1, dtype=t.float32, device=self.device)
         keys = [k for k in self.layout.entries if k in set(keys)]   # arena order
         segs = self._segments(keys, True)
-        self._check(self.lib.gqe_train_step(self.ctx, arr, len(descs), ptr, n_idx, on_dev, segs, len(keys), lr, betas[0], betas[1], eps,
-                                            losses.data_ptr(), self._stream()))
+        try:
+            self._check(self.lib.gqe_train_step(self.ctx, arr, len(descs), ptr, n_idx, on_dev, segs, len(keys), lr, betas[0], betas[1], eps,
+                                                losses.data_ptr(), self._stream()))
+        except Exception:
+            for k in keys:                      # (a refused call stepped nothing: the counters stay with the library's)
+                self.steps[k] -= 1
+            raise
         self._held_losses = losses
         return losses
 
@@ -749,7 +755,12 @@ class Engine(object):
     def adam_step(self, keys, lr=0.01, betas=(0.9, 0.999), eps=1e-8):
         keys = [k for k in self.layout.entries if k in set(keys)]   # arena order
         arr = self._segments(keys, True)
-        self._check(self.lib.gqe_adam_step(self.ctx, arr, len(keys), lr, betas[0], betas[1], eps, self._stream()))
+        try:
+            self._check(self.lib.gqe_adam_step(self.ctx, arr, len(keys), lr, betas[0], betas[1], eps, self._stream()))
+        except Exception:
+            for k in keys:
+                self.steps[k] -= 1
+            raise
 
     def sgd_step(self, keys, lr=0.01):
         keys = [k for k in self.layout.entries if k in set(keys)]
@@ -868,6 +879,13 @@ class Engine(object):
             self._check(self.lib.gqe_adam_step_count(self.ctx, self.layout.offset(k), C.byref(c)))
             if c.value > self.steps[k]:
                 self.steps[k] = int(c.value)
+
+    def push_step_counts(self):
+        """The library's per-tensor Adam step counters := this engine's (gqe_set_adam_step_count): behind a restored optimiser
+        checkpoint, so that native runs / library-counted steps continue the bias correction where the checkpoint was."""
+        self.sync()
+        for k in self.layout.entries:
+            self._check(self.lib.gqe_set_adam_step_count(self.ctx, self.layout.offset(k), int(self.steps[k])))
 
     # -- timing (bench.py roofline) ------------------------------------------------
     def timing_enable(self, stride):

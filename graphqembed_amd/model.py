@@ -217,16 +217,33 @@ class QueryEncoderDecoder(nn.Module):
         scores, ptr = self.forward_candidates(formula, queries, candidate_nodes)
         return self.engine.rank_candidates(scores, ptr)
 
+    POOL_ROWS_KEPT = 512      # query lists whose rows stay cached (least recently used beyond that are dropped with their lists)
+
     def pool_rows(self, formula, pool):
         """The table rows of ONE formula's query list, looked up once (``tensorize.PoolRows``: target rows, anchor rows, the
-        negative / hard-negative lists as CSR arrays of rows) and kept for as long as the list lives: training windows
-        (train_helpers) and every later validation (utils.eval_*) then work on arrays instead of Query objects.  The list is
-        assumed not to change (its length is checked)."""
+        negative / hard-negative lists as CSR arrays of rows): training windows (train_helpers) and every later validation
+        (utils.eval_*) then work on arrays instead of Query objects.  The reference reads its lists live; the cache stands in for
+        that as long as the list is not changed in place: its length and a probe of it (first / middle / last query and their
+        negative lists, by identity) are checked on every use — a shuffled, re-sampled or edited list is looked up again — and
+        ``invalidate_pool_rows`` drops entries by hand for changes the probe cannot see.  At most POOL_ROWS_KEPT lists are kept
+        (and kept alive), least recently used first out."""
         from .tensorize import PoolRows
-        rows = self._pool_rows.get(id(pool))
-        if rows is None or rows.pool is not pool or rows.n != len(pool):
-            rows = self._pool_rows[id(pool)] = PoolRows(self, formula, pool)
+        cache = self._pool_rows
+        rows = cache.pop(id(pool), None)
+        if rows is None or rows.pool is not pool or not rows.still_valid():
+            rows = PoolRows(self, formula, pool)
+        cache[id(pool)] = rows                       # (most recently used last)
+        while len(cache) > self.POOL_ROWS_KEPT:
+            cache.pop(next(iter(cache)))
         return rows
+
+    def invalidate_pool_rows(self, pool=None):
+        """Forget the cached rows of ``pool`` (of every list if None): after an in-place change of a query list that
+        keeps its length and its first / middle / last queries."""
+        if pool is None:
+            self._pool_rows.clear()
+        else:
+            self._pool_rows.pop(id(pool), None)
 
     def candidate_percentiles_rows(self, items):
         """``candidate_percentiles`` on row arrays, several formulas per launch: items = [(formula, anchors[k, n], ptr[n + 1],
@@ -289,15 +306,23 @@ class FusedAdam(_FusedOptimizer):
         self._done()
 
     def state_dict(self):
+        """Moments and per-tensor step counts.  ``engine.sync()`` first: a split train_step leaves the d x d matrices' update to
+        the next library call — a checkpoint taken right behind train_step / a native run must hold the moments those step
+        counts belong to."""
         e = self.model.engine
+        e.sync()
         return {"steps": dict(e.steps), "exp_avg": e.exp_avg.clone(), "exp_avg_sq": e.exp_avg_sq.clone(),
                 "lr": self.lr, "betas": self.betas, "eps": self.eps}
 
     def load_state_dict(self, sd):
+        """... and back: the step counts go to the library too (gqe_set_adam_step_count) — run_train's native runs and
+        Engine.run_train_step count steps there, and would otherwise restart the bias correction at 1 on warmed-up moments."""
         e = self.model.engine
+        e.sync()
         e.steps.update(sd["steps"])
         e.exp_avg.copy_(sd["exp_avg"])
         e.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        e.push_step_counts()
         self.lr, self.betas, self.eps = sd["lr"], tuple(sd["betas"]), sd["eps"]
 
 

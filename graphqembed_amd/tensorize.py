@@ -201,6 +201,23 @@ class PoolRows(object):
             return
         self.target = enc.rows([q.target_node for q in pool], formula.target_mode)
         self.anchors = np.stack([enc.rows([q.anchor_nodes[i] for q in pool], m) for i, m in enumerate(formula.anchor_modes)])
+        self._probe = self._take_probe()
+
+    def _take_probe(self):
+        """Identity of the first / middle / last query and of their negative lists (+ the lists' lengths): what an in-place
+        shuffle, a re-sampling of the negatives or an edit of the list almost surely changes."""
+        pool = self.pool
+        if getattr(pool, "flat_pool", None) is not None or len(pool) == 0:
+            return None
+        out = []
+        for i in (0, len(pool) // 2, len(pool) - 1):
+            q = pool[i]
+            for l in (getattr(q, "neg_samples", None), getattr(q, "hard_neg_samples", None)):
+                out.append((id(q), id(l), -1 if l is None else len(l)))
+        return tuple(out)
+
+    def still_valid(self):
+        return self.n == len(self.pool) and getattr(self, "_probe", None) == self._take_probe()
 
     def lists(self, model, hard):
         """(ptr[n + 1], rows) of every query's negative (hard-negative) list, or None if some query has none."""

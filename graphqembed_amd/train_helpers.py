@@ -403,31 +403,35 @@ def run_train(model, optimizer, train_queries, val_queries, test_queries, logger
         nxt += 1
         optimizer.zero_grad()
         executor.begin()
-        add(draw_window(train_queries["1-chain"], iteration, batch_size), 1.0, False)
-        if not all_types and (plateau.reached() or average.count >= max_burn_in):
-            logger.info("Edge converged at iteration {:d}".format(iteration - 1))
-            logger.info("Testing at edge conv...")
-            give_random()
-            score_at_switch = _macro(evaluate(model, test_queries, iteration, logger))
-            take_random()
-            all_types = True
-            plateau.reset()
-            average.reset()
-            if model_file is not None:
-                torch.save(model.state_dict(), model_file + "-edge_conv")
-        for spec in iteration_plan(train_queries, all_types, path_weight, inter_weight):
-            add(draw_window(train_queries[spec.query_type], iteration, batch_size), spec.weight, spec.hard)
-        if all_types and plateau.reached():
-            logger.info("Fully converged at iteration {:d}".format(iteration))
+        try:
+            add(draw_window(train_queries["1-chain"], iteration, batch_size), 1.0, False)
+            if not all_types and (plateau.reached() or average.count >= max_burn_in):
+                logger.info("Edge converged at iteration {:d}".format(iteration - 1))
+                logger.info("Testing at edge conv...")
+                give_random()
+                score_at_switch = _macro(evaluate(model, test_queries, iteration, logger))
+                take_random()
+                all_types = True
+                plateau.reset()
+                average.reset()
+                if model_file is not None:
+                    torch.save(model.state_dict(), model_file + "-edge_conv")
+            for spec in iteration_plan(train_queries, all_types, path_weight, inter_weight):
+                add(draw_window(train_queries[spec.query_type], iteration, batch_size), spec.weight, spec.hard)
+            if all_types and plateau.reached():
+                logger.info("Fully converged at iteration {:d}".format(iteration))
+                break
+            smoothed = average.add(executor.finish())
+            optimizer.step()
+            if iteration % log_every == 0:
+                logger.info("Iter: {:d}; ema_loss: {:f}".format(iteration, smoothed))
+            if iteration >= val_every and iteration % val_every == 0:
+                scores = evaluate(model, val_queries, iteration, logger)
+                plateau.add(_macro(scores) if all_types else scores["1-chain"])
+        finally:
+            # ``begin`` moved the ``random`` module's state into a native stream; whatever ends the iteration — its ``finish``, the
+            # convergence stop, the reference's exception for hard negatives on a chain query, an interrupt — hands it back
             getattr(executor, "_close_stream", lambda: None)()
-            break
-        smoothed = average.add(executor.finish())
-        optimizer.step()
-        if iteration % log_every == 0:
-            logger.info("Iter: {:d}; ema_loss: {:f}".format(iteration, smoothed))
-        if iteration >= val_every and iteration % val_every == 0:
-            scores = evaluate(model, val_queries, iteration, logger)
-            plateau.add(_macro(scores) if all_types else scores["1-chain"])
     native = getattr(executor, "_native", None)
     if native is not None:      # (its pinned buffers and events go with the run)
         native.close()

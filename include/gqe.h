@@ -453,6 +453,12 @@ int64_t gqe_split_steps(gqe_ctx* ctx);
  * count is committed to it): how a caller that keeps its own counters — torch.optim's state["step"] — catches up behind a native
  * run (gqe_feeder_run). */
 int gqe_adam_step_count(gqe_ctx* ctx, int64_t offset, int32_t* count);
+/* ... and the other direction: the library's counter of the tensor at `offset` := `count` (0 forgets it).  What restoring an optimiser
+ * checkpoint needs (torch.optim.Adam.load_state_dict restores state["step"], bio/train.py:62 + torch.save / torch.load): the runs
+ * that use the library's counters — gqe_feeder_run, segments with step <= 0 — continue the bias correction from the restored count
+ * instead of restarting at 1 on warmed-up moments.  GQE_ERR_STATE while a split step's matrix update is still pending
+ * (gqe_optimizer_sync first). */
+int gqe_set_adam_step_count(gqe_ctx* ctx, int64_t offset, int32_t count);
 /* replaces: torch.optim.SGD(momentum=0).step() + zero_grad (bio/train.py:60) */
 int gqe_sgd_step(gqe_ctx* ctx, const gqe_segment* segs, int32_t n_segs, float lr, void* stream);
 /* replaces: optimizer.zero_grad() alone */

@@ -24,6 +24,14 @@ Fixture schema (all index arrays are TABLE ROWS = node_maps[mode][node] + 1):
   eval_<dec>_<inter>_d<D>.npz      eval_auc_queries / eval_perc_queries captures.
   adam1_<dec>_<inter>_d32.npz      per case: grad/<key> (the reference's dense gradient) and after/<key> (the parameter after
      ONE torch.optim.Adam step on that gradient).
+  trainlong_<dec>_<inter>_d32.npz  ``run_train`` for 400 iterations (100 edge-only + 300 with every type, batch 64, validation every
+     100 iterations) on the d=32 world, per seed S of the run (``seed_all(S)`` right before ``run_train``):
+       s<S>/log (json list: every line the reference logged: ema_loss every 20 iterations, the val AUC / val perc lines of the
+       edge-convergence evaluation, of the three validations and of the final test, the macro average and the improvement),
+       s<S>/loss[400] (the iteration losses handed to update_loss), s<S>/n_batches[400],
+       s<S>/sig_full[400], s<S>/sig_rows[400] (CRC32 of the iteration's batches: tests/golden_utils.batch_signature),
+       s<S>/touched/<key> (per-tensor Adam step counts at the end);  param/<key> (initial decoder parameters, shared).
+     The evaluation queries of these runs are tests/golden/queries_long_test.pkl (serialize() tuples, up to 96 per type).
   reddit_<dec>_<inter>_d{32,128}.npz  Reddit-shaped world (post features = nn.EmbeddingBag mean over word ids):
        param/* (all tables incl. the word table enc.feat-post.weight), bag/post/{ptr,ids} (CSR of the posts'
        word ids; a post's index row = its bag index), cases as in model_*.npz.
@@ -519,6 +527,108 @@ def gen_adam1_case(world, by_formula, dec, inter, B, cases=("2-chain", "3-inter.
     np.savez_compressed(os.path.join(OUT, "adam1_%s_%s_d%d.npz" % (dec, inter, world.d)), **out)
 
 
+def gen_trainlong_case(world, by_formula, test_queries, dec, inter, seeds, B=64, max_burn_in=100, max_iter=400):
+    """The reference's run_train (train_helpers.py:40-93) over both phases with validations on the way, once per seed: what it
+    logged, every iteration's loss and a checksum of every iteration's batches -> trainlong_<dec>_<inter>_d32.npz."""
+    import netquery.train_helpers as th
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from golden_utils import batch_signature
+    out = {"meta": json.dumps({"batch_size": B, "max_burn_in": max_burn_in, "max_iter": max_iter, "log_every": 20, "val_every": 100,
+                               "lr": 0.01, "seeds": list(seeds)})}
+    for seed in seeds:
+        model = world.build_model(dec, inter)
+        if seed == seeds[0]:
+            for k, v in state_np(model).items():
+                if not k.startswith("enc."):
+                    out["param/" + k] = v
+        spy = Spy(model)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.01)
+        iter_losses = []
+        orig_update = th.update_loss
+
+        def update_spy(loss, losses, ema_loss, ema_alpha=0.01):
+            iter_losses.append((float(loss), len(spy.margin_calls)))
+            return orig_update(loss, losses, ema_loss, ema_alpha)
+        th.update_loss = update_spy
+        train_queries = {t: dict(by_formula[t]) for t in
+                         ["1-chain", "2-chain", "3-chain", "2-inter", "3-inter", "3-inter_chain", "3-chain_inter"]}
+        logger = ListLogger()
+        seed_all(seed)
+        try:
+            th.run_train(model, opt, train_queries, test_queries, test_queries, logger,
+                         max_burn_in=max_burn_in, batch_size=B, log_every=20, val_every=100, max_iter=max_iter)
+        finally:
+            th.update_loss = orig_update
+        assert len(iter_losses) == max_iter
+        start, sig_full, sig_rows, nb = 0, [], [], []
+        for loss, end in iter_losses:
+            full = rows = 0
+            for mc in spy.margin_calls[start:end]:
+                f, qs = mc["formula"], mc["queries"]
+                t = world.rows([q.target_node for q in qs], f.target_mode)
+                ng = world.rows(mc["neg_nodes"], f.target_mode)
+                a = anchors_rows(world, f, qs)
+                full = batch_signature(full, f.query_type, rels_to_json(f.rels), t, ng, a)
+                rows = batch_signature(rows, f.query_type, None, t, ng, a)
+            sig_full.append(full); sig_rows.append(rows); nb.append(end - start)
+            start = end
+        pre = "s%d/" % seed
+        out[pre + "log"] = json.dumps(logger.lines)
+        out[pre + "loss"] = np.asarray([l for l, _ in iter_losses], dtype=np.float64)
+        out[pre + "n_batches"] = np.asarray(nb, dtype=np.int32)
+        out[pre + "sig_full"] = np.asarray(sig_full, dtype=np.uint32)
+        out[pre + "sig_rows"] = np.asarray(sig_rows, dtype=np.uint32)
+        names = {id(p): k for k, p in model.named_parameters()}
+        for p, st in opt.state.items():
+            out[pre + "touched/" + names[id(p)]] = np.int32(int(st["step"]))
+        print("trainlong", dec, inter, "seed", seed, logger.lines[-2], flush=True)
+    np.savez_compressed(os.path.join(OUT, "trainlong_%s_%s_d%d.npz" % (dec, inter, world.d)), **out)
+
+
+def sample_long_test_queries(world, by_formula, per_type=96):
+    """The evaluation sets of the long runs.  The tiny graph is uniformly random, so queries the model never trained on score at
+    chance whatever the trainer does; an evaluation that can tell a working trainer from a broken one has to look at what training
+    fits.  ``one_neg`` (AUC) therefore takes the first ``per_type`` TRAINING queries of every type (their one stored negative; the
+    1-chain queries are the first training edges with one sampled negative each), ``full_neg`` (percentile) keeps freshly sampled
+    queries with up to 8 negatives as in sample_test_queries."""
+    from netquery.graph import Query
+    from collections import defaultdict
+    out = sample_test_queries(world, per_type=per_type)
+    one = defaultdict(lambda: defaultdict(list))
+    seed_all(23)
+    for t in by_formula:
+        n = 0
+        for f, qs in by_formula[t].items():
+            for q in qs:
+                if n >= per_type:
+                    break
+                if t == "1-chain":
+                    e = q.query_graph[1]
+                    q = Query(("1-chain", e), world.graph.get_negative_edge_samples(e, 1), None, 2, keep_graph=True)
+                elif "inter" in t and not q.hard_neg_samples:
+                    continue
+                one[t][f].append(q)
+                n += 1
+    out["one_neg"] = one
+    return out
+
+
+def gen_round6():
+    """Fixtures added in round 6: trainlong_<dec>_<inter>_d32.npz (400 iterations of the reference's run_train; three seeds for the
+    headline decoder pair — their spread is the band the device run is held to — one for the two other families) and the larger
+    evaluation query set those runs validate on (queries_long_test.pkl)."""
+    import pickle
+    world = World(32)
+    by_formula = sample_queries(world)          # the training queries of queries_tiny.pkl (same seeds)
+    test_queries = sample_long_test_queries(world, by_formula, per_type=96)
+    test = {s: [q.serialize() for t in test_queries[s] for f in test_queries[s][t] for q in test_queries[s][t][f]] for s in test_queries}
+    with open(os.path.join(OUT, "queries_long_test.pkl"), "wb") as f:
+        pickle.dump({"test": test}, f, protocol=2)
+    gen_trainlong_case(world, by_formula, test_queries, "bilinear-diag", "min", (41, 42, 43))
+    gen_trainlong_case(world, by_formula, test_queries, "bilinear", "mean", (41,))
+    gen_trainlong_case(world, by_formula, test_queries, "transe", "min-simple", (41,))
+
+
 def gen_round2():
     """Fixtures added in round 2 (each builds its own worlds, so the files above are unaffected):
       eval_bilinear-diag_min_d128.npz   eval_auc_queries / eval_perc_queries at the BASELINE dimension
@@ -541,6 +651,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     tmp = import_reference()
     logging.disable(logging.CRITICAL)
+    if "--round6-only" in sys.argv:          # the round-6 fixtures alone (bit-identical to what the full run writes)
+        try:
+            gen_round6()
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        return
     if "--round2-only" in sys.argv:          # the round-2 fixtures alone (bit-identical to what the full run writes)
         try:
             gen_round2()
@@ -576,6 +692,7 @@ def main():
                 print("train/eval", dec, inter, d, flush=True)
         gen_reddit_cases(32, 23)
         gen_round2()
+        gen_round6()
         with open(os.path.join(OUT, "META.json"), "w") as f:
             json.dump(meta, f, indent=1)
     finally:

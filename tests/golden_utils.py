@@ -12,6 +12,52 @@ def to_rels(x):
     return tuple(to_rels(y) if isinstance(y[0], list) else tuple(y) for y in x)
 
 
+def rels_to_lists(rels):
+    return [rels_to_lists(r) if isinstance(r[0], (tuple, list)) else list(r) for r in rels]
+
+
+def batch_signature(crc, query_type, rels_json, target, neg, anchors):
+    """Running CRC32 over an iteration's batches (trainlong_*.npz: sig_full with the formula's relations as
+    oracle/make_golden.py's rels_to_json writes them, sig_rows with ``rels_json=None``): type name, relations, then the int32
+    target / negative / anchor rows."""
+    import zlib
+    crc = zlib.crc32(query_type.encode(), crc)
+    if rels_json is not None:
+        crc = zlib.crc32(json.dumps(rels_json).encode(), crc)
+    for a in (target, neg, anchors):
+        crc = zlib.crc32(np.ascontiguousarray(a, dtype=np.int32).tobytes(), crc)
+    return crc & 0xffffffff
+
+
+def parse_train_log(lines):
+    """What run_train logged (train_helpers.py:19-38, 52-55, 80-93) as data: {"iters": [(iteration, ema_loss)],
+    "evals": [{tag: (auc, perc)} per evaluation, in order, with "iteration"], "edge_conv": iteration or None,
+    "macro": float or None, "improvement": float or None}."""
+    out = {"iters": [], "evals": [], "edge_conv": None, "macro": None, "improvement": None}
+    cur, cur_it = None, None
+    for l in lines:
+        if " val AUC: " in l:
+            tag, rest = l.split(" val AUC: ")
+            auc, rest = rest.split(" val perc ")
+            perc, it = rest.split("; iteration: ")
+            if cur is None or int(it) != cur_it or tag in cur:
+                cur, cur_it = {}, int(it)
+                out["evals"].append({"iteration": cur_it, "scores": cur})
+            cur[tag] = (float(auc), float(perc))
+            continue
+        cur = None
+        if l.startswith("Iter: "):
+            a, b = l.split("; ema_loss: ")
+            out["iters"].append((int(a[6:]), float(b)))
+        elif l.startswith("Edge converged at iteration "):
+            out["edge_conv"] = int(l.rsplit(" ", 1)[1])
+        elif l.startswith("Test macro-averaged val: "):
+            out["macro"] = float(l.rsplit(" ", 1)[1])
+        elif l.startswith("Improvement from edge conv: "):
+            out["improvement"] = float(l.rsplit(" ", 1)[1])
+    return out
+
+
 def model_files(d=None):
     out = []
     for p in sorted(glob.glob(os.path.join(GOLDEN, "model_*.npz"))):

@@ -37,6 +37,45 @@ def build_world(dec, inter, d, fixture):
     return model, z
 
 
+class TrainYardstick(object):
+    """What a run_train fixture (train_<dec>_<inter>_d<D>.npz: the reference's own 5-iteration run) allows a device run to differ
+    by, case by case instead of one blanket bound: the numpy oracle replays the recorded batches in float32 (gpu_utils.oracle_replay)
+    and its own deviation from the recorded numbers is the yardstick —
+      losses      |device - reference| <= 3 x |fp32 oracle - reference| + 1e-5 x |reference|   (per iteration; per batch likewise)
+      parameters  max |delta - recorded delta| <= min(6e-2, 3 x fp32 oracle's max deviation on that tensor + 2e-3), median likewise
+                  with a 5e-5 floor (Adam's first steps are sign-like: dp = lr g / (|g| + 1e-8) turns rounding noise around an exact
+                  zero gradient into lr-sized moves in the reference itself, tests/test_oracle_golden.py)
+      log         every ema_loss within the moving average of the loss allowances, every val AUC / val perc within 2 order flips
+                  of the evaluation set's quantum (24 queries per type: 1 / 576 of AUC per flipped pair), macro / improvement
+                  within what those flips can move them by (gpu_utils.compare_train_logs)."""
+
+    def __init__(self, z, dec, inter, d):
+        from gpu_utils import fixture_iterations, oracle_replay
+        from golden_utils import load_params
+        self.z, self.p0 = z, load_params(z, d)
+        self.iterations = fixture_iterations(z)
+        self.ref_loss = np.array([float(z["it%d/loss" % i]) for i in range(len(self.iterations))])
+        self.loss32, self.params32, _ = oracle_replay(self.p0, dec, inter, self.iterations, np.float32)
+        self.loss_allow = 3.0 * np.abs(self.loss32 - self.ref_loss) + 1e-5 * np.abs(self.ref_loss)
+
+    def batch_allow(self, i, j):
+        return 3.0 * abs(self.loss32[i] - self.ref_loss[i]) + 1e-5 * max(abs(float(self.z["it%d/b%d/loss" % (i, j)])), 1.0)
+
+    def check_params(self, got, p0):
+        for k in got:
+            delta = self.z["delta/" + k]
+            diff = np.abs(got[k].astype(np.float64) - p0[k] - delta)
+            dev32 = np.abs(self.params32[k].astype(np.float64) - self.p0[k] - delta)
+            allow = min(6e-2, 3.0 * float(dev32.max()) + 2e-3)
+            assert diff.max() < allow and np.median(diff) < max(5e-5, 3.0 * float(np.median(dev32))), (k, diff.max(), allow, np.median(diff))
+
+    def check_log(self, lines, test_queries, auc_flips=2, perc_flips=2):
+        from gpu_utils import compare_train_logs, eval_quanta
+        ref = json.loads(str(self.z["log"]))
+        resets = set(int(l.rsplit(" ", 1)[1]) + 1 for l in ref if l.startswith("Edge converged"))
+        return compare_train_logs(lines, ref, self.loss_allow, eval_quanta(test_queries), resets, auc_flips, perc_flips)
+
+
 def rebuild_queries():
     """The Query objects of the fixtures, negatives in their recorded order."""
     from graphqembed_amd.graph import Query
@@ -204,6 +243,7 @@ def test_run_train_reproduces_the_reference_run(dec, inter, d, monkeypatch):
     opt = FusedAdam(model, lr=0.01)
     train_helpers.run_train(model, opt, train, test, test, Log(), max_burn_in=2, batch_size=23, log_every=1, val_every=1000, max_iter=5)
     assert len(seen) == 5
+    yard = TrainYardstick(z, dec, inter, d)
     for i, (items, losses) in enumerate(seen):
         assert len(items) == int(z["it%d/n" % i]), i
         for j, (f, t, ng, a, w, m) in enumerate(items):
@@ -212,17 +252,14 @@ def test_run_train_reproduces_the_reference_run(dec, inter, d, monkeypatch):
             assert np.array_equal(t, z["it%d/b%d/target" % (i, j)]) and np.array_equal(ng, z["it%d/b%d/neg" % (i, j)]), (i, j)
             assert np.array_equal(a, z["it%d/b%d/anchors" % (i, j)]), (i, j)
         l = losses.cpu().numpy()
-        np.testing.assert_allclose(l[-1], float(z["it%d/loss" % i]), rtol=1e-4 if i == 0 else 3e-2, err_msg="iteration %d" % i)
+        assert abs(l[-1] - yard.ref_loss[i]) <= yard.loss_allow[i], ("iteration", i, l[-1], yard.ref_loss[i], yard.loss_allow[i])
     got = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    yard.check_params(got, p0)
     for k in got:
-        diff = np.abs(got[k].astype(np.float64) - p0[k] - z["delta/" + k])
-        assert diff.max() < 6e-2 and np.median(diff) < 1e-3, (k, diff.max(), np.median(diff))
         steps = int(z["touched/" + k]) if "touched/" + k in z.files else 0
         assert model.engine.steps[k] == steps, (k, model.engine.steps[k], steps)       # per-tensor Adam step counters
-    ref_log = json.loads(str(z["log"]))
-    mine = Log.lines
-    assert [l.split(";")[0] for l in mine if l.startswith("Iter")] == [l.split(";")[0] for l in ref_log if l.startswith("Iter")]
-    assert any(l.startswith("Edge converged at iteration 1") for l in mine)
+    worst = yard.check_log(Log.lines, test)
+    print("run_train per batch", dec, inter, d, "worst deviations in units of their allowances:", worst)
 
 
 @pytest.mark.parametrize("dec,inter,d", [("bilinear-diag", "min", 32), ("bilinear", "mean", 32), ("transe", "min-simple", 32)])
@@ -280,6 +317,7 @@ def test_run_train_native_runs_reproduce_the_reference_run(dec, inter, d):
 
     model, z, p0, got, feeds, python_its, lines, py_end, np_end = run(True)
     assert sorted(feeds) == [0, 1, 3, 4] and len(python_its) == 1, (sorted(feeds), python_its)
+    yard = TrainYardstick(z, dec, inter, d)
     for i, (batches, idx, loss) in feeds.items():
         assert len(batches) == int(z["it%d/n" % i]), i
         for j, (qtype, n, n_anchors, off, weight) in enumerate(batches):
@@ -288,15 +326,14 @@ def test_run_train_native_runs_reproduce_the_reference_run(dec, inter, d):
             assert qtype == QTYPES[meta["type"]] and n == len(t) and n_anchors == a.shape[0], (i, j)
             assert np.array_equal(idx[off:off + n], t) and np.array_equal(idx[off + n:off + 2 * n], ng), (i, j)
             assert np.array_equal(idx[off + 2 * n:off + (2 + n_anchors) * n].reshape(n_anchors, n), a), (i, j)
-        np.testing.assert_allclose(loss, float(z["it%d/loss" % i]), rtol=1e-4 if i == 0 else 3e-2, err_msg="iteration %d" % i)
+        assert abs(loss - yard.ref_loss[i]) <= yard.loss_allow[i], ("iteration", i, loss, yard.ref_loss[i], yard.loss_allow[i])
+    yard.check_params(got, p0)
     for k in got:
-        diff = np.abs(got[k].astype(np.float64) - p0[k] - z["delta/" + k])
-        assert diff.max() < 6e-2 and np.median(diff) < 1e-3, (k, diff.max(), np.median(diff))
         steps = int(z["touched/" + k]) if "touched/" + k in z.files else 0
         assert model.engine.steps[k] == steps, (k, model.engine.steps[k], steps)
-    ref_log = json.loads(str(z["log"]))
-    assert [l.split(";")[0] for l in lines if l.startswith("Iter")] == [l.split(";")[0] for l in ref_log if l.startswith("Iter")]
-    assert any(l.startswith("Edge converged at iteration 1") for l in lines)
+    _, test = rebuild_queries()
+    worst = yard.check_log(lines, test)
+    print("run_train native runs", dec, inter, d, "worst deviations in units of their allowances:", worst)
     # the per-batch path on the same seeds: the same log lines (moving averages to float-atomics noise) and the same generator states
     _, _, _, got2, feeds2, python_its2, lines2, py_end2, np_end2 = run(False)
     assert not feeds2 and len(python_its2) == 5
@@ -307,8 +344,8 @@ def test_run_train_native_runs_reproduce_the_reference_run(dec, inter, d):
         if a.startswith("Iter"):
             assert a.split(";")[0] == b.split(";")[0]
             np.testing.assert_allclose(float(a.rsplit(" ", 1)[1]), float(b.rsplit(" ", 1)[1]), rtol=2e-2, atol=1e-4)
-    for k in got:
-        assert np.abs(got[k] - got2[k]).max() < 6e-2, k
+    yard.check_params(got2, p0)
+    yard.check_log(lines2, test)
 
 
 def test_train_fixture_replay_d128():
@@ -319,6 +356,7 @@ def test_train_fixture_replay_d128():
     model, z = build_world("bilinear-diag", "min", 128, "train_bilinear-diag_min_d128.npz")
     p0 = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
     opt = FusedAdam(model, lr=0.01)
+    yard = TrainYardstick(z, "bilinear-diag", "min", 128)
     i = 0
     while "it%d/n" % i in z.files:
         items = []
@@ -330,16 +368,14 @@ def test_train_fixture_replay_d128():
         opt.zero_grad()
         losses, _, _ = model.margin_step(items)
         l = losses.cpu().numpy()
-        for j in range(len(items)):
-            np.testing.assert_allclose(l[j], float(z["it%d/b%d/loss" % (i, j)]), rtol=1e-4 if i == 0 else 5e-2, atol=1e-5, err_msg="it %d batch %d" % (i, j))
-        np.testing.assert_allclose(l[-1], float(z["it%d/loss" % i]), rtol=1e-4 if i == 0 else 3e-2)
+        for j in range(len(items)):       # (every batch's own loss, as margin_loss returned it)
+            assert abs(l[j] - float(z["it%d/b%d/loss" % (i, j)])) <= yard.batch_allow(i, j), ("it", i, "batch", j, l[j], float(z["it%d/b%d/loss" % (i, j)]))
+        assert abs(l[-1] - yard.ref_loss[i]) <= yard.loss_allow[i], ("iteration", i, l[-1], yard.ref_loss[i], yard.loss_allow[i])
         opt.step()
         i += 1
     assert i == 5
     got = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-    for k in got:
-        diff = np.abs(got[k].astype(np.float64) - p0[k] - z["delta/" + k])
-        assert diff.max() < 6e-2 and np.median(diff) < 1e-3, (k, diff.max(), np.median(diff))
+    yard.check_params(got, p0)
 
 
 def test_training_improves_auc_end_to_end():
@@ -770,3 +806,110 @@ def test_run_train_with_an_embedding_bag_mode():
                 np.testing.assert_allclose(float(u.strip(";")), float(v.strip(";")), rtol=3e-2, atol=3e-3)
             except ValueError:
                 assert u == v, (x, y)
+
+
+def test_optimizer_checkpoint_resumes_native_runs_where_it_was():
+    """FusedAdam.state_dict / load_state_dict around run_train: a checkpoint taken right behind a run (the split step's matrix
+    update possibly still pending in the library) holds the moments its step counts belong to, and a run resumed from it — on a
+    fresh model, natively — continues Adam's bias correction from the restored per-tensor counts (gqe_set_adam_step_count): the
+    same losses and parameters as the per-batch path resumed from the same checkpoint (which passes explicit step counts), and as
+    the original model simply trained on.  Restarting the counters at 1 on warmed-up moments would show in the first resumed
+    losses (the update is 1 / (1 - 0.9) = 10 x too large at step 1)."""
+    import torch
+    from graphqembed_amd import train_helpers
+    from graphqembed_amd.model import FusedAdam
+
+    class Log(object):
+        def __init__(self):
+            self.lines = []
+
+        def info(self, m):
+            self.lines.append(m)
+
+    def trained():
+        model, _ = build_world("bilinear-diag", "min", 32, "train_bilinear-diag_min_d32.npz")
+        train, test = rebuild_queries()
+        opt = FusedAdam(model, lr=0.01)
+        random.seed(5); np.random.seed(5); torch.manual_seed(5)
+        train_helpers.run_train(model, opt, train, test, test, Log(), max_burn_in=3, batch_size=23, log_every=1, val_every=1000, max_iter=30)
+        return model, opt, train, test
+
+    def resume(model, opt, train, test, native):
+        os.environ["GQE_RUN_TRAIN_NATIVE"] = "1" if native else "0"
+        try:
+            random.seed(6); np.random.seed(6); torch.manual_seed(6)
+            log = Log()
+            train_helpers.run_train(model, opt, train, test, test, log, max_burn_in=2, batch_size=23, log_every=1, val_every=1000, max_iter=8)
+        finally:
+            os.environ.pop("GQE_RUN_TRAIN_NATIVE", None)
+        ema = [float(l.rsplit(" ", 1)[1]) for l in log.lines if l.startswith("Iter")]
+        return ema, {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}, dict(model.engine.steps)
+
+    model, opt, train, test = trained()
+    ckpt_opt = opt.state_dict()                     # straight behind the run: no sync asked for by the caller
+    ckpt_model = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.engine.sync()
+    torch.cuda.synchronize()
+    after_sync = opt.state_dict()
+    assert torch.equal(ckpt_opt["exp_avg"], after_sync["exp_avg"]) and torch.equal(ckpt_opt["exp_avg_sq"], after_sync["exp_avg_sq"])
+    assert ckpt_opt["steps"] == after_sync["steps"] and 10 <= max(ckpt_opt["steps"].values()) <= 30
+    mats = [k for k in ckpt_opt["steps"] if k.endswith("mat") and ckpt_opt["steps"][k] > 0]
+    assert mats and all(float(model.engine.layout.view(ckpt_opt["exp_avg"], k).abs().max()) > 0 for k in mats)
+    ema_a, got_a, steps_a = resume(model, opt, train, test, native=True)          # the original model trained on
+
+    out = {}
+    for native in (True, False):
+        m2, _ = build_world("bilinear-diag", "min", 32, "train_bilinear-diag_min_d32.npz")
+        m2.load_state_dict(ckpt_model)
+        o2 = FusedAdam(m2, lr=0.5)
+        o2.load_state_dict(ckpt_opt)
+        assert o2.lr == 0.01 and dict(m2.engine.steps) == ckpt_opt["steps"]
+        tr2, te2 = rebuild_queries()
+        out[native] = resume(m2, o2, tr2, te2, native)
+    for name, (ema, got, steps) in (("native", out[True]), ("per batch", out[False])):
+        assert steps == steps_a, name
+        np.testing.assert_allclose(ema, ema_a, rtol=2e-5, atol=2e-6, err_msg=name)       # (log lines print 6 decimals)
+        for k in got:
+            diff = np.abs(got[k] - got_a[k])
+            assert np.median(diff) < 2e-6 and diff.max() < 2e-2, (name, k, np.median(diff), diff.max())
+    # ... and what the test is there to catch: the same resume with the library's counters left at zero lands elsewhere
+    m3, _ = build_world("bilinear-diag", "min", 32, "train_bilinear-diag_min_d32.npz")
+    m3.load_state_dict(ckpt_model)
+    o3 = FusedAdam(m3, lr=0.01)
+    o3.load_state_dict(ckpt_opt)
+    for k in m3.engine.layout.entries:
+        m3.engine._check(m3.engine.lib.gqe_set_adam_step_count(m3.engine.ctx, m3.engine.layout.offset(k), 0))
+    tr3, te3 = rebuild_queries()
+    ema_bad, _, _ = resume(m3, o3, tr3, te3, native=True)
+    assert np.abs(np.array(ema_bad) - np.array(ema_a)).max() > 1e-4, (ema_bad, ema_a)
+
+
+def test_pool_rows_follow_an_in_place_change_of_the_list():
+    """model.pool_rows caches a query list's rows; the reference reads its lists live.  An in-place shuffle (same list object, same
+    length) or replaced negatives are seen by the cache's probe and the rows are looked up again; invalidate_pool_rows drops
+    entries by hand; the cache is bounded."""
+    model, _ = build_world("bilinear-diag", "min", 32, "train_bilinear-diag_min_d32.npz")
+    train, _ = rebuild_queries()
+    formula, pool = max(train["2-inter"].items(), key=lambda kv: len(kv[1]))
+    rows = model.pool_rows(formula, pool)
+    assert model.pool_rows(formula, pool) is rows
+    want = model.enc.rows([q.target_node for q in pool], formula.target_mode)
+    assert np.array_equal(rows.target, want)
+    rnd = random.Random(3)
+    rnd.shuffle(pool)
+    rows2 = model.pool_rows(formula, pool)
+    assert rows2 is not rows
+    assert np.array_equal(rows2.target, model.enc.rows([q.target_node for q in pool], formula.target_mode))
+    before = rows2.lists(model, False)[1].copy()
+    pool[0].neg_samples = list(pool[0].neg_samples) + [pool[1].neg_samples[0]]          # (a re-sampled negative list)
+    rows3 = model.pool_rows(formula, pool)
+    assert rows3 is not rows2 and len(rows3.lists(model, False)[1]) == len(before) + 1
+    model.invalidate_pool_rows(pool)
+    assert model.pool_rows(formula, pool) is not rows3
+    keep = [[q] for q in pool[:40]]
+    model.POOL_ROWS_KEPT = 16
+    for l in keep:
+        model.pool_rows(formula, l)
+    assert len(model._pool_rows) == 16
+    model.invalidate_pool_rows()
+    assert not model._pool_rows

@@ -200,3 +200,64 @@ def test_adam_one_step_from_the_golden_gradient(path, dec, inter, d):
         O.adam_step(params, grads, {}, list(grads))
         for k in grads:
             np.testing.assert_allclose(params[k], after[k], rtol=0, atol=2e-7, err_msg="%s %s" % (case, k))
+
+
+@pytest.mark.parametrize("dec,inter,d", [("bilinear-diag", "min", 32), ("bilinear", "mean", 32), ("transe", "min-simple", 32), ("bilinear-diag", "min", 128)])
+def test_oracle_replays_the_recorded_run_train(dec, inter, d):
+    """The reference's own 5-iteration run_train (train_*.npz) through the oracle: weighted sum of the batch losses (1 / 0.01 /
+    0.005, train_helpers.py:51,69-72), one Adam step per iteration on the touched tensors only, per-tensor step counters — the
+    iteration losses to 1e-6 in float64 and float32 alike, the counters exactly, the ema_loss lines of the recorded log from the
+    oracle's losses (update_loss, train_helpers.py:11-17; the average starts over at the phase switch)."""
+    import json
+    from gpu_utils import ema_series, fixture_iterations, oracle_replay
+    from golden_utils import load_params, parse_train_log
+    z = np.load(os.path.join(GOLDEN, "train_%s_%s_d%d.npz" % (dec, inter, d)))
+    p0 = load_params(z, d)
+    its = fixture_iterations(z)
+    ref = np.array([float(z["it%d/loss" % i]) for i in range(len(its))])
+    log = parse_train_log(json.loads(str(z["log"])))
+    assert log["edge_conv"] == 1 and len(log["evals"]) == 2 and log["macro"] is not None and log["improvement"] is not None
+    assert all(len(e["scores"]) == 11 for e in log["evals"])
+    for dt in (np.float64, np.float32):
+        losses, params, steps = oracle_replay(p0, dec, inter, its, dt)
+        np.testing.assert_allclose(losses, ref, rtol=1e-6)
+        for k in p0:
+            assert steps.get(k, 0) == (int(z["touched/" + k]) if "touched/" + k in z.files else 0), k
+        ema = ema_series(losses, resets={log["edge_conv"] + 1})
+        for i, x in log["iters"]:
+            assert abs(ema[i] - x) < 2e-6, (i, ema[i], x)
+        if dt is np.float64:       # medians: the bulk of every tensor lands on the recorded parameters (the tail is Adam on rounding noise)
+            for k in params:
+                diff = np.abs(params[k] - p0[k] - z["delta/" + k])
+                assert np.median(diff) < 1e-6, (k, np.median(diff))
+
+
+def test_trainlong_fixture_is_self_consistent():
+    """trainlong_*.npz: 400 losses per seed, the recorded ema_loss lines ARE the moving average of the recorded losses (restart at
+    the phase switch), five evaluations of eleven lines each, the macro line is the mean of the last evaluation's AUCs."""
+    import glob
+    import json
+    from gpu_utils import ema_series
+    from golden_utils import parse_train_log
+    files = sorted(glob.glob(os.path.join(GOLDEN, "trainlong_*.npz")))
+    assert len(files) == 3
+    for path in files:
+        z = np.load(path)
+        meta = json.loads(str(z["meta"]))
+        for seed in meta["seeds"]:
+            pre = "s%d/" % seed
+            loss = z[pre + "loss"]
+            log = parse_train_log(json.loads(str(z[pre + "log"])))
+            assert len(loss) == meta["max_iter"] == 400 and log["edge_conv"] == 99
+            nb = z[pre + "n_batches"]
+            assert (nb[:100] == 1).all() and (nb[100:] == 11).all()
+            ema = ema_series(loss, resets={100})
+            assert [i for i, _ in log["iters"]] == list(range(0, 400, 20))
+            for i, x in log["iters"]:
+                assert abs(ema[i] - x) < 1e-6
+            assert [e["iteration"] for e in log["evals"]] == [100, 100, 200, 300, 399]
+            final = log["evals"][-1]["scores"]
+            assert len(final) == 11 and abs(np.mean([v[0] for v in final.values()]) - log["macro"]) < 1e-6
+            first = np.mean([v[0] for v in log["evals"][0]["scores"].values()])
+            assert abs((log["macro"] - first) / first - log["improvement"]) < 2e-5
+            assert log["macro"] > first + 0.1          # (training fits what the AUC sets hold: a trajectory with a signal)
