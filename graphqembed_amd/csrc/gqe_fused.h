@@ -778,6 +778,22 @@ __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t h
   }
 }
 
+// Is a query's negative its target?  (model.py:118 draws a 1-chain negative from the whole mode.)  Then s+ and s- are the same number
+// and every gradient of the query — both rows, the anchor, the relation parameters — cancels EXACTLY in the reference (+g and -g of
+// identical arithmetic), while two separately rounded halves would leave noise that Adam's sign-like step turns into lr-sized moves
+// of rows the reference does not move: such a query sends nothing.  Unsharded, the two index entries name the same row.  Row-sharded,
+// an entry is a position in the fetched-row buffer (the same row fetched twice has two positions): the rows themselves are compared
+// — bit-identical contents make s+ == s- and cancel the gradients just the same.
+template <int NC>
+__device__ __forceinline__ bool same_row(const TileEnv& e, int rt, int rn, const Vec<NC>& tp, const Vec<NC>& tn) {
+  if (rt == rn) return true;
+  if (!e.sharded) return false;
+  bool eq = true;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) eq = eq && (tp.v[c] == tn.v[c]);
+  return __all(eq) != 0;
+}
+
 // Row-sharded mode: every fetched row owns a slot of the send buffer, and the owner links whatever arrives — a query
 // whose hinge is inactive has to send zeros (the buffer still holds the previous step's contribution there).
 template <int NC, bool FULL>
@@ -1298,8 +1314,8 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
         }
         if (!BWD) continue;
         const float hinge = b.margin - (sp - sn);
-        if (hinge > 0.f) {
-          loss_part += hinge;
+        if (hinge > 0.f) loss_part += hinge;
+        if (hinge > 0.f && !same_row<NC>(e, RT.row[rr], RN.row[rr], tp, tn)) {   // (target == negative: nothing to send, see same_row)
           const float cp = -gscale, cn = gscale;
           Vec<NC> ga, gtp, gtn;
           if (DEC == DEC_DIAG) {
@@ -1397,8 +1413,8 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
         }
         if (!BWD) continue;
         const float hinge = b.margin - (su[0] - su[1]);
-        const bool act = (q < B) && hinge > 0.f;
-        if (act) loss_part += hinge;
+        if ((q < B) && hinge > 0.f) loss_part += hinge;
+        const bool act = (q < B) && hinge > 0.f && !same_row<NC>(e, RT.row[rr], RN.row[rr], RT.x[rr], RN.x[rr]);   // (target == negative: see same_row)
         const float cf[2] = {act ? -gscale : 0.f, act ? gscale : 0.f};
         Vec<NC> ga = vzero<NC>();
 #pragma unroll
@@ -1594,8 +1610,8 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
       }
       if (!BWD) continue;
       const float hinge = b.margin - (sp - sn);
-      const bool act = (q < B) && hinge > 0.f;
-      if (act) loss_part += hinge;
+      if ((q < B) && hinge > 0.f) loss_part += hinge;
+      const bool act = (q < B) && hinge > 0.f && !same_row<NC>(e, RT.row[rr], RN.row[rr], tp, tn);   // (target == negative: see same_row)
       const float cp = act ? -gscale : 0.f, cn = act ? gscale : 0.f;
       const float ipq = gqe_rcp(ncp * nq), inq = gqe_rcp(ncn * nq), iqq = gqe_rcp(nq * nq);
       Vec<NC> gq, gtp, gtn;

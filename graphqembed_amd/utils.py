@@ -29,6 +29,11 @@ def get_encoder(depth, graph, out_dims, feature_modules, cuda=True, node_maps=No
     if depth != 0:
         raise Exception("only the depth-0 DirectEncoder is on the MI355X fast path "
                         "(GraphSAGE-style encoders of netquery/encoders.py:47-129 are out of scope)")
+    # (a graph from reddit_data.load_graph carries what the reference's feature closure knows: the id -> row maps and the posts' word lists)
+    if node_maps is None:
+        node_maps = getattr(graph, "node_maps", None)
+    if bags is None:
+        bags = getattr(graph, "bags", None)
     return DirectEncoder(graph.features, feature_modules, node_maps=node_maps, bags=bags)
 
 

@@ -114,11 +114,14 @@ def toy_batch(rng, qtype, B, hub=False, sizes=None):
 
 
 # ---- run_train trajectories against what the reference recorded (tests/golden/train_*.npz, trainlong_*.npz) ----------------
-def oracle_replay(p0, dec, inter, iterations, dtype=np.float32, lr=0.01):
+def oracle_replay(p0, dec, inter, iterations, dtype=np.float32, lr=0.01, signal=None):
     """The oracle's own trajectory over recorded iterations: ``iterations`` = [[(query type, rels, target, neg, anchors, weight,
     margin), ...] per iteration]; every iteration is zero_grad -> weighted margin losses -> backward -> Adam on the touched
     tensors (train_helpers.py:50-79).  Returns (iteration losses, final params, per-tensor step counts).  In float32 this is the
-    yardstick of the device tests: how far fp32 arithmetic alone lands from the reference's recorded numbers."""
+    yardstick of the device tests: how far fp32 arithmetic alone lands from the reference's recorded numbers.  ``signal`` (a
+    dict, filled in place): per tensor the mask of SIGNAL elements — those whose gradient in every step that touched the tensor
+    was exactly 0 or above 1e-4 of the tensor's largest; everywhere else Adam's sign-like first steps (dp = lr g / (|g| + 1e-8))
+    turn summation-order noise into lr-sized moves in the reference itself."""
     params = {k: np.array(v, dtype=dtype) for k, v in p0.items()}
     state, losses = {}, []
     for batches in iterations:
@@ -130,6 +133,10 @@ def oracle_replay(p0, dec, inter, iterations, dtype=np.float32, lr=0.01):
             total += w * float(l)
             touched |= O.touched_keys(plan, dec, inter)
         losses.append(total)
+        if signal is not None:
+            for k in touched:
+                g = np.abs(grads[k])
+                signal[k] = signal.get(k, np.ones(g.shape, dtype=bool)) & ((g == 0) | (g > 1e-4 * g.max()))
         O.adam_step(params, grads, state, touched, lr=lr)
     return np.asarray(losses), params, {k: st["step"] for k, st in state.items()}
 

@@ -1,0 +1,153 @@
+"""-m gpu: the Reddit entry point end to end (reddit/data_utils_new.py:143-182 + reddit/new_train.py:1-80): a data set written in the
+reference's file layout -> reddit_data.load_graph -> the reference's call sequence -> run_train; the converted (flat) files
+through the same script; and the loader's row conventions tied to numbers by the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def data_dir(tmp_path_factory):
+    from graphqembed_amd import reddit_data
+    d = str(tmp_path_factory.mktemp("reddit"))
+    reddit_data.write_synthetic_dataset(d, n_user=150, n_post=200, n_comm=15, n_words=120, edges_per_kind=1500, train_queries=(500, 800),
+                                        test_per_type=12, seed=5)
+    return d
+
+
+def build_model(data_dir, d, dec="bilinear", inter="mean", seed=0):
+    import torch
+    from graphqembed_amd import reddit_data, utils
+    from graphqembed_amd.model import QueryEncoderDecoder
+    torch.manual_seed(seed)
+    graph, feats = reddit_data.load_graph(data_dir, d)
+    dims = {m: d for m in graph.relations}
+    enc = utils.get_encoder(0, graph, dims, feats, True)           # the reference's call: no node_maps / bags arguments
+    return QueryEncoderDecoder(graph, enc, utils.get_metapath_decoder(graph, dims, dec), utils.get_intersection_decoder(graph, dims, inter))
+
+
+@pytest.mark.parametrize("dec,inter", [("bilinear", "mean"), ("bilinear-diag", "min")])
+def test_loaded_model_scores_and_gradients_match_the_oracle(data_dir, dec, inter):
+    """margin_loss / backward on batches of the loaded data set (a post-targeted chain, an intersection with post anchors) against
+    the numpy oracle given the same parameters and the loader's bags: the id + 1 rows of users / communities and the posts'
+    EmbeddingBag means are the reference's (reddit/data_utils_new.py:162-169)."""
+    import random
+    from graphqembed_amd import data_utils
+    from oracle import netquery_numpy as O
+    d = 32
+    model = build_model(data_dir, d, dec, inter)
+    train = data_utils.load_queries_by_formula(os.path.join(data_dir, "train_queries_2.pkl"))
+    train.update(data_utils.load_queries_by_formula(os.path.join(data_dir, "train_queries_3.pkl")))
+    params = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in model.state_dict().items()}
+    ptr, ids = model.enc.bag_csr["post"]
+    params[O.BAGS_KEY] = {"post": (ptr, ids)}
+    checked = 0
+    for qt in ("2-chain", "3-inter", "3-inter_chain"):
+        with_posts = [f for f in train[qt] if "post" in (f.target_mode,) + tuple(f.anchor_modes) and len(train[qt][f]) >= 8]
+        f = max(with_posts, key=lambda f: len(train[qt][f]))
+        qs = train[qt][f][:40]
+        random.seed(1)
+        model.zero_grad()
+        loss = model.margin_loss(f, qs)
+        loss.backward()
+        random.seed(1)
+        negs = [random.choice(q.neg_samples) for q in qs]                        # model.py:119-120
+        rows = lambda nodes, mode: model.enc.rows(nodes, mode)
+        t, ng = rows([q.target_node for q in qs], f.target_mode), rows(negs, f.target_mode)
+        a = np.stack([rows([q.anchor_nodes[i] for q in qs], m) for i, m in enumerate(f.anchor_modes)])
+        plan = O.make_plan(f.query_type, f.rels)
+        want, _, _, grads = O.margin_fwd_bwd(params, plan, dec, inter, t, ng, a)
+        np.testing.assert_allclose(loss.item(), want, rtol=2e-5)
+        for k, p in model.named_parameters():
+            if k in O.touched_keys(plan, dec, inter):
+                scale = max(np.abs(grads[k]).max(), 1e-12)
+                np.testing.assert_allclose(p.grad.cpu().numpy(), grads[k], rtol=2e-3, atol=4e-6 * scale + 1e-9, err_msg=qt + " " + k)
+                checked += 1
+    assert checked >= 9
+
+
+def run_script(args, cwd):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "train_reddit.py")] + args, cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    return out.stdout + out.stderr
+
+
+def test_train_reddit_script_on_pickles_and_on_converted_files(data_dir, tmp_path):
+    """examples/train_reddit.py (= reddit/new_train.py) on the pickles, then on the directory tools/convert_data.py --reddit writes:
+    both train (the moving average of the loss falls, validation and test lines appear, the model file holds the reference's
+    state_dict keys) and — same seeds, same lists in the same order — log the same numbers to float-atomics noise."""
+    import torch
+    common = ["--embed_dim", "32", "--batch_size", "64", "--max_iter", "300", "--max_burn_in", "100", "--val_every", "100", "--seed", "2"]
+    a_dir, b_dir = tmp_path / "a", tmp_path / "b"
+    a_dir.mkdir(); b_dir.mkdir()
+    log_a = run_script(["--data_dir", data_dir, "--cuda", "--log_dir", str(a_dir), "--model_dir", str(a_dir)] + common, str(a_dir))
+    flat = str(tmp_path / "flat")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "convert_data.py"), "--reddit", data_dir, flat], stdout=subprocess.DEVNULL)
+    log_b = run_script(["--data_dir", flat, "--flat", "--log_dir", str(b_dir), "--model_dir", str(b_dir)] + common, str(b_dir))
+
+    def numbers(log):
+        ema = [float(l.rsplit(" ", 1)[1]) for l in log.splitlines() if "ema_loss" in l]
+        auc = [float(l.split("val AUC: ")[1].split()[0]) for l in log.splitlines() if "val AUC" in l]
+        macro = [float(l.rsplit(" ", 1)[1]) for l in log.splitlines() if "Test macro-averaged val" in l]
+        return ema, auc, macro
+    ema_a, auc_a, macro_a = numbers(log_a)
+    ema_b, auc_b, macro_b = numbers(log_b)
+    assert len(ema_a) == 3 and len(macro_a) == 1 and "Edge converged at iteration 99" in log_a, log_a[-1500:]
+    # phase 2 starts its average over; within it the loss falls
+    assert ema_a[0] > 0.5 and np.isfinite(ema_a).all() and len(auc_a) >= 4 * 11, (ema_a, len(auc_a))
+    assert 0.4 < macro_a[0] <= 1.0
+    np.testing.assert_allclose(ema_b, ema_a, rtol=2e-3)
+    assert len(auc_b) == len(auc_a) and np.abs(np.array(auc_b) - np.array(auc_a)).max() < 0.03 and abs(macro_a[0] - macro_b[0]) < 0.01
+    name = [n for n in os.listdir(str(a_dir)) if n.endswith(".model")]
+    assert name == ["%s-0-32-0.010000-bilinear-mean.model" % os.path.basename(data_dir)], os.listdir(str(a_dir))
+    sd = torch.load(os.path.join(str(a_dir), name[0]), map_location="cpu")
+    assert {"enc.feat-post.weight", "enc.feat-user.weight", "enc.feat-community.weight", "inter_dec.post_premat", "path_dec.user_make_post"} <= set(sd)
+    assert sd["path_dec.user_make_post"].shape == (32, 32)
+    assert os.path.exists(os.path.join(str(a_dir), name[0] + "-edge_conv"))          # train_helpers.py:61-62
+
+
+def test_run_train_on_the_loaded_data_learns(data_dir):
+    """run_train (FusedAdam, native runs) on the loaded lists: training-set AUC of the edge queries rises well above chance and the
+    word table moves."""
+    import random
+    import torch
+    from graphqembed_amd import data_utils, train_helpers, utils
+    from graphqembed_amd.graph import Query
+    from graphqembed_amd.model import FusedAdam
+    model = build_model(data_dir, 32, "bilinear-diag", "min", seed=1)
+    train = data_utils.load_queries_by_formula(os.path.join(data_dir, "train_edges.pkl"))
+    for i in (2, 3):
+        train.update(data_utils.load_queries_by_formula(os.path.join(data_dir, "train_queries_%d.pkl" % i)))
+    val = data_utils.load_test_queries_by_formula(os.path.join(data_dir, "val_edges-split.pkl"))
+    for i in (2, 3):
+        more = data_utils.load_test_queries_by_formula(os.path.join(data_dir, "val_queries_%d-clean.pkl" % i))
+        val["one_neg"].update(more["one_neg"]); val["full_neg"].update(more["full_neg"])
+    # what training fits: the first training edges of a few relations, each with one sampled negative
+    random.seed(4)
+    fit = {}
+    for f, qs in list(train["1-chain"].items())[:6]:
+        fit[f] = [Query(q.query_graph if q.query_graph is not None else ("1-chain", (q.target_node, f.rels[0], q.anchor_nodes[0])),
+                        model.graph.get_negative_edge_samples((q.target_node, f.rels[0], q.anchor_nodes[0]), 1), None, 2, keep_graph=True) for q in qs[:60]]
+    w0 = model.state_dict()["enc.feat-post.weight"].detach().cpu().clone()
+
+    class Log(object):
+        lines = []
+
+        def info(self, m):
+            self.lines.append(m)
+    before = utils.eval_auc_queries(fit, model)[0]
+    random.seed(7); np.random.seed(7)
+    train_helpers.run_train(model, FusedAdam(model, lr=0.01), train, val, val, Log(), max_burn_in=200, batch_size=128, log_every=100,
+                            val_every=200, max_iter=500)
+    after = utils.eval_auc_queries(fit, model)[0]
+    assert after > before + 0.15 and after > 0.7, (before, after)
+    w1 = model.state_dict()["enc.feat-post.weight"].detach().cpu()
+    assert torch.isfinite(w1).all() and float((w1 - w0).abs().max()) > 1e-3
+    assert sum("val AUC" in l for l in Log.lines) >= 3 * 11
