@@ -302,11 +302,14 @@ struct GqeSplitSegs {           // the rows the step's feed names: segment k = i
   int idx_begin[GQE_SPLIT_SEGS];     // int32 offset from the launch's idx pointer
   int8_t tid[GQE_SPLIT_SEGS];        // slot in GqeSplitTabs (-1: skip)
 };
+#define GQE_SPLIT_MAX_ENTRIES 65535   // feed entries of a split step: the owner of a row is named in 16 bits of its stamp
+#define GQE_SPLIT_MAX_EPOCH 32767     // ... under a 15-bit epoch
+
 struct GqeSplitRide {
   GqeSplitTabs t;
   float *p, *m, *v;
-  const int32_t* stamp;   // [total rows], indexed like head[]: == epoch: named by this step's feed (stepped by the second launch,
-  int epoch;              // which exchanges it with epoch + 1: claimed); anything else: an older step's — not named.  epoch += 2 per step
+  const int32_t* stamp;   // [total rows], indexed like head[]: epoch << 16 | e: named by this step's feed, owned by its entry e (which
+  int epoch;              // steps the row in the second launch); anything else: an older step's — not named.  epoch += 1 per step (15 bits)
   float b1, b2, eps;
   int blocks;             // rider workgroups of the launch (0: a plain fused launch) ...
   int lead;               // ... of which this many come FIRST in the grid (they start with the launch, on CUs of their own); the

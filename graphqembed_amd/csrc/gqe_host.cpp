@@ -119,7 +119,7 @@ struct gqe_ctx {
   // workgroups in its fused launch; split_t / split_segs / split_idx describe the stepped tables and the rows its feed names;
   // mat_pending = d x d matrices whose Adam step waits for the next step's first launch (or flush_split)
   bool split_active = false, split_launched = false;
-  int split_epoch = -1;   // stamp value of the current split step's named rows (odd; += 2 per step)
+  int split_epoch = -1;   // epoch of the current split step's stamps (gqe_split.h: stamp = epoch << 16 | owning feed entry; += 1 per step)
   GqeSplitTabs split_t;
   long long split_stream_bytes = 0;   // 12 B per parameter of the tables the riders stream (p, m, v): sizes the lead riders
   GqeSplitRide split_ride;   // the rider description of the fused launch (its second launch continues the same ticket counter)
@@ -931,13 +931,14 @@ int split_first_launch(gqe_ctx* ctx, const gqe_batch* batches, int n_batches, co
   if (!ok) return fail(ctx, GQE_ERR_STATE, "internal: split step with more than %d index segments", GQE_SPLIT_SEGS);
   ctx->split_idx = d_idx;
   int32_t* stamp = reinterpret_cast<int32_t*>(ctx->ws + L.stamp_off);
-  // stamps carry the step's epoch (odd: named; + 1: named and claimed): never reset, a step that failed between its launches
-  // leaves nothing a later step would read as its own
-  ctx->split_epoch += 2;
-  if (ctx->split_epoch > (1 << 30)) {
+  // stamps carry the step's epoch in their high bits (and the owning feed entry in the low 16, gqe_split.h): a step that failed
+  // between its launches leaves nothing a later step would read as its own; the array is cleared when the 15-bit epoch wraps
+  ctx->split_epoch = ctx->split_epoch < 1 ? 1 : ctx->split_epoch + 1;
+  if (ctx->split_epoch > GQE_SPLIT_MAX_EPOCH) {
     HIP_TRY(ctx, hipMemsetAsync(stamp, 0, sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), st));
     ctx->split_epoch = 1;
   }
+  if (sg.total > GQE_SPLIT_MAX_ENTRIES) return fail(ctx, GQE_ERR_STATE, "internal: split step with %d feed entries", sg.total);
   // The riders: `lead` of them come first in the grid — they own a CU each from the launch's first microsecond (the tiles are
   // 1024-thread workgroups, one per CU; ~100 streaming CUs come close to saturating the memory system and slow the tiles'
   // latency chains: tools/probes/rider_probe.hip, split_timeline.py) — the others follow the tiles and start where a tile has
@@ -2888,6 +2889,10 @@ int gqe_train_step(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, co
     for (int bi = 0; bi < n_batches; ++bi) tiles += (batches[bi].n_queries + GQE_TQ - 1) / GQE_TQ;
     static const bool many_ok = getenv("GQE_SPLIT_MANY_TILES") != nullptr;   // (experiment 85: the split step on launches of thousands of tiles)
     split = split && (tiles <= GQE_FW8_MIN_TILES || many_ok);
+    // (a row's stamp carries the feed entry that owns it in its low 16 bits: gqe_split.h)
+    long long feed_entries = 0;
+    for (int bi = 0; bi < n_batches; ++bi) feed_entries += (long long)batches[bi].n_queries * (2 + GQE_MAX_BRANCH);
+    split = split && feed_entries <= GQE_SPLIT_MAX_ENTRIES;
   }
   std::vector<gqe_segment> resolved(segs, segs + n_segs);
   GqeSplitTabs st;

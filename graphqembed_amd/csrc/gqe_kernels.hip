@@ -1032,7 +1032,8 @@ __device__ __forceinline__ bool split_entry(const GqeSplitSegs& segs, const int3
 
 // launch M: Adam on the d x d matrices the previous step left pending (their gradients were completed by that step's riding GEMM
 // units, a kernel boundary ago; their operand-ordered copies are rewritten for the fused launch behind this one), and the stamps
-// of the rows THIS step's feed names.  Duplicates store the same value.
+// of the rows THIS step's feed names: epoch << 16 | feed entry.  Entries that name the same row race with plain stores; the
+// one that stays is the row's owner in the second launch (no atomic claim there).
 __global__ __launch_bounds__(GQE_THREADS) void gqe_prestep_kernel(const GqeMatStep a, float* __restrict__ p, float* __restrict__ g,
                                                                  float* __restrict__ m, float* __restrict__ v, int d, float b1, float b2,
                                                                  float eps, int mat_blocks, int mark_blocks, const GqeSplitSegs segs,
@@ -1058,7 +1059,7 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_prestep_kernel(const GqeMatSt
   if (e >= segs.total) return;
   int lt, row;
   if (!split_entry(segs, idx, e, lt, row)) return;
-  stamp[ride.t.head_base[lt] + row] = ride.epoch;
+  stamp[ride.t.head_base[lt] + row] = (ride.epoch << 16) | e;   // (several entries, one row: one of the stores stays — that entry owns the row)
 }
 
 hipError_t gqe_launch_prestep(const GqeMatStep& ms, float* p, float* g, float* m, float* v, int d, float b1, float b2, float eps,
@@ -1072,7 +1073,7 @@ hipError_t gqe_launch_prestep(const GqeMatStep& ms, float* p, float* g, float* m
 }
 
 // launch B: workgroup 0 finalizes the losses, workgroups 1 .. units are the pair-GEMM units (gemm_ride_unit), then `row_blocks`
-// workgroups step the named rows — d / 4 lanes per feed entry; the entry that exchanges the row's stamp (epoch -> epoch + 1) owns the row
+// workgroups step the named rows — d / 4 lanes per feed entry; the entry the row's stamp names (launch M) owns the row
 // (a row named twice is stepped once), sums its gradient list and hot accumulators and applies Adam with exactly the eager pass's
 // arithmetic — and the rest are the ordinary chunk loop over the step's vectors (relation vectors: dense gradients the fused
 // tiles accumulated with atomics, complete since the kernel boundary).
@@ -1126,16 +1127,15 @@ __global__ __launch_bounds__(GQE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
   if (!split_entry(rsegs, idx, e, lt, row)) return;
   const long long hrow = t.head_base[lt] + row;
   const long long off = t.offset[lt] + (long long)row * d + c4;
-  // everything the update needs is requested before the claim's round trip is awaited
-  int mine = 0;
-  if (c4 == 0) mine = __hip_atomic_exchange(stamp + hrow, sr.epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sr.epoch ? 1 : 0;
+  // the owner of the row is the entry its stamp names (written by launch M: of the entries that name a row, one store stayed):
+  // a load next to the others, no atomic claim
+  const int owner = stamp[hrow];
   float4 pp = *reinterpret_cast<const float4*>(p + off);
   float4 mm = *reinterpret_cast<const float4*>(m + off);
   float4 vv = *reinterpret_cast<const float4*>(v + off);
   const int h0 = head[hrow];
   const int hs = hot.slot ? hot.slot[hrow] : -1;
-  mine = __shfl(mine, (threadIdx.x & 63) / tpr * tpr);
-  if (mine == 0) return;  // another entry of the feed names the same row and got there first
+  if (owner != ((sr.epoch << 16) | e)) return;  // another entry of the feed names the same row and owns it
   float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
   if (h0 >= 0) {
     int len;

@@ -3,12 +3,13 @@
 //
 // A dense Adam step moves every row of every stepped table, but a step's batches name ~15-20 % of them.  The other rows have
 // no gradient: their update reads nothing the fused kernel writes, and the fused kernel reads none of them.  So the step is
-//     launch M   Adam on the d x d matrices of the PREVIOUS step (gqe_prestep_kernel) + stamp[row] := epoch for every row this
-//                step's index feed names (the epoch grows by 2 per step: stamps are never reset),
+//     launch M   Adam on the d x d matrices of the PREVIOUS step (gqe_prestep_kernel) + stamp[row] := epoch << 16 | e for every
+//                entry e of this step's index feed (plain stores: of the entries that name a row, one — whichever store lands
+//                last — is left in the stamp and OWNS the row in launch B; the epoch grows by 1 per step, 15 bits),
 //     launch A   the fused tiles  |  "rider" workgroups: Adam (zero gradient) over rows without this step's stamp, until the
 //                last tile has finished,
-//     launch B   loss finalize + pair-GEMM units  |  the named rows: claim the stamp (exchange with epoch + 1: duplicates in
-//                the feed resolve to one owner), list / hot-accumulator gradient, Adam  |  what the riders left of the other
+//     launch B   loss finalize + pair-GEMM units  |  the named rows: the entry the stamp names owns the row (a load: duplicates in
+//                the feed resolved without an atomic), list / hot-accumulator gradient, Adam  |  what the riders left of the other
 //                rows  |  the relation vectors,
 // and the matrices of this step wait for the next launch M (or gqe_optimizer_sync / any other entry point).
 // There is no dependency inside a launch (on this part a dependency is a kernel boundary).
@@ -53,11 +54,10 @@ __device__ __forceinline__ int split_stamps(const GqeSplitRide& r, int wb, int l
 #pragma unroll
   for (int k = 1; k < GQE_SPLIT_TABLES; ++k) ti += (k < r.t.n && wb >= r.t.blk_begin[k]) ? 1 : 0;
   const long long r0 = (long long)(wb - r.t.blk_begin[ti]) * GQE_SPLIT_WROWS;
-  // 1 = named by this step's feed (r.epoch: stamped, r.epoch + 1: stamped and already claimed by the second launch — the
-  // leftover riders run next to the claims), or past the table's end: nothing to do
+  // 1 = named by this step's feed (stamp = epoch << 16 | owning feed entry), or past the table's end: nothing to do
   if (lane >= GQE_SPLIT_WROWS || r0 + lane >= r.t.rows[ti]) return 1;
   const int s = r.stamp[r.t.head_base[ti] + r0 + lane];
-  return (s == r.epoch || s == r.epoch + 1) ? 1 : 0;
+  return (s >> 16) == r.epoch ? 1 : 0;
 }
 
 // rider j's wave blocks [lo, hi): the lead riders (j < r.lead: on a CU of their own for the whole launch) own r.share times the
