@@ -156,7 +156,16 @@ class Workload(object):
         draw — hub rows collect hundreds of gradient contributions per step (synth.CsrGraph)."""
         from graphqembed_amd import synth
         self.name, self.d, self.decoder, self.inter, self.mix, self.B, self.zipf = name, d, decoder, inter, mix, B, zipf
-        self.g = synth.reddit_synth(seed=0, zipf=zipf) if name == "reddit-synth" else synth.bio_synth(seed=0, zipf=zipf)
+        if name == "reddit-synth":
+            # GQE_BENCH_REDDIT_SCALE (--reddit-scale): the config-5 world shrunk by that factor — functional runs of many ranks on one GPU
+            scale = float(os.environ.get("GQE_BENCH_REDDIT_SCALE", "1"))
+            kw = {}
+            if scale != 1.0:
+                kw = dict(sizes={m: max(64, int(n * scale)) for m, n in synth.REDDIT_SYNTH_SIZES.items()},
+                          edges_per_kind=max(2000, int(synth.REDDIT_SYNTH_EDGES_PER_KIND * scale)), n_words=max(256, int(synth.REDDIT_SYNTH_WORDS * scale)))
+            self.g = synth.reddit_synth(seed=0, zipf=zipf, **kw)
+        else:
+            self.g = synth.bio_synth(seed=0, zipf=zipf)
         self.layout = build_layout(self.g, d, decoder, inter)
         self.types = sorted(set(m[0] for m in mix))
         self.pools = synth.make_pools(self.g, self.types, formulas_per_type=formulas_per_type, pool_size=max(16 * B, 8192), seed=0)
@@ -687,9 +696,12 @@ def api_path(args, d, decoder, inter, B, iterations=120):
 
     def spy_run(self, first, n, all_types):
         q0 = self.model.engine.feeder_queries(self.feeder)
+        h0 = self.model.engine.feeder_host_seconds(self.feeder)
         t0 = time.perf_counter()
         res = orig_run(self, first, n, all_types)             # (returns behind the copy of the run's loss history: the device is idle)
-        runs.append((n, all_types, time.perf_counter() - t0, self.model.engine.feeder_queries(self.feeder) - q0))
+        dt = time.perf_counter() - t0
+        h1 = self.model.engine.feeder_host_seconds(self.feeder)
+        runs.append((n, all_types, dt, self.model.engine.feeder_queries(self.feeder) - q0, h1[0] - h0[0], h1[1] - h0[1]))
         return res
     train_helpers._NativeLoop.run = spy_run
     evals = []
@@ -714,6 +726,10 @@ def api_path(args, d, decoder, inter, B, iterations=120):
     n_it, dt, q = sum(r[0] for r in full), sum(r[2] for r in full), sum(r[3] for r in full)
     out = {"value": round(q / dt, 1), "unit": "queries/s", "iterations": n_it, "ms_per_iteration": round(dt / n_it * 1e3, 4),
            "queries_per_iteration": round(q / n_it, 1), "split_steps": model.engine.split_steps(),
+           "host_us_per_iteration": {"sampling_and_packing": round(sum(r[4] for r in full) / n_it * 1e6, 1), "inside_gqe_feeder_run": round(sum(r[5] for r in full) / n_it * 1e6, 1),
+                                     "note": "one host thread (gqe_feeder_host_seconds): the reference's formula draws and negatives replayed on its MT19937 streams, packing, "
+                                             "pinned upload and the three launches of every iteration; ms_per_iteration above is wall time — the loop is bound by the device when "
+                                             "the two agree.  queries_per_iteration < 9 x B: the reference's wrap-around windows (train_helpers.py:102-105) cut batches short at a list's end"},
            "native_runs": [{"iterations": r[0], "all_types": bool(r[1]), "ms": round(r[2] * 1e3, 3)} for r in runs],
            "run_train_seconds": round(t_run, 2), "setup_seconds": round(t_build, 1),
            "validation": {"queries": sum(len(q) for by in held.values() for q in by.values()), "calls": len(evals),
@@ -955,6 +971,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the other SURVEY §8d configurations (N=1)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the gqe_feeder_run measurement (N=1)")
     ap.add_argument("--no-reddit", action="store_true", help="skip the secondary reddit-synth d=256 measurement")
+    ap.add_argument("--reddit-scale", type=float, default=None, help="shrink the reddit-synth world (nodes, edges, words) by this factor: "
+                    "functional runs of the config-5 workload with many ranks sharing one GPU — the line says so, it is no measurement")
     ap.add_argument("--no-api-path", action="store_true", help="skip the measurement of the reference-shaped API (run_train on Query objects, N=1)")
     ap.add_argument("--only-main", action="store_true", help="main measurement only (profiling runs)")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="timed blocks of --steps steps repeat until this much time was "
@@ -964,6 +982,8 @@ def main():
     if args.only_main:
         args.no_lazy = args.no_configs = args.no_host_fed = args.no_reddit = args.no_cpu_baseline = args.no_api_path = True
 
+    if args.reddit_scale is not None:
+        os.environ["GQE_BENCH_REDDIT_SCALE"] = repr(args.reddit_scale)      # (inherited by the ranks of a self-launch)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, sys.argv[1:]))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
@@ -1037,6 +1057,9 @@ def main():
     }
     if backend_note:
         out["config"]["backend_note"] = backend_note
+    if os.environ.get("GQE_BENCH_REDDIT_SCALE"):
+        out["config"]["reddit_scale"] = float(os.environ["GQE_BENCH_REDDIT_SCALE"])
+        out["config"]["reddit_scale_note"] = "reddit-synth shrunk by this factor (nodes, edges, words): a functional run, not the config-5 measurement"
     if fell_back:
         out["config"]["fell_back"] = "row-sharded step unavailable on this node (%s): replicated tables + sparse exchange measured" % fell_back
     for key in ("exchange_ms_per_step", "exchange_parts_ms", "planning", "ranks_seen", "replicas_identical"):
@@ -1058,6 +1081,18 @@ def main():
                                   "optimiser_ms": r["roofline"]["avg_launch_ms"], "optimiser_bytes_per_launch": r["roofline"]["algorithmic_bytes_per_launch"],
                                   "replicas_identical": r.get("replicas_identical")} for name, r in forms.items()}
         eng = None
+        # ... and what ONE rank does without any exchange, measured in this very run on every rank's GPU at once (each on its own
+        # replica of the whole model: the N = 1 line's step, gqe_train_step): the slowest rank's time is reported, so that a scaling
+        # table can be read against a same-box, same-run single-GPU step instead of another box's BENCH line
+        import torch
+        w1 = Workload(args.workload, d, args.decoder, args.inter_decoder, synth.FULL_MIX, B)
+        r1, e1, _ = measure(w1, args, None, 0, 1, **short)
+        e1.close()
+        t1 = torch.tensor([r1["ms_per_step"]], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+        out["single_rank_step"] = {"ms_per_step": round(float(t1.item()), 4), "value": round(w1.qpi / (float(t1.item()) * 1e-3), 1), "unit": "queries/s per GPU",
+                                   "step_form": r1.get("step_form"), "ranks_measured_at_once": world,
+                                   "note": "no exchange: every rank steps its own full replica on its own GPU, all ranks at the same time; max over ranks"}
     if world == 1 and not args.no_lazy and not args.lazy_adam:
         rl, el, _ = measure(wl, args, None, 0, 1, lazy=True)
         el.close()

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <string>
@@ -280,6 +281,7 @@ struct gqe_feeder {
   int64_t loss_stride = 0;   // > 0: iteration i of a run writes its losses at losses + (i - first_iteration) * loss_stride
   int64_t run_end = 0;       // (copy mode samples a group of iterations together: never past the end of the run)
   int64_t queries_fed = 0;   // queries of every batch packed so far (gqe_feeder_queries)
+  double host_build_s = 0, host_run_s = 0;   // wall time spent sampling + packing feeds / inside gqe_feeder_run (gqe_feeder_host_seconds)
   bool sgd = false;          // gqe_feeder_set_sgd: the iteration closes with gqe_sgd_step(lr) instead of the Adam step
 };
 
@@ -3295,7 +3297,15 @@ static void feeder_touch(gqe_feeder* f, int64_t offset, int64_t numel) {
 // sample + pack iteration `it` into f->batches / f->idx / f->segs: the reference's schedule (train_helpers.py:50-72): 1-chain
 // always; after burn-in every other type, chains once (path_weight), intersections with regular and with hard negatives
 // (inter_weight each)
+static int feeder_build_inner(gqe_feeder* f, int64_t it, int32_t burn_in);
 static int feeder_build(gqe_feeder* f, int64_t it, int32_t burn_in) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = feeder_build_inner(f, it, burn_in);
+  f->host_build_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
+}
+
+static int feeder_build_inner(gqe_feeder* f, int64_t it, int32_t burn_in) {
   gqe_ctx* ctx = f->ctx;
   const int d = ctx->cfg.dim;
   const bool bil = ctx->cfg.decoder == GQE_DEC_BILINEAR;
@@ -3438,9 +3448,20 @@ static int feeder_ensure(gqe_feeder* f, int64_t it, int32_t burn_in, hipStream_t
   return GQE_OK;
 }
 
+static int feeder_run_inner(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations, int32_t burn_in, float lr, float beta1, float beta2, float eps,
+                            float* losses, void* stream);
+
 int gqe_feeder_run(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations, int32_t burn_in, float lr, float beta1,
                    float beta2, float eps, float* losses, void* stream) {
   if (!f) return GQE_ERR_ARG;
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = feeder_run_inner(f, first_iteration, n_iterations, burn_in, lr, beta1, beta2, eps, losses, stream);
+  f->host_run_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
+}
+
+static int feeder_run_inner(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations, int32_t burn_in, float lr, float beta1, float beta2, float eps,
+                            float* losses, void* stream) {
   gqe_ctx* ctx = f->ctx;
   if (n_iterations < 1 || !losses) return fail(ctx, GQE_ERR_ARG, "bad arguments");
   if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
@@ -3519,6 +3540,13 @@ int gqe_feeder_run(gqe_feeder* f, int64_t first_iteration, int32_t n_iterations,
 }
 
 int64_t gqe_feeder_queries(gqe_feeder* f) { return f ? f->queries_fed : 0; }
+
+int gqe_feeder_host_seconds(gqe_feeder* f, double* build_s, double* run_s) {
+  if (!f || !build_s || !run_s) return GQE_ERR_ARG;
+  *build_s = f->host_build_s;
+  *run_s = f->host_run_s;
+  return GQE_OK;
+}
 
 int gqe_feeder_debug_feed(gqe_feeder* f, int64_t iteration, gqe_batch* batches, int32_t max_batches, int32_t* n_batches, int32_t* idx,
                           int64_t max_idx, int64_t* n_idx) {

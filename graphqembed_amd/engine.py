@@ -140,6 +140,7 @@ SYMBOLS = OrderedDict([
     ("gqe_adam_step_count", (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int32)])),
     ("gqe_set_adam_step_count", (C.c_int, [_P, C.c_int64, C.c_int32])),
     ("gqe_feeder_queries", (C.c_int64, [_P])),
+    ("gqe_feeder_host_seconds", (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)])),
     ("gqe_feeder_debug_feed", (C.c_int, [_P, C.c_int64, C.POINTER(gqe_batch), C.c_int32, C.POINTER(C.c_int32), _P, C.c_int64,
                                          C.POINTER(C.c_int64)])),
     ("gqe_feeder_run", (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P])),
@@ -861,6 +862,12 @@ class Engine(object):
 
     def feeder_queries(self, feeder):
         return int(self.lib.gqe_feeder_queries(feeder))
+
+    def feeder_host_seconds(self, feeder):
+        """(seconds spent sampling + packing, seconds inside gqe_feeder_run) of this feeder so far (gqe_feeder_host_seconds)."""
+        a, b = C.c_double(0), C.c_double(0)
+        self._check(self.lib.gqe_feeder_host_seconds(feeder, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def feeder_debug_feed(self, feeder, iteration):
         """(batches, idx) of one of the feeder's last prepared iterations: [(qtype, n_queries, n_anchors, idx_offset, loss_weight)]

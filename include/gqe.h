@@ -502,6 +502,9 @@ int gqe_feeder_set_loss_stride(gqe_feeder* f, int64_t stride);
 int gqe_feeder_set_sgd(gqe_feeder* f, int32_t enable);
 /* Queries of every batch the feeder has packed so far (throughput accounting: the windows at a list's end are shorter). */
 int64_t gqe_feeder_queries(gqe_feeder* f);
+/* Host wall time this feeder has spent so far sampling + packing feeds (build_s) and inside gqe_feeder_run altogether (run_s: the
+ * former + enqueueing uploads and launches + waiting for ring slots): what the host cores' share of a fed iteration is (bench.py). */
+int gqe_feeder_host_seconds(gqe_feeder* f, double* build_s, double* run_s);
 /* Debug / tests: the batches and the packed index feed (target | negative | anchors per batch) of one of the last prepared
  * iterations, as the kernels were given them; a NULL / too small output only reports the sizes. */
 int gqe_feeder_debug_feed(gqe_feeder* f, int64_t iteration, gqe_batch* batches, int32_t max_batches, int32_t* n_batches, int32_t* idx,

@@ -39,6 +39,8 @@ def test_bench_two_ranks_self_launch():
     assert "row-sharded" in out["config"]["gradient_exchange"]
     assert out["reddit_synth"]["ranks_seen"] == 2 and out["reddit_synth"]["replicas_identical"] is True
     assert out["scaling"] == "weak" and out["cpu_baseline"] is None
+    one = out["single_rank_step"]              # the N = 1 step measured inside the N-rank run (what a scaling table is read against)
+    assert one["ranks_measured_at_once"] == 2 and one["ms_per_step"] > 0 and one["step_form"] == "split"
 
 
 def test_bench_eight_ranks_gloo_smoke():
@@ -52,6 +54,23 @@ def test_bench_eight_ranks_gloo_smoke():
         assert form["replicas_identical"] is True and form["exchange_ms_per_step"] > 0 and form["value"] > 0
     assert out["exchange"]["sharded"]["optimiser_bytes_per_launch"] < 0.2 * out["exchange"]["dense"]["optimiser_bytes_per_launch"]
     assert out["config"]["queries_per_step_per_gpu"] == 4608 and "row-sharded" in out["config"]["gradient_exchange"]
+
+
+def test_bench_config5_eight_ranks_gloo_smoke():
+    """BASELINE config 5 at its named parallelism, functionally: the Reddit-shaped workload (EmbeddingBag post features, d = 256) as the
+    MAIN measurement on 8 ranks sharing this box's GPU over gloo — the row-sharded step with its replicated bag table, the slab
+    all-gather and north_star's dense all-reduce of the whole gradient arena, replicas compared after every form.  The world is
+    shrunk 20 x (--reddit-scale 0.05: 25 k users, 20 k posts over a 2 500-word table; 8 full replicas of the 141.7 M-parameter world
+    next to each other are a memory sweep, not a test) — the line says so."""
+    out = _run(["--gpus", "8", "--backend", "gloo", "--workload", "reddit-synth", "--reddit-scale", "0.05", "--steps", "4", "--warmup", "2",
+                "--exchange", "dense", "--no-reddit"], 1800)
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["replicas_identical"] is True
+    assert out["metric"].startswith("queries/sec, Reddit full conjunctive mix d=256")
+    assert set(out["exchange"]) == {"sharded", "sparse", "dense"}
+    for form in out["exchange"].values():
+        assert form["replicas_identical"] is True and form["value"] > 0
+    assert "all-reduce of the" in out["config"]["gradient_exchange"] and out["config"]["reddit_scale"] == 0.05
+    assert out["single_rank_step"]["ranks_measured_at_once"] == 8
 
 
 def test_bench_falls_back_to_the_sparse_exchange_when_the_sharded_session_fails():
