@@ -935,7 +935,11 @@ int split_first_launch(gqe_ctx* ctx, const gqe_batch* batches, int n_batches, co
   int32_t* stamp = reinterpret_cast<int32_t*>(ctx->ws + L.stamp_off);
   // stamps carry the step's epoch in their high bits (and the owning feed entry in the low 16, gqe_split.h): a step that failed
   // between its launches leaves nothing a later step would read as its own; the array is cleared when the 15-bit epoch wraps
-  ctx->split_epoch = ctx->split_epoch < 1 ? 1 : ctx->split_epoch + 1;
+  static const int epoch0 = [] {   // GQE_SPLIT_DEBUG_EPOCH0 (tests): the first split step's epoch — so that a few steps cross the wrap
+    const char* e = getenv("GQE_SPLIT_DEBUG_EPOCH0");
+    return e && atoi(e) > 0 && atoi(e) <= GQE_SPLIT_MAX_EPOCH ? atoi(e) : 1;
+  }();
+  ctx->split_epoch = ctx->split_epoch < 1 ? epoch0 : ctx->split_epoch + 1;
   if (ctx->split_epoch > GQE_SPLIT_MAX_EPOCH) {
     HIP_TRY(ctx, hipMemsetAsync(stamp, 0, sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), st));
     ctx->split_epoch = 1;

@@ -372,3 +372,51 @@ def test_train_step_with_a_bag_table(d):
     assert float(b.grads.abs().max()) == 0.0
     a.close()
     b.close()
+
+
+def test_split_step_epoch_wraps(tmp_path):
+    """The stamps carry a 15-bit epoch (gqe_split.h): every 32 767 split steps the array is cleared and the epoch starts over.  A
+    child process starts its epochs at 32 760 (GQE_SPLIT_DEBUG_EPOCH0) and runs 20 iterations across the wrap: every iteration
+    against the two-call step on the same state — same losses, unnamed rows bit-equal in p, m, v, named rows stepped (a stamp
+    misread on either side of the wrap would leave a named row to the riders, or an unnamed one to nobody)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import test_gpu_split as T
+from gpu_utils import read_arena
+from graphqembed_amd.tensorize import pack_margin_batches
+rng = np.random.RandomState(9)
+params, make = T._world(rng, 64, "bilinear-diag", "min")
+a, b = make(), make()
+for it in range(20):
+    items = T._batches(a, rng, ["1-chain", "2-inter", "3-chain"], 40 + it)
+    descs, idx, n = pack_margin_batches(items)
+    keys = set().union(*[p[0].touched for p in items])
+    b.params.copy_(a.params); b.exp_avg.copy_(a.exp_avg); b.exp_avg_sq.copy_(a.exp_avg_sq)
+    before = read_arena(b, b.params)
+    la, _, _ = a.margin_fwd_bwd(descs, idx, n)
+    a.adam_step(keys)
+    lb = b.train_step(descs, idx, keys)
+    np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=2e-5, atol=1e-7)
+    named = T._named_rows(items, a.layout)
+    for fa, fb in ((a.params, b.params), (a.exp_avg, b.exp_avg), (a.exp_avg_sq, b.exp_avg_sq)):
+        xa, xb = read_arena(a, fa), read_arena(b, fb)
+        for k in xa:
+            if k.startswith("enc."):
+                rows = np.ones(xa[k].shape[0], dtype=bool)
+                rows[sorted(named.get(k, ()))] = False
+                assert np.array_equal(xa[k][rows], xb[k][rows]), (it, k)
+                assert np.abs(xa[k][~rows].astype(np.float64) - xb[k][~rows]).max() < 1.1e-2, (it, k)
+    after = read_arena(b, b.params)
+    for k, rows in named.items():
+        moved = np.abs(after[k][sorted(rows)] - before[k][sorted(rows)]).max(axis=1)
+        assert (moved > 0).mean() > 0.5, (it, k)          # the named rows were stepped by somebody
+assert b.split_steps() == 20
+print("wrapped ok")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GQE_SPLIT_DEBUG_EPOCH0="32760")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "wrapped ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
