@@ -1262,6 +1262,10 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       // (a split step's second launch has no 45-us stream to hide behind: its units are the launch's critical chain and keep
       // the 128-query chunks)
       if (ride_candidate && !ctx->split_active && kmul < 2) kmul = 2;
+      // ... until there are so many of them that their atomic rows outweigh the chain: 256 queries per unit from 640 units on
+      // (round 6, one box: full Bilinear B = 512, 768 units: 85.5 -> 84.5 us per step; the headline's 320 units: 68.1 -> 69.8 the
+      // other way, full Bilinear B = 256, 384 units: 69.5 -> 71.5)
+      if (ride_candidate && ctx->split_active && kmul < 2 && units1 >= 640) kmul = 2;
       static const int forced = [] {   // GQE_DEBUG_GEMM_KMUL: tuning runs only
         const char* e = getenv("GQE_DEBUG_GEMM_KMUL");
         return e ? atoi(e) : 0;
