@@ -24,7 +24,7 @@ Fixture schema (all index arrays are TABLE ROWS = node_maps[mode][node] + 1):
   eval_<dec>_<inter>_d<D>.npz      eval_auc_queries / eval_perc_queries captures.
   adam1_<dec>_<inter>_d32.npz      per case: grad/<key> (the reference's dense gradient) and after/<key> (the parameter after
      ONE torch.optim.Adam step on that gradient).
-  trainlong_<dec>_<inter>_d32.npz  ``run_train`` for 400 iterations (100 edge-only + 300 with every type, batch 64, validation every
+  trainlong_<dec>_<inter>_d{32,128}.npz  ``run_train`` for 400 iterations (100 edge-only + 300 with every type, batch 64, validation every
      100 iterations) on the d=32 world, per seed S of the run (``seed_all(S)`` right before ``run_train``):
        s<S>/log (json list: every line the reference logged: ema_loss every 20 iterations, the val AUC / val perc lines of the
        edge-convergence evaluation, of the three validations and of the final test, the macro average and the improvement),
@@ -627,6 +627,14 @@ def gen_round6():
     gen_trainlong_case(world, by_formula, test_queries, "bilinear-diag", "min", (41, 42, 43))
     gen_trainlong_case(world, by_formula, test_queries, "bilinear", "mean", (41,))
     gen_trainlong_case(world, by_formula, test_queries, "transe", "min-simple", (41,))
+    # ... and the headline decoder pair at d = 128 — the dimension whose kernels carry the split step's riders (the timed path):
+    # the same graph, the same query sets (they do not depend on d), tables_d128.npz
+    world128 = World(128)
+    by128 = sample_queries(world128)
+    test128 = sample_long_test_queries(world128, by128, per_type=96)
+    same = {s: [q.serialize() for t in test128[s] for f in test128[s][t] for q in test128[s][t][f]] for s in test128}
+    assert same == test, "the evaluation queries of the d = 128 run differ from queries_long_test.pkl"
+    gen_trainlong_case(world128, by128, test128, "bilinear-diag", "min", (41,))
 
 
 def gen_round2():
