@@ -635,6 +635,7 @@ def gen_round6():
     same = {s: [q.serialize() for t in test128[s] for f in test128[s][t] for q in test128[s][t][f]] for s in test128}
     assert same == test, "the evaluation queries of the d = 128 run differ from queries_long_test.pkl"
     gen_trainlong_case(world128, by128, test128, "bilinear-diag", "min", (41,))
+    gen_trainlong_case(world128, by128, test128, "bilinear", "mean", (41,))       # BASELINE config 4's decoder pair (MFMA hops)
 
 
 def gen_round2():
