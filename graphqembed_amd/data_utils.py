@@ -74,6 +74,34 @@ def make_synthetic_graph(mode_sizes, kinds=BIO_SYNTH_KINDS, edges_per_kind=BIO_S
     return dict(relations), adj_lists, node_ids
 
 
+REDDIT_RELATIONS = {   # netquery/reddit/data_utils_new.py:193-197
+    "user": [("post", "up"), ("post", "down"), ("post", "make"), ("post", "comment"), ("community", "subscribe")],
+    "post": [("user", "up"), ("user", "down"), ("user", "make"), ("user", "comment"), ("community", "belong")],
+    "community": [("post", "belong"), ("user", "subscribe")],
+}
+
+
+def make_reddit_tiny(n_user=80, n_post=120, n_comm=12, n_words=60, seed=0):
+    """The tiny Reddit-shaped world of the golden fixtures (oracle/make_golden.py::RedditWorld and the tests that rebuild it): node
+    ids PER MODE, 500 random edges per user-post kind, 250 per kind that involves communities, 3..12 word ids per post.
+    Returns (relations, adj_lists, post_words) with ``post_words[p]`` an int64 array.  The draw order is part of the fixtures."""
+    rng = np.random.RandomState(seed)
+    sizes = {"user": n_user, "post": n_post, "community": n_comm}
+    adj_lists = {}
+    for m1, lst in REDDIT_RELATIONS.items():
+        for (m2, name) in lst:
+            adj_lists.setdefault((m1, name, m2), defaultdict(set))
+    for (m1, name, m2) in list(adj_lists.keys()):
+        if m1 > m2:
+            continue                                   # fill each undirected kind once
+        n_edges = 500 if "community" not in (m1, m2) else 250
+        for u, v in zip(rng.randint(0, sizes[m1], n_edges).tolist(), rng.randint(0, sizes[m2], n_edges).tolist()):
+            adj_lists[(m1, name, m2)][u].add(v)
+            adj_lists[(m2, name, m1)][v].add(u)
+    post_words = {p: rng.randint(0, n_words, size=rng.randint(3, 13)).astype(np.int64) for p in range(n_post)}
+    return REDDIT_RELATIONS, adj_lists, post_words
+
+
 def make_node_maps(node_ids):
     """``{mode: {node_id: row}}`` with the reference's extra ``-1 -> -1`` entry
     (netquery/bio/data_utils.py:13-15); table row of a node = map value + 1."""

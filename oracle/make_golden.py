@@ -32,6 +32,8 @@ Fixture schema (all index arrays are TABLE ROWS = node_maps[mode][node] + 1):
        s<S>/sig_full[400], s<S>/sig_rows[400] (CRC32 of the iteration's batches: tests/golden_utils.batch_signature),
        s<S>/touched/<key> (per-tensor Adam step counts at the end);  param/<key> (initial decoder parameters, shared).
      The evaluation queries of these runs are tests/golden/queries_long_test.pkl (serialize() tuples, up to 96 per type).
+  trainlong-reddit_<dec>_<inter>_d32.npz  the same on the Reddit-shaped world (graphqembed_amd.data_utils.make_reddit_tiny; param/* holds
+     every table incl. the word table, bag/post/{ptr,ids} the posts' words; queries: queries_reddit_long.pkl).
   reddit_<dec>_<inter>_d{32,128}.npz  Reddit-shaped world (post features = nn.EmbeddingBag mean over word ids):
        param/* (all tables incl. the word table enc.feat-post.weight), bag/post/{ptr,ids} (CSR of the posts'
        word ids; a post's index row = its bag index), cases as in model_*.npz.
@@ -384,32 +386,14 @@ class RedditWorld(object):
     feature closure (lines 162-169, CPU branch) is restated below; everything downstream (Graph,
     DirectEncoder, decoders, QueryEncoderDecoder, optim) is the imported reference."""
 
-    RELATIONS = {  # reddit/data_utils_new.py:193-197
-        "user": [("post", "up"), ("post", "down"), ("post", "make"), ("post", "comment"), ("community", "subscribe")],
-        "post": [("user", "up"), ("user", "down"), ("user", "make"), ("user", "comment"), ("community", "belong")],
-        "community": [("post", "belong"), ("user", "subscribe")],
-    }
-
     def __init__(self, d, n_user=80, n_post=120, n_comm=12, n_words=60, seed=0):
-        from collections import defaultdict
         from netquery.graph import Graph
+        from graphqembed_amd.data_utils import make_reddit_tiny
         self.d = d
-        rng = np.random.RandomState(seed)
-        sizes = {"user": n_user, "post": n_post, "community": n_comm}
-        self.relations = self.RELATIONS
-        self.adj_lists = {}
-        for m1, lst in self.relations.items():
-            for (m2, name) in lst:
-                self.adj_lists.setdefault((m1, name, m2), defaultdict(set))
-        for (m1, name, m2) in list(self.adj_lists.keys()):
-            if m1 > m2:
-                continue                                   # fill each undirected kind once
-            n_edges = 500 if "community" not in (m1, m2) else 250
-            for u, v in zip(rng.randint(0, sizes[m1], n_edges).tolist(), rng.randint(0, sizes[m2], n_edges).tolist()):
-                self.adj_lists[(m1, name, m2)][u].add(v)
-                self.adj_lists[(m2, name, m1)][v].add(u)
+        # (the graph itself lives in the package, so that tests can rebuild it without the reference: same draws, same order)
+        self.relations, self.adj_lists, self.post_words_np = make_reddit_tiny(n_user, n_post, n_comm, n_words, seed)
+        self.RELATIONS = self.relations
         self.post_ids = list(range(n_post))
-        self.post_words_np = {p: rng.randint(0, n_words, size=rng.randint(3, 13)).astype(np.int64) for p in self.post_ids}
         post_words = {p: torch.LongTensor(w) for p, w in self.post_words_np.items()}
         seed_all(2000 + d)
         self.feature_modules = {"post": torch.nn.EmbeddingBag(n_words, d), "user": torch.nn.Embedding(n_user + 1, d),
@@ -527,7 +511,7 @@ def gen_adam1_case(world, by_formula, dec, inter, B, cases=("2-chain", "3-inter.
     np.savez_compressed(os.path.join(OUT, "adam1_%s_%s_d%d.npz" % (dec, inter, world.d)), **out)
 
 
-def gen_trainlong_case(world, by_formula, test_queries, dec, inter, seeds, B=64, max_burn_in=100, max_iter=400):
+def gen_trainlong_case(world, by_formula, test_queries, dec, inter, seeds, B=64, max_burn_in=100, max_iter=400, tag=None):
     """The reference's run_train (train_helpers.py:40-93) over both phases with validations on the way, once per seed: what it
     logged, every iteration's loss and a checksum of every iteration's batches -> trainlong_<dec>_<inter>_d32.npz."""
     import netquery.train_helpers as th
@@ -539,7 +523,7 @@ def gen_trainlong_case(world, by_formula, test_queries, dec, inter, seeds, B=64,
         model = world.build_model(dec, inter)
         if seed == seeds[0]:
             for k, v in state_np(model).items():
-                if not k.startswith("enc."):
+                if tag is not None or not k.startswith("enc."):      # (a tagged world ships its own tables: no tables_d<D>.npz)
                     out["param/" + k] = v
         spy = Spy(model)
         opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.01)
@@ -582,7 +566,10 @@ def gen_trainlong_case(world, by_formula, test_queries, dec, inter, seeds, B=64,
         for p, st in opt.state.items():
             out[pre + "touched/" + names[id(p)]] = np.int32(int(st["step"]))
         print("trainlong", dec, inter, "seed", seed, logger.lines[-2], flush=True)
-    np.savez_compressed(os.path.join(OUT, "trainlong_%s_%s_d%d.npz" % (dec, inter, world.d)), **out)
+    if tag is not None and hasattr(world, "bag_ptr"):
+        out["bag/post/ptr"], out["bag/post/ids"] = world.bag_ptr, world.bag_ids
+    name = "trainlong_%s_%s_d%d.npz" % (dec, inter, world.d) if tag is None else "trainlong-%s_%s_%s_d%d.npz" % (tag, dec, inter, world.d)
+    np.savez_compressed(os.path.join(OUT, name), **out)
 
 
 def sample_long_test_queries(world, by_formula, per_type=96):
@@ -636,6 +623,16 @@ def gen_round6():
     assert same == test, "the evaluation queries of the d = 128 run differ from queries_long_test.pkl"
     gen_trainlong_case(world128, by128, test128, "bilinear-diag", "min", (41,))
     gen_trainlong_case(world128, by128, test128, "bilinear", "mean", (41,))       # BASELINE config 4's decoder pair (MFMA hops)
+    # ... and a Reddit-shaped world (posts = nn.EmbeddingBag means over word rows): the bag path inside the loop.  Its graph is
+    # graphqembed_amd.data_utils.make_reddit_tiny; its query sets travel as serialize() tuples (queries_reddit_long.pkl)
+    rw = RedditWorld(32)
+    rby = sample_queries(rw, n2=500, n3=1000)
+    rtest = sample_long_test_queries(rw, rby, per_type=64)
+    rtrain = {t: [q.serialize() for f in rby[t] for q in rby[t][f]] for t in rby}
+    rtest_ser = {s: [q.serialize() for t in rtest[s] for f in rtest[s][t] for q in rtest[s][t][f]] for s in rtest}
+    with open(os.path.join(OUT, "queries_reddit_long.pkl"), "wb") as f:
+        pickle.dump({"train": rtrain, "test": rtest_ser}, f, protocol=2)
+    gen_trainlong_case(rw, rby, rtest, "bilinear-diag", "min", (41,), tag="reddit")
 
 
 def gen_round2():

@@ -122,7 +122,7 @@ def oracle_replay(p0, dec, inter, iterations, dtype=np.float32, lr=0.01, signal=
     dict, filled in place): per tensor the mask of SIGNAL elements — those whose gradient in every step that touched the tensor
     was exactly 0 or above 1e-4 of the tensor's largest; everywhere else Adam's sign-like first steps (dp = lr g / (|g| + 1e-8))
     turn summation-order noise into lr-sized moves in the reference itself."""
-    params = {k: np.array(v, dtype=dtype) for k, v in p0.items()}
+    params = {k: (v if k == O.BAGS_KEY else np.array(v, dtype=dtype)) for k, v in p0.items()}      # (the bag registry travels as it is)
     state, losses = {}, []
     for batches in iterations:
         grads = O.zero_grads_like(params, dtype)

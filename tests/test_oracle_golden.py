@@ -239,8 +239,8 @@ def test_trainlong_fixture_is_self_consistent():
     import json
     from gpu_utils import ema_series
     from golden_utils import parse_train_log
-    files = sorted(glob.glob(os.path.join(GOLDEN, "trainlong_*.npz")))
-    assert len(files) == 5          # three decoder families at d = 32 + the headline and the full-Bilinear pair at d = 128
+    files = sorted(glob.glob(os.path.join(GOLDEN, "trainlong*.npz")))
+    assert len(files) == 6          # three decoder families at d = 32, the headline and the full-Bilinear pair at d = 128, the Reddit-shaped world
     for path in files:
         z = np.load(path)
         meta = json.loads(str(z["meta"]))
