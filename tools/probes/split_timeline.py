@@ -9,7 +9,7 @@ os.environ.setdefault("GQE_SPLIT_PROF", "1")
 import torch
 import bench
 from graphqembed_amd import synth
-wl = bench.Workload("bio-synth", 128, "bilinear-diag", "min", synth.FULL_MIX, 512, n_distinct=4)
+wl = bench.Workload("bio-synth", 128, os.environ.get("TIMELINE_DECODER", "bilinear-diag"), os.environ.get("TIMELINE_INTER", "min"), synth.FULL_MIX, 512, n_distinct=4)
 eng = wl.engine()
 prep = wl.prepare(eng)
 for i in range(6):
