@@ -444,7 +444,7 @@ int gqe_set_intersection(gqe_ctx* ctx, int64_t pre_param, int64_t post_param, co
  * Where the split does not apply the call runs the two-call sequence (with the matrix-gradient units riding in the Adam pass as
  * under gqe_set_deferred_gemm when that applies): lazy Adam, gqe_set_exchange / gqe_set_shard, ordered sums, tables
  * far beyond the Infinity Cache (p + m + v of the stepped tables above 384 MB), gradients already pending from an earlier gqe_margin_fwd_bwd, dims whose kernels are not the
- * straight-line ones (d % 64 != 0), more than GQE_LAUNCH_BATCHES batches or 8 stepped tables.  GQE_SPLIT=0 in the environment
+ * straight-line ones (d % 64 != 0), more than GQE_LAUNCH_BATCHES batches or 8 stepped tables, feeds of more than 65 535 entries (a row's stamp names its owning feed entry in 16 bits).  GQE_SPLIT=0 in the environment
  * forces that sequence.  gqe_split_steps: how many calls ran as split steps (diagnostics, tests). */
 int gqe_train_step(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const int32_t* idx, int64_t n_idx, int32_t idx_on_device,
                    const gqe_segment* segs, int32_t n_segs, float lr, float beta1, float beta2, float eps, float* losses, void* stream);
