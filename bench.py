@@ -424,7 +424,8 @@ class Loop(object):
         # (profiles/r02_experiment_event_stride.log), every 16th still 1.1 us of this round's 71 us step (stride 16 / 64 / 256:
         # 71.6 / 70.5 / 70.2 us per step, two runs each on one box)
         # (several ranks: every 16th — their steps are longer, their timed regions hold fewer of them)
-        eng.timing_enable(int(os.environ.get("GQE_BENCH_EVENT_STRIDE", "64" if self.world == 1 else "16")))
+        # (... and never sparser than half a block: a 5-step smoke run of 8 ranks sharing one GPU may time a single block)
+        eng.timing_enable(int(os.environ.get("GQE_BENCH_EVENT_STRIDE", "64" if self.world == 1 else str(min(16, max(1, steps // 2))))))
         for i in range(warmup):
             step(i)
         self.fence()
