@@ -39,6 +39,8 @@ __device__ __forceinline__ void finalize_losses(const GqeDynPlan& plan, const fl
   }
 }
 
+__device__ __forceinline__ int unit_of_workgroup(int x, int units);
+
 __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDynPlan plan,
                                                                    const GqeDevFormula* __restrict__ formulas,
                                                                    const float* __restrict__ ws,
@@ -58,8 +60,8 @@ __global__ __launch_bounds__(GQE_THREADS) void gqe_pair_gemm_kernel(const GqeDyn
   // one workgroup = one unit (batch, job, K chunk of GQE_GEMM_KCHUNK queries, 64x64 block of the d x d gradient).
   // Both operand panels go through LDS in 64-query halves (float4 global loads, 80-float rows: the four k-rows an
   // MFMA step reads land 16 banks apart); each wave owns a 2x2 group of 16x16 MFMA tiles.
-  const int unit = (int)blockIdx.x - 1;
-  if (unit >= plan.units) return;
+  if ((int)blockIdx.x - 1 >= plan.units) return;
+  const int unit = unit_of_workgroup((int)blockIdx.x - 1, plan.units);   // (the blocks of one (job, chunk) on one XCD: defined below)
   constexpr int MT = GQE_GEMM_MT, KS = 64, STR = MT + 16;
   __shared__ float sL[KS * STR], sR[KS * STR];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -687,6 +689,16 @@ hipError_t gqe_launch_pair_gemm(const GqeFusedArgs& a, float* losses) {
 // columns j0 + 16 w ..) of the unit's 64 x 64 block; per step of four queries a lane reads ONE float4 of L — four consecutive
 // gradient rows: the A operands of four MFMAs whose output rows interleave (row = i0 + 4 * (lane & 15) + t) — and one float of R.
 #define GQE_RIDE_DEPTH 4   // steps of operands in flight per lane (8 measured the same)
+// Which unit a workgroup of a units' launch takes.  The 64 x 64 blocks of one (job, query chunk) are consecutive units and read the
+// same operand rows (at d = 128: four blocks, each half of L and of R read twice); consecutive workgroups go to different XCDs, each
+// with an L2 of its own (PMC, round 6: the units of the headline step fetched 20.7 MB for 10.5 MB of operand rows).  Workgroups x,
+// x + 8, x + 16, x + 24 share an XCD: those get four consecutive units.  (x = workgroup index among the units; a bijection on the
+// first units / 32 * 32 of them, the identity on the rest.)
+__device__ __forceinline__ int unit_of_workgroup(int x, int units) {
+  const int full = (units >> 5) << 5;
+  return x < full ? (((((x >> 3) >> 2) << 3) | (x & 7)) << 2) | ((x >> 3) & 3) : x;
+}
+
 __device__ __forceinline__ void gemm_ride_unit(const GqeDynPlan& plan, const GqeDevFormula* __restrict__ formulas, const float* __restrict__ ws,
                                                float* __restrict__ grads, int d, int unit) {
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -760,7 +772,7 @@ __global__ __launch_bounds__(GQE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
   }
   const int front = ride.plan.units + 1;
   if ((int)blockIdx.x < front) {
-    gemm_ride_unit(ride.plan, ride.formulas, ride.ws, g, d, (int)blockIdx.x - 1);
+    gemm_ride_unit(ride.plan, ride.formulas, ride.ws, g, d, unit_of_workgroup((int)blockIdx.x - 1, ride.plan.units));
     return;
   }
   GqeLazyArgs lazy;   // (never read: LAZY = false)
@@ -968,7 +980,7 @@ __global__ __launch_bounds__(GQE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
   const int front = ride.plan.units + 1;
   if ((int)blockIdx.x < front) {
     if (blockIdx.x == 0) finalize_losses(ride.plan, ride.tile_loss, ride.losses);
-    else gemm_ride_unit(ride.plan, ride.formulas, ride.ws, g, d, (int)blockIdx.x - 1);
+    else gemm_ride_unit(ride.plan, ride.formulas, ride.ws, g, d, unit_of_workgroup((int)blockIdx.x - 1, ride.plan.units));
     return;
   }
   const int rb = (int)blockIdx.x - front;
@@ -1089,8 +1101,11 @@ __global__ __launch_bounds__(GQE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
   const GqeSplitTabs& t = sr.t;
   const int front = ride.plan.units + 1;   // (units == -1: the pair GEMM and the finalize block ran as a launch of their own)
   if ((int)blockIdx.x < front) {
-    if (blockIdx.x == 0) finalize_losses(ride.plan, ride.tile_loss, ride.losses);
-    else gemm_ride_unit(ride.plan, ride.formulas, ride.ws, g, d, (int)blockIdx.x - 1);
+    if (blockIdx.x == 0) {
+      finalize_losses(ride.plan, ride.tile_loss, ride.losses);
+    } else {
+      gemm_ride_unit(ride.plan, ride.formulas, ride.ws, g, d, unit_of_workgroup((int)blockIdx.x - 1, ride.plan.units));
+    }
     return;
   }
   if ((int)blockIdx.x >= front + row_blocks + rider_blocks) {
