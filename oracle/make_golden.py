@@ -34,6 +34,7 @@ Fixture schema (all index arrays are TABLE ROWS = node_maps[mode][node] + 1):
      The evaluation queries of these runs are tests/golden/queries_long_test.pkl (serialize() tuples, up to 96 per type).
   trainlong-reddit_<dec>_<inter>_d32.npz  the same on the Reddit-shaped world (graphqembed_amd.data_utils.make_reddit_tiny; param/* holds
      every table incl. the word table, bag/post/{ptr,ids} the posts' words; queries: queries_reddit_long.pkl).
+  trainlong-sgd_<dec>_<inter>_d32.npz  the same on the d = 32 world with torch.optim.SGD(lr 0.1, momentum 0) (bio/train.py:59-60).
   reddit_<dec>_<inter>_d{32,128}.npz  Reddit-shaped world (post features = nn.EmbeddingBag mean over word ids):
        param/* (all tables incl. the word table enc.feat-post.weight), bag/post/{ptr,ids} (CSR of the posts'
        word ids; a post's index row = its bag index), cases as in model_*.npz.
@@ -511,14 +512,14 @@ def gen_adam1_case(world, by_formula, dec, inter, B, cases=("2-chain", "3-inter.
     np.savez_compressed(os.path.join(OUT, "adam1_%s_%s_d%d.npz" % (dec, inter, world.d)), **out)
 
 
-def gen_trainlong_case(world, by_formula, test_queries, dec, inter, seeds, B=64, max_burn_in=100, max_iter=400, tag=None):
+def gen_trainlong_case(world, by_formula, test_queries, dec, inter, seeds, B=64, max_burn_in=100, max_iter=400, tag=None, sgd_lr=None):
     """The reference's run_train (train_helpers.py:40-93) over both phases with validations on the way, once per seed: what it
     logged, every iteration's loss and a checksum of every iteration's batches -> trainlong_<dec>_<inter>_d32.npz."""
     import netquery.train_helpers as th
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from golden_utils import batch_signature
     out = {"meta": json.dumps({"batch_size": B, "max_burn_in": max_burn_in, "max_iter": max_iter, "log_every": 20, "val_every": 100,
-                               "lr": 0.01, "seeds": list(seeds)})}
+                               "lr": 0.01 if sgd_lr is None else sgd_lr, "optimizer": "adam" if sgd_lr is None else "sgd", "seeds": list(seeds)})}
     for seed in seeds:
         model = world.build_model(dec, inter)
         if seed == seeds[0]:
@@ -526,7 +527,10 @@ def gen_trainlong_case(world, by_formula, test_queries, dec, inter, seeds, B=64,
                 if tag is not None or not k.startswith("enc."):      # (a tagged world ships its own tables: no tables_d<D>.npz)
                     out["param/" + k] = v
         spy = Spy(model)
-        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.01)
+        if sgd_lr is None:
+            opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.01)
+        else:                                                   # bio/train.py:59-60: --opt sgd
+            opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=sgd_lr, momentum=0)
         iter_losses = []
         orig_update = th.update_loss
 
@@ -564,7 +568,8 @@ def gen_trainlong_case(world, by_formula, test_queries, dec, inter, seeds, B=64,
         out[pre + "sig_rows"] = np.asarray(sig_rows, dtype=np.uint32)
         names = {id(p): k for k, p in model.named_parameters()}
         for p, st in opt.state.items():
-            out[pre + "touched/" + names[id(p)]] = np.int32(int(st["step"]))
+            if "step" in st:                                    # (SGD without momentum keeps no state)
+                out[pre + "touched/" + names[id(p)]] = np.int32(int(st["step"]))
         print("trainlong", dec, inter, "seed", seed, logger.lines[-2], flush=True)
     if tag is not None and hasattr(world, "bag_ptr"):
         out["bag/post/ptr"], out["bag/post/ids"] = world.bag_ptr, world.bag_ids
@@ -633,6 +638,8 @@ def gen_round6():
     with open(os.path.join(OUT, "queries_reddit_long.pkl"), "wb") as f:
         pickle.dump({"train": rtrain, "test": rtest_ser}, f, protocol=2)
     gen_trainlong_case(rw, rby, rtest, "bilinear-diag", "min", (41,), tag="reddit")
+    # ... and --opt sgd (bio/train.py:59-60: torch.optim.SGD, momentum 0) on the d = 32 world
+    gen_trainlong_case(world, by_formula, test_queries, "bilinear-diag", "min", (41,), tag="sgd", sgd_lr=0.1)
 
 
 def gen_round2():

@@ -114,7 +114,7 @@ def toy_batch(rng, qtype, B, hub=False, sizes=None):
 
 
 # ---- run_train trajectories against what the reference recorded (tests/golden/train_*.npz, trainlong_*.npz) ----------------
-def oracle_replay(p0, dec, inter, iterations, dtype=np.float32, lr=0.01, signal=None):
+def oracle_replay(p0, dec, inter, iterations, dtype=np.float32, lr=0.01, signal=None, sgd=False):
     """The oracle's own trajectory over recorded iterations: ``iterations`` = [[(query type, rels, target, neg, anchors, weight,
     margin), ...] per iteration]; every iteration is zero_grad -> weighted margin losses -> backward -> Adam on the touched
     tensors (train_helpers.py:50-79).  Returns (iteration losses, final params, per-tensor step counts).  In float32 this is the
@@ -137,7 +137,10 @@ def oracle_replay(p0, dec, inter, iterations, dtype=np.float32, lr=0.01, signal=
             for k in touched:
                 g = np.abs(grads[k])
                 signal[k] = signal.get(k, np.ones(g.shape, dtype=bool)) & ((g == 0) | (g > 1e-4 * g.max()))
-        O.adam_step(params, grads, state, touched, lr=lr)
+        if sgd:
+            O.sgd_step(params, grads, touched, lr=lr)                 # torch.optim.SGD(momentum=0), bio/train.py:59-60
+        else:
+            O.adam_step(params, grads, state, touched, lr=lr)
     return np.asarray(losses), params, {k: st["step"] for k, st in state.items()}
 
 

@@ -240,7 +240,7 @@ def test_trainlong_fixture_is_self_consistent():
     from gpu_utils import ema_series
     from golden_utils import parse_train_log
     files = sorted(glob.glob(os.path.join(GOLDEN, "trainlong*.npz")))
-    assert len(files) == 6          # three decoder families at d = 32, the headline and the full-Bilinear pair at d = 128, the Reddit-shaped world
+    assert len(files) == 7          # three decoder families at d = 32, the headline and the full-Bilinear pair at d = 128, the Reddit-shaped world, --opt sgd
     for path in files:
         z = np.load(path)
         meta = json.loads(str(z["meta"]))
@@ -260,4 +260,4 @@ def test_trainlong_fixture_is_self_consistent():
             assert len(final) == 11 and abs(np.mean([v[0] for v in final.values()]) - log["macro"]) < 1e-6
             first = np.mean([v[0] for v in log["evals"][0]["scores"].values()])
             assert abs((log["macro"] - first) / first - log["improvement"]) < 2e-5
-            assert log["macro"] > first + 0.1          # (training fits what the AUC sets hold: a trajectory with a signal)
+            assert log["macro"] > first + (0.05 if meta.get("optimizer") == "sgd" else 0.1)      # (training fits what the AUC sets hold: a trajectory with a signal)
