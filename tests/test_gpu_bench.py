@@ -48,11 +48,11 @@ def test_bench_eight_ranks_gloo_smoke():
     8-way owner sort, every exchange form with 8 blocks per collective, tables of 10 002 / 40 002 / 27 002 rows sharded 8 ways
     (remainders of 2) — functional, not a measurement."""
     out = _run(["--gpus", "8", "--backend", "gloo", "--steps", "5", "--warmup", "2", "--no-reddit"], 1500)
-    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["replicas_identical"] is True
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["replicas_identical"] is True, {k: out.get(k) for k in ("n_gpus", "ranks_seen", "replicas_identical")}
     assert set(out["exchange"]) == {"sharded", "sparse", "dense"}
-    for form in out["exchange"].values():
-        assert form["replicas_identical"] is True and form["exchange_ms_per_step"] > 0 and form["value"] > 0
-    assert out["exchange"]["sharded"]["optimiser_bytes_per_launch"] < 0.2 * out["exchange"]["dense"]["optimiser_bytes_per_launch"]
+    for name, form in out["exchange"].items():
+        assert form["replicas_identical"] is True and form["exchange_ms_per_step"] > 0 and form["value"] > 0, (name, form)
+    assert out["exchange"]["sharded"]["optimiser_bytes_per_launch"] < 0.2 * out["exchange"]["dense"]["optimiser_bytes_per_launch"], out["exchange"]
     assert out["config"]["queries_per_step_per_gpu"] == 4608 and "row-sharded" in out["config"]["gradient_exchange"]
 
 

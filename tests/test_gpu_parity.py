@@ -909,8 +909,8 @@ def _second_step_vs_oracle(eng, wl, items, descs, didx, n, keys, dec, inter, mod
     "deferred": the same with gqe_set_deferred_gemm — the pair-GEMM units ride in the Adam pass; "train-step": gqe_train_step —
     the split step where it applies), and the PARAMETERS AFTER IT against the oracle: O.adam_step (fp64) on the oracle's gradient at
     the device's parameters / moments of the moment.  Rows the iteration names, vectors, matrices: elements whose gradient is
-    signal (|g| > 1e-4 max|g|, or exactly 0) within 2e-3 of the lr-sized move, at most 0.2 % of them on the other side of a relu /
-    arg-min decision; rows it does not name: the zero-gradient Adam formula to 1e-4 of the move (v_sqrt_f32 / v_rcp_f32 are 1 ulp)."""
+    signal (|g| > 1e-4 max|g|, or exactly 0) within 2e-3 of the lr-sized move, at most 0.2 % of them (or two rows of a d x d matrix) on
+    the other side of a relu / arg-min decision; rows it does not name: the zero-gradient Adam formula to 1e-4 of the move (v_sqrt_f32 / v_rcp_f32 are 1 ulp)."""
     import torch
     entries = eng.layout.entries
     # (the caller folded the lists with gqe_materialize_grads: until a pass consumes them the tables' DENSE gradients are
@@ -960,7 +960,12 @@ def _second_step_vs_oracle(eng, wl, items, descs, didx, n, keys, dec, inter, mod
             g, move, diff = g[named], move[named], diff[named]
         signal = (g == 0) | (g > 1e-4 * g.max())
         bad = signal & (diff > 2e-3 * move + 2e-7)
-        assert bad.sum() <= max(2, 2e-3 * signal.sum()), (mode, k, int(bad.sum()), int(signal.sum()), float(diff[signal].max()))
+        # (a d x d matrix: ONE query on the other side of a relu / arg-min decision changes a whole row or column of its gradient —
+        # d elements at once, 0.39 % of a 256 x 256 matrix: two such rows are allowed whatever the 0.2 % comes to)
+        allowed = max(2, 2e-3 * signal.sum())
+        if not k.startswith("enc.") and after[k].ndim == 2:
+            allowed = max(allowed, 2 * after[k].shape[1])
+        assert bad.sum() <= allowed, (mode, k, int(bad.sum()), int(signal.sum()), float(diff[signal].max()))
     for k in set(after) - set(keys):
         assert np.array_equal(after[k], before[k]), (mode, k)
     eng.materialize()
