@@ -1161,8 +1161,12 @@ def main():
             # the same workload with Zipfian word frequencies and node degrees (a real vocabulary: reddit/data_utils_new.py:155,162-169)
             wz = Workload("reddit-synth", 256, args.decoder, args.inter_decoder, synth.FULL_MIX, B, n_distinct=16, zipf=1.0)
             rz, ez, _ = measure(wz, args, None, 0, 1, **short)
+            hot_rows, (sub_lists, sub_on) = ez.hot_rows(), ez.hot_sub_lists()
             ez.close()
             zs = slim(rz)
+            zs["hot_rows"] = {"promoted": hot_rows, "word_sub_lists": sub_lists, "fused_launches_use_them": sub_on,
+                              "note": "include/gqe.h, gqe_hot_rows / gqe_hot_sub_lists; kernels_ms.fused_fwd_bwd here = the fused launch + the "
+                                      "gather launch behind it (one timing slot)"}
             zs["config"] = "reddit-synth with Zipf(1) word frequencies and node degrees (%s), same mix / d / decoders" % wz.describe()
             zs["rows_with_over_32_contributions"] = rz["rows_with_over_32_contributions"]
             zs["optimiser_vs_uniform"] = round(zs["optimiser"]["avg_launch_ms"] / rs["optimiser"]["avg_launch_ms"], 3)
@@ -1179,7 +1183,7 @@ def main():
             zs["after_300_steps"] = {"fused_fwd_bwd_ms": fz, "uniform_fused_fwd_bwd_ms": fu, "fused_vs_uniform": round(fz / fu, 3),
                                      "value": rz2["value"], "uniform_value": ru["value"], "unit": "queries/s",
                                      "note": "the same two workloads measured behind 300 training steps instead of 10: fewer active hinges, "
-                                             "so fewer contributions to the hot words' accumulators (DESIGN.md section 3, Hot rows; experiment 81)"}
+                                             "so fewer contributions to the hot words (DESIGN.md section 3, Hot rows; experiments 81, 101)"}
             out["reddit_synth_zipf"] = zs
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not reddit:
         out["cpu_baseline"] = cpu_baseline(eng, args.decoder, args.inter_decoder, wl.item_sets[:8], args.cpu_seconds, wl.qpi)

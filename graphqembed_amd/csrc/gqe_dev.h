@@ -132,6 +132,32 @@ struct GqeBagTable {
 #define GQE_HOT_SLOTS 2048
 #define GQE_HOT_MIN_LEN 24
 #define GQE_HOT_ROW(rep, slot) ((size_t)(slot) * GQE_HOT_REPS + (rep))
+// Hot WORD rows (bag tables).  A frequent word of an nn.EmbeddingBag table collects thousands of contributions per step, one per
+// bag that holds it: an atomic row (d floats) for each of them is 125 k x 1 KB of atomic traffic per step on reddit-synth with
+// Zipf(1) words — 1.3-1.5 x the fused launch of the uniform data set.  Such a row therefore also gets 2^lg SUB-LISTS (a power of two
+// sized from the list length that promoted it: ~GQE_HOT_SUB_LEN entries per sub-list and step) out of a pool.  A sub-list is an
+// ARRAY of GQE_HOT_SUB_CAP contribution entries behind a counter: the fused kernel takes a position with one 4-byte atomic add
+// (at the end of the kernel, where nothing waits for its round trip) and stores the bag's entry there; what does not fit goes onto
+// an overflow chain of ordinary link nodes.  gqe_hot_gather_kernel — launched behind the fused kernel — gives every sub-list a wave:
+// one load for the counter, one for the entries, the rows behind them all in flight, ONE atomic row into the word's accumulators.
+// (Linked sub-lists were the first form: a chain of a dozen dependent loads per list made the gather 54 us — EXPERIMENTS.md 101.)
+// The consumers see what they saw before: accumulators.  slot[] value of a hot row = slot | (lg + 1) << 11 | first sub-list << 15;
+// (lg + 1) == 0: no sub-lists (the pool was full) — contributions are added directly.  Plain (non-bag) roles always add directly.
+#define GQE_HOT_SUB_POOL 32768
+#define GQE_HOT_SUB_CAP 128
+#define GQE_HOT_SUB_LEN 32
+#define GQE_HOT_SUB_MAX_LG 10
+#define GQE_HOT_SLOT_OF(v) ((v) & (GQE_HOT_SLOTS - 1))
+#define GQE_HOT_SUB_LG1(v) (((v) >> 11) & 15)
+#define GQE_HOT_SUB_BASE(v) ((v) >> 15)
+// the pool (GqeHot.sub): counters, overflow-chain heads, the accumulator slot of each sub-list, the entry arrays
+#define GQE_HOT_SUB_CNT(sub) (sub)
+#define GQE_HOT_SUB_OVF(sub) ((sub) + GQE_HOT_SUB_POOL)
+#define GQE_HOT_SUB_SLOT(sub) ((sub) + 2 * GQE_HOT_SUB_POOL)
+#define GQE_HOT_SUB_BUF(sub) ((sub) + 3 * GQE_HOT_SUB_POOL)
+#define GQE_HOT_SUB_INTS ((size_t)(3 + GQE_HOT_SUB_CAP) * GQE_HOT_SUB_POOL)
+// what a lane keeps for push_links instead of a previous list head when its word goes to sub-list i: -2 - i
+#define GQE_HOT_SUB_TAG(i) (-2 - (i))
 // Row-sharded margin steps run by a session (gqe_shard_step): an index of the position feed that is >= GQE_OWN_ROW names row
 // (index - GQE_OWN_ROW) of this rank's OWN shard of the role's table — the fused kernel reads it where it lives and links its
 // contribution itself, exactly as in the unsharded step; smaller indices are positions in the fetched-row buffer.
@@ -142,6 +168,12 @@ struct GqeHot {
   float* acc;        // [cap][GQE_HOT_REPS][d]
   int32_t* count;    // slots handed out so far (may run past cap: rows promoted beyond it stay on lists)
   int32_t cap, min_len;
+  // sub-lists of hot word rows (above).  sub == NULL in the struct a PRODUCER gets: it adds directly whatever slot[] says (the
+  // host has not seen a promotion yet — `seen` is a word of pinned host memory a promoting kernel sets — or the mode has no
+  // gather launch); consumers always get the pointers
+  int32_t* sub;        // the pool (GQE_HOT_SUB_CNT / OVF / SLOT / BUF), handed out in blocks of 2^lg sub-lists
+  int32_t* sub_count;  // sub-lists handed out so far (may run past the pool: later promotions get none)
+  int32_t* seen;       // pinned host memory, or NULL
 };
 
 struct GqeDynPlan {
@@ -355,6 +387,9 @@ struct GqeFusedArgs {
 // can the fused kernel this launch would select carry rider workgroups (split.blocks > 0)?  (the straight-line d % 64 == 0 kernels)
 int gqe_fused_can_ride(int dec, int mlp, int d, int tiles);
 hipError_t gqe_launch_fused(int dec, int mlp, const GqeFusedArgs& a);
+// the hot word rows' sub-lists summed into their accumulators (GqeHot): behind every backward fused launch that got hot.sub
+hipError_t gqe_launch_hot_gather(const GqeHot& hot, const int32_t* next, const float* contrib, const int32_t* link_contrib, int max_entries, int d,
+                                 hipStream_t stream);
 int gqe_config_supported(int dec, int inter, int d);   // gqe_kernels.hip, next to the dispatcher
 void gqe_fused_variant(int dec, int d, int tiles, int* nc, int* full, int* fw);
 hipError_t gqe_launch_pair_gemm(const GqeFusedArgs& a, float* losses);

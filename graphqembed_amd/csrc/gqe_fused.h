@@ -65,6 +65,7 @@ struct TileEnv {
   // contribution is an entry on a list
   const int32_t* hot_slot;
   float* hot_acc;
+  int32_t* hot_sub;           // sub-lists of the hot word rows (GqeHot.sub; NULL: hot words are added directly)
   int rep;                    // the replica of a hot row's accumulators this wave adds to: (its XCD, its wave index mod 4)
   int hotv;                   // lane role * RPW + rr: the hot slot of the plain row this wave owns for that role (-1: not hot).
                               // ONE vector load issued in front of the row gathers (same in-order counter: it has landed when
@@ -77,7 +78,7 @@ struct TileEnv {
 // hundreds (hub nodes) or thousands (frequent words) of entries, one dependent load each.
 template <int NC, bool FULL>
 __device__ __forceinline__ void hot_add(const TileEnv& e, int slot, const Vec<NC>& gx) {
-  float* acc = e.hot_acc + GQE_HOT_ROW(e.rep, slot) * e.d;
+  float* acc = e.hot_acc + GQE_HOT_ROW(e.rep, GQE_HOT_SLOT_OF(slot)) * e.d;
   gatomic_add<NC, FULL>(acc, gx, e.d, e.lane);
 }
 
@@ -721,6 +722,20 @@ __device__ __forceinline__ void scatter_norm_bwd(const TileEnv& e, int64_t head_
   }
 }
 
+// A bag's entry onto sub-list `sub` of a hot word row (gqe_dev.h): a position from the counter, the entry stored there; a full
+// array (GQE_HOT_SUB_CAP: four times what the row's promotion sized it for) overflows onto a chain of ordinary link nodes.
+__device__ __forceinline__ void hot_sub_store(const TileEnv& e, int sub, int pos, int entry, int node) {
+  if (pos < GQE_HOT_SUB_CAP) {
+    GQE_HOT_SUB_BUF(e.hot_sub)[(size_t)sub * GQE_HOT_SUB_CAP + pos] = entry;
+  } else {
+    e.link_contrib[node] = entry;
+    e.next[e.max_entries + node] = __hip_atomic_exchange(GQE_HOT_SUB_OVF(e.hot_sub) + sub, e.max_entries + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ void hot_sub_push(const TileEnv& e, int sub, int entry, int node) {
+  hot_sub_store(e, sub, __hip_atomic_fetch_add(GQE_HOT_SUB_CNT(e.hot_sub) + sub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), entry, node);
+}
+
 // bag mode: one contribution (already divided by the bag length: EmbeddingBag mean backward) shared by every
 // word row of the bag through link nodes: node -> (contribution entry, next).  The nodes of entry e are e * max_len + k
 // (k = position of the word in the bag): no allocator, no counter to reset.  As for plain rows, the previous list heads
@@ -748,12 +763,22 @@ __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t h
   const int base = (int)entry * max_len;
   for (int c0 = 0; c0 < len; c0 += 64) {
     const int k = c0 + e.lane;
-    int hs = -1;   // this lane's word row is hot: its slot
+    int hs = -1;   // this lane's word row is hot and has no sub-lists: its slot
     if (k < len) {
       const int node = base + k;
       const int w = ids[p0 + k];
       if (e.hot_slot) hs = e.hot_slot[head_base + w];
-      if (hs < 0) {
+      int sub = -1;   // a frequent word with sub-lists (gqe_dev.h): the one this bag's entry goes to
+      if (hs >= 0 && e.hot_sub && GQE_HOT_SUB_LG1(hs)) {
+        sub = GQE_HOT_SUB_BASE(hs) + ((int)entry & ((1 << (GQE_HOT_SUB_LG1(hs) - 1)) - 1));
+        hs = -1;
+      }
+      if (sub >= 0) {
+        if (DEFER && c0 == 0)
+          old_head = GQE_HOT_SUB_TAG(sub);   // push_links takes the position: nothing here waits for an atomic's round trip
+        else
+          hot_sub_push(e, sub, (int)entry, node);
+      } else if (hs < 0) {
         e.link_contrib[node] = (int)entry;
         const int old = __hip_atomic_exchange(e.head + head_base + w, e.max_entries + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (DEFER && c0 == 0)
@@ -764,7 +789,7 @@ __device__ __forceinline__ void scatter_norm_bwd_bag(const TileEnv& e, int64_t h
         old_head = GQE_NO_PUSH;   // nothing was linked for this word
       }
     }
-    // frequent words: the bag's contribution is added to each hot word's accumulators, one wave-wide atomic row per word
+    // frequent words without sub-lists: the bag's contribution is added to the word's accumulators, one wave-wide atomic row each
     if (e.hot_slot) {
       unsigned long long todo = __ballot(hs >= 0);
       while (todo) {
@@ -830,15 +855,31 @@ __device__ __forceinline__ void push_links(const TileEnv& e, const int (&olds)[R
           e.next[e.bag_shift + e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + e.wave * RPW + rr)] = olds[rr][role];
     return;
   }
+  // hot words with sub-lists (lanes that kept GQE_HOT_SUB_TAG(sub)): the positions of all roles first — their atomics travel
+  // together, one round trip per wave at the end of the kernel — then the stores
+  int pos[RPW][2 + GQE_MAX_BRANCH];
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+    for (int role = 0; role < 2 + GQE_MAX_BRANCH; ++role) {
+      const int o = olds[rr][role];
+      pos[rr][role] = -1;
+      if (e.hot_sub && blens[rr][role] > 0 && e.lane < blens[rr][role] && o <= GQE_HOT_SUB_TAG(0) && o != GQE_NO_PUSH)
+        pos[rr][role] = __hip_atomic_fetch_add(GQE_HOT_SUB_CNT(e.hot_sub) + (GQE_HOT_SUB_TAG(0) - o), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
     for (int role = 0; role < 2 + GQE_MAX_BRANCH; ++role) {
       const int64_t q = e.b.entry_base + (int64_t)role * e.b.B + (e.q0 + e.wave * RPW + rr);
+      const int o = olds[rr][role];
       if (blens[rr][role] > 0) {
-        if (e.lane < blens[rr][role] && olds[rr][role] != GQE_NO_PUSH) e.next[e.max_entries + (int)(e.bag_shift + q) * max_len + e.lane] = olds[rr][role];
-      } else if (e.lane == 0 && olds[rr][role] != GQE_NO_PUSH) {
-        e.next[e.bag_shift + q] = olds[rr][role];
+        if (pos[rr][role] >= 0)
+          hot_sub_store(e, GQE_HOT_SUB_TAG(0) - o, pos[rr][role], (int)(e.bag_shift + q), (int)(e.bag_shift + q) * max_len + e.lane);
+        else if (e.lane < blens[rr][role] && o != GQE_NO_PUSH && (!e.hot_sub || o > GQE_HOT_SUB_TAG(0)))
+          e.next[e.max_entries + (int)(e.bag_shift + q) * max_len + e.lane] = o;
+      } else if (e.lane == 0 && o != GQE_NO_PUSH) {
+        e.next[e.bag_shift + q] = o;
       }
     }
 }
@@ -1014,6 +1055,7 @@ __global__ __launch_bounds__(GQE_FWT, (FusedShape<DEC, MLP, NC, FULL, FW>::MIN_W
   e.q0 = (tile_id - b.tile_begin) * GQE_TQ;
   e.hot_slot = BWD ? hot.slot : nullptr;
   e.hot_acc = hot.acc;
+  e.hot_sub = BWD ? hot.sub : nullptr;
   e.rep = 0;
   e.hotv = -1;
   if (BWD && hot.slot) {

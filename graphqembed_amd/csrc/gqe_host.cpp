@@ -83,6 +83,7 @@ struct Layout {  // byte offsets inside the bound workspace
   int64_t tile_floats;
   int n_tile_spans;
   int64_t tile_span_lo[8], tile_span_hi[8], tile_span_base[8];   // arena floats [lo, hi) -> mirror floats from base (base = lo mod 64)
+  size_t hot_sub_off;                 // hot word rows: the pool of sub-lists (GQE_HOT_SUB_INTS)
   size_t hot_slot_off, hot_acc_off;   // hot rows (GqeHot): slot per table row, GQE_HOT_REPS x GQE_HOT_SLOTS accumulators of dim floats
   size_t stamp_off;   // split step (gqe_train_step): one int32 per table row, 1 = named by the step's index feed
   size_t progress_off;   // ... and the riders' progress slots (GqeSplitRide::progress)
@@ -107,6 +108,11 @@ struct gqe_ctx {
   std::vector<Table> tables;
   std::vector<Bag> bags;
   bool links_used = false;  // link nodes were allocated since the last consumption
+  // hot word rows' sub-lists (GqeHot): a word of pinned host memory that a promoting kernel sets, its device address, and whether
+  // the fused launches link onto sub-lists yet (set when the host first reads the word as non-zero)
+  int32_t* hot_seen = nullptr;
+  int32_t* hot_seen_dev = nullptr;
+  mutable bool hot_sub_on = false;
   // the d x d matrices the registered formulas contract with (arena offsets, sorted); tiles_dirty: their operand-ordered copies
   // have to be rebuilt before the next fused launch (new workspace, new matrix, gqe_params_changed)
   std::vector<int64_t> matrices;
@@ -396,7 +402,8 @@ Layout make_layout(const gqe_ctx* ctx, int64_t max_queries, int32_t max_batches)
   L.ring_off = L.last_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
   L.hot_slot_off = L.ring_off + align_up(sizeof(float) * 2 * GQE_LAZY_TABLES * GQE_LAZY_RING, 256);
   L.hot_acc_off = L.hot_slot_off + align_up(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->total_rows, 1), 256);
-  L.tile_off = L.hot_acc_off + align_up(sizeof(float) * (size_t)GQE_HOT_REPS * GQE_HOT_SLOTS * ctx->cfg.dim, 256);
+  L.hot_sub_off = L.hot_acc_off + align_up(sizeof(float) * (size_t)GQE_HOT_REPS * GQE_HOT_SLOTS * ctx->cfg.dim, 256);
+  L.tile_off = L.hot_sub_off + (ctx->bags.empty() ? 0 : align_up(sizeof(int32_t) * GQE_HOT_SUB_INTS, 256));
   {
     GqeSpans sp = dense_spans(ctx);
     if (sp.n < 0) {   // more than 8 non-table spans: mirror the whole arena
@@ -775,6 +782,22 @@ GqeHot hot_args(const gqe_ctx* ctx, bool produce) {
   h.cap = GQE_HOT_SLOTS;
   h.min_len = off ? 0x7fffffff : min_len;
   if (produce && (off || ctx->world > 1 || ctx->ordered_sums)) h.slot = nullptr;
+  // sub-lists of hot word rows: only contexts with bag tables have the pool.  A producer gets it once the host has seen a
+  // promotion (the word of pinned memory a promoting kernel sets; until then it adds directly, which is always correct) —
+  // run_queries launches the gather behind every producer that got it
+  static const bool sub_off = [] {
+    const char* e = getenv("GQE_HOT_SUB");
+    return e && atoi(e) == 0;
+  }();
+  h.sub = h.sub_count = h.seen = nullptr;
+  if (!ctx->bags.empty() && !sub_off && ctx->hot_seen) {
+    if (!ctx->hot_sub_on && *static_cast<volatile int32_t*>(ctx->hot_seen) != 0) ctx->hot_sub_on = true;
+    if (!produce || (h.slot && ctx->hot_sub_on)) {
+      h.sub = reinterpret_cast<int32_t*>(ctx->ws + L.hot_sub_off);
+      h.sub_count = reinterpret_cast<int32_t*>(ctx->ws + L.counter_off + 68);
+      h.seen = ctx->hot_seen_dev;
+    }
+  }
   return h;
 }
 
@@ -1364,6 +1387,8 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
     rc = timing_begin(ctx, 0, st);
     if (rc != GQE_OK) return rc;
     HIP_TRY(ctx, gqe_launch_fused(ctx->cfg.decoder, is_mlp(ctx) ? 1 : 0, fa));
+    if (bwd && fa.hot.slot && fa.hot.sub)   // hot word rows: their sub-lists into their accumulators (inside the fused launch's timing slot)
+      HIP_TRY(ctx, gqe_launch_hot_gather(fa.hot, fa.next, fa.contrib_bag, fa.link_contrib, fa.max_entries, d, st));
     rc = timing_end(ctx, 0, st);
     if (rc != GQE_OK) return rc;
     if (any_candidates) HIP_TRY(ctx, gqe_launch_eval_score(fa, ctx->cfg.decoder, pos));
@@ -2173,6 +2198,7 @@ void shard_session_free_fwd(gqe_ctx* ctx);
 int gqe_destroy(gqe_ctx* ctx) {
   if (!ctx) return GQE_OK;
   shard_session_free_fwd(ctx);
+  if (ctx->hot_seen) (void)hipHostFree(ctx->hot_seen);
   for (auto& s : ctx->ring) {
     if (s.in_flight) (void)hipEventSynchronize(s.done);
     if (s.done) (void)hipEventDestroy(s.done);
@@ -2326,6 +2352,18 @@ int gqe_bind_workspace(gqe_ctx* ctx, void* workspace, int64_t bytes, void* strea
   // hot rows: none yet, empty accumulators
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.hot_slot_off, 0xff, L.hot_acc_off - L.hot_slot_off, reinterpret_cast<hipStream_t>(stream)));
   HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.hot_acc_off, 0, sizeof(float) * (size_t)GQE_HOT_REPS * GQE_HOT_SLOTS * ctx->cfg.dim, reinterpret_cast<hipStream_t>(stream)));
+  if (L.tile_off > L.hot_sub_off) {   // hot word rows' sub-lists: empty counters, empty overflow chains
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.hot_sub_off, 0, sizeof(int32_t) * (size_t)GQE_HOT_SUB_POOL, reinterpret_cast<hipStream_t>(stream)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ws + L.hot_sub_off + sizeof(int32_t) * (size_t)GQE_HOT_SUB_POOL, 0xff, sizeof(int32_t) * (size_t)GQE_HOT_SUB_POOL,
+                                reinterpret_cast<hipStream_t>(stream)));
+  }
+  if (!ctx->bags.empty() && !ctx->hot_seen) {
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->hot_seen), 64, hipHostMallocMapped));
+    HIP_TRY(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->hot_seen_dev), ctx->hot_seen, 0));
+  }
+  // (a promotion still in flight on another stream could set the word again after this: the gather then runs over empty sub-lists)
+  if (ctx->hot_seen) *static_cast<volatile int32_t*>(ctx->hot_seen) = 0;
+  ctx->hot_sub_on = false;
   for (auto& t : ctx->tables) {
     t.pending = false;
     t.since_full = 0;
@@ -2429,6 +2467,16 @@ int gqe_hot_rows(gqe_ctx* ctx, int32_t* n_hot) {
   int32_t n = 0;
   HIP_TRY(ctx, hipMemcpy(&n, ctx->ws + ctx->lay.counter_off + 64, sizeof n, hipMemcpyDeviceToHost));
   *n_hot = std::min<int32_t>(n, GQE_HOT_SLOTS);
+  return GQE_OK;
+}
+
+int gqe_hot_sub_lists(gqe_ctx* ctx, int32_t* n_heads, int32_t* active) {
+  if (!ctx || !n_heads || !active) return GQE_ERR_ARG;
+  if (!ctx->ws) return fail(ctx, GQE_ERR_STATE, "gqe_bind_workspace has not been called");
+  int32_t n = 0;
+  HIP_TRY(ctx, hipMemcpy(&n, ctx->ws + ctx->lay.counter_off + 68, sizeof n, hipMemcpyDeviceToHost));
+  *n_heads = ctx->bags.empty() ? 0 : std::min<int32_t>(n, GQE_HOT_SUB_POOL);
+  *active = hot_args(ctx, true).sub != nullptr;
   return GQE_OK;
 }
 

@@ -289,6 +289,7 @@ __device__ __forceinline__ float4 hot_take(const GqeHot& hot, int hs, int d, int
   // <= 64 VGPRs, i.e. its occupancy)
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 s = zero4;
+  hs = GQE_HOT_SLOT_OF(hs);   // (the value of slot[] also names the row's sub-lists)
 #pragma unroll 1
   for (int x = 0; x < GQE_HOT_REPS; x += 2) {
     float* p0 = hot.acc + GQE_HOT_ROW(x, hs) * d + c4;
@@ -311,7 +312,91 @@ __device__ __forceinline__ void hot_promote(const GqeHot& hot, long long hrow, i
   // counter for ever — one contended atomic each, and after ~1e5 steps an int32 wrap that hands slots out twice)
   if (__hip_atomic_load(hot.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hot.cap) return;
   const int s = __hip_atomic_fetch_add(hot.count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (s >= 0 && s < hot.cap) hot.slot[hrow] = s;
+  if (s < 0 || s >= hot.cap) return;
+  // sub-lists for the row's bag entries (gqe_dev.h): ~GQE_HOT_SUB_LEN entries each at the length that promoted the row
+  int v = s;
+  if (hot.sub) {
+    int lg = 0;
+    while ((GQE_HOT_SUB_LEN << lg) < len && lg < GQE_HOT_SUB_MAX_LG) ++lg;
+    const int n = 1 << lg;
+    if (__hip_atomic_load(hot.sub_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + n <= GQE_HOT_SUB_POOL) {
+      const int base = __hip_atomic_fetch_add(hot.sub_count, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (base >= 0 && base + n <= GQE_HOT_SUB_POOL) {
+        for (int i = 0; i < n; ++i) GQE_HOT_SUB_SLOT(hot.sub)[base + i] = s;
+        v = s | ((lg + 1) << 11) | (base << 15);
+      }
+    }
+  }
+  hot.slot[hrow] = v;
+  if (hot.seen) __hip_atomic_store(hot.seen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the host starts the gather launches
+}
+
+// The sub-lists of the hot word rows (gqe_dev.h), behind a fused launch with bag roles: one wave per sub-list — its counter, its
+// entries (lanes i and i + 64 = entries i, i + 64), the contribution rows behind them (eight in flight), then the SUM
+// into the row's accumulators with one atomic row; the counter is reset.  An overflow chain (more than GQE_HOT_SUB_CAP entries
+// in one step) is walked node by node.
+__global__ void __launch_bounds__(256) gqe_hot_gather_kernel(const GqeHot hot, const int32_t* __restrict__ next, const float* __restrict__ contrib,
+                                                             const int32_t* __restrict__ link_contrib, int max_entries, int d) {
+  const int n_sub = min(__hip_atomic_load(hot.sub_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), GQE_HOT_SUB_POOL);
+  const int lane = threadIdx.x & 63;
+  const int waves = (int)gridDim.x * 4;
+  int32_t* cnt = GQE_HOT_SUB_CNT(hot.sub);
+  int32_t* ovf = GQE_HOT_SUB_OVF(hot.sub);
+  for (int h = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)); h < n_sub; h += waves) {
+    const int taken = __builtin_amdgcn_readfirstlane(cnt[h]);
+    const int x0 = __builtin_amdgcn_readfirstlane(ovf[h]);
+    if (taken == 0 && x0 < 0) continue;
+    const int n = min(taken, GQE_HOT_SUB_CAP);
+    if (lane == 0) {
+      cnt[h] = 0;
+      if (x0 >= 0) ovf[h] = -1;
+    }
+    const int slot = __builtin_amdgcn_readfirstlane(GQE_HOT_SUB_SLOT(hot.sub)[h]);
+    const int32_t* buf = GQE_HOT_SUB_BUF(hot.sub) + (size_t)h * GQE_HOT_SUB_CAP;
+    const int mine0 = lane < n ? buf[lane] : 0, mine1 = lane + 64 < n ? buf[lane + 64] : 0;   // (GQE_HOT_SUB_CAP == 128)
+    float* acc = hot.acc + GQE_HOT_ROW(h & (GQE_HOT_REPS - 1), slot) * d;
+    // columns lane, lane + 64, ...: every load and every atomic instruction of the wave covers 256 contiguous bytes (16-byte
+    // lane slices made the atomic rows four times as many 64-byte operations: 42 us for this kernel instead of 18)
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};   // (d <= 256)
+#define GQE_SUB_ENTRY(j) ((j) < 64 ? __builtin_amdgcn_readlane(mine0, (j)) : __builtin_amdgcn_readlane(mine1, (j) - 64))
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {   // eight rows in flight (a group never straddles entry 64)
+      const float* r[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) r[k] = contrib + (size_t)GQE_SUB_ENTRY(j + k) * d + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (lane + 64 * c < d) {
+          float a[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) a[k] = r[k][64 * c];
+          s0[c] += (a[0] + a[2]) + (a[4] + a[6]);
+          s1[c] += (a[1] + a[3]) + (a[5] + a[7]);
+        }
+    }
+    for (; j < n; ++j) {
+      const float* r0 = contrib + (size_t)GQE_SUB_ENTRY(j) * d + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (lane + 64 * c < d) s0[c] += r0[64 * c];
+    }
+#undef GQE_SUB_ENTRY
+    for (int y = x0; y >= 0; y = __builtin_amdgcn_readfirstlane(next[y])) {   // the overflow chain (rare)
+      const float* r0 = contrib + (size_t)__builtin_amdgcn_readfirstlane(link_contrib[y - max_entries]) * d + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (lane + 64 * c < d) s1[c] += r0[64 * c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (lane + 64 * c < d) unsafeAtomicAdd(acc + lane + 64 * c, s0[c] + s1[c]);
+  }
+}
+
+hipError_t gqe_launch_hot_gather(const GqeHot& hot, const int32_t* next, const float* contrib, const int32_t* link_contrib, int max_entries, int d,
+                                 hipStream_t stream) {
+  hipLaunchKernelGGL(gqe_hot_gather_kernel, dim3(2048), dim3(256), 0, stream, hot, next, contrib, link_contrib, max_entries, d);
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------

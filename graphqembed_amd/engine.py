@@ -101,6 +101,7 @@ SYMBOLS = OrderedDict([
     ("gqe_set_shard", (C.c_int, [_P, C.c_int32, C.c_int32])),
     ("gqe_set_ordered_sums", (C.c_int, [_P, C.c_int32])),
     ("gqe_hot_rows", (C.c_int, [_P, C.POINTER(C.c_int32)])),
+    ("gqe_hot_sub_lists", (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)])),
     ("gqe_shard_layout", (C.c_int, [_P, C.POINTER(gqe_shard_buffers)])),
     ("gqe_shard_plan", (C.c_int, [_P, C.POINTER(gqe_batch), C.c_int32, _P, C.c_int64, C.c_int32, _P, _P, _P])),
     ("gqe_shard_serve", (C.c_int, [_P, _P, C.c_int64, _P, _P])),
@@ -737,6 +738,13 @@ class Engine(object):
         n = C.c_int32(0)
         self._check(self.lib.gqe_hot_rows(self.ctx, C.byref(n)))
         return int(n.value)
+
+    def hot_sub_lists(self):
+        """(sub-list heads handed out to hot word rows so far, whether the fused launches link onto them yet) — include/gqe.h,
+        gqe_hot_sub_lists; synchronises."""
+        n, on = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.gqe_hot_sub_lists(self.ctx, C.byref(n), C.byref(on)))
+        return int(n.value), bool(on.value)
 
     def materialize(self):
         """Fold pending per-row gradient lists into the dense gradient arena (gqe_materialize_grads)."""

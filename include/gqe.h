@@ -326,6 +326,15 @@ int gqe_set_ordered_sums(gqe_ctx* ctx, int32_t enable);
  * gqe_set_ordered_sums (atomic sums are order-dependent); GQE_HOT=0 in the environment disables it, GQE_HOT_MIN_LEN=n changes
  * the promotion threshold.  gqe_hot_rows: how many rows have been promoted so far (synchronises the device). */
 int gqe_hot_rows(gqe_ctx* ctx, int32_t* n_hot);
+/* Hot WORD rows (contexts with bag tables).  A frequent word collects thousands of contributions per step, one per bag that holds
+ * it; an atomic row for each is what made the fused launch of reddit-synth with Zipf(1) words 1.3-1.5 x the uniform one.  A
+ * promoted row therefore also gets 2^k sub-lists out of a pool of 65536 list heads (k from the list length that promoted it: about
+ * a dozen nodes per sub-list and step): the fused kernel links a bag's node onto one of them — the 4-byte exchange every other word
+ * costs — and a gather launch behind it sums every sub-list with a wave of its own into the row's accumulators.  The fused launches
+ * switch to sub-lists when the host has seen a promotion (a word of pinned memory the promoting kernel sets: no synchronisation);
+ * GQE_HOT_SUB=0 in the environment keeps the atomic rows.  gqe_hot_sub_lists: heads handed out so far, and whether the fused
+ * launches link onto them yet (synchronises the device). */
+int gqe_hot_sub_lists(gqe_ctx* ctx, int32_t* n_heads, int32_t* active);
 int gqe_shard_layout(gqe_ctx* ctx, gqe_shard_buffers* out);     /* after gqe_bind_workspace */
 /* idx: HOST index feed of GLOBAL table rows laid out as gqe_batch describes (with_negatives: margin layout).  Outputs
  * (host): positions[n_idx] — the feed to hand to gqe_margin_fwd_bwd / gqe_forward (device copy); requests[n_idx] — grouped

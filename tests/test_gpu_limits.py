@@ -401,6 +401,92 @@ def test_hot_rows_state_machine(dec, inter, d):
         eng.close()
 
 
+def test_hot_word_sub_lists_and_their_overflow_chains():
+    """Hot WORD rows (include/gqe.h, gqe_hot_sub_lists): a promoted row of a bag table gets sub-lists sized from the list length that
+    promoted it — arrays of 128 entries behind a counter, an overflow chain of link nodes behind the array — and a gather launch
+    behind the fused kernel sums them into the row's accumulators.  A child process promotes EVERY word row of the toy world on a
+    short list (GQE_HOT_MIN_LEN=2, batches of 40 queries: one sub-list each) and then sends hub batches of 300 queries through
+    them: the busiest word gets more than 128 entries in a step, i.e. the array AND the chain.  Gradients against the fp64 oracle
+    (materialize folds the accumulators), zero_grads leaves nothing behind, and Adam steps agree with the ordered-sums engine
+    (which never promotes)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from oracle import netquery_numpy as O
+from gpu_utils import (TOY_FORMULAS, TOY_KINDS, TOY_SIZES, engine_from_params, plan_for, random_params, read_arena, toy_batch)
+from graphqembed_amd.tensorize import pack_margin_batches
+from test_gpu_parity import assert_grads_close
+d, dec, inter = 128, "bilinear-diag", "min"
+rng = np.random.RandomState(3)
+params = random_params(rng, d, dec, inter, TOY_SIZES, TOY_KINDS, bag_modes=("b",))
+ptr, ids = params[O.BAGS_KEY]["b"]
+QT = ("1-chain", "2-inter", "3-inter_chain", "3-chain")
+def batches(eng, seed, B, hub):
+    r = np.random.RandomState(seed)
+    out = []
+    for j, qtype in enumerate(QT):
+        t, g, a = toy_batch(r, qtype, B - j, hub=hub)
+        out.append((plan_for(eng, qtype, TOY_FORMULAS[qtype]), t, g, a, [1.0, 0.5, 0.25, 0.1][j], 1.0))
+    return out
+def sent_to_words(items):     # bag entries a step sends to every word row (an upper bound: inactive hinges send nothing)
+    sent = np.zeros(params[O.table_key("b")].shape[0], dtype=np.int64)
+    for (pl, t, g, a, w, m), qtype in zip(items, QT):
+        op = O.make_plan(qtype, TOY_FORMULAS[qtype])
+        rows = [t, g] if op["target_mode"] == "b" else []
+        rows += [a[i] for i, am in enumerate(op["anchor_modes"]) if am == "b"]
+        for r in rows:
+            for b in np.asarray(r).ravel():
+                np.add.at(sent, ids[ptr[b]:ptr[b + 1]], 1)
+    return sent
+hot = engine_from_params(params, d, dec, inter, max_queries=4 * 300, max_batches=4)
+ref = engine_from_params(params, d, dec, inter, max_queries=4 * 300, max_batches=4, ordered_sums=True)
+keys = list(hot.layout.entries)
+items777 = batches(hot, 777, 300, hub=True)
+sent = sent_to_words(items777)
+busiest = int(np.argmax(sent))
+assert sent[busiest] > 128 + 64, sent[busiest]                # more than the one array of its sub-list holds
+for step, B in enumerate((40, 300, 300, 300)):
+    for eng in (hot, ref):
+        items = batches(eng, 50 + step, B, hub=step > 0)
+        descs, idx, n = pack_margin_batches(items)
+        eng.margin_fwd_bwd(descs, idx, n)
+        eng.adam_step(keys)
+    if step == 0:
+        sent0 = sent_to_words(items)
+        # the word that will be the busiest below is promoted here, on a list of <= 32 entries like every other row: one sub-list
+        assert sent0[busiest] >= 8 and sent0.max() <= 32, (sent0[busiest], sent0.max())
+        heads, on = hot.hot_sub_lists()
+        rows0 = hot.hot_rows()
+        assert rows0 >= int((sent0 >= 8).sum()) and heads == rows0 and on, (rows0, heads, on)
+torch.cuda.synchronize()
+assert float((hot.params - ref.params).abs().mean()) <= 2e-4, float((hot.params - ref.params).abs().mean())
+assert float((hot.params - ref.params).abs().max()) <= 2e-3 * float(ref.params.abs().max()) + 0.021
+cur = read_arena(hot, hot.params)
+cur[O.BAGS_KEY] = params[O.BAGS_KEY]
+items = items777
+grads = O.zero_grads_like(cur)
+for (pl, t, g, a, w, m), qtype in zip(items, QT):
+    O.margin_fwd_bwd(cur, O.make_plan(qtype, TOY_FORMULAS[qtype]), dec, inter, t, g, a, weight=w, grads=grads)
+grads.pop(O.BAGS_KEY, None)
+descs, idx, n = pack_margin_batches(items)
+hot.margin_fwd_bwd(descs, idx, n)
+assert_grads_close(read_arena(hot, hot.grads), grads, "hot word rows: arrays + overflow chains")
+hot.zero_grads(keys)
+hot.margin_fwd_bwd(descs, idx, n)
+hot.zero_grads(keys)
+hot.materialize()
+assert float(hot.grads.abs().max()) == 0.0
+print("sub-lists ok", rows0, hot.hot_rows(), hot.hot_sub_lists(), int(sent0[busiest]), int(sent0.max()), int(sent[busiest]))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GQE_HOT_MIN_LEN="2")
+    env.pop("GQE_HOT_SUB", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "sub-lists ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
 @pytest.mark.parametrize("dec,inter,d", [("bilinear", "min", 64), ("bilinear-diag", "mean", 256), ("transe", "min", 80)])
 def test_operand_copies_follow_every_parameter_write(dec, inter, d):
     """The fused kernels read the d x d matrices from operand-ordered copies in the workspace (include/gqe.h,

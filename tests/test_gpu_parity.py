@@ -1,6 +1,7 @@
 """-m gpu: the HIP path (through libgqe.so's C ABI) against the golden vectors of the
 reference and against the fp64 oracle.  Tolerances (fp32 device arithmetic, atomics in
 arbitrary order): scores atol 2e-5, loss rtol 1e-4, gradients rtol 2e-3 + atol 1e-6*scale."""
+import os
 import numpy as np
 import pytest
 
@@ -1081,6 +1082,11 @@ def _full_size_vs_oracle(workload, d, dec, inter, min_params, n_relations, zipf=
         # that path: gradients against the oracle on the parameters of the moment (materialize folds accumulators and lists
         # alike), then a step that must consume every accumulator.
         assert eng.hot_rows() >= 4, eng.hot_rows()
+        if wl.g.bags:
+            # hot WORD rows got sub-lists (include/gqe.h, gqe_hot_sub_lists): the two steps below link the bags' nodes onto them
+            # and the gather launch behind the fused kernel sums them into the accumulators
+            heads, on = eng.hot_sub_lists()
+            assert heads >= 2 * eng.hot_rows() // 3 and on == (os.environ.get("GQE_HOT_SUB", "1") != "0"), (heads, on, eng.hot_rows())
         for rnd in range(2):
             host = eng.params.cpu().numpy()
             params = {k: host[off:off + int(np.prod(shape))].reshape(shape) for k, (off, shape) in eng.layout.entries.items()}

@@ -58,3 +58,5 @@ for rep in range(20):
 loss = float(prep[(50 + 2000 - 1) % n]["losses"][-1].item())
 print(("lazy (%d rides) " % eng.gemm_rides() if a.lazy else "") + ("train_step (%d split) " % eng.split_steps() if a.train_step else "") + ("deferred GEMM " if a.defer else "") + "%s d=%d %s B=%d: %.1f us/step (median of 20 x 100), final loss %.6f, params checksum %.6f"
       % (a.workload, a.dim, a.decoder, a.batch, np.median(ts) * 1e6, loss, float(eng._params.double().abs().sum())), flush=True)
+if a.zipf:
+    print("hot rows %d, sub-list heads %d (fused launches link onto them: %s)" % ((eng.hot_rows(),) + eng.hot_sub_lists()), flush=True)
