@@ -158,6 +158,11 @@ struct GqeBagTable {
 #define GQE_HOT_SUB_INTS ((size_t)(3 + GQE_HOT_SUB_CAP) * GQE_HOT_SUB_POOL)
 // what a lane keeps for push_links instead of a previous list head when its word goes to sub-list i: -2 - i
 #define GQE_HOT_SUB_TAG(i) (-2 - (i))
+// a row with sub-lists is added to by the gather's waves, one atomic row per sub-list and step — GQE_HOT_SUB_REPS of the
+// GQE_HOT_REPS accumulators spread that; the pass that steps the row reads and re-zeroes only those (direct adds to such a row — a
+// producer that has no pool yet — keep to them too)
+#define GQE_HOT_SUB_REPS 8
+#define GQE_HOT_REPS_OF(v) (GQE_HOT_SUB_LG1(v) ? GQE_HOT_SUB_REPS : GQE_HOT_REPS)
 // Row-sharded margin steps run by a session (gqe_shard_step): an index of the position feed that is >= GQE_OWN_ROW names row
 // (index - GQE_OWN_ROW) of this rank's OWN shard of the role's table — the fused kernel reads it where it lives and links its
 // contribution itself, exactly as in the unsharded step; smaller indices are positions in the fetched-row buffer.

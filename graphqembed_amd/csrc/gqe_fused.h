@@ -78,7 +78,7 @@ struct TileEnv {
 // hundreds (hub nodes) or thousands (frequent words) of entries, one dependent load each.
 template <int NC, bool FULL>
 __device__ __forceinline__ void hot_add(const TileEnv& e, int slot, const Vec<NC>& gx) {
-  float* acc = e.hot_acc + GQE_HOT_ROW(e.rep, GQE_HOT_SLOT_OF(slot)) * e.d;
+  float* acc = e.hot_acc + GQE_HOT_ROW(e.rep & (GQE_HOT_REPS_OF(slot) - 1), GQE_HOT_SLOT_OF(slot)) * e.d;
   gatomic_add<NC, FULL>(acc, gx, e.d, e.lane);
 }
 

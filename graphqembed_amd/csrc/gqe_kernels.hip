@@ -289,9 +289,10 @@ __device__ __forceinline__ float4 hot_take(const GqeHot& hot, int hs, int d, int
   // <= 64 VGPRs, i.e. its occupancy)
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 s = zero4;
-  hs = GQE_HOT_SLOT_OF(hs);   // (the value of slot[] also names the row's sub-lists)
+  const int reps = GQE_HOT_REPS_OF(hs);   // (the value of slot[] also names the row's sub-lists: such a row uses fewer accumulators)
+  hs = GQE_HOT_SLOT_OF(hs);
 #pragma unroll 1
-  for (int x = 0; x < GQE_HOT_REPS; x += 2) {
+  for (int x = 0; x < reps; x += 2) {
     float* p0 = hot.acc + GQE_HOT_ROW(x, hs) * d + c4;
     float* p1 = p0 + d;
     const float4 a = *reinterpret_cast<const float4*>(p0), b = *reinterpret_cast<const float4*>(p1);
@@ -337,24 +338,28 @@ __device__ __forceinline__ void hot_promote(const GqeHot& hot, long long hrow, i
 // in one step) is walked node by node.
 __global__ void __launch_bounds__(256) gqe_hot_gather_kernel(const GqeHot hot, const int32_t* __restrict__ next, const float* __restrict__ contrib,
                                                              const int32_t* __restrict__ link_contrib, int max_entries, int d) {
-  const int n_sub = min(__hip_atomic_load(hot.sub_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), GQE_HOT_SUB_POOL);
   const int lane = threadIdx.x & 63;
   const int waves = (int)gridDim.x * 4;
   int32_t* cnt = GQE_HOT_SUB_CNT(hot.sub);
   int32_t* ovf = GQE_HOT_SUB_OVF(hot.sub);
-  for (int h = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)); h < n_sub; h += waves) {
+  // (everything a sub-list's wave needs before its rows is requested at once — the pool's size bounds h, the number of sub-lists
+  // handed out is only needed for the answer: one round trip in front of the rows instead of three)
+  const int n_sub = min(__hip_atomic_load(hot.sub_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), GQE_HOT_SUB_POOL);
+  for (int h = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)); h < GQE_HOT_SUB_POOL; h += waves) {
+    const int32_t* buf = GQE_HOT_SUB_BUF(hot.sub) + (size_t)h * GQE_HOT_SUB_CAP;
+    const int b0 = buf[lane], b1 = buf[lane + 64];   // (GQE_HOT_SUB_CAP == 128; stale beyond the counter)
     const int taken = __builtin_amdgcn_readfirstlane(cnt[h]);
     const int x0 = __builtin_amdgcn_readfirstlane(ovf[h]);
+    const int slot = __builtin_amdgcn_readfirstlane(GQE_HOT_SUB_SLOT(hot.sub)[h]);
+    if (h >= n_sub) break;
     if (taken == 0 && x0 < 0) continue;
     const int n = min(taken, GQE_HOT_SUB_CAP);
     if (lane == 0) {
       cnt[h] = 0;
       if (x0 >= 0) ovf[h] = -1;
     }
-    const int slot = __builtin_amdgcn_readfirstlane(GQE_HOT_SUB_SLOT(hot.sub)[h]);
-    const int32_t* buf = GQE_HOT_SUB_BUF(hot.sub) + (size_t)h * GQE_HOT_SUB_CAP;
-    const int mine0 = lane < n ? buf[lane] : 0, mine1 = lane + 64 < n ? buf[lane + 64] : 0;   // (GQE_HOT_SUB_CAP == 128)
-    float* acc = hot.acc + GQE_HOT_ROW(h & (GQE_HOT_REPS - 1), slot) * d;
+    const int mine0 = lane < n ? b0 : 0, mine1 = lane + 64 < n ? b1 : 0;
+    float* acc = hot.acc + GQE_HOT_ROW(h & (GQE_HOT_SUB_REPS - 1), slot) * d;
     // columns lane, lane + 64, ...: every load and every atomic instruction of the wave covers 256 contiguous bytes (16-byte
     // lane slices made the atomic rows four times as many 64-byte operations: 42 us for this kernel instead of 18)
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};   // (d <= 256)
