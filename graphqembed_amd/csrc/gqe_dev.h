@@ -415,7 +415,13 @@ struct GqeGemmRide {
   const float* ws;
   const float* tile_loss;
   float* losses;
+  // 0: the units lead the grid (CUs of their own for the units' few microseconds, then the chunks).  K > 0 — next to the long
+  // non-temporal pass over tables beyond the Infinity Cache: every K-th workgroup behind the finalize block is a unit, the others
+  // stream chunks — the units' MFMA work runs in the shadow of a launch that is bound by HBM for hundreds of microseconds
+  int32_t spread;
 };
+// units that may ride SPREAD through a non-temporal pass (GqeGemmRide.spread): the limit of what one launch carries
+#define GQE_RIDE_MAX_UNITS_SPREAD 16384
 hipError_t gqe_launch_opt_gemm(const GqeOptArgs& a, const GqeGemmRide& r);
 // ... and that second launch: Adam on up to GQE_MATSTEP_MAX d x d matrices named in the kernel arguments (no universe scan, one
 // round trip to memory: it sits between the pass and the next fused kernel, on the step's critical path)

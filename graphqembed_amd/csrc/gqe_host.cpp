@@ -801,6 +801,17 @@ GqeHot hot_args(const gqe_ctx* ctx, bool produce) {
   return h;
 }
 
+// p + m + v of the context's tables beyond what the optimiser pass streams with the default cache policy (GQE_NT_STREAM_BYTES)
+bool ride_spread_off() {   // GQE_RIDE_SPREAD=0 (A / B runs): the pair GEMM keeps a launch of its own in front of a non-temporal pass
+  static const bool off = getenv("GQE_RIDE_SPREAD") && atoi(getenv("GQE_RIDE_SPREAD")) == 0;
+  return off;
+}
+bool big_tables(const gqe_ctx* ctx) {
+  long long bytes = 0;
+  for (const Table& t : ctx->tables) bytes += 12ll * t.rows * ctx->cfg.dim;
+  return !ride_spread_off() && bytes > GQE_NT_STREAM_BYTES;
+}
+
 bool any_dense(const gqe_ctx* ctx) {
   for (const Table& t : ctx->tables)
     if (t.dense) return true;
@@ -1398,7 +1409,10 @@ int run_queries(gqe_ctx* ctx, const gqe_batch* batches, int32_t n_batches, const
       // optimiser does — the units wait for the Adam pass and run in front of its chunks (GqeGemmRide)
       // (a launch without matrix jobs — chains of the element-wise decoders: the reference's whole edge-only burn-in phase —
       // still defers: its finalize block rides, and the step loses a launch that did nothing else)
-      const bool ride = ride_candidate && P.units <= GQE_RIDE_MAX_UNITS;
+      // (more units than that are MFMA work of their own — unless the context's tables are beyond the Infinity Cache: next to
+      // their long non-temporal pass the units ride SPREAD through the grid, GqeGemmRide.spread; run_opt launches them alone
+      // in front of any other pass)
+      const bool ride = ride_candidate && (P.units <= GQE_RIDE_MAX_UNITS || (P.units <= GQE_RIDE_MAX_UNITS_SPREAD && big_tables(ctx) && !ctx->lazy && !ctx->split_active));
       if (ride) {
         ctx->ride_fa = fa;
         ctx->ride_losses = losses;
@@ -1478,6 +1492,7 @@ int lazy_rows_ride(gqe_ctx* ctx, const GqeRowsArgs& ra) {
   r.ws = ctx->ride_fa.ws;
   r.tile_loss = ctx->ride_fa.tile_loss;
   r.losses = ctx->ride_losses;
+  r.spread = 0;
   const hipError_t e = gqe_launch_rows_ride(ra, r);
   if (e == hipErrorInvalidValue) {   // (a feed offset beyond 32 bits: the two launches instead — the caller's ride flag stays harmless)
     const int rc = flush_ride(ctx, ra.stream);
@@ -2001,6 +2016,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       rc = upload_staging();
       if (rc != GQE_OK) return rc;
       GqeGemmRide r;
+      r.spread = 0;
       if (ctx->ride_pending) {
         r.plan = ctx->ride_fa.plan;
         r.formulas = ctx->ride_fa.formulas;
@@ -2053,8 +2069,19 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       goto consumed;
     }
     {
-    // (not next to the non-temporal pass over tables beyond the Infinity Cache: reddit-synth 663 -> 687 us per step with it)
-    const bool ride = ctx->ride_pending && may_ride && oa.lists && !oa.sorted && !oa.dense_tables && !oa.lazy && !oa.nt && !merged_matrix;
+    // (next to the non-temporal pass over tables beyond the Infinity Cache the units do not LEAD the grid — reddit-synth 663 ->
+    // 687 us per step with that — they are SPREAD through it: every K-th workgroup, K = 1 mod 8)
+    const int ride_units = ctx->ride_pending ? ctx->ride_fa.plan.units : 0;
+    int spread = 0;
+    if (oa.nt && ride_units > 0 && !ride_spread_off()) {
+      const long long chunks = emit([&](size_t ui) { return ctx->universe[ui].tile == nullptr; }, oa.active, oa.coef, &oa.act, &oa.n_act);
+      const long long room = std::min<long long>(chunks, 262144);
+      static const int forced = getenv("GQE_RIDE_SPREAD") ? atoi(getenv("GQE_RIDE_SPREAD")) : 0;   // (tuning runs: K, 1 mod 8)
+      for (int k : {forced > 1 && forced % 8 == 1 ? forced : 33, 33, 17, 9})
+        if (!spread && (long long)k * ride_units <= room) spread = k;
+    }
+    const bool ride = ctx->ride_pending && may_ride && oa.lists && !oa.sorted && !oa.dense_tables && !oa.lazy && !merged_matrix &&
+                      (oa.nt ? !ride_spread_off() && (spread > 0 || ride_units == 0) : ride_units <= GQE_RIDE_MAX_UNITS);
     if (ctx->ride_pending && !ride) {
       rc = flush_ride(ctx, st);
       if (rc != GQE_OK) return rc;
@@ -2082,6 +2109,7 @@ int run_opt(gqe_ctx* ctx, int mode_in, const gqe_segment* segs, int32_t n_segs, 
       r.ws = ctx->ride_fa.ws;
       r.tile_loss = ctx->ride_fa.tile_loss;
       r.losses = ctx->ride_losses;
+      r.spread = spread;
       ctx->ride_pending = false;
       ++ctx->rides;
       if (timed) {

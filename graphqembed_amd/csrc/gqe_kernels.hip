@@ -861,12 +861,21 @@ __global__ __launch_bounds__(GQE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     return;
   }
   const int front = ride.plan.units + 1;
-  if ((int)blockIdx.x < front) {
+  long long first = (long long)blockIdx.x - front;
+  if (ride.spread > 0) {
+    // workgroups 1, 1 + K, 1 + 2 K, ... are units (K = 1 mod 8: unit j on the XCD unit_of_workgroup expects); the others stream
+    const int x = (int)blockIdx.x - 1, j = x / ride.spread;
+    if (j < ride.plan.units && j * ride.spread == x) {
+      gemm_ride_unit(ride.plan, ride.formulas, ride.ws, g, d, unit_of_workgroup(j, ride.plan.units));
+      return;
+    }
+    first = x - min(ride.plan.units, j + 1);
+  } else if ((int)blockIdx.x < front) {
     gemm_ride_unit(ride.plan, ride.formulas, ride.ws, g, d, unit_of_workgroup((int)blockIdx.x - 1, ride.plan.units));
     return;
   }
   GqeLazyArgs lazy;   // (never read: LAZY = false)
-  opt_body<GQE_OPT_ADAM, true, false, false, false, NT>((long long)blockIdx.x - front, (long long)gridDim.x - front, segs, n_segs, total_chunks, p, g, m,
+  opt_body<GQE_OPT_ADAM, true, false, false, false, NT>(first, (long long)gridDim.x - front, segs, n_segs, total_chunks, p, g, m,
                                                        v, head, next, contrib, link_contrib, max_entries, d, lr, b1, b2, eps, coef, active, act,
                                                        n_act, lazy, hot);
 }
