@@ -149,7 +149,7 @@ struct GqeBagTable {
 #define GQE_HOT_SUB_MAX_LG 10
 #define GQE_HOT_SLOT_OF(v) ((v) & (GQE_HOT_SLOTS - 1))
 #define GQE_HOT_SUB_LG1(v) (((v) >> 11) & 15)
-#define GQE_HOT_SUB_BASE(v) ((v) >> 15)
+#define GQE_HOT_SUB_BASE(v) (((v) >> 15) & (GQE_HOT_SUB_POOL - 1))
 // the pool (GqeHot.sub): counters, overflow-chain heads, the accumulator slot of each sub-list, the entry arrays
 #define GQE_HOT_SUB_CNT(sub) (sub)
 #define GQE_HOT_SUB_OVF(sub) ((sub) + GQE_HOT_SUB_POOL)
@@ -162,7 +162,13 @@ struct GqeBagTable {
 // GQE_HOT_REPS accumulators spread that; the pass that steps the row reads and re-zeroes only those (direct adds to such a row — a
 // producer that has no pool yet — keep to them too)
 #define GQE_HOT_SUB_REPS 8
-#define GQE_HOT_REPS_OF(v) (GQE_HOT_SUB_LG1(v) ? GQE_HOT_SUB_REPS : GQE_HOT_REPS)
+// ... and so does a row promoted on a list of fewer than GQE_HOT_FEW_LEN entries (bit 30 of its slot[] value): a hub node's few
+// hundred contributions per step need no 32-way spread (36 same-address atomic rows of 24 ns per accumulator), and the lane group
+// that steps the row reads its accumulators two at a time — 16 dependent round trips for 32 of them, on the critical chain of a
+// split step's second launch
+#define GQE_HOT_FEW_LEN 512
+#define GQE_HOT_FEW_BIT (1 << 30)
+#define GQE_HOT_REPS_OF(v) ((GQE_HOT_SUB_LG1(v) || ((v) & GQE_HOT_FEW_BIT)) ? GQE_HOT_SUB_REPS : GQE_HOT_REPS)
 // Row-sharded margin steps run by a session (gqe_shard_step): an index of the position feed that is >= GQE_OWN_ROW names row
 // (index - GQE_OWN_ROW) of this rank's OWN shard of the role's table — the fused kernel reads it where it lives and links its
 // contribution itself, exactly as in the unsharded step; smaller indices are positions in the fetched-row buffer.
