@@ -179,6 +179,7 @@ struct GqeHot {
   float* acc;        // [cap][GQE_HOT_REPS][d]
   int32_t* count;    // slots handed out so far (may run past cap: rows promoted beyond it stay on lists)
   int32_t cap, min_len;
+  int32_t few_len;   // a row promoted on a shorter list uses GQE_HOT_SUB_REPS accumulators (GQE_HOT_FEW_LEN; the environment may change it)
   // sub-lists of hot word rows (above).  sub == NULL in the struct a PRODUCER gets: it adds directly whatever slot[] says (the
   // host has not seen a promotion yet — `seen` is a word of pinned host memory a promoting kernel sets — or the mode has no
   // gather launch); consumers always get the pointers

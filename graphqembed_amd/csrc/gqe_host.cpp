@@ -781,6 +781,11 @@ GqeHot hot_args(const gqe_ctx* ctx, bool produce) {
   h.count = reinterpret_cast<int32_t*>(ctx->ws + L.counter_off + 64);
   h.cap = GQE_HOT_SLOTS;
   h.min_len = off ? 0x7fffffff : min_len;
+  static const int few_len = [] {   // GQE_HOT_FEW_LEN (tuning runs): 0 = every hot row spreads over all its accumulators
+    const char* e = getenv("GQE_HOT_FEW_LEN");
+    return e ? atoi(e) : GQE_HOT_FEW_LEN;
+  }();
+  h.few_len = few_len;
   if (produce && (off || ctx->world > 1 || ctx->ordered_sums)) h.slot = nullptr;
   // sub-lists of hot word rows: only contexts with bag tables have the pool.  A producer gets it once the host has seen a
   // promotion (the word of pinned memory a promoting kernel sets; until then it adds directly, which is always correct) —

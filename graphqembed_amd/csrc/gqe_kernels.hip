@@ -328,7 +328,7 @@ __device__ __forceinline__ void hot_promote(const GqeHot& hot, long long hrow, i
       }
     }
   }
-  if (len < GQE_HOT_FEW_LEN) v |= GQE_HOT_FEW_BIT;
+  if (len < hot.few_len) v |= GQE_HOT_FEW_BIT;
   hot.slot[hrow] = v;
   if (hot.seen) __hip_atomic_store(hot.seen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the host starts the gather launches
 }
