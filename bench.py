@@ -1148,7 +1148,8 @@ def main():
         rs["config"] = ("BASELINE config 5 workload: reddit-synth (%s; EmbeddingBag post features over a %d-word table, bags U[5,30]), "
                         "full mix %d batches x B=%d per GPU, d=256, %s + SetIntersection(%s), P=%d"
                         % (wr.describe(), wr.g.table_rows["post"], len(wr.mix), B, args.decoder, args.inter_decoder, wr.layout.total))
-        rs["optimiser"]["traffic"] = pmc_traffic("gqe_opt_kernel", "reddit-synth") if world == 1 else None
+        rides_r = str(rr["roofline"].get("kernel", "")).startswith("gqe_opt_gemm_kernel")   # (the pair-GEMM units spread through the pass)
+        rs["optimiser"]["traffic"] = pmc_traffic("gqe_opt_gemm_kernel" if rides_r else "gqe_opt_kernel", "reddit-synth") if world == 1 else None
         if world == 1 and not args.no_lazy:
             # the same workload with lazy (deferred, bit-exact) Adam: at Reddit-sized tables the eager pass streams 3.5 GB per step
             rl, el, _ = measure(wr, args, None, 0, 1, lazy=True, **short)

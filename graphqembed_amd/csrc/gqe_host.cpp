@@ -807,8 +807,11 @@ GqeHot hot_args(const gqe_ctx* ctx, bool produce) {
 }
 
 // p + m + v of the context's tables beyond what the optimiser pass streams with the default cache policy (GQE_NT_STREAM_BYTES)
-bool ride_spread_off() {   // GQE_RIDE_SPREAD=0 (A / B runs): the pair GEMM keeps a launch of its own in front of a non-temporal pass
-  static const bool off = getenv("GQE_RIDE_SPREAD") && atoi(getenv("GQE_RIDE_SPREAD")) == 0;
+// GQE_RIDE_SPREAD=1 (or K): the deferred pair-GEMM units ride spread through a non-temporal pass.  OFF by default: on most boxes the
+// step gains 12-14 us of ~630 (reddit-synth), but one run in three lands in a mode where the pass with the units takes 40-60 us
+// longer (581 / 598 / 601 us against 540-560) — EXPERIMENTS.md 102
+bool ride_spread_off() {
+  static const bool off = !(getenv("GQE_RIDE_SPREAD") && atoi(getenv("GQE_RIDE_SPREAD")) > 0);
   return off;
 }
 bool big_tables(const gqe_ctx* ctx) {

@@ -146,9 +146,9 @@ int gqe_params_changed(gqe_ctx* ctx);
  * optimiser: with enable != 0 gqe_margin_fwd_bwd launches only the fused kernel; the matrix-gradient units and the block that
  * turns the per-tile hinge sums into losses[] run in FRONT of the next gqe_adam_step's chunks, in the same launch (the pass over
  * the tables does not depend on them and is HBM-bound, the units are a short latency chain), and the d x d matrices are stepped
- * by a small second launch.  (Over tables beyond the Infinity Cache — p + m + v above 192 MB, the non-temporal pass — the units do
- * not lead the grid: every 33rd workgroup of the pass is a unit, so that their MFMA work runs in the shadow of a launch that is
- * bound by HBM for hundreds of microseconds; GQE_RIDE_SPREAD=0 in the environment keeps the pair GEMM's own launch there.)
+ * by a small second launch.  (Over tables beyond the Infinity Cache — p + m + v above 192 MB, the non-temporal pass — the pair GEMM
+ * keeps its own launch; with GQE_RIDE_SPREAD=1 in the environment every 33rd workgroup of that pass is a unit instead: faster by 2 %
+ * on most runs, slower by 6-9 % on one in three, hence off by default.)
  * Any other call that needs the gradients first (gqe_materialize_grads, gqe_sgd_step,
  * gqe_zero_grads, another gqe_margin_fwd_bwd / gqe_forward, lazy or order-independent passes) launches the deferred work on its
  * own, as without the switch.  THE CONTRACT: losses[] (and the dense gradient of the matrices) of a gqe_margin_fwd_bwd call are

@@ -981,7 +981,7 @@ def _second_step_vs_oracle(eng, wl, items, descs, didx, n, keys, dec, inter, mod
         assert eng.split_steps() == splits0 + 1, "gqe_train_step was expected to run as a split step"
     if mode == "train-step" and eng.bag_keys and d_rides(eng):
         # the two-call sequence inside gqe_train_step defers the pair GEMM: next to the non-temporal pass over tables beyond the
-        # Infinity Cache its units ride SPREAD through the pass's grid (gqe_dev.h, GqeGemmRide.spread)
+        # Infinity Cache its units ride SPREAD through the pass's grid when GQE_RIDE_SPREAD=1 (gqe_dev.h, GqeGemmRide.spread)
         assert eng.gemm_rides() == rides0 + 1, "the pair GEMM was expected to ride in the Adam pass"
     if mode == "deferred":
         eng.set_deferred_gemm(False)
@@ -989,9 +989,9 @@ def _second_step_vs_oracle(eng, wl, items, descs, didx, n, keys, dec, inter, mod
 
 def d_rides(eng):
     """can this engine's Adam pass carry the pair-GEMM units?  (d % 64 == 0; in front of its chunks when the tables are inside the
-    Infinity Cache, spread through its grid when they are beyond it — GQE_RIDE_SPREAD=0 switches that off: include/gqe.h)"""
+    Infinity Cache, spread through its grid when they are beyond it and GQE_RIDE_SPREAD=1 asks for it: include/gqe.h)"""
     stream = 12 * sum(int(np.prod(shape)) for k, (off, shape) in eng.layout.entries.items() if k.startswith("enc."))
-    return eng.dim % 64 == 0 and (stream <= (192 << 20) or os.environ.get("GQE_RIDE_SPREAD", "1") != "0")
+    return eng.dim % 64 == 0 and (stream <= (192 << 20) or os.environ.get("GQE_RIDE_SPREAD", "0") != "0")
 
 
 def _full_size_vs_oracle(workload, d, dec, inter, min_params, n_relations, zipf=None, min_longest_list=0, mode="two-call"):
