@@ -401,6 +401,22 @@ def test_hot_rows_state_machine(dec, inter, d):
         eng.close()
 
 
+@pytest.mark.parametrize("env", [{"GQE_HOT_FEW_LEN": "0", "GQE_HOT_SUB": "0"}, {"GQE_HOT_FEW_LEN": "0"}, {"GQE_HOT_SUB": "0"}])
+def test_hot_row_switches_do_not_change_results(env):
+    """The hot rows' forms have to agree: all 32 accumulators for every promoted row (GQE_HOT_FEW_LEN=0: rows promoted on short lists
+    otherwise keep to 8), word rows without sub-lists (GQE_HOT_SUB=0: one atomic row per word and bag, as before round 6), both.  The
+    state-machine test and the sub-list test run again in a process of their own under each setting (the switches are read once per
+    process; the sub-list test's own child process inherits them — without sub-lists it is skipped)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    k = "hot_rows_state_machine" + ("" if env.get("GQE_HOT_SUB") == "0" else " or sub_lists_and_their_overflow")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_gpu_limits.py"), "-k", k],
+                       cwd=root, env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:]
+
+
 def test_hot_word_sub_lists_and_their_overflow_chains():
     """Hot WORD rows (include/gqe.h, gqe_hot_sub_lists): a promoted row of a bag table gets sub-lists sized from the list length that
     promoted it — arrays of 128 entries behind a counter, an overflow chain of link nodes behind the array — and a gather launch
