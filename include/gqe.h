@@ -327,7 +327,10 @@ int gqe_set_ordered_sums(gqe_ctx* ctx, int32_t enable);
  * contributions are added into 32 dense accumulators of dim floats with float atomics, and the pass sums those instead of
  * chasing hundreds or thousands of links.  Automatic, up to 2048 rows per ctx; off in gqe_set_exchange mode and with
  * gqe_set_ordered_sums (atomic sums are order-dependent); GQE_HOT=0 in the environment disables it, GQE_HOT_MIN_LEN=n changes
- * the promotion threshold.  gqe_hot_rows: how many rows have been promoted so far (synchronises the device). */
+ * the promotion threshold.  A row promoted on a list of fewer than 512 entries (a hub node) keeps to 8 of its 32 accumulators: the
+ * lane group that steps it reads them two at a time, and four dependent round trips instead of sixteen matter on the critical chain of
+ * a split step's second launch (GQE_HOT_FEW_LEN=n moves that, 0 = never).  gqe_hot_rows: how many rows have been promoted so far
+ * (synchronises the device). */
 int gqe_hot_rows(gqe_ctx* ctx, int32_t* n_hot);
 /* Hot WORD rows (contexts with bag tables).  A frequent word collects thousands of contributions per step, one per bag that holds
  * it; an atomic row for each is what made the fused launch of reddit-synth with Zipf(1) words 1.3-1.5 x the uniform one.  A
