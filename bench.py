@@ -1172,6 +1172,7 @@ def main():
             zs["rows_with_over_32_contributions"] = rz["rows_with_over_32_contributions"]
             zs["optimiser_vs_uniform"] = round(zs["optimiser"]["avg_launch_ms"] / rs["optimiser"]["avg_launch_ms"], 3)
             zs["fused_vs_uniform"] = round(zs["kernels_ms"]["fused_fwd_bwd"] / rs["kernels_ms"]["fused_fwd_bwd"], 3)
+            zs["step_vs_uniform"] = round(zs["ms_per_step"] / rs["ms_per_step"], 3)
             # The ratio above is the FIRST steps of training, where every hinge is active and every hot word collects a gradient
             # from every query that holds it; both workloads run again behind 300 training steps (tools/probes/hot_settle_probe.py:
             # the fused launch settles over ~250 steps at a constant hot set), same engines' parameters, same feeds.
